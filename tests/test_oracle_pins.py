@@ -1,0 +1,106 @@
+"""Pins the CPU oracle to the reference's own artefacts.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _golden_lines():
+    rows = np.loadtxt(os.path.join(G, "doc_warp_lines.csv"), delimiter=",")
+    assert rows.shape == (848, 7)
+    return rows
+
+
+def test_pin1_transform_kat():
+    """doc/image.jpg_warp_lines.csv -> doc/image.jpg_warp_tform.csv, cfg of autorectify.cpp:343-348
+    (h_strategy given on the command line as ROTATE_V for the doc artefacts).  6 printed digits."""
+    rows = _golden_lines()
+    lines = O.lines_from_rows(rows)
+    cfg = O.RectificationConfig(40.0, 1.5, O.RECTIFY, 2.0, O.ROTATE_V)
+    T = O.compute_rectification_transform(lines, 1000, 563, cfg)
+    got = O.transform_to_array(T)
+    exp = [l.strip().split(",") for l in open(os.path.join(G, "doc_warp_tform.csv"))]
+    exp = [[float(x) for x in r] for r in exp]
+    for k in range(4):  # TL, TR, BL, BR
+        np.testing.assert_allclose(got[k, :2], exp[k], rtol=2e-5, atol=2e-4)
+    np.testing.assert_allclose(got[4], exp[4], rtol=2e-5, atol=2e-4)  # hvp (ideal)
+    np.testing.assert_allclose(got[5], exp[5], rtol=2e-5, atol=2e-4)  # vvp
+
+
+def test_pin1_group_vps():
+    rows = _golden_lines()
+    ids, vps = O.fit_vanishing_points(O.lines_from_rows(rows))
+    assert list(ids) == [0, 1, 2, 3]
+    exp = {0: (445.749, -2111.33), 1: (1620.86, 536.44), 2: (-136.68, 576.30), 3: (251.54, 347.33)}
+    for g, v in zip(ids, vps):
+        assert v[2] == 1.0
+        np.testing.assert_allclose(v[:2], exp[int(g)], rtol=2e-5, atol=0.02)
+
+
+def test_pin2_detector_structural_kat():
+    """doc/image.jpg at TRACE_TOLERANCE=0.3 reproduces >=700 of the 848 golden rows within 0.01 px
+    (the doc artefacts predate today's 0.25)."""
+    gray = np.load(os.path.join(G, "doc_image_gray.npy"))
+    img = gray.astype(np.float32) / np.float32(256.0)
+    r = O.find_line_segments(img, tolerance=0.3, want_label=False)
+    lines = O.filter_lines(r["lines"], 10.0)
+    gold = _golden_lines()[:, :4]
+    mine = np.stack([lines["x1"], lines["y1"], lines["x2"], lines["y2"]], 1).astype(np.float64)
+    hits = 0
+    for g in gold:
+        d = np.abs(mine - g).max(axis=1)
+        if d.min() <= 0.01:
+            hits += 1
+    assert hits >= 700, hits
+
+
+def test_pin3_analytic_kats():
+    """src/test.cpp:19-39 inputs; answers derived in SURVEY.md §4."""
+    rows = np.array(
+        [[0, 0, 10, 0, 1, 0, 10], [10, 0, 8, 5, 1, 0, 1], [8, 5, 2, 5, 1, 0, 10], [2, 5, 0, 0, 1, 0, 1]], np.float64
+    )
+    ls = O.lines_from_rows(rows)
+    vp1 = O.fit_vanishing_point(ls, 1)
+    np.testing.assert_allclose(vp1, [5.0, 12.5, 1.0], rtol=1e-4)
+    vp2 = O.fit_vanishing_point(ls, 10)
+    assert vp2[2] == 0.0
+    np.testing.assert_allclose(np.abs(vp2[:2]) / np.linalg.norm(vp2[:2]), [1.0, 0.0], atol=1e-4)
+    vp_all = O.fit_vanishing_point(ls, -1)
+    vp_zero = O.fit_vanishing_point(ls, 0)  # transform.cpp:35 tests g > 0: group 0 also means "all lines"
+    np.testing.assert_array_equal(vp_all, vp_zero)
+    probe = O.lines_from_rows(np.array([[5, 1, 5, 4, 1, 0, -1]], np.float64))
+    out = O.assign_to_group(ls, probe, 10.0)
+    assert out["group_id"][0] == 1
+
+
+def test_gauss_kernel_matches_formula():
+    for dir_x in (True, False):
+        K = O.gauss_deriv_kernel(2, 1.0, dir_x)
+        j, i = np.meshgrid(np.arange(5) - 2, np.arange(5) - 2)
+        z = j if dir_x else i
+        ref = z / (2 * np.pi) * np.exp(-(j**2 + i**2) / 2.0)
+        np.testing.assert_allclose(K, ref, rtol=1e-6, atol=1e-9)
+
+
+def test_sampler_distribution_matches_knuth():
+    """The counter-based sampler and choice_knuth (math_utils.cpp:14-39) both draw uniform sorted pairs."""
+    N = 12
+    nd = 60000
+    k = O.choice_knuth_mt(123, N, 2, nd)
+    assert (k[:, 0] < k[:, 1]).all()
+    hk = np.zeros((N, N))
+    np.add.at(hk, (k[:, 0], k[:, 1]), 1)
+    hc = np.zeros((N, N))
+    for it in range(nd):
+        a, b = O.sample_pair(7, 0, it, N)
+        assert a < b < N
+        hc[a, b] += 1
+    exp = nd / (N * (N - 1) / 2)
+    iu = np.triu_indices(N, 1)
+    for hist in (hk, hc):
+        chi2 = ((hist[iu] - exp) ** 2 / exp).sum()
+        assert chi2 < 120, chi2  # 65 dof; p ~ 1e-5 at 120
