@@ -1,0 +1,125 @@
+/*
+ * librectify_amd.h — extensions of the MI355X build beyond the reference's six functions.
+ *
+ * Plain C ABI (pointers and sizes only).  Everything here is additive: the drop-in symbols
+ * of include/librectify.h behave as the reference's (src/interface.cpp) and are thin
+ * wrappers over a thread-local context of this API.
+ *
+ * Why these exist:
+ *  - the reference API takes a host buffer and has no device/stream notion
+ *    (src/librectify.h:111-116); a caller that already holds frames in HBM, or wants many
+ *    frames in flight, needs device-pointer and batch entry points;
+ *  - parity tests and bench.py need stage-level access (filter / seeds / flood / fit /
+ *    RANSAC scoring) and per-stage HIP-event timings.
+ *
+ * All functions return 0 on success, non-zero on failure (lr_last_error() has the text).
+ * No function falls back to a CPU path: if no GPU is present they fail.
+ */
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include "librectify.h"
+
+#ifdef __cplusplus
+using librectify::ImageTransform;
+using librectify::LineSegment;
+using librectify::Point;
+using librectify::RectificationConfig;
+extern "C" {
+#endif
+
+typedef struct lr_context lr_context;
+
+/* ---- context ------------------------------------------------------------------------- */
+/* One context = one device, one HIP stream, one reusable workspace.  Not thread-safe; use
+ * one context per host thread (the drop-in functions do exactly that). */
+int lr_context_create(int device, lr_context** out);
+void lr_context_destroy(lr_context* ctx);
+const char* lr_last_error(void);
+int lr_synchronize(lr_context* ctx);
+/* RANSAC sample stream seed (the reference seeds from std::random_device, estimator.h:35;
+ * this build is reproducible: default 0 or env LIBRECTIFY_SEED). */
+void lr_set_ransac_seed(lr_context* ctx, uint64_t seed);
+/* RANSAC iterations per model (reference config.h:36 RANSAC_MAX_ITER = 10000). */
+void lr_set_ransac_iterations(lr_context* ctx, int n_iter);
+/* Flood implementation: 0 = ordered single-wave (simple, slow), 1 = parallel rounds (default). */
+void lr_set_flood_mode(lr_context* ctx, int mode);
+int lr_device_count(void);
+
+/* ---- full path ------------------------------------------------------------------------ */
+/* find_line_segment_groups on an image already resident in HBM (row-major float, `stride`
+ * elements between rows, stride >= width).  Writes at most `capacity` segments to the HOST
+ * array `out`; *n_lines is the number found (0 on the reference's NULL paths,
+ * interface.cpp:50-54,65-69). */
+int lr_find_line_segment_groups_device(lr_context* ctx, const float* d_image, int width, int height, int stride,
+                                       float min_length, int refine, int num_threads, LineSegment* out, int capacity,
+                                       int* n_lines);
+/* Same, host buffer (any stride sign, as the reference: image.cpp:11-19). */
+int lr_find_line_segment_groups_host(lr_context* ctx, const float* buffer, int width, int height, int stride,
+                                     float min_length, int refine, int num_threads, LineSegment* out, int capacity,
+                                     int* n_lines);
+/* Batch of `batch` device-resident frames of one size, frame b at d_images + b*image_stride.
+ * Output b goes to out + b*capacity; n_lines[b]; transforms[b] (may be NULL) is
+ * compute_rectification_transform(lines_b, cfg). */
+int lr_find_line_segment_groups_batch_device(lr_context* ctx, const float* d_images, size_t image_stride, int batch,
+                                             int width, int height, int stride, float min_length, int refine,
+                                             int num_threads, LineSegment* out, int capacity, int* n_lines,
+                                             const RectificationConfig* cfg, ImageTransform* transforms);
+
+/* ---- stage API (tests, bench) --------------------------------------------------------- */
+/* Stage 1: fused 5x5 derivative filter + magnitude + direction bin + dilated-bin mask +
+ * 5x5 non-max candidates (reference line_detector.cpp:41-49,126-182, filter.cpp:29-98,161-168). */
+int lr_stage_filter(lr_context* ctx, const float* d_image, int width, int height, int stride);
+/* Same on a host buffer (uploaded to the context's staging image first; any stride sign). */
+int lr_stage_filter_host(lr_context* ctx, const float* buffer, int width, int height, int stride);
+/* Stage 2: global max, seed threshold, ordered seed list (line_detector.cpp:209-220, filter.cpp:168-194). */
+int lr_stage_seeds(lr_context* ctx, int* n_seeds);
+/* Stage 3: ordered flood (filter.cpp:101-153, line_detector.cpp:92-122). */
+int lr_stage_flood(lr_context* ctx, int* n_components);
+/* Stage 4: weighted-PCA line fit per component (geometry.cpp:20-61); output in seed order. */
+int lr_stage_fit(lr_context* ctx, LineSegment* out, int capacity, int* n_lines);
+
+enum lr_buffer_id {
+    LR_BUF_DX = 0,        /* float  w*h */
+    LR_BUF_DY = 1,        /* float  w*h */
+    LR_BUF_DMASK = 2,     /* uint8  w*h: bit b = pixel is inside the 3x3 dilation of grad_bin==b */
+    LR_BUF_LABEL = 3,     /* int32  w*h: claiming seed index or -1 */
+    LR_BUF_SEED_IDX = 4,  /* int32  n_seeds: row*w+col, canonical order */
+    LR_BUF_SEED_BIN = 5,  /* int32  n_seeds */
+    LR_BUF_SEED_THR = 6,  /* float  n_seeds: (1-TRACE_TOLERANCE)*value at the seed */
+    LR_BUF_MAXMAG = 7,    /* float  1 */
+    LR_BUF_SEED_SIZE = 8, /* int32  n_seeds: pixels claimed by each seed's flood (0 = skipped) */
+};
+int lr_download(lr_context* ctx, int buffer_id, void* dst, size_t bytes);
+
+enum lr_stage_id {
+    LR_T_UPLOAD = 0,
+    LR_T_FILTER = 1,
+    LR_T_SEEDS = 2,
+    LR_T_FLOOD = 3,
+    LR_T_FIT = 4,
+    LR_T_RANSAC = 5,
+    LR_T_TOTAL = 6,
+    LR_T_FILTER_KERNEL = 7, /* the fused filter kernel alone */
+    LR_T_COUNT = 8,
+};
+/* HIP-event times (ms) of the stages of the last call on this context. */
+int lr_stage_times(lr_context* ctx, float* ms, int count);
+/* Extra counters of the last call: [0] seeds, [1] components, [2] flood rounds, [3] labelled pixels. */
+int lr_stage_counters(lr_context* ctx, int64_t* out, int count);
+
+/* ---- RANSAC --------------------------------------------------------------------------- */
+/* Scores n_iter two-line hypotheses of the line-pencil model (line_pencil.cpp:89-140,
+ * estimator.h:37-71) over the lines listed in `indices`, on the GPU.  lines_norm are
+ * bbox-normalised segments (HOST).  Outputs the raw best hypothesis (first strictly best),
+ * its score and iteration (-1 if every sample was degenerate). */
+int lr_ransac_best(lr_context* ctx, const LineSegment* lines_norm, int n, const int32_t* indices, int n_idx, float tol,
+                   int n_iter, uint64_t seed, uint32_t round, float* best_h3, float* best_score, int* best_iter);
+/* estimate_line_pencils (line_pencil.cpp:148-177): writes group_id in place (HOST array). */
+int lr_estimate_line_pencils(lr_context* ctx, LineSegment* lines, int n, int max_models, float inlier_deg,
+                             float garbage_deg, int n_iter, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif

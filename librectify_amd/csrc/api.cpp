@@ -1,0 +1,251 @@
+// C ABI of librectify_amd.so: the reference's six functions (include/librectify.h) and the
+// lr_* extensions (include/librectify_amd.h).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <new>
+
+#include "context.h"
+
+using namespace lramd;
+
+namespace {
+
+struct CtxDeleter {
+    void operator()(lr_context* c) const { ctx_destroy(c); }
+};
+
+// The reference API is stateless and re-entrant: each host thread lazily gets
+// its own context on the device named by LIBRECTIFY_DEVICE (default 0).
+lr_context* thread_context() {
+    thread_local std::unique_ptr<lr_context, CtxDeleter> ctx;
+    if (!ctx) {
+        const char* env = std::getenv("LIBRECTIFY_DEVICE");
+        lr_context* c = nullptr;
+        if (ctx_create(env ? std::atoi(env) : 0, &c)) return nullptr;
+        ctx.reset(c);
+    }
+    return ctx.get();
+}
+
+int upload_host_image(lr_context* c, const float* buffer, int width, int height, int stride) {
+    // image_from_buffer (reference image.cpp:11-19): a negative stride addresses the same rows from the other end
+    if (stride < 0) {
+        buffer = buffer + (std::ptrdiff_t)(height - 1) * stride;
+        stride = -stride;
+    }
+    if (ctx_ensure_image_capacity(c, width, height)) return 1;
+    LR_HIP(hipSetDevice(c->device));
+    LR_HIP(hipMemcpy2DAsync(c->d_img, (size_t)width * sizeof(float), buffer, (size_t)stride * sizeof(float),
+                            (size_t)width * sizeof(float), (size_t)height, hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+
+int copy_out(const std::vector<LineSegment>& v, LineSegment* out, int capacity, int* n_lines) {
+    const int n = (int)v.size();
+    if (n_lines) *n_lines = n;
+    if (out && capacity > 0) std::memcpy(out, v.data(), sizeof(LineSegment) * (size_t)std::min(n, capacity));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- the reference's six entry points ----------------------------------------------------
+
+LineSegment* find_line_segment_groups(float* buffer, int width, int height, int stride, float min_length, bool refine,
+                                      int num_threads, int* n_lines) {
+    (void)num_threads;  // the reference's OpenMP knob; the per-pixel stages run on the GPU regardless
+    if (n_lines) *n_lines = 0;
+    set_error("");
+    // The reference signals "nothing found" by NULL (interface.cpp:50-54,65-69) and has no error
+    // channel; a missing GPU or a HIP failure is therefore reported on stderr (and through
+    // lr_last_error()) before the same NULL is returned.  There is no CPU fallback.
+    auto fail = []() -> LineSegment* {
+        std::fprintf(stderr, "librectify_amd: find_line_segment_groups failed: %s\n", get_error().c_str());
+        return nullptr;
+    };
+    lr_context* c = thread_context();
+    if (!c) return fail();
+    std::vector<LineSegment> res;
+    if (upload_host_image(c, buffer, width, height, stride)) return fail();
+    if (ctx_find_groups_device(c, c->d_img, width, height, width, min_length, refine, res)) return fail();
+    if (res.empty()) return nullptr;
+    LineSegment* out = new (std::nothrow) LineSegment[res.size()];
+    if (!out) return nullptr;
+    std::memcpy(out, res.data(), res.size() * sizeof(LineSegment));
+    if (n_lines) *n_lines = (int)res.size();
+    return out;
+}
+
+void release_line_segments(LineSegment** lines) {
+    if (lines && *lines != nullptr) {
+        delete[] * lines;
+        *lines = nullptr;
+    }
+}
+
+ImageTransform compute_rectification_transform(LineSegment* lines, int n_lines, int width, int height,
+                                               const RectificationConfig& cfg) {
+    return rectification_transform(lines, n_lines, width, height, cfg);
+}
+
+ImageTransform compute_rectification_transform_from_vp(int width, int height, const Point& vp_h, const Point& vp_v) {
+    return rectification_transform_from_vp(width, height, vp_h, vp_v);
+}
+
+Point fit_vanishing_point(const LineSegment* lines, int n_lines, int group) {
+    const Vec3 v = fit_single_vanishing_point(std::vector<LineSegment>(lines, lines + n_lines), group);
+    return Point{v.x, v.y, v.z};
+}
+
+void assign_to_group(const LineSegment* lines_array, int n_lines, LineSegment* new_lines_array, int n_new_lines,
+                     float angular_tolarance) {
+    assign_groups(lines_array, n_lines, new_lines_array, n_new_lines, angular_tolarance);
+}
+
+// ---- extensions -----------------------------------------------------------------------------
+
+int lr_context_create(int device, lr_context** out) { return ctx_create(device, out); }
+void lr_context_destroy(lr_context* ctx) { ctx_destroy(ctx); }
+const char* lr_last_error(void) { return get_error().c_str(); }
+int lr_synchronize(lr_context* ctx) {
+    LR_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+void lr_set_ransac_seed(lr_context* ctx, uint64_t seed) { ctx->ransac_seed = seed; }
+void lr_set_ransac_iterations(lr_context* ctx, int n_iter) { ctx->ransac_iters = n_iter; }
+void lr_set_flood_mode(lr_context* ctx, int mode) { ctx->flood_mode = mode; }
+int lr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int lr_find_line_segment_groups_device(lr_context* ctx, const float* d_image, int width, int height, int stride,
+                                       float min_length, int refine, int num_threads, LineSegment* out, int capacity,
+                                       int* n_lines) {
+    (void)num_threads;
+    std::vector<LineSegment> res;
+    if (ctx_find_groups_device(ctx, d_image, width, height, stride, min_length, refine != 0, res)) return 1;
+    return copy_out(res, out, capacity, n_lines);
+}
+
+int lr_find_line_segment_groups_host(lr_context* ctx, const float* buffer, int width, int height, int stride,
+                                     float min_length, int refine, int num_threads, LineSegment* out, int capacity,
+                                     int* n_lines) {
+    (void)num_threads;
+    if (upload_host_image(ctx, buffer, width, height, stride)) return 1;
+    std::vector<LineSegment> res;
+    if (ctx_find_groups_device(ctx, ctx->d_img, width, height, width, min_length, refine != 0, res)) return 1;
+    return copy_out(res, out, capacity, n_lines);
+}
+
+int lr_find_line_segment_groups_batch_device(lr_context* ctx, const float* d_images, size_t image_stride, int batch,
+                                             int width, int height, int stride, float min_length, int refine,
+                                             int num_threads, LineSegment* out, int capacity, int* n_lines,
+                                             const RectificationConfig* cfg, ImageTransform* transforms) {
+    (void)num_threads;
+    for (int b = 0; b < batch; ++b) {
+        std::vector<LineSegment> res;
+        if (ctx_find_groups_device(ctx, d_images + (size_t)b * image_stride, width, height, stride, min_length,
+                                   refine != 0, res))
+            return 1;
+        copy_out(res, out + (size_t)b * capacity, capacity, n_lines ? n_lines + b : nullptr);
+        if (transforms) {
+            const RectificationConfig def;
+            transforms[b] = rectification_transform(res.data(), (int)std::min<size_t>(res.size(), (size_t)capacity),
+                                                    width, height, cfg ? *cfg : def);
+        }
+    }
+    return 0;
+}
+
+int lr_stage_filter(lr_context* ctx, const float* d_image, int width, int height, int stride) {
+    return ctx_stage_filter(ctx, d_image, width, height, stride);
+}
+int lr_stage_filter_host(lr_context* ctx, const float* buffer, int width, int height, int stride) {
+    if (upload_host_image(ctx, buffer, width, height, stride)) return 1;
+    return ctx_stage_filter(ctx, ctx->d_img, width, height, width);
+}
+int lr_stage_seeds(lr_context* ctx, int* n_seeds) {
+    if (ctx_stage_seeds(ctx)) return 1;
+    if (n_seeds) *n_seeds = (int)ctx->n_seeds;
+    return 0;
+}
+int lr_stage_flood(lr_context* ctx, int* n_components) {
+    if (ctx_stage_flood(ctx)) return 1;
+    LR_HIP(hipStreamSynchronize(ctx->stream));
+    if (n_components) *n_components = -1;  // known after lr_stage_fit
+    return 0;
+}
+int lr_stage_fit(lr_context* ctx, LineSegment* out, int capacity, int* n_lines) {
+    std::vector<LineSegment> res;
+    if (ctx_stage_fit(ctx, res)) return 1;
+    return copy_out(res, out, capacity, n_lines);
+}
+
+int lr_download(lr_context* ctx, int buffer_id, void* dst, size_t bytes) {
+    const size_t npix = (size_t)ctx->w * ctx->h;
+    const void* src = nullptr;
+    size_t have = 0;
+    switch (buffer_id) {
+        case LR_BUF_DX: src = ctx->dx; have = npix * 4; break;
+        case LR_BUF_DY: src = ctx->dy; have = npix * 4; break;
+        case LR_BUF_DMASK: src = ctx->dmask; have = npix; break;
+        case LR_BUF_LABEL: src = ctx->label; have = npix * 4; break;
+        case LR_BUF_SEED_IDX: src = ctx->seed_idx; have = (size_t)ctx->n_seeds * 4; break;
+        case LR_BUF_SEED_BIN: src = ctx->seed_bin; have = (size_t)ctx->n_seeds * 4; break;
+        case LR_BUF_SEED_THR: src = ctx->seed_thr; have = (size_t)ctx->n_seeds * 4; break;
+        case LR_BUF_MAXMAG: src = ctx->maxmag; have = 4; break;
+        case LR_BUF_SEED_SIZE: src = ctx->seed_size; have = (size_t)ctx->n_seeds * 4; break;
+        default: set_error("lr_download: unknown buffer id"); return 1;
+    }
+    if (bytes > have) {
+        set_error("lr_download: request larger than the buffer");
+        return 1;
+    }
+    LR_HIP(hipSetDevice(ctx->device));
+    LR_HIP(hipStreamSynchronize(ctx->stream));
+    LR_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int lr_stage_times(lr_context* ctx, float* ms, int count) {
+    for (int i = 0; i < count && i < LR_T_COUNT; ++i) ms[i] = ctx->stage_ms[i];
+    return 0;
+}
+
+int lr_stage_counters(lr_context* ctx, int64_t* out, int count) {
+    const int64_t v[4] = {(int64_t)ctx->n_seeds, (int64_t)ctx->n_comp, (int64_t)ctx->flood_rounds, (int64_t)ctx->n_px};
+    for (int i = 0; i < count && i < 4; ++i) out[i] = v[i];
+    return 0;
+}
+
+int lr_ransac_best(lr_context* ctx, const LineSegment* lines_norm, int n, const int32_t* indices, int n_idx, float tol,
+                   int n_iter, uint64_t seed, uint32_t round, float* best_h3, float* best_score, int* best_iter) {
+    const PencilModel model(std::vector<LineSegment>(lines_norm, lines_norm + n));
+    const std::vector<int> idx(indices, indices + n_idx);
+    Vec3 h;
+    float s;
+    int it;
+    if (ctx_ransac_best(ctx, model, idx, tol, n_iter, seed, round, &h, &s, &it)) return 1;
+    best_h3[0] = h.x;
+    best_h3[1] = h.y;
+    best_h3[2] = h.z;
+    *best_score = s;
+    *best_iter = it;
+    return 0;
+}
+
+int lr_estimate_line_pencils(lr_context* ctx, LineSegment* lines, int n, int max_models, float inlier_deg,
+                             float garbage_deg, int n_iter, uint64_t seed) {
+    std::vector<LineSegment> v(lines, lines + n);
+    if (ctx_estimate_line_pencils(ctx, v, max_models, inlier_deg, garbage_deg, n_iter, seed)) return 1;
+    std::memcpy(lines, v.data(), sizeof(LineSegment) * (size_t)n);
+    return 0;
+}
+
+}  // extern "C"

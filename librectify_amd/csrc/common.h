@@ -1,0 +1,134 @@
+// Internal declarations shared by the HIP kernels and the host pipeline.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "../../include/librectify_amd.h"
+
+namespace lramd {
+
+// reference config.h:23-59
+constexpr float kEps = 1e-6f;
+constexpr int kMaxModels = 4;
+constexpr float kInlierDeg = 2.0f;
+constexpr float kGarbageDeg = 4.0f;
+constexpr int kRansacMaxIter = 10000;
+constexpr int kEdgeKernelSize = 2;
+constexpr float kEdgeKernelSigma = 1.0f;
+constexpr int kSeedDist = 2;
+constexpr float kSeedRatio = 0.95f;
+constexpr float kTraceTolerance = 0.25f;
+constexpr float kLineMaxErr = 2.0f;
+constexpr float kLineMinLength = 5.f;
+constexpr int kComponentMinSize = 5;
+constexpr int kBins = 8;
+
+// Filter tile geometry (kernels_filter.hip)
+constexpr int kTileW = 64;
+constexpr int kTileH = 32;
+constexpr int kCandPerTile = kTileW * kTileH;  // worst case: every core pixel is a plateau peak
+
+struct FilterConsts {
+    float kx[25];   // Hx taps, row-major (reference filter.cpp:65-78, dir_x = true)
+    float ky[25];   // Hy taps
+    float st[kBins];  // sin(theta_b), theta_b = float(b*pi)/8 (line_detector.cpp:144-145)
+    float ct[kBins];  // cos(theta_b)
+};
+
+struct BinTrig {
+    float st[kBins];
+    float ct[kBins];
+};
+
+constexpr uint32_t kLabelFree = 0xFFFFFFFFu;
+
+// Directional edge response of bin b (line_detector.cpp:145), canonical form.
+__host__ __device__ inline float directional(float dx, float dy, float s, float c) {
+    return fabsf(fmaf(dx, s, dy * c));
+}
+
+// Counter-based RANSAC sample generator: a uniform sorted pair (a < b) out of n, a pure function
+// of (seed, round, iteration).  Replaces choice_knuth under mt19937(random_device)
+// (reference estimator.h:35,49-50, math_utils.cpp:14-39): same distribution, no sequential state.
+__host__ __device__ inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__host__ __device__ inline void sample_pair(uint64_t seed, uint32_t round, uint32_t iter, uint32_t n, uint32_t& a,
+                                            uint32_t& b) {
+    const uint64_t z = splitmix64(seed ^ splitmix64(((uint64_t)round << 32) | iter));
+    const uint32_t u1 = (uint32_t)z, u2 = (uint32_t)(z >> 32);
+    const uint32_t i = (uint32_t)(((uint64_t)u1 * n) >> 32);
+    uint32_t j = (uint32_t)(((uint64_t)u2 * (n - 1)) >> 32);
+    if (j >= i) ++j;
+    a = i < j ? i : j;
+    b = i < j ? j : i;
+}
+
+void set_error(const std::string& msg);
+
+#define LR_HIP(expr)                                                                                     \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess) {                                                                          \
+            ::lramd::set_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + ":" + \
+                               std::to_string(__LINE__) + ")");                                          \
+            return 1;                                                                                    \
+        }                                                                                                \
+    } while (0)
+
+// ---- launchers (each enqueues on `s`, never synchronises unless stated) -----------------
+// kernels_filter.hip
+int launch_filter(const float* img, int w, int h, int stride, const FilterConsts& fc, float* dx, float* dy,
+                  uint8_t* dmask, uint64_t* cand, uint32_t* cand_count, uint32_t* tile_max, hipStream_t s);
+inline int tiles_x(int w) { return (w + kTileW - 1) / kTileW; }
+inline int tiles_y(int h) { return (h + kTileH - 1) / kTileH; }
+
+// kernels_seeds.hip
+size_t seeds_temp_bytes(int n_tiles, size_t max_seeds);
+int launch_seed_select(const uint64_t* cand, const uint32_t* cand_count, const uint32_t* tile_max, int n_tiles,
+                       float seed_keep_ratio, float* maxmag, uint32_t* tile_pass, uint32_t* tile_off, uint64_t* keys,
+                       uint32_t* n_seeds, void* temp, size_t temp_bytes, hipStream_t s);
+int launch_seed_sort(uint64_t* keys_in, uint64_t* keys_out, uint32_t n, void* temp, size_t temp_bytes, hipStream_t s);
+int launch_seed_setup(const uint64_t* keys_sorted, uint32_t n, const float* dx, const float* dy, BinTrig trig,
+                      float trace_tolerance, int32_t* seed_idx, int32_t* seed_bin, float* seed_thr, hipStream_t s);
+
+// kernels_flood.hip
+int launch_label_init(uint32_t* label, size_t n, hipStream_t s);
+int launch_flood_ordered(const float* dx, const float* dy, const uint8_t* dmask, int w, int h, const int32_t* seed_idx,
+                         const int32_t* seed_bin, const float* seed_thr, uint32_t n_seeds, BinTrig trig,
+                         uint32_t* label, int32_t* seed_size, int32_t* queue, hipStream_t s);
+
+// kernels_fit.hip
+size_t fit_temp_bytes(size_t max_pixels, uint32_t max_segments);
+int launch_component_offsets(const int32_t* seed_size, uint32_t n_seeds, int min_size, uint32_t* comp_rank,
+                             uint32_t* comp_seed, uint32_t* comp_off, uint32_t* totals /*[0]=n_comp,[1]=n_px*/,
+                             void* temp, size_t temp_bytes, hipStream_t s);
+int launch_component_scatter(const uint32_t* label, size_t npix, const uint32_t* comp_rank, const uint32_t* comp_off,
+                             uint32_t* cursor, uint32_t* px, hipStream_t s);
+int launch_component_sort(uint32_t* px_in, uint32_t* px_out, uint32_t n_px, uint32_t n_comp, const uint32_t* comp_off,
+                          int idx_bits, void* temp, size_t temp_bytes, hipStream_t s);
+int launch_fit(const uint32_t* px_sorted, const uint32_t* comp_off, const uint32_t* comp_seed, uint32_t n_comp,
+               const int32_t* seed_bin, const float* dx, const float* dy, int w, BinTrig trig, float* scratch_w,
+               LineSegment* out, hipStream_t s);
+
+// kernels_ransac.hip
+struct PencilSoA {  // device pointers, n entries each (lines of the current round, compacted)
+    const float* ax;
+    const float* ay;
+    const float* dx;
+    const float* dy;
+    const float* len;
+    const float* hx;
+    const float* hy;
+    const float* hz;
+};
+int launch_ransac_score(PencilSoA m, uint32_t n, float tol, float degeneracy_tol, uint32_t n_iter, uint64_t seed,
+                        uint32_t round, float* scores, hipStream_t s);
+int launch_ransac_argmax(const float* scores, uint32_t n_iter, float* best_score, int32_t* best_iter, hipStream_t s);
+
+}  // namespace lramd

@@ -1,0 +1,95 @@
+// lr_context: one device, one stream, one reusable workspace (see include/librectify_amd.h).
+#pragma once
+#include <vector>
+
+#include "common.h"
+#include "vp_host.h"
+
+struct lr_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+
+    // geometry of the workspace / last frame
+    size_t cap_pix = 0;
+    int cap_tiles = 0;
+    int w = 0, h = 0;
+
+    // stage 1
+    float* d_img = nullptr;  // staging for the host-buffer entry points
+    float* dx = nullptr;
+    float* dy = nullptr;
+    uint8_t* dmask = nullptr;
+    uint64_t* cand = nullptr;
+    uint32_t* cand_count = nullptr;
+    uint32_t* tile_max = nullptr;
+    // stage 2
+    uint32_t* tile_pass = nullptr;
+    uint32_t* tile_off = nullptr;
+    float* maxmag = nullptr;
+    uint64_t* keys_a = nullptr;
+    uint64_t* keys_b = nullptr;
+    uint32_t* d_counts = nullptr;  // [0] n_seeds, [1] n_comp, [2] n_px, [3..] flood scratch
+    int32_t* seed_idx = nullptr;
+    int32_t* seed_bin = nullptr;
+    float* seed_thr = nullptr;
+    int32_t* seed_size = nullptr;
+    // stage 3
+    uint32_t* label = nullptr;
+    int32_t* queue = nullptr;
+    // stage 4
+    uint32_t* comp_rank = nullptr;
+    uint32_t* comp_seed = nullptr;
+    uint32_t* comp_off = nullptr;
+    uint32_t* cursor = nullptr;
+    uint32_t* px_a = nullptr;
+    uint32_t* px_b = nullptr;
+    float* scratch_w = nullptr;
+    LineSegment* d_lines = nullptr;
+    void* temp = nullptr;
+    size_t temp_bytes = 0;
+    // RANSAC
+    size_t cap_lines = 0;
+    float* d_model = nullptr;  // 8 arrays of cap_lines
+    float* h_model = nullptr;  // pinned mirror
+    size_t cap_iter = 0;
+    float* d_scores = nullptr;
+    float* d_best_score = nullptr;
+    int32_t* d_best_iter = nullptr;
+    // pinned host scalars
+    uint32_t* h_counts = nullptr;  // 8 words
+    float* h_best = nullptr;       // [0] score, [1] iter (as int bits)
+
+    // constants
+    lramd::FilterConsts fconsts;
+    lramd::BinTrig trig;
+    float seed_keep_ratio = 0.f;
+
+    // state of the last run
+    uint32_t n_seeds = 0, n_comp = 0, n_px = 0;
+    int flood_rounds = 0;
+    uint64_t ransac_seed = 0;
+    int ransac_iters = lramd::kRansacMaxIter;
+    int flood_mode = 0;
+    hipEvent_t ev[16] = {};
+    float stage_ms[LR_T_COUNT] = {};
+    bool stage_valid[4] = {false, false, false, false};
+};
+
+namespace lramd {
+int ctx_create(int device, lr_context** out);
+void ctx_destroy(lr_context* c);
+const std::string& get_error();
+int ctx_ensure_image_capacity(lr_context* c, int w, int h);
+int ctx_ensure_ransac_capacity(lr_context* c, size_t n_lines, size_t n_iter);
+int ctx_stage_filter(lr_context* c, const float* d_image, int w, int h, int stride);
+int ctx_stage_seeds(lr_context* c);
+int ctx_stage_flood(lr_context* c);
+int ctx_stage_fit(lr_context* c, std::vector<LineSegment>& out);
+int ctx_detect(lr_context* c, const float* d_image, int w, int h, int stride, std::vector<LineSegment>& raw);
+int ctx_ransac_best(lr_context* c, const PencilModel& model, const std::vector<int>& indices, float tol, int n_iter,
+                    uint64_t seed, uint32_t round, Vec3* best_h, float* best_score, int* best_iter);
+int ctx_estimate_line_pencils(lr_context* c, std::vector<LineSegment>& lines, int max_models, float inlier_deg,
+                              float garbage_deg, int n_iter, uint64_t seed);
+int ctx_find_groups_device(lr_context* c, const float* d_image, int w, int h, int stride, float min_length, bool refine,
+                           std::vector<LineSegment>& out);
+}  // namespace lramd

@@ -1,0 +1,397 @@
+// Host pipeline: owns the workspace, enqueues the stages on the context stream, and runs the
+// (sequential, tiny) vanishing-point peeling loop around the GPU scoring kernel.
+#include "context.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+namespace lramd {
+
+namespace {
+
+thread_local std::string g_error;
+
+template <class T>
+int dev_alloc(T*& p, size_t count) {
+    if (p) {
+        (void)hipFree(p);
+        p = nullptr;
+    }
+    LR_HIP(hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)));
+    return 0;
+}
+
+// reference filter.cpp:65-78
+void gauss_deriv_taps(int size, float sigma, bool dir_x, float* H) {
+    const int n = 2 * size + 1;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            const float x = float(j - size);
+            const float y = float(i - size);
+            const float z = dir_x ? x : y;
+            const float a = float(2 * M_PI * std::pow(sigma, 4.0f));
+            const float e = std::exp(-(std::pow(x, 2.0f) + std::pow(y, 2.0f)) / (2 * std::pow(sigma, 2.0f)));
+            H[i * n + j] = z / a * e;
+        }
+}
+
+void init_constants(lr_context* c) {
+    gauss_deriv_taps(kEdgeKernelSize, kEdgeKernelSigma, true, c->fconsts.kx);
+    gauss_deriv_taps(kEdgeKernelSize, kEdgeKernelSigma, false, c->fconsts.ky);
+    for (int b = 0; b < kBins; ++b) {
+        const float theta = float(b * M_PI) / kBins;  // line_detector.cpp:144
+        c->trig.st[b] = std::sin(theta);
+        c->trig.ct[b] = std::cos(theta);
+        c->fconsts.st[b] = c->trig.st[b];
+        c->fconsts.ct[b] = c->trig.ct[b];
+    }
+    c->seed_keep_ratio = 1 - std::max(std::min(kSeedRatio, 1.f), 0.f);  // line_detector.cpp:209
+}
+
+int idx_bits_for(size_t npix) {
+    int b = 1;
+    while (((size_t)1 << b) < npix) ++b;
+    return b;
+}
+
+}  // namespace
+
+void set_error(const std::string& msg) { g_error = msg; }
+const std::string& get_error() { return g_error; }
+
+int ctx_ensure_image_capacity(lr_context* c, int w, int h) {
+    const size_t npix = (size_t)w * h;
+    const int ntiles = tiles_x(w) * tiles_y(h);
+    if (npix <= c->cap_pix && ntiles <= c->cap_tiles) return 0;
+    LR_HIP(hipStreamSynchronize(c->stream));
+    const size_t cp = std::max(npix, c->cap_pix);
+    const int ct = std::max(ntiles, c->cap_tiles);
+    if (dev_alloc(c->d_img, cp) || dev_alloc(c->dx, cp) || dev_alloc(c->dy, cp) || dev_alloc(c->dmask, cp + 16) ||
+        dev_alloc(c->cand, (size_t)ct * kCandPerTile) || dev_alloc(c->cand_count, ct) || dev_alloc(c->tile_max, ct) ||
+        dev_alloc(c->tile_pass, ct) || dev_alloc(c->tile_off, ct) || dev_alloc(c->keys_a, cp) ||
+        dev_alloc(c->keys_b, cp) || dev_alloc(c->seed_idx, cp) || dev_alloc(c->seed_bin, cp) ||
+        dev_alloc(c->seed_thr, cp) || dev_alloc(c->seed_size, cp) || dev_alloc(c->label, cp) ||
+        dev_alloc(c->queue, cp) || dev_alloc(c->comp_rank, cp) || dev_alloc(c->comp_seed, cp) ||
+        dev_alloc(c->comp_off, cp + 1) || dev_alloc(c->cursor, cp) || dev_alloc(c->px_a, cp) ||
+        dev_alloc(c->px_b, cp) || dev_alloc(c->scratch_w, cp) || dev_alloc(c->d_lines, cp / 6 + 16))
+        return 1;
+    const size_t tb = std::max(seeds_temp_bytes(ct, cp), fit_temp_bytes(cp, (uint32_t)std::min<size_t>(cp / 6 + 16, 0xFFFFFFFFu)));
+    if (c->temp) (void)hipFree(c->temp);
+    c->temp = nullptr;
+    LR_HIP(hipMalloc(&c->temp, tb));
+    c->temp_bytes = tb;
+    c->cap_pix = cp;
+    c->cap_tiles = ct;
+    return 0;
+}
+
+int ctx_ensure_ransac_capacity(lr_context* c, size_t n_lines, size_t n_iter) {
+    if (n_lines > c->cap_lines) {
+        LR_HIP(hipStreamSynchronize(c->stream));
+        const size_t cl = std::max<size_t>(n_lines, 4096);
+        if (dev_alloc(c->d_model, 8 * cl)) return 1;
+        if (c->h_model) (void)hipHostFree(c->h_model);
+        c->h_model = nullptr;
+        LR_HIP(hipHostMalloc((void**)&c->h_model, 8 * cl * sizeof(float)));
+        c->cap_lines = cl;
+    }
+    if (n_iter > c->cap_iter) {
+        LR_HIP(hipStreamSynchronize(c->stream));
+        const size_t ci = std::max<size_t>(n_iter, 16384);
+        if (dev_alloc(c->d_scores, ci)) return 1;
+        c->cap_iter = ci;
+    }
+    return 0;
+}
+
+int ctx_create(int device, lr_context** out) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device available: librectify_amd has no CPU fallback");
+        return 1;
+    }
+    if (device < 0 || device >= ndev) {
+        set_error("device index out of range");
+        return 1;
+    }
+    LR_HIP(hipSetDevice(device));
+    lr_context* c = new lr_context();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        set_error("hipStreamCreate failed");
+        return 1;
+    }
+    for (auto& e : c->ev) (void)hipEventCreate(&e);
+    (void)hipMalloc((void**)&c->maxmag, sizeof(float));
+    (void)hipMalloc((void**)&c->d_counts, 64 * sizeof(uint32_t));
+    (void)hipMalloc((void**)&c->d_best_score, sizeof(float));
+    (void)hipMalloc((void**)&c->d_best_iter, sizeof(int32_t));
+    (void)hipHostMalloc((void**)&c->h_counts, 64 * sizeof(uint32_t));
+    (void)hipHostMalloc((void**)&c->h_best, 2 * sizeof(float));
+    init_constants(c);
+    const char* env = std::getenv("LIBRECTIFY_SEED");
+    c->ransac_seed = env ? std::strtoull(env, nullptr, 0) : 0ull;
+    const char* fm = std::getenv("LIBRECTIFY_FLOOD_MODE");
+    c->flood_mode = fm ? std::atoi(fm) : 0;
+    *out = c;
+    return 0;
+}
+
+void ctx_destroy(lr_context* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    void* ptrs[] = {c->d_img, c->dx, c->dy, c->dmask, c->cand, c->cand_count, c->tile_max, c->tile_pass, c->tile_off,
+                    c->maxmag, c->keys_a, c->keys_b, c->d_counts, c->seed_idx, c->seed_bin, c->seed_thr, c->seed_size,
+                    c->label, c->queue, c->comp_rank, c->comp_seed, c->comp_off, c->cursor, c->px_a, c->px_b,
+                    c->scratch_w, c->d_lines, c->temp, c->d_model, c->d_scores, c->d_best_score, c->d_best_iter};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (c->h_model) (void)hipHostFree(c->h_model);
+    if (c->h_counts) (void)hipHostFree(c->h_counts);
+    if (c->h_best) (void)hipHostFree(c->h_best);
+    for (auto& e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// ---- stages ------------------------------------------------------------------------------
+
+int ctx_stage_filter(lr_context* c, const float* d_image, int w, int h, int stride) {
+    LR_HIP(hipSetDevice(c->device));
+    if (w < 5 || h < 5) {
+        set_error("image smaller than the 5x5 filter");
+        return 1;
+    }
+    if (ctx_ensure_image_capacity(c, w, h)) return 1;
+    c->w = w;
+    c->h = h;
+    c->n_seeds = c->n_comp = c->n_px = 0;
+    for (bool& v : c->stage_valid) v = false;
+    LR_HIP(hipEventRecord(c->ev[0], c->stream));
+    if (launch_filter(d_image, w, h, stride, c->fconsts, c->dx, c->dy, c->dmask, c->cand, c->cand_count, c->tile_max,
+                      c->stream))
+        return 1;
+    LR_HIP(hipEventRecord(c->ev[1], c->stream));
+    c->stage_valid[0] = true;
+    return 0;
+}
+
+int ctx_stage_seeds(lr_context* c) {
+    if (!c->stage_valid[0]) {
+        set_error("lr_stage_seeds: run lr_stage_filter first");
+        return 1;
+    }
+    const int ntiles = tiles_x(c->w) * tiles_y(c->h);
+    if (launch_seed_select(c->cand, c->cand_count, c->tile_max, ntiles, c->seed_keep_ratio, c->maxmag, c->tile_pass,
+                           c->tile_off, c->keys_a, c->d_counts, c->temp, c->temp_bytes, c->stream))
+        return 1;
+    LR_HIP(hipMemcpyAsync(c->h_counts, c->d_counts, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    LR_HIP(hipStreamSynchronize(c->stream));
+    c->n_seeds = c->h_counts[0];
+    if (launch_seed_sort(c->keys_a, c->keys_b, c->n_seeds, c->temp, c->temp_bytes, c->stream)) return 1;
+    if (launch_seed_setup(c->keys_b, c->n_seeds, c->dx, c->dy, c->trig, kTraceTolerance, c->seed_idx, c->seed_bin,
+                          c->seed_thr, c->stream))
+        return 1;
+    LR_HIP(hipEventRecord(c->ev[2], c->stream));
+    c->stage_valid[1] = true;
+    return 0;
+}
+
+int ctx_stage_flood(lr_context* c) {
+    if (!c->stage_valid[1]) {
+        set_error("lr_stage_flood: run lr_stage_seeds first");
+        return 1;
+    }
+    const size_t npix = (size_t)c->w * c->h;
+    if (launch_label_init(c->label, npix, c->stream)) return 1;
+    c->flood_rounds = 1;
+    if (launch_flood_ordered(c->dx, c->dy, c->dmask, c->w, c->h, c->seed_idx, c->seed_bin, c->seed_thr, c->n_seeds,
+                             c->trig, c->label, c->seed_size, c->queue, c->stream))
+        return 1;
+    LR_HIP(hipEventRecord(c->ev[3], c->stream));
+    c->stage_valid[2] = true;
+    return 0;
+}
+
+int ctx_stage_fit(lr_context* c, std::vector<LineSegment>& out) {
+    if (!c->stage_valid[2]) {
+        set_error("lr_stage_fit: run lr_stage_flood first");
+        return 1;
+    }
+    out.clear();
+    const size_t npix = (size_t)c->w * c->h;
+    c->n_comp = c->n_px = 0;
+    if (c->n_seeds > 0) {
+        if (launch_component_offsets(c->seed_size, c->n_seeds, kComponentMinSize, c->comp_rank, c->comp_seed,
+                                     c->comp_off, c->d_counts + 1, c->temp, c->temp_bytes, c->stream))
+            return 1;
+        LR_HIP(hipMemcpyAsync(c->h_counts + 1, c->d_counts + 1, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        LR_HIP(hipStreamSynchronize(c->stream));
+        c->n_comp = c->h_counts[1];
+        c->n_px = c->h_counts[2];
+    }
+    if (c->n_comp > 0) {
+        if ((size_t)c->n_comp > c->cap_pix / 6 + 16) {
+            set_error("component count exceeds workspace");
+            return 1;
+        }
+        LR_HIP(hipMemsetAsync(c->cursor, 0, (size_t)c->n_comp * sizeof(uint32_t), c->stream));
+        if (launch_component_scatter(c->label, npix, c->comp_rank, c->comp_off, c->cursor, c->px_a, c->stream)) return 1;
+        if (launch_component_sort(c->px_a, c->px_b, c->n_px, c->n_comp, c->comp_off, idx_bits_for(npix), c->temp,
+                                  c->temp_bytes, c->stream))
+            return 1;
+        if (launch_fit(c->px_b, c->comp_off, c->comp_seed, c->n_comp, c->seed_bin, c->dx, c->dy, c->w, c->trig,
+                       c->scratch_w, c->d_lines, c->stream))
+            return 1;
+        out.resize(c->n_comp);
+        LR_HIP(hipMemcpyAsync(out.data(), c->d_lines, (size_t)c->n_comp * sizeof(LineSegment), hipMemcpyDeviceToHost,
+                              c->stream));
+    }
+    LR_HIP(hipEventRecord(c->ev[4], c->stream));
+    LR_HIP(hipStreamSynchronize(c->stream));
+    c->stage_valid[3] = true;
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+    c->stage_ms[LR_T_FILTER] = ms;
+    c->stage_ms[LR_T_FILTER_KERNEL] = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]);
+    c->stage_ms[LR_T_SEEDS] = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[2], c->ev[3]);
+    c->stage_ms[LR_T_FLOOD] = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]);
+    c->stage_ms[LR_T_FIT] = ms;
+    return 0;
+}
+
+int ctx_detect(lr_context* c, const float* d_image, int w, int h, int stride, std::vector<LineSegment>& raw) {
+    if (ctx_stage_filter(c, d_image, w, h, stride)) return 1;
+    if (ctx_stage_seeds(c)) return 1;
+    if (ctx_stage_flood(c)) return 1;
+    return ctx_stage_fit(c, raw);
+}
+
+// ---- RANSAC ------------------------------------------------------------------------------
+
+int ctx_ransac_best(lr_context* c, const PencilModel& model, const std::vector<int>& indices, float tol, int n_iter,
+                    uint64_t seed, uint32_t round, Vec3* best_h, float* best_score, int* best_iter) {
+    LR_HIP(hipSetDevice(c->device));
+    const size_t n = indices.size();
+    *best_h = {0.f, 0.f, 0.f};  // the reference leaves best_h uninitialised when nothing scores (estimator.h:39)
+    *best_score = 0.f;
+    *best_iter = -1;
+    if (n < 2 || n_iter <= 0) return 0;
+    if (ctx_ensure_ransac_capacity(c, n, (size_t)n_iter)) return 1;
+    float* hm = c->h_model;
+    for (size_t j = 0; j < n; ++j) {
+        const int i = indices[j];
+        hm[0 * n + j] = model.anchor[i].x;
+        hm[1 * n + j] = model.anchor[i].y;
+        hm[2 * n + j] = model.direction[i].x;
+        hm[3 * n + j] = model.direction[i].y;
+        hm[4 * n + j] = model.length[i];
+        hm[5 * n + j] = model.h[i].x;
+        hm[6 * n + j] = model.h[i].y;
+        hm[7 * n + j] = model.h[i].z;
+    }
+    LR_HIP(hipMemcpyAsync(c->d_model, hm, 8 * n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    PencilSoA m{c->d_model + 0 * n, c->d_model + 1 * n, c->d_model + 2 * n, c->d_model + 3 * n,
+                c->d_model + 4 * n, c->d_model + 5 * n, c->d_model + 6 * n, c->d_model + 7 * n};
+    if (launch_ransac_score(m, (uint32_t)n, tol, model.degeneracy_tol, (uint32_t)n_iter, seed, round, c->d_scores,
+                            c->stream))
+        return 1;
+    if (launch_ransac_argmax(c->d_scores, (uint32_t)n_iter, c->d_best_score, c->d_best_iter, c->stream)) return 1;
+    LR_HIP(hipMemcpyAsync(&c->h_best[0], c->d_best_score, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    LR_HIP(hipMemcpyAsync(&c->h_best[1], c->d_best_iter, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    LR_HIP(hipStreamSynchronize(c->stream));
+    int32_t it;
+    std::memcpy(&it, &c->h_best[1], sizeof(it));
+    *best_score = c->h_best[0];
+    *best_iter = it;
+    if (it >= 0) {
+        uint32_t a, b;
+        sample_pair(seed, round, (uint32_t)it, (uint32_t)n, a, b);
+        *best_h = model.fit(indices[a], indices[b]);
+    }
+    return 0;
+}
+
+// estimate_multiple_structures (estimator.h:99-145) around the GPU scorer.
+int ctx_estimate_line_pencils(lr_context* c, std::vector<LineSegment>& lines, int max_models, float inlier_deg,
+                              float garbage_deg, int n_iter, uint64_t seed) {
+    if (lines.empty()) return 0;
+    const Normalisation nrm = bbox_normalisation(lines);
+    const PencilModel model(normalise(lines, nrm));
+    const float tol = cos_threshold(inlier_deg);
+    const float garbage_tol = cos_threshold(garbage_deg);
+    const int N = model.size();
+    std::vector<int> inlier_flag(N, -1), garbage_flag(N, 0);
+    int remaining = N;
+    int k = 0;
+    while (remaining >= 2 && k < max_models) {
+        std::vector<int> obs;
+        obs.reserve(remaining);
+        for (int i = 0; i < N; ++i)
+            if (inlier_flag[i] < 0 && garbage_flag[i] == 0) obs.push_back(i);
+        Vec3 best_h;
+        float best_score;
+        int best_iter;
+        if (ctx_ransac_best(c, model, obs, tol, n_iter, seed, (uint32_t)k, &best_h, &best_score, &best_iter)) return 1;
+        std::vector<int> inl;  // estimator.h:74-76: refit on the inliers of the best hypothesis
+        for (int i : obs)
+            if (model.error(best_h, i) < tol) inl.push_back(i);
+        const Vec3 hfit = model.fit_optimal(inl);
+        int n_in = 0, n_gb = 0;
+        for (int i : obs) {
+            const float e = model.error(hfit, i);
+            if (e < tol) {
+                inlier_flag[i] = k;
+                ++n_in;
+            } else if (e >= tol && e < garbage_tol) {
+                garbage_flag[i] = 1;
+                ++n_gb;
+            }
+        }
+        remaining -= n_in + n_gb;
+        ++k;
+    }
+    for (int i = 0; i < N; ++i) {
+        if (garbage_flag[i] == 1) inlier_flag[i] = -1;
+        lines[i].group_id = inlier_flag[i];
+    }
+    return 0;
+}
+
+// find_line_segment_groups (interface.cpp:35-80) on a device-resident image.
+int ctx_find_groups_device(lr_context* c, const float* d_image, int w, int h, int stride, float min_length, bool refine,
+                           std::vector<LineSegment>& out) {
+    out.clear();
+    std::vector<LineSegment> raw;
+    if (ctx_detect(c, d_image, w, h, stride, raw)) return 1;
+    if (raw.size() < 2) return 0;
+    if (refine) raw = refine_lines(raw);
+    std::vector<LineSegment> filtered = filter_lines(raw, min_length);
+    if (filtered.empty()) return 0;
+    LR_HIP(hipEventRecord(c->ev[5], c->stream));
+    if (ctx_estimate_line_pencils(c, filtered, kMaxModels, kInlierDeg, kGarbageDeg, c->ransac_iters, c->ransac_seed))
+        return 1;
+    LR_HIP(hipEventRecord(c->ev[6], c->stream));
+    LR_HIP(hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, c->ev[5], c->ev[6]);
+    c->stage_ms[LR_T_RANSAC] = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[6]);
+    c->stage_ms[LR_T_TOTAL] = ms;
+    out.swap(filtered);
+    return 0;
+}
+
+}  // namespace lramd

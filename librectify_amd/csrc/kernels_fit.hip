@@ -1,0 +1,269 @@
+// Stage 4 — components from the label image and the weighted-PCA line fit
+// (reference line_detector.cpp:66-89,111, geometry.cpp:20-61).
+//
+// Components are the floods with more than COMPONENT_MIN_SIZE pixels, in seed order.  Their
+// pixel lists are rebuilt from the label image (scatter by label, then a segmented radix sort
+// by pixel index), which puts every component in the canonical row-major order regardless of
+// how the flood discovered it.  One wavefront fits one component with the canonical
+// reduction tree T(): lane-strided sequential partial sums, then an xor butterfly.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.h"
+
+namespace lramd {
+namespace {
+
+constexpr uint32_t kNoComp = 0xFFFFFFFFu;
+
+// Single-workgroup scan over the seeds: rank and pixel offset of every kept flood.
+__global__ __launch_bounds__(1024) void component_offsets_kernel(const int32_t* __restrict__ seed_size,
+                                                                 uint32_t n_seeds, int min_size,
+                                                                 uint32_t* __restrict__ comp_rank,
+                                                                 uint32_t* __restrict__ comp_seed,
+                                                                 uint32_t* __restrict__ comp_off,
+                                                                 uint32_t* __restrict__ totals) {
+    __shared__ uint32_t s_cnt[16], s_px[16];
+    __shared__ uint32_t s_carry_cnt, s_carry_px;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) {
+        s_carry_cnt = 0;
+        s_carry_px = 0;
+    }
+    __syncthreads();
+    for (uint32_t base = 0; base < n_seeds; base += 1024) {
+        const uint32_t k = base + tid;
+        const int sz = (k < n_seeds) ? seed_size[k] : 0;
+        const bool keep = sz > min_size;
+        uint32_t c = keep ? 1u : 0u, p = keep ? (uint32_t)sz : 0u;
+        // inclusive scan inside the wave
+        uint32_t ic = c, ip = p;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t tc = (uint32_t)__shfl_up((int)ic, off);
+            const uint32_t tp = (uint32_t)__shfl_up((int)ip, off);
+            if (lane >= off) {
+                ic += tc;
+                ip += tp;
+            }
+        }
+        if (lane == 63) {
+            s_cnt[wv] = ic;
+            s_px[wv] = ip;
+        }
+        __syncthreads();
+        uint32_t wc = 0, wp = 0;
+        for (int i = 0; i < wv; ++i) {
+            wc += s_cnt[i];
+            wp += s_px[i];
+        }
+        const uint32_t carry_c = s_carry_cnt, carry_p = s_carry_px;
+        const uint32_t rank = carry_c + wc + ic - c;
+        const uint32_t off_px = carry_p + wp + ip - p;
+        if (k < n_seeds) {
+            comp_rank[k] = keep ? rank : kNoComp;
+            if (keep) {
+                comp_seed[rank] = k;
+                comp_off[rank] = off_px;
+            }
+        }
+        __syncthreads();
+        if (tid == 1023) {
+            s_carry_cnt = carry_c + wc + ic;
+            s_carry_px = carry_p + wp + ip;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        totals[0] = s_carry_cnt;
+        totals[1] = s_carry_px;
+        comp_off[s_carry_cnt] = s_carry_px;
+    }
+}
+
+__global__ __launch_bounds__(256) void component_scatter_kernel(const uint32_t* __restrict__ label, size_t npix,
+                                                                const uint32_t* __restrict__ comp_rank,
+                                                                const uint32_t* __restrict__ comp_off,
+                                                                uint32_t* __restrict__ cursor,
+                                                                uint32_t* __restrict__ px) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * 256;
+    for (; i < npix; i += step) {
+        const uint32_t l = label[i];
+        if (l != kLabelFree) {
+            const uint32_t r = comp_rank[l];
+            if (r != kNoComp) {
+                const uint32_t pos = comp_off[r] + atomicAdd(&cursor[r], 1u);
+                px[pos] = (uint32_t)i;
+            }
+        }
+    }
+}
+
+__device__ inline float wave_tree(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off);
+    return v;
+}
+
+// Closed-form symmetric 2x2 eigen-decomposition in double (sqrt and divide only): unit major
+// axis (row, col), sign chosen so that row-component >= col-component (the orientation the
+// reference's Eigen solver produces on all 848 rows of doc/image.jpg_warp_lines.csv).
+__device__ inline void major_axis_2x2(float a_, float b_, float c_, float& d_r, float& d_c) {
+    const double a = a_, b = b_, c = c_;
+    const double hd = (a - c) * 0.5;
+    const double rad = sqrt(hd * hd + b * b);
+    const double lmax = (a + c) * 0.5 + rad;
+    double vr, vc;
+    if (a >= c) {
+        vr = lmax - c;
+        vc = b;
+    } else {
+        vr = b;
+        vc = lmax - a;
+    }
+    const double nn = sqrt(vr * vr + vc * vc);
+    if (nn > 0.0) {
+        vr = vr / nn;
+        vc = vc / nn;
+    } else {
+        vr = 1.0;
+        vc = 0.0;
+    }
+    float fr = (float)vr, fc = (float)vc;
+    if (fr < fc || (fr == fc && fr < 0.0f)) {
+        fr = -fr;
+        fc = -fc;
+    }
+    d_r = fr;
+    d_c = fc;
+}
+
+// fit_line_parameters (geometry.cpp:20-61) for one component per wavefront.
+__global__ __launch_bounds__(256) void fit_kernel(const uint32_t* __restrict__ px, const uint32_t* __restrict__ comp_off,
+                                                  const uint32_t* __restrict__ comp_seed, uint32_t n_comp,
+                                                  const int32_t* __restrict__ seed_bin, const float* __restrict__ dx,
+                                                  const float* __restrict__ dy, int w, BinTrig trig,
+                                                  float* __restrict__ scratch_w, LineSegment* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t comp = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (comp >= n_comp) return;
+    const uint32_t off = comp_off[comp];
+    const uint32_t n = comp_off[comp + 1] - off;
+    const int b = seed_bin[comp_seed[comp]];
+    const float s = trig.st[b], c = trig.ct[b];
+    const uint32_t uw = (uint32_t)w;
+
+    float acc = 0.f;
+    for (uint32_t i = lane; i < n; i += 64) {
+        const uint32_t p = px[off + i];
+        const float wv = directional(dx[p], dy[p], s, c);
+        scratch_w[off + i] = wv;
+        acc = acc + wv;
+    }
+    const float S = wave_tree(acc);
+
+    float ar = 0.f, ac = 0.f;
+    for (uint32_t i = lane; i < n; i += 64) {
+        const uint32_t p = px[off + i];
+        const float r = (float)(p / uw), cc = (float)(p % uw);
+        const float wn = scratch_w[off + i] / S;
+        ar = ar + wn * r;
+        ac = ac + wn * cc;
+    }
+    const float a_r = wave_tree(ar), a_c = wave_tree(ac);
+
+    float crr = 0.f, crc = 0.f, ccc = 0.f;
+    for (uint32_t i = lane; i < n; i += 64) {
+        const uint32_t p = px[off + i];
+        const float cr = (float)(p / uw) - a_r, cc = (float)(p % uw) - a_c;
+        const float wn = scratch_w[off + i] / S;
+        const float t = cr * wn, u = cc * wn;
+        crr = crr + t * cr;
+        crc = crc + t * cc;
+        ccc = ccc + u * cc;
+    }
+    const float cov_rr = wave_tree(crr), cov_rc = wave_tree(crc), cov_cc = wave_tree(ccc);
+
+    float d_r, d_c;
+    major_axis_2x2(cov_rr, cov_rc, cov_cc, d_r, d_c);
+    const float n_r = -d_c, n_c = d_r;
+
+    float t0 = INFINITY, t1 = -INFINITY, es = 0.f;
+    for (uint32_t i = lane; i < n; i += 64) {
+        const uint32_t p = px[off + i];
+        const float cr = (float)(p / uw) - a_r, cc = (float)(p % uw) - a_c;
+        const float t = cr * d_r + cc * d_c;
+        t0 = fminf(t0, t);
+        t1 = fmaxf(t1, t);
+        es = es + fabsf(cr * n_r + cc * n_c);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        t0 = fminf(t0, __shfl_xor(t0, o));
+        t1 = fmaxf(t1, __shfl_xor(t1, o));
+    }
+    const float esum = wave_tree(es);
+    if (lane == 0) {
+        LineSegment l;
+        l.x1 = a_c + d_c * t0;
+        l.y1 = a_r + d_r * t0;
+        l.x2 = a_c + d_c * t1;
+        l.y2 = a_r + d_r * t1;
+        l.weight = S / (float)n;
+        l.err = esum / (float)n;
+        l.group_id = -1;
+        out[comp] = l;
+    }
+}
+
+}  // namespace
+
+size_t fit_temp_bytes(size_t max_pixels, uint32_t max_segments) {
+    size_t b = 0;
+    (void)rocprim::segmented_radix_sort_keys(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, max_pixels,
+                                             max_segments, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 32u);
+    return b + 256;
+}
+
+int launch_component_offsets(const int32_t* seed_size, uint32_t n_seeds, int min_size, uint32_t* comp_rank,
+                             uint32_t* comp_seed, uint32_t* comp_off, uint32_t* totals, void* temp, size_t temp_bytes,
+                             hipStream_t s) {
+    (void)temp;
+    (void)temp_bytes;
+    hipLaunchKernelGGL(component_offsets_kernel, dim3(1), dim3(1024), 0, s, seed_size, n_seeds, min_size, comp_rank,
+                       comp_seed, comp_off, totals);
+    LR_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_component_scatter(const uint32_t* label, size_t npix, const uint32_t* comp_rank, const uint32_t* comp_off,
+                             uint32_t* cursor, uint32_t* px, hipStream_t s) {
+    const size_t want = (npix + 255) / 256;
+    const int blocks = (int)(want < 8192 ? want : 8192);
+    hipLaunchKernelGGL(component_scatter_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, label, npix, comp_rank,
+                       comp_off, cursor, px);
+    LR_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_component_sort(uint32_t* px_in, uint32_t* px_out, uint32_t n_px, uint32_t n_comp, const uint32_t* comp_off,
+                          int idx_bits, void* temp, size_t temp_bytes, hipStream_t s) {
+    if (n_px == 0 || n_comp == 0) return 0;
+    LR_HIP(rocprim::segmented_radix_sort_keys(temp, temp_bytes, px_in, px_out, (size_t)n_px, n_comp, comp_off,
+                                              comp_off + 1, 0u, (unsigned)idx_bits, s));
+    return 0;
+}
+
+int launch_fit(const uint32_t* px_sorted, const uint32_t* comp_off, const uint32_t* comp_seed, uint32_t n_comp,
+               const int32_t* seed_bin, const float* dx, const float* dy, int w, BinTrig trig, float* scratch_w,
+               LineSegment* out, hipStream_t s) {
+    if (n_comp == 0) return 0;
+    hipLaunchKernelGGL(fit_kernel, dim3((n_comp + 3) / 4), dim3(256), 0, s, px_sorted, comp_off, comp_seed, n_comp,
+                       seed_bin, dx, dy, w, trig, scratch_w, out);
+    LR_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace lramd

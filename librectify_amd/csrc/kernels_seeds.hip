@@ -1,0 +1,138 @@
+// Stage 2 — seed selection and ordering.
+//
+// Reference: min_seed_value = mag.maxCoeff() * (1 - SEED_RATIO) (line_detector.cpp:209),
+// find_peaks keeps (max5x5 == mag) && (mag > min_seed_value) and sorts by value, descending
+// (filter.cpp:168-188).  The sort there is unstable; the canonical order of this build is
+// (value desc, row asc, col asc), i.e. ascending order of the 64-bit key
+//      ~bits(mag) : 32 | (row*w+col) : 29 | bin : 3
+// which one radix sort delivers.  The candidate lists come per filter tile, so no global
+// atomic counter is touched: per-tile pass counts, one exclusive scan, one ordered write.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.h"
+
+namespace lramd {
+namespace {
+
+__global__ __launch_bounds__(256) void reduce_max_kernel(const uint32_t* __restrict__ tile_max, int n_tiles,
+                                                         float* __restrict__ maxmag) {
+    __shared__ uint32_t s[4];
+    uint32_t m = 0;  // magnitudes are >= 0, so their bit patterns order like the floats
+    for (int i = threadIdx.x; i < n_tiles; i += 256) m = max(m, tile_max[i]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) *maxmag = __uint_as_float(max(max(s[0], s[1]), max(s[2], s[3])));
+}
+
+// one wave per tile
+__global__ __launch_bounds__(256) void seed_count_kernel(const uint64_t* __restrict__ cand,
+                                                         const uint32_t* __restrict__ cand_count, int n_tiles,
+                                                         const float* __restrict__ maxmag, float keep_ratio,
+                                                         uint32_t* __restrict__ tile_pass) {
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (tile >= n_tiles) return;
+    const float thr = *maxmag * keep_ratio;
+    const uint32_t n = cand_count[tile];
+    const uint64_t* c = cand + (size_t)tile * kCandPerTile;
+    uint32_t cnt = 0;
+    for (uint32_t i = lane; i < n; i += 64) cnt += (__uint_as_float((uint32_t)(c[i] >> 32)) > thr) ? 1u : 0u;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, off);
+    if (lane == 0) tile_pass[tile] = cnt;
+}
+
+__global__ __launch_bounds__(256) void seed_write_kernel(const uint64_t* __restrict__ cand,
+                                                         const uint32_t* __restrict__ cand_count, int n_tiles,
+                                                         const float* __restrict__ maxmag, float keep_ratio,
+                                                         const uint32_t* __restrict__ tile_pass,
+                                                         const uint32_t* __restrict__ tile_off,
+                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ n_seeds) {
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (tile >= n_tiles) return;
+    const float thr = *maxmag * keep_ratio;
+    const uint32_t n = cand_count[tile];
+    const uint64_t* c = cand + (size_t)tile * kCandPerTile;
+    uint32_t base = tile_off[tile];
+    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        uint64_t k = 0;
+        bool pass = false;
+        if (i < n) {
+            k = c[i];
+            pass = __uint_as_float((uint32_t)(k >> 32)) > thr;
+        }
+        const uint64_t m = __ballot(pass);
+        if (pass) {
+            const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
+            keys[base + rank] = ((uint64_t)(~(uint32_t)(k >> 32)) << 32) | (k & 0xFFFFFFFFull);
+        }
+        base += (uint32_t)__popcll(m);
+    }
+    if (tile == n_tiles - 1 && lane == 0) *n_seeds = tile_off[tile] + tile_pass[tile];
+}
+
+__global__ __launch_bounds__(256) void seed_setup_kernel(const uint64_t* __restrict__ keys, uint32_t n,
+                                                         const float* __restrict__ dx, const float* __restrict__ dy,
+                                                         BinTrig trig, float trace_tolerance,
+                                                         int32_t* __restrict__ seed_idx, int32_t* __restrict__ seed_bin,
+                                                         float* __restrict__ seed_thr) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t lo = (uint32_t)keys[k];
+    const uint32_t idx = lo >> 3;
+    const int b = (int)(lo & 7u);
+    // flood(): min_val = (1 - tolerance) * image(seed) with image = grad[seed_bin] (filter.cpp:112-113)
+    const float v = directional(dx[idx], dy[idx], trig.st[b], trig.ct[b]);
+    seed_idx[k] = (int32_t)idx;
+    seed_bin[k] = b;
+    seed_thr[k] = (1 - trace_tolerance) * v;
+}
+
+}  // namespace
+
+size_t seeds_temp_bytes(int n_tiles, size_t max_seeds) {
+    size_t a = 0, b = 0;
+    (void)rocprim::exclusive_scan(nullptr, a, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)n_tiles,
+                                  rocprim::plus<uint32_t>());
+    (void)rocprim::radix_sort_keys(nullptr, b, (uint64_t*)nullptr, (uint64_t*)nullptr, max_seeds, 0u, 64u);
+    return (a > b ? a : b) + 256;
+}
+
+int launch_seed_select(const uint64_t* cand, const uint32_t* cand_count, const uint32_t* tile_max, int n_tiles,
+                       float seed_keep_ratio, float* maxmag, uint32_t* tile_pass, uint32_t* tile_off, uint64_t* keys,
+                       uint32_t* n_seeds, void* temp, size_t temp_bytes, hipStream_t s) {
+    hipLaunchKernelGGL(reduce_max_kernel, dim3(1), dim3(256), 0, s, tile_max, n_tiles, maxmag);
+    const int blocks = (n_tiles + 3) / 4;
+    hipLaunchKernelGGL(seed_count_kernel, dim3(blocks), dim3(256), 0, s, cand, cand_count, n_tiles, maxmag,
+                       seed_keep_ratio, tile_pass);
+    LR_HIP(rocprim::exclusive_scan(temp, temp_bytes, tile_pass, tile_off, 0u, (size_t)n_tiles,
+                                   rocprim::plus<uint32_t>(), s));
+    hipLaunchKernelGGL(seed_write_kernel, dim3(blocks), dim3(256), 0, s, cand, cand_count, n_tiles, maxmag,
+                       seed_keep_ratio, tile_pass, tile_off, keys, n_seeds);
+    LR_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_seed_sort(uint64_t* keys_in, uint64_t* keys_out, uint32_t n, void* temp, size_t temp_bytes,
+                     hipStream_t s) {
+    if (n == 0) return 0;
+    LR_HIP(rocprim::radix_sort_keys(temp, temp_bytes, keys_in, keys_out, (size_t)n, 0u, 64u, s));
+    return 0;
+}
+
+int launch_seed_setup(const uint64_t* keys_sorted, uint32_t n, const float* dx, const float* dy, BinTrig trig,
+                      float trace_tolerance, int32_t* seed_idx, int32_t* seed_bin, float* seed_thr, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(seed_setup_kernel, dim3((n + 255) / 256), dim3(256), 0, s, keys_sorted, n, dx, dy, trig,
+                       trace_tolerance, seed_idx, seed_bin, seed_thr);
+    LR_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace lramd

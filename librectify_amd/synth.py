@@ -1,0 +1,95 @@
+"""Seeded synthetic frames for tests and bench.py (SURVEY.md §8d "Synthetic inputs").
+
+frame(W, H, seed): float32 in ~[0,1]: background 0.5 plus K straight bars drawn from three
+pencils (two finite vanishing points outside the frame and one near-vertical), edge contrast
+U(0.1, 0.5), blurred by sigma = 1, plus N(0, 0.005) noise so that magnitude ties have measure
+zero.  Pure numpy; deterministic for a given (W, H, seed, K).
+"""
+import numpy as np
+
+
+def _gauss_blur(img, sigma=1.0):
+    r = int(3 * sigma + 0.5)
+    x = np.arange(-r, r + 1, dtype=np.float64)
+    k = np.exp(-(x * x) / (2 * sigma * sigma))
+    k /= k.sum()
+    pad = np.pad(img, ((0, 0), (r, r)), mode="edge")
+    tmp = np.zeros_like(img)
+    for i, kv in enumerate(k):
+        tmp += kv * pad[:, i : i + img.shape[1]]
+    pad = np.pad(tmp, ((r, r), (0, 0)), mode="edge")
+    out = np.zeros_like(img)
+    for i, kv in enumerate(k):
+        out += kv * pad[i : i + img.shape[0], :]
+    return out
+
+
+def default_bars(W, H):
+    return max(12, int(round(320 * (W * H / (3840.0 * 2160.0)) ** 0.5)))
+
+
+def frame(W, H, seed, bars=None, noise=0.005, tile=None):
+    """tile: if given (e.g. 512), bars are confined to tile x tile blocks ("aerial style")."""
+    rng = np.random.RandomState(seed)
+    K = default_bars(W, H) if bars is None else bars
+    img = np.full((H, W), 0.5, np.float64)
+    diag = float(np.hypot(W, H))
+    vps = [
+        np.array([W / 2 + rng.uniform(1.2, 2.5) * diag, H / 2 + rng.uniform(-0.3, 0.3) * diag]),
+        np.array([W / 2 - rng.uniform(1.2, 2.5) * diag, H / 2 + rng.uniform(-0.3, 0.3) * diag]),
+        np.array([W / 2 + rng.uniform(-0.2, 0.2) * diag, H / 2 - rng.uniform(3.0, 6.0) * diag]),
+    ]
+    for _ in range(K):
+        vp = vps[rng.randint(0, 3)]
+        if tile:
+            tx = rng.randint(0, max(1, W // tile)) * tile
+            ty = rng.randint(0, max(1, H // tile)) * tile
+            c = np.array([tx + rng.uniform(0.1, 0.9) * min(tile, W - tx), ty + rng.uniform(0.1, 0.9) * min(tile, H - ty)])
+            length = rng.uniform(0.15, 0.6) * tile
+        else:
+            c = np.array([rng.uniform(0.05, 0.95) * W, rng.uniform(0.05, 0.95) * H])
+            length = rng.uniform(0.03, 0.22) * max(W, H)
+        d = vp - c
+        d /= np.linalg.norm(d)
+        nrm = np.array([-d[1], d[0]])
+        half_w = rng.uniform(2.0, 0.004 * max(W, H) + 4.0)
+        contrast = rng.uniform(0.1, 0.5) * (1 if rng.rand() < 0.5 else -1)
+        ext = length / 2 + half_w + 2
+        x0, x1 = int(max(0, c[0] - ext)), int(min(W, c[0] + ext + 1))
+        y0, y1 = int(max(0, c[1] - ext)), int(min(H, c[1] + ext + 1))
+        if x1 <= x0 or y1 <= y0:
+            continue
+        yy, xx = np.mgrid[y0:y1, x0:x1]
+        px, py = xx - c[0], yy - c[1]
+        along = px * d[0] + py * d[1]
+        across = px * nrm[0] + py * nrm[1]
+        m = (np.abs(along) <= length / 2) & (np.abs(across) <= half_w)
+        img[y0:y1, x0:x1][m] += contrast
+    img = np.clip(img, 0.0, 1.0)
+    img = _gauss_blur(img, 1.0)
+    if noise > 0:
+        img = img + rng.normal(0.0, noise, size=img.shape)
+    return img.astype(np.float32)
+
+
+def random_segments(n, seed, frac_on_pencils=0.6, size=1000.0):
+    """Synthetic LineSegment rows for the RANSAC micro-benchmark: 60 % on 3 pencils, 40 % uniform."""
+    rng = np.random.RandomState(seed)
+    from . import LINE_DTYPE
+
+    out = np.zeros(n, LINE_DTYPE)
+    vps = [np.array([3.1 * size, 0.4 * size]), np.array([-2.2 * size, 0.7 * size]), np.array([0.45 * size, -5.0 * size])]
+    for i in range(n):
+        c = rng.uniform(0.05, 0.95, 2) * size
+        L = rng.uniform(0.02, 0.15) * size
+        if rng.rand() < frac_on_pencils:
+            d = vps[rng.randint(0, 3)] - c
+            d /= np.linalg.norm(d)
+            ang = rng.normal(0, 0.004)
+            d = np.array([d[0] * np.cos(ang) - d[1] * np.sin(ang), d[0] * np.sin(ang) + d[1] * np.cos(ang)])
+        else:
+            a = rng.uniform(0, np.pi)
+            d = np.array([np.cos(a), np.sin(a)])
+        p1, p2 = c - d * L / 2, c + d * L / 2
+        out[i] = (p1[0], p1[1], p2[0], p2[1], rng.uniform(0.05, 0.5), rng.uniform(0.1, 0.8), -1)
+    return out

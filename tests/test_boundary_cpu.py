@@ -1,0 +1,113 @@
+"""CPU-only checks of the C-ABI boundary: the library loads, exports every symbol the headers
+declare, fails loudly without a GPU, and its host-side functions agree with the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def L():
+    import librectify_amd as L
+    from librectify_amd import build
+
+    build.build(verbose=False)
+    L.lib()
+    return L
+
+
+def _declared_functions():
+    names = []
+    for hdr in ("librectify.h", "librectify_amd.h"):
+        txt = open(os.path.join(ROOT, "include", hdr)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        for m in re.finditer(r"^[A-Za-z_][\w\s\*]*?\b(\w+)\s*\([^;{]*\)\s*;", txt, flags=re.M):
+            names.append(m.group(1))
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol(L):
+    names = _declared_functions()
+    assert "find_line_segment_groups" in names and "lr_stage_filter" in names and len(names) >= 25
+    lib = C.CDLL(L.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), n
+    for n in L.EXPORTS:
+        assert n in names, n
+
+
+def test_struct_layout_matches_reference(L):
+    assert L.LINE_DTYPE.itemsize == 28  # librectify.h:44-54
+    assert C.sizeof(L.Point) == 12
+    assert C.sizeof(L.ImageTransform) == 80
+    assert C.sizeof(L.RectificationConfig) == 20
+
+
+def test_no_gpu_means_loud_failure(L):
+    if L.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(L.LibrectifyError):
+        L.Context(0)
+    img = np.zeros((32, 32), np.float32)
+    with pytest.raises(L.LibrectifyError):  # NULL + message, never a silent CPU path
+        L.find_line_segment_groups(img, 5.0)
+
+
+def _golden_lines(L):
+    rows = np.loadtxt(os.path.join(G, "doc_warp_lines.csv"), delimiter=",")
+    return O.lines_from_rows(rows)
+
+
+def test_transform_kat_through_c_abi(L):
+    lines = _golden_lines(L)
+    cfg = L.RectificationConfig(40.0, 1.5, L.RECTIFY, 2.0, L.ROTATE_V)
+    T = L.compute_rectification_transform(lines, 1000, 563, cfg).as_array()
+    exp = [[float(x) for x in l.strip().split(",")] for l in open(os.path.join(G, "doc_warp_tform.csv"))]
+    for k in range(4):
+        np.testing.assert_allclose(T[k, :2], exp[k], rtol=2e-5, atol=2e-4)
+    np.testing.assert_allclose(T[4], exp[4], rtol=2e-5, atol=2e-4)
+    np.testing.assert_allclose(T[5], exp[5], rtol=2e-5, atol=2e-4)
+    # and bit-for-bit against the oracle, every strategy combination
+    for hs in range(4):
+        for vs in range(4):
+            cfg = L.RectificationConfig(40.0, 1.5, vs, 2.0, hs)
+            a = L.compute_rectification_transform(lines, 1000, 563, cfg).as_array()
+            b = O.transform_to_array(O.compute_rectification_transform(lines, 1000, 563, O.RectificationConfig(40.0, 1.5, vs, 2.0, hs)))
+            np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_host_functions_match_oracle(L):
+    lines = _golden_lines(L)
+    for g in (-1, 0, 1, 2, 3):
+        np.testing.assert_array_equal(L.fit_vanishing_point(lines, g), O.fit_vanishing_point(lines, g))
+    probe = lines[:50].copy()
+    probe["group_id"] = -1
+    a = L.assign_to_group(lines, probe, 3.0)
+    b = O.assign_to_group(lines, probe, 3.0)
+    np.testing.assert_array_equal(a["group_id"], b["group_id"])
+    T1 = L.compute_rectification_transform_from_vp(1000, 563, (2392.84, -54.25, 0.0), (445.75, -2111.3, 1.0)).as_array()
+    T2 = O.transform_to_array(O.compute_rectification_transform_from_vp(1000, 563, (2392.84, -54.25, 0.0), (445.75, -2111.3, 1.0)))
+    np.testing.assert_array_equal(T1, T2)
+
+
+def test_analytic_kats_through_c_abi(L):
+    rows = np.array([[0, 0, 10, 0, 1, 0, 10], [10, 0, 8, 5, 1, 0, 1], [8, 5, 2, 5, 1, 0, 10], [2, 5, 0, 0, 1, 0, 1]], np.float64)
+    ls = O.lines_from_rows(rows)
+    np.testing.assert_allclose(L.fit_vanishing_point(ls, 1), [5.0, 12.5, 1.0], rtol=1e-4)
+    vp2 = L.fit_vanishing_point(ls, 10)
+    assert vp2[2] == 0.0 and abs(abs(vp2[0]) / np.linalg.norm(vp2[:2]) - 1) < 1e-4
+    np.testing.assert_array_equal(L.fit_vanishing_point(ls, -1), L.fit_vanishing_point(ls, 0))
+    probe = O.lines_from_rows(np.array([[5, 1, 5, 4, 1, 0, -1]], np.float64))
+    assert L.assign_to_group(ls, probe, 10.0)["group_id"][0] == 1
+
+
+def test_empty_input_transform_is_identity(L):
+    T = L.compute_rectification_transform(np.zeros(0, L.LINE_DTYPE), 640, 480).as_array()
+    np.testing.assert_allclose(T[:4, :2], [[0, 0], [640, 0], [0, 480], [640, 480]], atol=1e-4)

@@ -1,0 +1,255 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the committed
+golden vectors.  Bars: bit-exact for dx/dy, masks, seeds, labels, segment records and group ids;
+1e-4 (relative, on homogeneous coordinates scaled to unit norm) for vanishing points."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def L():
+    import librectify_amd as L
+
+    L.lib()
+    assert L.device_count() > 0, "GPU tests need a GPU"
+    return L
+
+
+@pytest.fixture(scope="module")
+def ctx(L):
+    c = L.Context(0)
+    yield c
+    c.close()
+
+
+def _frames():
+    from librectify_amd import synth
+
+    return {
+        "96x64": synth.frame(96, 64, 11, bars=10),
+        "257x131": synth.frame(257, 131, 12, bars=14),  # width not a multiple of 4
+        "320x240": synth.frame(320, 240, 13, bars=24),
+        "67x45": synth.frame(67, 45, 14, bars=6),  # ragged, smaller than 2 tiles
+        "640x480": synth.frame(640, 480, 5),
+        "noiseless": synth.frame(200, 150, 21, bars=12, noise=0.0),  # exact zeros and magnitude ties
+    }
+
+
+FRAMES = _frames()
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _assert_lines_equal(a, b):
+    assert len(a) == len(b), (len(a), len(b))
+    if len(a):
+        av = np.frombuffer(np.ascontiguousarray(a).tobytes(), np.uint32).reshape(len(a), 7)
+        bv = np.frombuffer(np.ascontiguousarray(b).tobytes(), np.uint32).reshape(len(b), 7)
+        bad = np.nonzero((av != bv).any(axis=1))[0]
+        assert len(bad) == 0, "first mismatch at %d: %s vs %s" % (bad[0], a[bad[0]], b[bad[0]])
+
+
+@pytest.mark.parametrize("name", list(FRAMES))
+def test_filter_stage_bit_exact(L, ctx, name):
+    img = FRAMES[name]
+    ref = O.filter_stage(img)
+    ctx.stage_filter_host(img)
+    dx = ctx.download(L.BUF_DX)
+    dy = ctx.download(L.BUF_DY)
+    dm = ctx.download(L.BUF_DMASK)
+    assert (_bits(dx) != _bits(ref["dx"])).sum() == 0
+    assert (_bits(dy) != _bits(ref["dy"])).sum() == 0
+    np.testing.assert_array_equal(dm, ref["dmask"])
+
+
+@pytest.mark.parametrize("name", list(FRAMES))
+def test_seeds_match(L, ctx, name):
+    img = FRAMES[name]
+    h, w = img.shape
+    ref = O.filter_stage(img, planes=True)
+    seeds = O.find_seeds(ref["mag"], ref["bin"])
+    ctx.stage_filter_host(img)
+    n = ctx.stage_seeds()
+    assert n == len(seeds["rows"])
+    assert ctx.download(L.BUF_MAXMAG)[0] == ref["mag"].max()
+    idx = ctx.download(L.BUF_SEED_IDX)
+    np.testing.assert_array_equal(idx, seeds["rows"] * w + seeds["cols"])
+    np.testing.assert_array_equal(ctx.download(L.BUF_SEED_BIN), seeds["bins"])
+    thr = np.float32(0.75) * ref["planes"][seeds["bins"], seeds["rows"], seeds["cols"]]
+    assert (_bits(ctx.download(L.BUF_SEED_THR)) != _bits(thr.astype(np.float32))).sum() == 0
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("name", list(FRAMES))
+def test_flood_labels_and_segments_bit_exact(L, ctx, name, mode):
+    img = FRAMES[name]
+    ref = O.find_line_segments(img)
+    ctx.set_flood_mode(mode)
+    ctx.stage_filter_host(img)
+    ctx.stage_seeds()
+    ctx.stage_flood()
+    lab = ctx.download(L.BUF_LABEL)
+    bad = np.argwhere(lab != ref["label"])
+    assert len(bad) == 0, "%d label mismatches, first at %s: gpu %d oracle %d" % (
+        len(bad), bad[0], lab[tuple(bad[0])], ref["label"][tuple(bad[0])])
+    lines = ctx.stage_fit()
+    _assert_lines_equal(lines, ref["lines"])
+    ctx.set_flood_mode(0)
+
+
+def _unit(v):
+    v = np.asarray(v, np.float64)
+    return v / np.linalg.norm(v)
+
+
+@pytest.mark.parametrize("name", ["96x64", "257x131", "320x240", "640x480"])
+def test_full_path_matches_oracle(L, ctx, name):
+    img = FRAMES[name]
+    h, w = img.shape
+    ml = float(max(w, h)) / 100.0
+    ref, _ = O.find_line_segment_groups(img, ml, seed=0)
+    ctx.set_seed(0)
+    got = ctx.find_line_segment_groups(img, ml)
+    _assert_lines_equal(got, ref)  # endpoints, weight, err and group ids
+    Tg = L.compute_rectification_transform(got, w, h).as_array()
+    Tr = O.transform_to_array(O.compute_rectification_transform(ref, w, h))
+    for k in (4, 5):
+        assert np.abs(_unit(Tg[k]) - _unit(Tr[k])).max() < 1e-4
+    np.testing.assert_allclose(Tg[:4], Tr[:4], rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("case", ["synth_96x64_s11", "synth_257x131_s12", "synth_320x240_s13"])
+def test_against_committed_golden(L, ctx, case):
+    z = np.load(os.path.join(G, case + ".npz"))
+    img = z["image"]
+    h, w = img.shape
+    ctx.stage_filter_host(img)
+    if "dx" in z:
+        assert (_bits(ctx.download(L.BUF_DX)) != _bits(z["dx"])).sum() == 0
+        assert (_bits(ctx.download(L.BUF_DY)) != _bits(z["dy"])).sum() == 0
+    np.testing.assert_array_equal(ctx.download(L.BUF_DMASK), z["dmask"])
+    assert ctx.stage_seeds() == len(z["seed_idx"])
+    np.testing.assert_array_equal(ctx.download(L.BUF_SEED_IDX), z["seed_idx"])
+    ctx.stage_flood()
+    np.testing.assert_array_equal(ctx.download(L.BUF_LABEL), z["label"])
+    _assert_lines_equal(ctx.stage_fit(), z["raw_lines"].view(L.LINE_DTYPE).reshape(-1))
+    ctx.set_seed(0)
+    got = ctx.find_line_segment_groups(img, float(max(w, h)) / 100.0)
+    _assert_lines_equal(got, z["grouped_lines"].view(L.LINE_DTYPE).reshape(-1))
+    T = L.compute_rectification_transform(got, w, h).as_array()
+    for k in (4, 5):
+        assert np.abs(_unit(T[k]) - _unit(z["transform"][k])).max() < 1e-4
+
+
+def test_doc_image_detector_kat_on_gpu(L, ctx):
+    """doc/image.jpg through the HIP detector, compared with the oracle bit for bit (the oracle
+    itself is pinned to the reference's golden rows in test_oracle_pins.py)."""
+    gray = np.load(os.path.join(G, "doc_image_gray.npy"))
+    img = gray.astype(np.float32) / np.float32(256.0)
+    ref = O.find_line_segments(img)
+    ctx.stage_filter_host(img)
+    assert ctx.stage_seeds() == ref["n_seeds"] == 6649
+    ctx.stage_flood()
+    np.testing.assert_array_equal(ctx.download(L.BUF_LABEL), ref["label"])
+    lines = ctx.stage_fit()
+    _assert_lines_equal(lines, ref["lines"])
+    assert len(lines) == 1927
+
+
+def test_ransac_scoring_matches_oracle(L, ctx):
+    from librectify_amd import synth
+
+    for n, n_iter, seed in [(50, 500, 1), (333, 2000, 42), (1000, 10000, 7)]:
+        segs = synth.random_segments(n, seed)
+        norm, _, _ = O.normalize_lines(segs)
+        idx = np.arange(n, dtype=np.int32)[:: 1 if n < 100 else 2]  # a strict subset as in later peeling rounds
+        tol = O.cos_threshold(2.0)
+        ref = O.ransac_best(norm, idx, tol, n_iter, seed, rnd=1)
+        got = ctx.ransac_best(norm, idx, tol, n_iter, seed, rnd=1)
+        assert got["iter"] == ref["iter"]
+        assert np.float32(got["score"]) == np.float32(ref["score"])
+        np.testing.assert_array_equal(got["best_h"], ref["best_h"])
+        a, _ = O.estimate_line_pencils(segs, n_iter=n_iter, seed=seed)
+        b = ctx.estimate_line_pencils(segs, n_iter=n_iter, seed=seed)
+        np.testing.assert_array_equal(a["group_id"], b["group_id"])
+
+
+def test_reference_error_convention_and_strides(L, ctx):
+    flat = np.full((64, 80), 0.25, np.float32)
+    assert len(L.find_line_segment_groups(flat, 5.0)) == 0  # NULL, *n_lines = 0 (interface.cpp:50-54)
+    img = FRAMES["257x131"]
+    h, w = img.shape
+    ml = float(max(w, h)) / 100.0
+    base = L.find_line_segment_groups(img, ml)
+    assert len(base) > 0
+    padded = np.zeros((h, w + 13), np.float32)
+    padded[:, :w] = img
+    _assert_lines_equal(L.find_line_segment_groups(padded[:, :w], ml), base)  # stride > width
+    # negative stride addresses the same rows from the other end (image.cpp:14-18): no flip
+    import ctypes as C
+
+    n = C.c_int(0)
+    buf = np.ascontiguousarray(img)
+    last_row = buf.ctypes.data + (h - 1) * w * 4
+    p = L.lib().find_line_segment_groups(C.c_void_p(last_row), w, h, -w, ml, False, -1, C.byref(n))
+    assert p and n.value == len(base)
+    got = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_ubyte)), shape=(n.value * 28,)).view(L.LINE_DTYPE).copy()
+    pp = C.c_void_p(p)
+    L.lib().release_line_segments(C.byref(pp))
+    _assert_lines_equal(got, base)
+
+
+def test_refine_flag_matches_oracle(L, ctx):
+    img = FRAMES["320x240"]
+    ml = 3.2
+    ref, _ = O.find_line_segment_groups(img, ml, refine=True, seed=0)
+    ctx.set_seed(0)
+    got = ctx.find_line_segment_groups(img, ml, refine=True)
+    _assert_lines_equal(got, ref)
+
+
+def test_size_independent_properties_at_full_size(L, ctx):
+    """3840x2160 (BASELINE configs[1..2]): properties that need no oracle run."""
+    from librectify_amd import synth
+
+    img = synth.frame(3840, 2160, 1)
+    h, w = img.shape
+    ctx.stage_filter_host(img)
+    n_seeds = ctx.stage_seeds()
+    idx = ctx.download(L.BUF_SEED_IDX)
+    thr = ctx.download(L.BUF_SEED_THR)
+    dx, dy = ctx.download(L.BUF_DX), ctx.download(L.BUF_DY)
+    mag = np.sqrt(dx * dx + dy * dy)
+    assert (dx[:2] == 0).all() and (dx[-2:] == 0).all() and (dx[:, :2] == 0).all() and (dx[:, -2:] == 0).all()
+    sm = mag.reshape(-1)[idx]
+    assert (np.diff(sm) <= 0).all()  # sortedness
+    assert len(np.unique(idx)) == n_seeds
+    assert (sm > mag.max() * np.float32(1 - np.float32(0.95))).all()
+    ctx.stage_flood()
+    lab = ctx.download(L.BUF_LABEL)
+    sizes = ctx.download(L.BUF_SEED_SIZE)
+    counts = np.bincount(lab[lab >= 0], minlength=n_seeds)
+    np.testing.assert_array_equal(counts, sizes)  # checksum of the label image against per-seed sizes
+    started = sizes > 0
+    assert (lab.reshape(-1)[idx[started]] == np.nonzero(started)[0]).all()  # a started seed owns its own pixel
+    assert (lab.reshape(-1)[idx[~started]] >= 0).all()  # a skipped seed was claimed by an earlier one
+    assert (lab.reshape(-1)[idx[~started]] < np.nonzero(~started)[0]).all()
+    assert (lab[0] == -1).all() and (lab[-1] == -1).all() and (lab[:, 0] == -1).all() and (lab[:, -1] == -1).all()
+    lines = ctx.stage_fit()
+    assert len(lines) == (sizes > 5).sum()
+    assert np.isfinite(np.stack([lines[k] for k in ("x1", "y1", "x2", "y2", "weight", "err")])).all()
+    # idempotence: the same frame again gives the same records
+    ctx.stage_filter_host(img)
+    ctx.stage_seeds()
+    ctx.stage_flood()
+    _assert_lines_equal(ctx.stage_fit(), lines)
