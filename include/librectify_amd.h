@@ -43,7 +43,9 @@ int lr_synchronize(lr_context* ctx);
 void lr_set_ransac_seed(lr_context* ctx, uint64_t seed);
 /* RANSAC iterations per model (reference config.h:36 RANSAC_MAX_ITER = 10000). */
 void lr_set_ransac_iterations(lr_context* ctx, int n_iter);
-/* Flood implementation: 0 = ordered single-wave (simple, slow), 1 = parallel rounds (default). */
+/* Flood implementation: 0 = ordered single-wave (simple, slow), 1 = parallel rounds (default);
+ * 2 / 3 = parallel rounds with no / two overflow slabs (test hooks for the exhausted-storage paths).
+ * All modes give identical results. */
 void lr_set_flood_mode(lr_context* ctx, int mode);
 int lr_device_count(void);
 

@@ -103,6 +103,29 @@ int launch_flood_ordered(const float* dx, const float* dy, const uint8_t* dmask,
                          const int32_t* seed_bin, const float* seed_thr, uint32_t n_seeds, BinTrig trig,
                          uint32_t* label, int32_t* seed_size, int32_t* queue, hipStream_t s);
 
+// parallel-round flood (mode 1): per-seed round state, active lists and overflow slabs
+struct FloodBuffers {
+    uint32_t* blocked = nullptr;
+    uint32_t* count = nullptr;
+    uint32_t* flags = nullptr;
+    uint8_t* state = nullptr;
+    uint8_t* alive = nullptr;
+    uint32_t* act_a = nullptr;
+    uint32_t* act_b = nullptr;
+    uint32_t* ctrl = nullptr;       // 16 words
+    uint32_t* slab_ring = nullptr;  // n_slabs x slab_ring_cap
+    uint64_t* slab_hash = nullptr;  // n_slabs x slab_hash_cap
+    uint32_t n_slabs = 0, slab_ring_cap = 0, slab_hash_cap = 0;
+    void* select_temp = nullptr;
+    size_t select_temp_bytes = 0;
+};
+size_t flood_select_temp_bytes(uint32_t max_seeds);
+// Runs all rounds (synchronises the stream once per round).  h_ctrl: >= 16 words of pinned host memory.
+int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, const uint8_t* dmask, int w, int h,
+                   const int32_t* seed_idx, const int32_t* seed_bin, const float* seed_thr, uint32_t n_seeds,
+                   BinTrig trig, uint32_t* label, int32_t* seed_size, int32_t* queue, uint32_t* h_ctrl, int* rounds_out,
+                   hipStream_t s);
+
 // kernels_fit.hip
 size_t fit_temp_bytes(size_t max_pixels, uint32_t max_segments);
 int launch_component_offsets(const int32_t* seed_size, uint32_t n_seeds, int min_size, uint32_t* comp_rank,

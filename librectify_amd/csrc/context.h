@@ -36,6 +36,8 @@ struct lr_context {
     // stage 3
     uint32_t* label = nullptr;
     int32_t* queue = nullptr;
+    lramd::FloodBuffers fb;
+    size_t fb_cap_seeds = 0;
     // stage 4
     uint32_t* comp_rank = nullptr;
     uint32_t* comp_seed = nullptr;
@@ -69,7 +71,7 @@ struct lr_context {
     int flood_rounds = 0;
     uint64_t ransac_seed = 0;
     int ransac_iters = lramd::kRansacMaxIter;
-    int flood_mode = 0;
+    int flood_mode = 1;
     hipEvent_t ev[16] = {};
     float stage_ms[LR_T_COUNT] = {};
     bool stage_valid[4] = {false, false, false, false};

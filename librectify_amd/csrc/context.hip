@@ -91,6 +91,31 @@ int ctx_ensure_image_capacity(lr_context* c, int w, int h) {
     return 0;
 }
 
+static int ensure_flood_buffers(lr_context* c) {
+    FloodBuffers& f = c->fb;
+    if (c->fb_cap_seeds >= c->cap_pix && f.slab_ring) return 0;
+    LR_HIP(hipStreamSynchronize(c->stream));
+    const size_t cs = c->cap_pix;
+    if (dev_alloc(f.blocked, cs) || dev_alloc(f.count, cs) || dev_alloc(f.flags, cs) || dev_alloc(f.state, cs) ||
+        dev_alloc(f.alive, cs) || dev_alloc(f.act_a, cs) || dev_alloc(f.act_b, cs) || dev_alloc(f.ctrl, 16))
+        return 1;
+    f.n_slabs = 2048;  // 2048 x 576 KB = 1.2 GB of the 288 GB: enough for every weak seed of a 4K frame that must walk a long edge
+    if (const char* e = std::getenv("LIBRECTIFY_FLOOD_SLABS")) f.n_slabs = (uint32_t)std::max(1, std::atoi(e));
+    f.slab_ring_cap = 1u << 14;
+    f.slab_hash_cap = 1u << 16;
+    if (dev_alloc(f.slab_ring, (size_t)f.n_slabs * f.slab_ring_cap) ||
+        dev_alloc(f.slab_hash, (size_t)f.n_slabs * f.slab_hash_cap))
+        return 1;
+    LR_HIP(hipMemsetAsync(f.slab_hash, 0, (size_t)f.n_slabs * f.slab_hash_cap * sizeof(uint64_t), c->stream));
+    LR_HIP(hipMemsetAsync(f.ctrl, 0, 16 * sizeof(uint32_t), c->stream));
+    f.select_temp_bytes = flood_select_temp_bytes((uint32_t)std::min<size_t>(cs, 0xFFFFFFFFu));
+    if (f.select_temp) (void)hipFree(f.select_temp);
+    f.select_temp = nullptr;
+    LR_HIP(hipMalloc(&f.select_temp, f.select_temp_bytes));
+    c->fb_cap_seeds = cs;
+    return 0;
+}
+
 int ctx_ensure_ransac_capacity(lr_context* c, size_t n_lines, size_t n_iter) {
     if (n_lines > c->cap_lines) {
         LR_HIP(hipStreamSynchronize(c->stream));
@@ -139,7 +164,7 @@ int ctx_create(int device, lr_context** out) {
     const char* env = std::getenv("LIBRECTIFY_SEED");
     c->ransac_seed = env ? std::strtoull(env, nullptr, 0) : 0ull;
     const char* fm = std::getenv("LIBRECTIFY_FLOOD_MODE");
-    c->flood_mode = fm ? std::atoi(fm) : 0;
+    if (fm) c->flood_mode = std::atoi(fm);
     *out = c;
     return 0;
 }
@@ -151,7 +176,9 @@ void ctx_destroy(lr_context* c) {
     void* ptrs[] = {c->d_img, c->dx, c->dy, c->dmask, c->cand, c->cand_count, c->tile_max, c->tile_pass, c->tile_off,
                     c->maxmag, c->keys_a, c->keys_b, c->d_counts, c->seed_idx, c->seed_bin, c->seed_thr, c->seed_size,
                     c->label, c->queue, c->comp_rank, c->comp_seed, c->comp_off, c->cursor, c->px_a, c->px_b,
-                    c->scratch_w, c->d_lines, c->temp, c->d_model, c->d_scores, c->d_best_score, c->d_best_iter};
+                    c->scratch_w, c->d_lines, c->temp, c->d_model, c->d_scores, c->d_best_score, c->d_best_iter,
+                    c->fb.blocked, c->fb.count, c->fb.flags, c->fb.state, c->fb.alive, c->fb.act_a, c->fb.act_b,
+                    c->fb.ctrl, c->fb.slab_ring, c->fb.slab_hash, c->fb.select_temp};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_model) (void)hipHostFree(c->h_model);
@@ -214,9 +241,20 @@ int ctx_stage_flood(lr_context* c) {
     const size_t npix = (size_t)c->w * c->h;
     if (launch_label_init(c->label, npix, c->stream)) return 1;
     c->flood_rounds = 1;
-    if (launch_flood_ordered(c->dx, c->dy, c->dmask, c->w, c->h, c->seed_idx, c->seed_bin, c->seed_thr, c->n_seeds,
-                             c->trig, c->label, c->seed_size, c->queue, c->stream))
-        return 1;
+    if (c->flood_mode == 0) {
+        if (launch_flood_ordered(c->dx, c->dy, c->dmask, c->w, c->h, c->seed_idx, c->seed_bin, c->seed_thr,
+                                 c->n_seeds, c->trig, c->label, c->seed_size, c->queue, c->stream))
+            return 1;
+    } else {
+        if (ensure_flood_buffers(c)) return 1;
+        FloodBuffers fbuf = c->fb;
+        if (c->flood_mode == 2) fbuf.n_slabs = 0;  // test hooks: exercise the exhausted-storage paths
+        if (c->flood_mode == 3) fbuf.n_slabs = 2;
+        if (flood_parallel(fbuf, c->dx, c->dy, c->dmask, c->w, c->h, c->seed_idx, c->seed_bin, c->seed_thr,
+                           c->n_seeds, c->trig, c->label, c->seed_size, c->queue, c->h_counts + 16, &c->flood_rounds,
+                           c->stream))
+            return 1;
+    }
     LR_HIP(hipEventRecord(c->ev[3], c->stream));
     c->stage_valid[2] = true;
     return 0;

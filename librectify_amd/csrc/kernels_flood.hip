@@ -11,6 +11,13 @@
 // The eight masked directional planes are never stored; the acceptance test evaluates
 //      (dmask[q] >> bin) & 1  &&  |fmaf(dx[q], sin_bin, dy[q]*cos_bin)| > thr
 // on the fly (dmask = 0 on the 1-px border, which also stands in for flood_init_mask).
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
 #include "common.h"
 
 namespace lramd {
@@ -103,6 +110,449 @@ int launch_flood_ordered(const float* dx, const float* dy, const uint8_t* dmask,
     hipLaunchKernelGGL(flood_ordered_kernel, dim3(1), dim3(64), 0, s, dx, dy, dmask, w, seed_idx, seed_bin, seed_thr,
                        n_seeds, trig, label, seed_size, queue);
     LR_HIP(hipGetLastError());
+    return 0;
+}
+
+namespace {
+
+// =============================================================================================
+// Mode 1: parallel rounds, exact.
+//
+// The ordered semantics above are a well-founded recursion on the seed index: the flood of
+// seed k is the connected set around it in {response_k > thr_k} minus everything claimed by
+// seeds < k.  Rounds evaluate that recursion for many seeds at once:
+//
+//   explore  every active seed walks its WHOLE reachable set w.r.t. the labels committed so far
+//            (its "footprint", a superset of its final flood) and stamps each pixel with
+//            atomicMin(label, MARK|k).  A seed that meets a lower stamp, or whose stamp is
+//            overwritten by a lower seed, is "blocked": a lower active seed can reach one of
+//            its pixels, so its flood is not decided yet.  Footprints are never truncated
+//            at other seeds' stamps; pixels stamped lower than k are tracked in a private hash
+//            set so that the walk still terminates.
+//   decide   unblocked seeds have footprints disjoint from every lower active footprint, so
+//            their footprint IS their final flood: commit.  If some seed could not finish its
+//            walk (private storage exhausted) only seeds below the lowest such seed commit.
+//   commit   stamps of committed seeds become labels, all other stamps are erased; seeds whose
+//            own pixel got committed by someone else are dead (the reference skips them).
+//
+// The lowest active seed is never blocked, so every round commits at least one seed; on real
+// frames 4-8 rounds finish everything (longest chain of overlapping footprints with increasing
+// index).  If a round makes no progress (only possible when storage is exhausted) the host
+// finishes the remaining seeds with the ordered kernel, which is always exact.
+// =============================================================================================
+
+constexpr uint32_t kMarkBit = 0x80000000u;
+constexpr int kRing = 512;       // per-wave LDS frontier ring (entries)
+constexpr int kHash = 1024;      // per-wave LDS foreign-pixel hash (slots)
+constexpr uint32_t kFlagIncomplete = 1u, kFlagSelfFail = 2u;
+
+struct FloodArgs {
+    const float* dx;
+    const float* dy;
+    const uint8_t* dmask;
+    int w;
+    const int32_t* seed_idx;
+    const int32_t* seed_bin;
+    const float* seed_thr;
+    uint32_t* label;
+    uint32_t* blocked;  // per seed
+    uint32_t* count;    // per seed: pixels walked this round
+    uint32_t* flags;    // per seed
+    uint32_t* ctrl;     // kCtrl* words
+    uint32_t* slab_ring;   // n_slabs x slab_ring_cap
+    unsigned long long* slab_hash;  // n_slabs x slab_hash_cap
+    uint32_t n_slabs, slab_ring_cap, slab_hash_cap;  // caps are powers of two
+};
+// words 0..7 are reset every frame; kCtrlGen lives on for the lifetime of the slab memory (hash entries are
+// tagged with it, so a generation must never be reused while old entries are around)
+enum { kCtrlBarrier = 0, kCtrlSlabs = 1, kCtrlNCommit = 3, kCtrlNNext = 4, kCtrlError = 5, kCtrlGen = 8 };
+
+struct WalkState {
+    uint32_t head, tail, cnt, nforeign;
+    bool blocked;
+};
+
+struct LdsStore {
+    uint32_t* ring;
+    uint32_t* hash;
+    __device__ uint32_t ring_cap() const { return kRing; }
+    __device__ uint32_t hash_limit() const { return kHash * 3 / 4; }
+    __device__ uint32_t get(uint32_t i) const { return ring[i & (kRing - 1)]; }
+    __device__ void put(uint32_t i, uint32_t v) { ring[i & (kRing - 1)] = v; }
+    __device__ bool insert(uint32_t key) {  // key = pixel + 1
+        uint32_t h = (key * 2654435761u) >> 22;  // 10 bits
+        for (int probe = 0; probe < kHash; ++probe) {  // the load limit keeps the table 3/4 empty; bounded anyway
+            const uint32_t old = atomicCAS(&hash[h], 0u, key);
+            if (old == 0u) return true;
+            if (old == key) return false;
+            h = (h + 1) & (kHash - 1);
+        }
+        return false;
+    }
+    __device__ void sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+};
+
+struct SlabStore {
+    uint32_t* ring;
+    unsigned long long* hash;
+    uint32_t rcap, hcap, gen;
+    __device__ uint32_t ring_cap() const { return rcap; }
+    __device__ uint32_t hash_limit() const { return hcap / 4 * 3; }
+    __device__ uint32_t get(uint32_t i) const {
+        return __hip_atomic_load(&ring[i & (rcap - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ void put(uint32_t i, uint32_t v) {
+        __hip_atomic_store(&ring[i & (rcap - 1)], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ bool insert(uint32_t key) {  // entries are (generation << 32 | key); other generations read as empty
+        const unsigned long long want = ((unsigned long long)gen << 32) | key;
+        uint32_t h = (key * 2654435761u) & (hcap - 1);
+        for (uint32_t probe = 0; probe < 2u * hcap; ++probe) {  // bounded: a full table must never spin a wave
+            unsigned long long cur = __hip_atomic_load(&hash[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == want) return false;
+            if ((uint32_t)(cur >> 32) != gen) {
+                const unsigned long long old = atomicCAS(&hash[h], cur, want);
+                if (old == cur) return true;
+                if (old == want) return false;
+                if ((uint32_t)(old >> 32) != gen) continue;  // raced with a stale slot changing: retry the slot
+            }
+            h = (h + 1) & (hcap - 1);
+        }
+        return false;
+    }
+    __device__ void sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+};
+
+// Walks the footprint of seed k from the state in `st`.  Returns 0 when the walk is complete,
+// 1 when the store ran out (ring full or hash past its load limit); `st` then holds a resumable
+// state (every pushed pixel is stamped/hashed and sits in the ring).
+template <class Store>
+__device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, float cs, Store& S, WalkState& st,
+                    int lane) {
+    const uint32_t mine = kMarkBit | k;
+    const int si = lane >> 3, ni = lane & 7;
+    const int dr = (ni == 2 || ni == 6 || ni == 7) ? 1 : ((ni == 3 || ni == 4 || ni == 5) ? -1 : 0);
+    const int dc = (ni == 0 || ni == 4 || ni == 6) ? -1 : ((ni == 1 || ni == 5 || ni == 7) ? 1 : 0);
+    const int noff = dr * A.w + dc;
+    while (st.head != st.tail) {
+        S.sync();
+        const uint32_t avail = st.tail - st.head;
+        const uint32_t nsrc = avail < 8u ? avail : 8u;
+        // room for the worst case of 64 pushes (never onto a slot still to be read), head-room for 64 inserts
+        if (avail + 64u > S.ring_cap() || st.nforeign + 64u > S.hash_limit()) return 1;
+        bool fresh = false, foreign = false;
+        uint32_t q = 0;
+        if ((uint32_t)si < nsrc) {
+            const uint32_t p = S.get(st.head + si);
+            q = p + noff;  // sources are never on the image border (dmask = 0 there)
+            const uint32_t lab = A.label[q];
+            if (lab >= kMarkBit && lab != mine && ((A.dmask[q] >> b) & 1) &&
+                directional(A.dx[q], A.dy[q], sn, cs) > thr) {
+                const uint32_t old = atomicMin(&A.label[q], mine);
+                if (old >= kMarkBit && old != mine) {
+                    if (old > mine) {  // free, or stamped by a higher seed that is hereby blocked
+                        fresh = true;
+                        if (old != kLabelFree) A.blocked[old & ~kMarkBit] = 1u;
+                    } else {  // a lower active seed reaches this pixel too
+                        foreign = true;
+                    }
+                }
+            }
+        }
+        if (foreign) fresh = S.insert(q + 1u);
+        const uint64_t mf = __ballot(foreign);
+        const uint64_t mfresh = __ballot(fresh);
+        const uint64_t mnewf = __ballot(fresh && foreign);
+        if (mf) st.blocked = true;
+        if (fresh) S.put(st.tail + (uint32_t)__popcll(mfresh & ((1ull << lane) - 1ull)), q);
+        st.tail += (uint32_t)__popcll(mfresh);
+        st.cnt += (uint32_t)__popcll(mfresh);
+        st.nforeign += (uint32_t)__popcll(mnewf);
+        st.head += nsrc;
+    }
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void flood_explore_kernel(FloodArgs A, BinTrig trig, const uint32_t* __restrict__ act,
+                                                            uint32_t n_act) {
+    __shared__ uint32_t s_ring[4][kRing];
+    __shared__ uint32_t s_hash[4][kHash];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t ai = blockIdx.x * 4 + wv;
+    if (ai >= n_act) return;
+    const uint32_t k = act[ai];
+    const int s = A.seed_idx[k];
+    const int b = A.seed_bin[k];
+    const float thr = A.seed_thr[k];
+    const float sn = trig.st[b], cs = trig.ct[b];
+    const uint32_t mine = kMarkBit | k;
+    if (A.label[s] < kMarkBit) return;  // claimed by an earlier flood: dead (found again by the compaction)
+    if (!(((A.dmask[s] >> b) & 1) && directional(A.dx[s], A.dy[s], sn, cs) > thr)) {
+        if (lane == 0) A.flags[k] = kFlagSelfFail;  // flood() accepts nothing, not even the seed
+        return;
+    }
+    LdsStore L{s_ring[wv], s_hash[wv]};
+    for (int i = lane; i < kHash; i += 64) L.hash[i] = 0u;
+    WalkState st{0u, 1u, 1u, 0u, false};
+    uint32_t old = 0;
+    if (lane == 0) {
+        old = atomicMin(&A.label[s], mine);
+        L.ring[0] = (uint32_t)s;
+    }
+    old = (uint32_t)__shfl((int)old, 0);
+    if (old != kLabelFree && old != mine) {
+        if (old > mine) {
+            if (lane == 0) A.blocked[old & ~kMarkBit] = 1u;
+        } else {
+            st.blocked = true;
+            if (lane == 0) L.insert((uint32_t)s + 1u);
+            st.nforeign = 1u;
+        }
+    }
+    int rc = walk(A, k, b, thr, sn, cs, L, st, lane);
+    if (rc != 0) {
+        // LDS storage exhausted: move the walk to a global slab and carry on
+        uint32_t slab = 0;
+        if (lane == 0) slab = atomicAdd(&A.ctrl[kCtrlSlabs], 1u);
+        slab = (uint32_t)__shfl((int)slab, 0);
+        if (slab < A.n_slabs) {
+            uint32_t gen = 0;
+            if (lane == 0) gen = atomicAdd(&A.ctrl[kCtrlGen], 1u) + 1u;
+            gen = (uint32_t)__shfl((int)gen, 0);
+            SlabStore G{A.slab_ring + (size_t)slab * A.slab_ring_cap, A.slab_hash + (size_t)slab * A.slab_hash_cap,
+                        A.slab_ring_cap, A.slab_hash_cap, gen};
+            for (uint32_t i = st.head + lane; i != st.tail && (int32_t)(st.tail - i) > 0; i += 64) G.put(i, L.get(i));
+            for (int i = lane; i < kHash; i += 64) {
+                const uint32_t key = L.hash[i];
+                if (key) G.insert(key);
+            }
+            rc = walk(A, k, b, thr, sn, cs, G, st, lane);
+        }
+        if (rc != 0 && lane == 0) {
+            A.flags[k] = kFlagIncomplete;
+            atomicMin(&A.ctrl[kCtrlBarrier], k);
+        }
+    }
+    if (lane == 0) {
+        A.count[k] = st.cnt;
+        if (st.blocked) A.blocked[k] = 1u;
+    }
+}
+
+// state: 0 = active, 1 = committed in this round, 2 = finished earlier / dead
+__global__ __launch_bounds__(256) void flood_decide_kernel(FloodArgs A, const uint32_t* __restrict__ act, uint32_t n_act,
+                                                           uint8_t* __restrict__ state, int32_t* __restrict__ seed_size) {
+    const uint32_t ai = blockIdx.x * 256 + threadIdx.x;
+    if (ai >= n_act) return;
+    const uint32_t k = act[ai];
+    const uint32_t fl = A.flags[k];
+    if (fl & kFlagSelfFail) {
+        state[k] = 2;
+        seed_size[k] = 0;
+        return;
+    }
+    const uint32_t barrier = A.ctrl[kCtrlBarrier];
+    const bool walked = A.count[k] > 0u;
+    if (walked && A.blocked[k] == 0u && !(fl & kFlagIncomplete) && k < barrier) {
+        state[k] = 1;
+        seed_size[k] = (int32_t)A.count[k];
+        atomicAdd(&A.ctrl[kCtrlNCommit], 1u);
+    }
+}
+
+__global__ __launch_bounds__(256) void flood_commit_pixels_kernel(uint32_t* __restrict__ label, size_t npix,
+                                                                  const uint8_t* __restrict__ state) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * 256;
+    for (; i < npix; i += step) {
+        const uint32_t v = label[i];
+        if (v >= kMarkBit && v != kLabelFree) {
+            const uint32_t k = v & ~kMarkBit;
+            label[i] = (state[k] == 1) ? k : kLabelFree;
+        }
+    }
+}
+
+// After the commit: which seeds go on to the next round?  alive[k] = 1 for still-active seeds.
+__global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, const uint32_t* __restrict__ act,
+                                                              uint32_t n_act, uint8_t* __restrict__ state,
+                                                              int32_t* __restrict__ seed_size,
+                                                              uint8_t* __restrict__ alive) {
+    const uint32_t ai = blockIdx.x * 256 + threadIdx.x;
+    if (ai >= n_act) return;
+    const uint32_t k = act[ai];
+    uint8_t a = 0;
+    if (state[k] == 1) {
+        state[k] = 2;
+    } else if (state[k] == 0) {
+        if (A.label[A.seed_idx[k]] < kMarkBit) {  // its pixel now belongs to a committed flood: skipped forever
+            state[k] = 2;
+            seed_size[k] = 0;
+        } else {
+            a = 1;
+            A.blocked[k] = 0u;
+            A.count[k] = 0u;
+            A.flags[k] = 0u;
+        }
+    }
+    alive[k] = a;
+}
+
+__global__ __launch_bounds__(256) void flood_init_seeds_kernel(uint32_t n_seeds, uint32_t* __restrict__ act,
+                                                               uint8_t* __restrict__ state, uint8_t* __restrict__ alive,
+                                                               uint32_t* __restrict__ blocked, uint32_t* __restrict__ count,
+                                                               uint32_t* __restrict__ flags, int32_t* __restrict__ seed_size) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_seeds) return;
+    act[k] = k;
+    state[k] = 0;
+    alive[k] = 0;
+    blocked[k] = 0u;
+    count[k] = 0u;
+    flags[k] = 0u;
+    seed_size[k] = 0;
+}
+
+// Ordered tail: the reference's loop over an (ascending) list of remaining seeds, starting from
+// the labels committed so far.  Same walk as flood_ordered_kernel.
+__global__ __launch_bounds__(64) void flood_ordered_tail_kernel(const float* __restrict__ dx, const float* __restrict__ dy,
+                                                                const uint8_t* __restrict__ dmask, int w,
+                                                                const int32_t* __restrict__ seed_idx,
+                                                                const int32_t* __restrict__ seed_bin,
+                                                                const float* __restrict__ seed_thr,
+                                                                const uint32_t* __restrict__ act, uint32_t n_act,
+                                                                BinTrig trig, uint32_t* label, int32_t* seed_size,
+                                                                int32_t* queue) {
+    const int lane = threadIdx.x;
+    const int si = lane >> 3, ni = lane & 7;
+    const int dr = (ni == 2 || ni == 6 || ni == 7) ? 1 : ((ni == 3 || ni == 4 || ni == 5) ? -1 : 0);
+    const int dc = (ni == 0 || ni == 4 || ni == 6) ? -1 : ((ni == 1 || ni == 5 || ni == 7) ? 1 : 0);
+    const int noff = dr * w + dc;
+    for (uint32_t ai = 0; ai < n_act; ++ai) {
+        const uint32_t k = act[ai];
+        const int sidx = seed_idx[k];
+        int size = 0;
+        if (ld_agent(&label[sidx]) == kLabelFree) {
+            const int b = seed_bin[k];
+            const float thr = seed_thr[k];
+            const float s = trig.st[b], c = trig.ct[b];
+            if (((dmask[sidx] >> b) & 1) && (directional(dx[sidx], dy[sidx], s, c) > thr)) {
+                if (lane == 0) {
+                    atomicExch(&label[sidx], k);
+                    __hip_atomic_store(&queue[0], sidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                int head = 0, tail = 1;
+                while (head < tail) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    const int nsrc = min(8, tail - head);
+                    bool claim = false;
+                    int q = 0;
+                    if (si < nsrc) {
+                        const int p = __hip_atomic_load(&queue[head + si], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        q = p + noff;
+                        if (((dmask[q] >> b) & 1) && directional(dx[q], dy[q], s, c) > thr)
+                            claim = atomicCAS(&label[q], kLabelFree, k) == kLabelFree;
+                    }
+                    const uint64_t m = __ballot(claim);
+                    if (claim)
+                        __hip_atomic_store(&queue[tail + __popcll(m & ((1ull << lane) - 1ull))], q, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    tail += (int)__popcll(m);
+                    head += nsrc;
+                }
+                size = tail;
+            }
+        }
+        if (lane == 0) seed_size[k] = size;
+    }
+}
+
+}  // namespace
+
+// ---- host side of the rounds ------------------------------------------------------------------
+
+size_t flood_select_temp_bytes(uint32_t max_seeds) {
+    size_t b = 0;
+    (void)rocprim::select(nullptr, b, rocprim::counting_iterator<uint32_t>(0), (const uint8_t*)nullptr,
+                          (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)max_seeds);
+    return b + 256;
+}
+
+int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, const uint8_t* dmask, int w, int h,
+                   const int32_t* seed_idx, const int32_t* seed_bin, const float* seed_thr, uint32_t n_seeds,
+                   BinTrig trig, uint32_t* label, int32_t* seed_size, int32_t* queue, uint32_t* h_ctrl, int* rounds_out,
+                   hipStream_t s) {
+    *rounds_out = 0;
+    if (n_seeds == 0) return 0;
+    const size_t npix = (size_t)w * h;
+    FloodArgs A;
+    A.dx = dx;
+    A.dy = dy;
+    A.dmask = dmask;
+    A.w = w;
+    A.seed_idx = seed_idx;
+    A.seed_bin = seed_bin;
+    A.seed_thr = seed_thr;
+    A.label = label;
+    A.blocked = B.blocked;
+    A.count = B.count;
+    A.flags = B.flags;
+    A.ctrl = B.ctrl;
+    A.slab_ring = B.slab_ring;
+    A.slab_hash = (unsigned long long*)B.slab_hash;
+    A.n_slabs = B.n_slabs;
+    A.slab_ring_cap = B.slab_ring_cap;
+    A.slab_hash_cap = B.slab_hash_cap;
+
+    uint32_t* act = B.act_a;
+    uint32_t* act_next = B.act_b;
+    uint32_t n_act = n_seeds;
+    hipLaunchKernelGGL(flood_init_seeds_kernel, dim3((n_seeds + 255) / 256), dim3(256), 0, s, n_seeds, act, B.state,
+                       B.alive, B.blocked, B.count, B.flags, seed_size);
+    LR_HIP(hipMemsetAsync(B.ctrl, 0, 8 * sizeof(uint32_t), s));
+    const int pix_blocks = (int)std::min<size_t>((npix + 255) / 256, 4096);
+    int rounds = 0;
+    static const bool debug = std::getenv("LIBRECTIFY_FLOOD_DEBUG") != nullptr;
+    while (n_act > 0) {
+        ++rounds;
+        const uint32_t init[2] = {0xFFFFFFFFu, 0u};  // barrier, slabs used
+        h_ctrl[8] = init[0];
+        h_ctrl[9] = init[1];
+        LR_HIP(hipMemcpyAsync(B.ctrl + kCtrlBarrier, h_ctrl + 8, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        LR_HIP(hipMemsetAsync(B.ctrl + kCtrlNCommit, 0, 2 * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(flood_explore_kernel, dim3((n_act + 3) / 4), dim3(256), 0, s, A, trig, act, n_act);
+        hipLaunchKernelGGL(flood_decide_kernel, dim3((n_act + 255) / 256), dim3(256), 0, s, A, act, n_act, B.state,
+                           seed_size);
+        hipLaunchKernelGGL(flood_commit_pixels_kernel, dim3(pix_blocks), dim3(256), 0, s, label, npix, B.state);
+        hipLaunchKernelGGL(flood_survivors_kernel, dim3((n_act + 255) / 256), dim3(256), 0, s, A, act, n_act, B.state,
+                           seed_size, B.alive);
+        size_t tb = B.select_temp_bytes;
+        LR_HIP(rocprim::select(B.select_temp, tb, rocprim::counting_iterator<uint32_t>(0), B.alive, act_next,
+                               B.ctrl + kCtrlNNext, (size_t)n_seeds, s));
+        LR_HIP(hipMemcpyAsync(h_ctrl, B.ctrl, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        LR_HIP(hipStreamSynchronize(s));
+        const uint32_t n_commit = h_ctrl[kCtrlNCommit];
+        const uint32_t n_next = h_ctrl[kCtrlNNext];
+        if (debug)
+            std::fprintf(stderr, "flood round %d: active %u committed %u next %u barrier %u slabs %u\n", rounds, n_act,
+                         n_commit, n_next, h_ctrl[kCtrlBarrier], h_ctrl[kCtrlSlabs]);
+        std::swap(act, act_next);
+        const bool progress = n_commit > 0 || n_next < n_act;
+        n_act = n_next;
+        if (n_act > 0 && !progress) {
+            // storage exhausted on the lowest active seed: finish in order (always exact)
+            hipLaunchKernelGGL(flood_ordered_tail_kernel, dim3(1), dim3(64), 0, s, dx, dy, dmask, w, seed_idx, seed_bin,
+                               seed_thr, act, n_act, trig, label, seed_size, queue);
+            ++rounds;
+            n_act = 0;
+        }
+    }
+    LR_HIP(hipGetLastError());
+    if (h_ctrl[kCtrlGen] > 0xF0000000u) {  // generation counter about to wrap: forget every tagged hash entry
+        LR_HIP(hipMemsetAsync(B.slab_hash, 0, (size_t)B.n_slabs * B.slab_hash_cap * sizeof(uint64_t), s));
+        LR_HIP(hipMemsetAsync(B.ctrl + kCtrlGen, 0, sizeof(uint32_t), s));
+    }
+    *rounds_out = rounds;
     return 0;
 }
 

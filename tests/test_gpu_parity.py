@@ -89,7 +89,7 @@ def test_seeds_match(L, ctx, name):
     assert (_bits(ctx.download(L.BUF_SEED_THR)) != _bits(thr.astype(np.float32))).sum() == 0
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 @pytest.mark.parametrize("name", list(FRAMES))
 def test_flood_labels_and_segments_bit_exact(L, ctx, name, mode):
     img = FRAMES[name]
@@ -104,7 +104,7 @@ def test_flood_labels_and_segments_bit_exact(L, ctx, name, mode):
         len(bad), bad[0], lab[tuple(bad[0])], ref["label"][tuple(bad[0])])
     lines = ctx.stage_fit()
     _assert_lines_equal(lines, ref["lines"])
-    ctx.set_flood_mode(0)
+    ctx.set_flood_mode(1)
 
 
 def _unit(v):
@@ -151,12 +151,14 @@ def test_against_committed_golden(L, ctx, case):
         assert np.abs(_unit(T[k]) - _unit(z["transform"][k])).max() < 1e-4
 
 
-def test_doc_image_detector_kat_on_gpu(L, ctx):
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_doc_image_detector_kat_on_gpu(L, ctx, mode):
     """doc/image.jpg through the HIP detector, compared with the oracle bit for bit (the oracle
     itself is pinned to the reference's golden rows in test_oracle_pins.py)."""
     gray = np.load(os.path.join(G, "doc_image_gray.npy"))
     img = gray.astype(np.float32) / np.float32(256.0)
     ref = O.find_line_segments(img)
+    ctx.set_flood_mode(mode)
     ctx.stage_filter_host(img)
     assert ctx.stage_seeds() == ref["n_seeds"] == 6649
     ctx.stage_flood()
@@ -164,6 +166,7 @@ def test_doc_image_detector_kat_on_gpu(L, ctx):
     lines = ctx.stage_fit()
     _assert_lines_equal(lines, ref["lines"])
     assert len(lines) == 1927
+    ctx.set_flood_mode(1)
 
 
 def test_ransac_scoring_matches_oracle(L, ctx):
@@ -216,6 +219,33 @@ def test_refine_flag_matches_oracle(L, ctx):
     ctx.set_seed(0)
     got = ctx.find_line_segment_groups(img, ml, refine=True)
     _assert_lines_equal(got, ref)
+
+
+def test_many_frames_through_one_context_stay_exact(L, ctx):
+    """Workspace reuse (overflow slabs, hash generations, candidate lists) must not leak state from
+    one frame into the next: 40 passes over 3 frames with long edges, each equal to its first pass
+    and to the oracle."""
+    from librectify_amd import synth
+
+    frames = [synth.frame(1280, 720, 31 + i, bars=60) for i in range(3)]
+    first = []
+    for f in frames:
+        ref = O.find_line_segments(f)
+        ctx.stage_filter_host(f)
+        ctx.stage_seeds()
+        ctx.stage_flood()
+        np.testing.assert_array_equal(ctx.download(L.BUF_LABEL), ref["label"])
+        lines = ctx.stage_fit()
+        _assert_lines_equal(lines, ref["lines"])
+        first.append(lines)
+    for rep in range(40):
+        i = rep % 3
+        ctx.stage_filter_host(frames[i][:, ::-1] if rep % 7 == 3 else frames[i])
+        ctx.stage_seeds()
+        ctx.stage_flood()
+        lines = ctx.stage_fit()
+        if rep % 7 != 3:
+            _assert_lines_equal(lines, first[i])
 
 
 def test_size_independent_properties_at_full_size(L, ctx):

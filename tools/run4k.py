@@ -1,0 +1,10 @@
+import os, sys; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np, time, sys
+import librectify_amd as L
+from librectify_amd import synth
+ctx=L.Context(0)
+W,H=3840,2160
+img=synth.frame(W,H,1)
+for rep in range(3):
+    t=time.time(); got=ctx.find_line_segment_groups(img, max(W,H)/100.0); dt=time.time()-t
+    print(W,H,"total %.1f ms"%(dt*1e3), "lines",len(got), ctx.stage_counters(), ctx.stage_times().round(3))
