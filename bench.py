@@ -99,6 +99,7 @@ def main():
     import torch.distributed as dist
 
     import librectify_amd as L
+    from librectify_amd import distributed as D
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -143,12 +144,7 @@ def main():
                 filt_ms.append(float(t[L.T_FILTER_KERNEL]))
                 stage_acc[:] += t
         if world > 1:  # the path's one exchange step: gather the per-frame results over RCCL
-            payload = torch.from_numpy(out.view(np.uint8).reshape(B, -1)).to(dev)
-            meta = torch.from_numpy(np.concatenate([n_lines.astype(np.float32)[:, None], tforms.reshape(B, -1)], 1)).to(dev)
-            gl = [torch.empty_like(payload) for _ in range(world)]
-            gm = [torch.empty_like(meta) for _ in range(world)]
-            dist.all_gather(gl, payload)
-            dist.all_gather(gm, meta)
+            D.gather_results([out[b][: n_lines[b]] for b in range(B)], tforms, B * world, device=dev)
 
     for _ in range(args.warmup):
         step(False)
