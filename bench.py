@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--height", type=int, default=H4K)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flood-mode", type=int, default=None)
+    ap.add_argument("--streams", type=int, default=4, help="frames in flight per GPU (one context + HIP stream + host thread each)")
     args = ap.parse_args()
 
     import torch
@@ -121,10 +122,15 @@ def main():
         d_frames[i].copy_(torch.from_numpy(f))
     torch.cuda.synchronize()
 
-    ctx = L.Context(local_rank)
-    ctx.set_seed(0)
-    if args.flood_mode is not None:
-        ctx.set_flood_mode(args.flood_mode)
+    from concurrent.futures import ThreadPoolExecutor
+
+    S = max(1, min(args.streams, B))
+    ctxs = [L.Context(local_rank) for _ in range(S)]
+    for c in ctxs:
+        c.set_seed(0)
+        if args.flood_mode is not None:
+            c.set_flood_mode(args.flood_mode)
+    pool = ThreadPoolExecutor(max_workers=S)
     cap = 8192
     out = np.zeros((B, cap), L.LINE_DTYPE)
     n_lines = np.zeros(B, np.int32)
@@ -133,16 +139,27 @@ def main():
     filt_ms = []
     stage_acc = np.zeros(L.T_COUNT)
 
-    def step(record):
-        base = d_frames.data_ptr()
-        for b in range(B):
+    base = d_frames.data_ptr()
+
+    def lane(si, record):
+        # frames si, si+S, ... on context si: independent frames overlap their latency-bound stages
+        ctx = ctxs[si]
+        acc, fl = np.zeros(L.T_COUNT), []
+        for b in range(si, B, S):
             res = ctx.find_line_segment_groups_device(base + b * h * w * 4, w, h, min_length, capacity=cap, out=out[b])
             n_lines[b] = len(res)
             tforms[b] = L.compute_rectification_transform(res, w, h, cfg).as_array()
             if record:
                 t = ctx.stage_times()
-                filt_ms.append(float(t[L.T_FILTER_KERNEL]))
-                stage_acc[:] += t
+                fl.append(float(t[L.T_FILTER_KERNEL]))
+                acc += t
+        return acc, fl
+
+    def step(record):
+        for acc, fl in pool.map(lambda si: lane(si, record), range(S)):
+            if record:
+                filt_ms.extend(fl)
+                stage_acc[:] += acc
         if world > 1:  # the path's one exchange step: gather the per-frame results over RCCL
             D.gather_results([out[b][: n_lines[b]] for b in range(B)], tforms, B * world, device=dev)
 
@@ -152,7 +169,8 @@ def main():
     def fence():
         if world > 1:
             dist.barrier()
-        ctx.synchronize()
+        for c in ctxs:
+            c.synchronize()
         torch.cuda.synchronize()
 
     fence()
@@ -188,6 +206,7 @@ def main():
             "config": {
                 "workload": "%dx%d frames, find_line_segment_groups + compute_rectification_transform, default constants, refine=false, min_length=max(W,H)/100" % (w, h),
                 "frames_per_gpu_per_step": B,
+                "frames_in_flight_per_gpu": S,
                 "ransac_iterations": 10000,
                 "segments_per_frame": float(np.mean(n_lines)),
                 "parallelism": "frames sharded over %d GPU(s), RCCL all_gather of results" % n_gpus,

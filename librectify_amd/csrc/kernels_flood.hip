@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include <rocprim/rocprim.hpp>
 
@@ -142,15 +143,15 @@ namespace {
 // =============================================================================================
 
 constexpr uint32_t kMarkBit = 0x80000000u;
-constexpr int kRing = 512;       // per-wave LDS frontier ring (entries)
-constexpr int kHash = 1024;      // per-wave LDS foreign-pixel hash (slots)
+constexpr int kRingT = 256;  // per-wave LDS frontier ring: (tile, entry mask) records
+constexpr int kHashT = 256;  // per-wave LDS hash: tile -> mask of foreign pixels already walked
 constexpr uint32_t kFlagIncomplete = 1u, kFlagSelfFail = 2u;
 
 struct FloodArgs {
     const float* dx;
     const float* dy;
     const uint8_t* dmask;
-    int w;
+    int w, h, tiles_x;
     const int32_t* seed_idx;
     const int32_t* seed_bin;
     const float* seed_thr;
@@ -159,8 +160,8 @@ struct FloodArgs {
     uint32_t* count;    // per seed: pixels walked this round
     uint32_t* flags;    // per seed
     uint32_t* ctrl;     // kCtrl* words
-    uint32_t* slab_ring;   // n_slabs x slab_ring_cap
-    unsigned long long* slab_hash;  // n_slabs x slab_hash_cap
+    uint4* slab_ring;   // n_slabs x slab_ring_cap records {tile, -, mask.lo, mask.hi}
+    uint4* slab_hash;   // n_slabs x slab_hash_cap records {generation, tile+1, mask.lo, mask.hi}
     uint32_t n_slabs, slab_ring_cap, slab_hash_cap;  // caps are powers of two
 };
 // words 0..7 are reset every frame; kCtrlGen lives on for the lifetime of the slab memory (hash entries are
@@ -172,111 +173,195 @@ struct WalkState {
     bool blocked;
 };
 
+// The walk works on 8x8 pixel tiles, one tile per step, one pixel per lane: the acceptance test of the
+// whole tile is a 64-bit ballot, connectivity inside the tile is a handful of scalar shift/and
+// operations on that mask, and the frontier holds (tile, entry-mask) records instead of pixels.
+// All store operations below are wave-uniform (every lane performs the same access).
 struct LdsStore {
-    uint32_t* ring;
-    uint32_t* hash;
-    __device__ uint32_t ring_cap() const { return kRing; }
-    __device__ uint32_t hash_limit() const { return kHash * 3 / 4; }
-    __device__ uint32_t get(uint32_t i) const { return ring[i & (kRing - 1)]; }
-    __device__ void put(uint32_t i, uint32_t v) { ring[i & (kRing - 1)] = v; }
-    __device__ bool insert(uint32_t key) {  // key = pixel + 1
-        uint32_t h = (key * 2654435761u) >> 22;  // 10 bits
-        for (int probe = 0; probe < kHash; ++probe) {  // the load limit keeps the table 3/4 empty; bounded anyway
-            const uint32_t old = atomicCAS(&hash[h], 0u, key);
-            if (old == 0u) return true;
-            if (old == key) return false;
-            h = (h + 1) & (kHash - 1);
-        }
-        return false;
+    uint32_t* rt;   // ring: tile
+    uint32_t* rlo;  // ring: entry mask
+    uint32_t* rhi;
+    uint32_t* hk;   // hash: tile + 1 (0 = empty)
+    uint32_t* hlo;
+    uint32_t* hhi;
+    __device__ uint32_t ring_cap() const { return kRingT; }
+    __device__ uint32_t hash_limit() const { return kHashT * 3 / 4; }
+    __device__ void get(uint32_t i, uint32_t& tile, uint64_t& m) const {
+        const uint32_t j = i & (kRingT - 1);
+        tile = rt[j];
+        m = ((uint64_t)rhi[j] << 32) | rlo[j];
     }
-    __device__ void sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+    __device__ void put(uint32_t i, uint32_t tile, uint64_t m) {
+        const uint32_t j = i & (kRingT - 1);
+        rt[j] = tile;
+        rlo[j] = (uint32_t)m;
+        rhi[j] = (uint32_t)(m >> 32);
+    }
+    __device__ uint64_t lookup(uint32_t tile, uint32_t& slot) const {
+        const uint32_t key = tile + 1u;
+        uint32_t hs = (key * 2654435761u) >> 24;  // 8 bits
+        for (int probe = 0; probe < kHashT; ++probe) {
+            const uint32_t cur = hk[hs];
+            if (cur == key) {
+                slot = hs;
+                return ((uint64_t)hhi[hs] << 32) | hlo[hs];
+            }
+            if (cur == 0u) break;
+            hs = (hs + 1) & (kHashT - 1);
+        }
+        slot = hs;
+        return 0ull;
+    }
+    __device__ bool update(uint32_t slot, uint32_t tile, uint64_t m) {
+        const bool ins = hk[slot] == 0u;
+        hk[slot] = tile + 1u;
+        hlo[slot] = (uint32_t)m;
+        hhi[slot] = (uint32_t)(m >> 32);
+        return ins;
+    }
 };
 
 struct SlabStore {
-    uint32_t* ring;
-    unsigned long long* hash;
+    uint4* ring;
+    uint4* hash;
     uint32_t rcap, hcap, gen;
     __device__ uint32_t ring_cap() const { return rcap; }
     __device__ uint32_t hash_limit() const { return hcap / 4 * 3; }
-    __device__ uint32_t get(uint32_t i) const {
-        return __hip_atomic_load(&ring[i & (rcap - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __device__ static uint4 ld(const uint4* p) {
+        uint4 v;
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+        v.x = __hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v.y = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v.z = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v.w = __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return v;
     }
-    __device__ void put(uint32_t i, uint32_t v) {
-        __hip_atomic_store(&ring[i & (rcap - 1)], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __device__ static void st(uint4* p, uint4 v) {
+        uint32_t* q = reinterpret_cast<uint32_t*>(p);
+        __hip_atomic_store(q + 0, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 3, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __device__ bool insert(uint32_t key) {  // entries are (generation << 32 | key); other generations read as empty
-        const unsigned long long want = ((unsigned long long)gen << 32) | key;
-        uint32_t h = (key * 2654435761u) & (hcap - 1);
-        for (uint32_t probe = 0; probe < 2u * hcap; ++probe) {  // bounded: a full table must never spin a wave
-            unsigned long long cur = __hip_atomic_load(&hash[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (cur == want) return false;
-            if ((uint32_t)(cur >> 32) != gen) {
-                const unsigned long long old = atomicCAS(&hash[h], cur, want);
-                if (old == cur) return true;
-                if (old == want) return false;
-                if ((uint32_t)(old >> 32) != gen) continue;  // raced with a stale slot changing: retry the slot
+    __device__ void get(uint32_t i, uint32_t& tile, uint64_t& m) const {
+        const uint4 v = ld(&ring[i & (rcap - 1)]);
+        tile = v.x;
+        m = ((uint64_t)v.w << 32) | v.z;
+    }
+    __device__ void put(uint32_t i, uint32_t tile, uint64_t m) {
+        st(&ring[i & (rcap - 1)], make_uint4(tile, 0u, (uint32_t)m, (uint32_t)(m >> 32)));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    }
+    __device__ uint64_t lookup(uint32_t tile, uint32_t& slot) const {
+        const uint32_t key = tile + 1u;
+        uint32_t hs = (key * 2654435761u) & (hcap - 1);
+        for (uint32_t probe = 0; probe < hcap; ++probe) {
+            const uint4 v = ld(&hash[hs]);
+            if (v.x != gen) break;  // another generation's record reads as empty
+            if (v.y == key) {
+                slot = hs;
+                return ((uint64_t)v.w << 32) | v.z;
             }
-            h = (h + 1) & (hcap - 1);
+            hs = (hs + 1) & (hcap - 1);
         }
-        return false;
+        slot = hs;
+        return 0ull;
     }
-    __device__ void sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+    __device__ bool update(uint32_t slot, uint32_t tile, uint64_t m) {
+        const bool ins = ld(&hash[slot]).x != gen;
+        st(&hash[slot], make_uint4(gen, tile + 1u, (uint32_t)m, (uint32_t)(m >> 32)));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        return ins;
+    }
 };
 
-// Walks the footprint of seed k from the state in `st`.  Returns 0 when the walk is complete,
-// 1 when the store ran out (ring full or hash past its load limit); `st` then holds a resumable
-// state (every pushed pixel is stamped/hashed and sits in the ring).
+// 8-neighbour dilation of a bit-board (bit = row*8 + col) restricted to the tile
+__device__ inline uint64_t dilate8(uint64_t r) {
+    const uint64_t hz = r | ((r << 1) & 0xFEFEFEFEFEFEFEFEull) | ((r >> 1) & 0x7F7F7F7F7F7F7F7Full);
+    return hz | (hz << 8) | (hz >> 8);
+}
+
+// Walks the footprint of seed k from the state in `st`.  Returns 0 when the walk is complete, 1 when
+// the store ran out; `st` then holds a resumable state.
 template <class Store>
 __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, float cs, Store& S, WalkState& st,
                     int lane) {
     const uint32_t mine = kMarkBit | k;
-    const int si = lane >> 3, ni = lane & 7;
-    const int dr = (ni == 2 || ni == 6 || ni == 7) ? 1 : ((ni == 3 || ni == 4 || ni == 5) ? -1 : 0);
-    const int dc = (ni == 0 || ni == 4 || ni == 6) ? -1 : ((ni == 1 || ni == 5 || ni == 7) ? 1 : 0);
-    const int noff = dr * A.w + dc;
+    const int lr = lane >> 3, lc = lane & 7;
+    const int tiles_y = (A.h + 7) >> 3;
     while (st.head != st.tail) {
-        S.sync();
-        const uint32_t avail = st.tail - st.head;
-        const uint32_t nsrc = avail < 8u ? avail : 8u;
-        // room for the worst case of 64 pushes (never onto a slot still to be read), head-room for 64 inserts
-        if (avail + 64u > S.ring_cap() || st.nforeign + 64u > S.hash_limit()) return 1;
+        if ((st.tail - st.head) + 8u > S.ring_cap() || st.nforeign + 1u > S.hash_limit()) return 1;
+        uint32_t tile;
+        uint64_t E;
+        S.get(st.head, tile, E);
+        st.head += 1;
+        const int ty = (int)(tile / (uint32_t)A.tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)A.tiles_x);
+        const int r = ty * 8 + lr, c = tx * 8 + lc;
+        const size_t q = (size_t)r * A.w + c;
+        uint32_t lab = 0;
+        bool acc = false;
+        if (r < A.h && c < A.w) {
+            lab = ld_agent(&A.label[q]);
+            if (lab >= kMarkBit && ((A.dmask[q] >> b) & 1)) acc = directional(A.dx[q], A.dy[q], sn, cs) > thr;
+        }
+        const uint64_t Am = __ballot(acc);
+        uint64_t R = E & Am;
+        if (R == 0ull) continue;
+        for (;;) {  // connected closure of the entry pixels inside the tile
+            const uint64_t Rn = dilate8(R) & Am;
+            if (Rn == R) break;
+            R = Rn;
+        }
+        const uint64_t Mine = __ballot(acc && lab == mine);
+        uint32_t slot;
+        const uint64_t VF = S.lookup(tile, slot);
+        const uint64_t New = R & ~(Mine | VF);
+        if (New == 0ull) continue;
         bool fresh = false, foreign = false;
-        uint32_t q = 0;
-        if ((uint32_t)si < nsrc) {
-            const uint32_t p = S.get(st.head + si);
-            q = p + noff;  // sources are never on the image border (dmask = 0 there)
-            const uint32_t lab = A.label[q];
-            if (lab >= kMarkBit && lab != mine && ((A.dmask[q] >> b) & 1) &&
-                directional(A.dx[q], A.dy[q], sn, cs) > thr) {
-                const uint32_t old = atomicMin(&A.label[q], mine);
-                if (old >= kMarkBit && old != mine) {
-                    if (old > mine) {  // free, or stamped by a higher seed that is hereby blocked
-                        fresh = true;
-                        if (old != kLabelFree) A.blocked[old & ~kMarkBit] = 1u;
-                    } else {  // a lower active seed reaches this pixel too
-                        foreign = true;
-                    }
-                }
+        if ((New >> lane) & 1ull) {
+            const uint32_t old = atomicMin(&A.label[q], mine);
+            if (old > mine) {  // free, or stamped by a higher seed that is hereby blocked
+                fresh = true;
+                if (old != kLabelFree) A.blocked[old & ~kMarkBit] = 1u;
+            } else if (old < mine && old >= kMarkBit) {  // a lower active seed reaches this pixel too
+                foreign = true;
             }
         }
-        if (foreign) fresh = S.insert(q + 1u);
-        const uint64_t mf = __ballot(foreign);
-        const uint64_t mfresh = __ballot(fresh);
-        const uint64_t mnewf = __ballot(fresh && foreign);
-        if (mf) st.blocked = true;
-        if (fresh) S.put(st.tail + (uint32_t)__popcll(mfresh & ((1ull << lane) - 1ull)), q);
-        st.tail += (uint32_t)__popcll(mfresh);
-        st.cnt += (uint32_t)__popcll(mfresh);
-        st.nforeign += (uint32_t)__popcll(mnewf);
-        st.head += nsrc;
+        const uint64_t Fr = __ballot(fresh), Fm = __ballot(foreign);
+        if (Fm) {
+            st.blocked = true;
+            if (S.update(slot, tile, VF | Fm)) st.nforeign += 1;
+        }
+        const uint64_t X = Fr | Fm;  // newly walked pixels: their neighbours outside the tile become entries
+        st.cnt += (uint32_t)__popcll(X);
+        if (X == 0ull) continue;
+        const bool has_l = tx > 0, has_r = tx + 1 < A.tiles_x, has_u = ty > 0, has_d = ty + 1 < tiles_y;
+        {
+            uint64_t m = (X & 0x8080808080808080ull) >> 7;  // col 7 -> col 0 of the right tile
+            m = m | (m << 8) | (m >> 8);
+            if (has_r && m) S.put(st.tail++, tile + 1u, m);
+            m = (X & 0x0101010101010101ull) << 7;  // col 0 -> col 7 of the left tile
+            m = m | (m << 8) | (m >> 8);
+            if (has_l && m) S.put(st.tail++, tile - 1u, m);
+            uint64_t t = X >> 56;  // row 7 -> row 0 of the tile below
+            t = (t | (t << 1) | (t >> 1)) & 0xFFull;
+            if (has_d && t) S.put(st.tail++, tile + (uint32_t)A.tiles_x, t);
+            t = X & 0xFFull;  // row 0 -> row 7 of the tile above
+            t = ((t | (t << 1) | (t >> 1)) & 0xFFull) << 56;
+            if (has_u && t) S.put(st.tail++, tile - (uint32_t)A.tiles_x, t);
+            if (has_d && has_r && (X >> 63)) S.put(st.tail++, tile + (uint32_t)A.tiles_x + 1u, 1ull);
+            if (has_d && has_l && ((X >> 56) & 1ull)) S.put(st.tail++, tile + (uint32_t)A.tiles_x - 1u, 1ull << 7);
+            if (has_u && has_r && ((X >> 7) & 1ull)) S.put(st.tail++, tile - (uint32_t)A.tiles_x + 1u, 1ull << 56);
+            if (has_u && has_l && (X & 1ull)) S.put(st.tail++, tile - (uint32_t)A.tiles_x - 1u, 1ull << 63);
+        }
     }
     return 0;
 }
 
 __global__ __launch_bounds__(256) void flood_explore_kernel(FloodArgs A, BinTrig trig, const uint32_t* __restrict__ act,
                                                             uint32_t n_act) {
-    __shared__ uint32_t s_ring[4][kRing];
-    __shared__ uint32_t s_hash[4][kHash];
+    __shared__ uint32_t s_ring[4][3][kRingT];
+    __shared__ uint32_t s_hash[4][3][kHashT];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t ai = blockIdx.x * 4 + wv;
     if (ai >= n_act) return;
@@ -285,30 +370,16 @@ __global__ __launch_bounds__(256) void flood_explore_kernel(FloodArgs A, BinTrig
     const int b = A.seed_bin[k];
     const float thr = A.seed_thr[k];
     const float sn = trig.st[b], cs = trig.ct[b];
-    const uint32_t mine = kMarkBit | k;
     if (A.label[s] < kMarkBit) return;  // claimed by an earlier flood: dead (found again by the compaction)
     if (!(((A.dmask[s] >> b) & 1) && directional(A.dx[s], A.dy[s], sn, cs) > thr)) {
         if (lane == 0) A.flags[k] = kFlagSelfFail;  // flood() accepts nothing, not even the seed
         return;
     }
-    LdsStore L{s_ring[wv], s_hash[wv]};
-    for (int i = lane; i < kHash; i += 64) L.hash[i] = 0u;
-    WalkState st{0u, 1u, 1u, 0u, false};
-    uint32_t old = 0;
-    if (lane == 0) {
-        old = atomicMin(&A.label[s], mine);
-        L.ring[0] = (uint32_t)s;
-    }
-    old = (uint32_t)__shfl((int)old, 0);
-    if (old != kLabelFree && old != mine) {
-        if (old > mine) {
-            if (lane == 0) A.blocked[old & ~kMarkBit] = 1u;
-        } else {
-            st.blocked = true;
-            if (lane == 0) L.insert((uint32_t)s + 1u);
-            st.nforeign = 1u;
-        }
-    }
+    LdsStore L{s_ring[wv][0], s_ring[wv][1], s_ring[wv][2], s_hash[wv][0], s_hash[wv][1], s_hash[wv][2]};
+    for (int i = lane; i < kHashT; i += 64) L.hk[i] = 0u;
+    const int sr = s / A.w, sc = s - sr * A.w;
+    WalkState st{0u, 1u, 0u, 0u, false};
+    L.put(0u, (uint32_t)((sr >> 3) * A.tiles_x + (sc >> 3)), 1ull << ((sr & 7) * 8 + (sc & 7)));
     int rc = walk(A, k, b, thr, sn, cs, L, st, lane);
     if (rc != 0) {
         // LDS storage exhausted: move the walk to a global slab and carry on
@@ -321,10 +392,19 @@ __global__ __launch_bounds__(256) void flood_explore_kernel(FloodArgs A, BinTrig
             gen = (uint32_t)__shfl((int)gen, 0);
             SlabStore G{A.slab_ring + (size_t)slab * A.slab_ring_cap, A.slab_hash + (size_t)slab * A.slab_hash_cap,
                         A.slab_ring_cap, A.slab_hash_cap, gen};
-            for (uint32_t i = st.head + lane; i != st.tail && (int32_t)(st.tail - i) > 0; i += 64) G.put(i, L.get(i));
-            for (int i = lane; i < kHash; i += 64) {
-                const uint32_t key = L.hash[i];
-                if (key) G.insert(key);
+            for (uint32_t i = st.head; i != st.tail; ++i) {
+                uint32_t t;
+                uint64_t m;
+                L.get(i, t, m);
+                G.put(i, t, m);
+            }
+            for (int i = 0; i < kHashT; ++i) {
+                const uint32_t key = L.hk[i];
+                if (key) {
+                    uint32_t slot;
+                    (void)G.lookup(key - 1u, slot);
+                    G.update(slot, key - 1u, ((uint64_t)L.hhi[i] << 32) | L.hlo[i]);
+                }
             }
             rc = walk(A, k, b, thr, sn, cs, G, st, lane);
         }
@@ -490,6 +570,8 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
     A.dy = dy;
     A.dmask = dmask;
     A.w = w;
+    A.h = h;
+    A.tiles_x = (w + 7) / 8;
     A.seed_idx = seed_idx;
     A.seed_bin = seed_bin;
     A.seed_thr = seed_thr;
@@ -498,8 +580,8 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
     A.count = B.count;
     A.flags = B.flags;
     A.ctrl = B.ctrl;
-    A.slab_ring = B.slab_ring;
-    A.slab_hash = (unsigned long long*)B.slab_hash;
+    A.slab_ring = (uint4*)B.slab_ring;
+    A.slab_hash = (uint4*)B.slab_hash;
     A.n_slabs = B.n_slabs;
     A.slab_ring_cap = B.slab_ring_cap;
     A.slab_hash_cap = B.slab_hash_cap;
@@ -523,6 +605,21 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
         hipLaunchKernelGGL(flood_explore_kernel, dim3((n_act + 3) / 4), dim3(256), 0, s, A, trig, act, n_act);
         hipLaunchKernelGGL(flood_decide_kernel, dim3((n_act + 255) / 256), dim3(256), 0, s, A, act, n_act, B.state,
                            seed_size);
+        if (debug) {
+            std::vector<uint32_t> cnt(n_seeds), blk(n_seeds);
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(cnt.data(), B.count, n_seeds * sizeof(uint32_t), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(blk.data(), B.blocked, n_seeds * sizeof(uint32_t), hipMemcpyDeviceToHost);
+            unsigned long long tot = 0, totb = 0;
+            uint32_t mx = 0, big = 0, nb = 0;
+            for (uint32_t i = 0; i < n_seeds; ++i) {
+                tot += cnt[i];
+                if (blk[i]) { totb += cnt[i]; ++nb; }
+                mx = std::max(mx, cnt[i]);
+                big += cnt[i] > 768;
+            }
+            std::fprintf(stderr, "  visits %llu (blocked seeds: %llu over %u seeds) max %u, >768: %u\n", tot, totb, nb, mx, big);
+        }
         hipLaunchKernelGGL(flood_commit_pixels_kernel, dim3(pix_blocks), dim3(256), 0, s, label, npix, B.state);
         hipLaunchKernelGGL(flood_survivors_kernel, dim3((n_act + 255) / 256), dim3(256), 0, s, A, act, n_act, B.state,
                            seed_size, B.alive);
@@ -533,9 +630,10 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
         LR_HIP(hipStreamSynchronize(s));
         const uint32_t n_commit = h_ctrl[kCtrlNCommit];
         const uint32_t n_next = h_ctrl[kCtrlNNext];
-        if (debug)
+        if (debug) {
             std::fprintf(stderr, "flood round %d: active %u committed %u next %u barrier %u slabs %u\n", rounds, n_act,
                          n_commit, n_next, h_ctrl[kCtrlBarrier], h_ctrl[kCtrlSlabs]);
+        }
         std::swap(act, act_next);
         const bool progress = n_commit > 0 || n_next < n_act;
         n_act = n_next;
@@ -549,7 +647,7 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
     }
     LR_HIP(hipGetLastError());
     if (h_ctrl[kCtrlGen] > 0xF0000000u) {  // generation counter about to wrap: forget every tagged hash entry
-        LR_HIP(hipMemsetAsync(B.slab_hash, 0, (size_t)B.n_slabs * B.slab_hash_cap * sizeof(uint64_t), s));
+        LR_HIP(hipMemsetAsync(B.slab_hash, 0, (size_t)B.n_slabs * B.slab_hash_cap * 16, s));
         LR_HIP(hipMemsetAsync(B.ctrl + kCtrlGen, 0, sizeof(uint32_t), s));
     }
     *rounds_out = rounds;
