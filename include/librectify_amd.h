@@ -108,6 +108,9 @@ enum lr_stage_id {
 };
 /* HIP-event times (ms) of the stages of the last call on this context. */
 int lr_stage_times(lr_context* ctx, float* ms, int count);
+/* Duration (ms) of the last fused filter kernel alone (HIP events around its launch); valid right after
+ * lr_stage_filter*, without running the later stages. */
+int lr_filter_kernel_ms(lr_context* ctx, float* ms);
 /* Extra counters of the last call: [0] seeds, [1] components, [2] flood rounds, [3] labelled pixels. */
 int lr_stage_counters(lr_context* ctx, int64_t* out, int count);
 

@@ -67,7 +67,7 @@ EXPORTS = [
     "lr_set_ransac_iterations", "lr_set_flood_mode", "lr_device_count", "lr_find_line_segment_groups_device",
     "lr_find_line_segment_groups_host", "lr_find_line_segment_groups_batch_device", "lr_stage_filter",
     "lr_stage_filter_host", "lr_stage_seeds", "lr_stage_flood", "lr_stage_fit", "lr_download", "lr_stage_times",
-    "lr_stage_counters", "lr_ransac_best", "lr_estimate_line_pencils",
+    "lr_stage_counters", "lr_filter_kernel_ms", "lr_ransac_best", "lr_estimate_line_pencils",
 ]
 
 _lib = None
@@ -121,6 +121,7 @@ def lib():
         L.lr_download.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.lr_stage_times.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.lr_stage_counters.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.lr_filter_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.lr_ransac_best.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         L.lr_estimate_line_pencils.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_uint64]
         _lib = L
@@ -225,6 +226,12 @@ class Context:
         t = np.zeros(T_COUNT, np.float32)
         _check(lib().lr_stage_times(self._h, _ptr(t), T_COUNT))
         return t
+
+    def stage_times_partial(self):
+        """ms of the last filter kernel alone (valid right after stage_filter_*)."""
+        ms = C.c_float(0)
+        _check(lib().lr_filter_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
 
     def stage_counters(self):
         c = np.zeros(4, np.int64)

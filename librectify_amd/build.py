@@ -22,8 +22,10 @@ SOURCES = [
 ]
 # -ffp-contract=off: every FMA in the canonical arithmetic is an explicit fmaf(); division and
 # sqrt stay correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
+# -fno-slp-vectorize: left alone, clang packs neighbouring scalar f32 FMAs into v_pk_fma_f32, which on gfx950
+# issues slower than the two v_fma_f32 it replaces (MI355X_MICROARCH.md, "price of one filler").
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
-         "-Wno-unused-function"]
+         "-Wno-unused-function", "-fno-slp-vectorize"]
 
 
 def _hipcc():

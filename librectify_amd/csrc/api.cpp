@@ -213,6 +213,12 @@ int lr_download(lr_context* ctx, int buffer_id, void* dst, size_t bytes) {
     return 0;
 }
 
+int lr_filter_kernel_ms(lr_context* ctx, float* ms) {
+    LR_HIP(hipStreamSynchronize(ctx->stream));
+    LR_HIP(hipEventElapsedTime(ms, ctx->ev[0], ctx->ev[1]));
+    return 0;
+}
+
 int lr_stage_times(lr_context* ctx, float* ms, int count) {
     for (int i = 0; i < count && i < LR_T_COUNT; ++i) ms[i] = ctx->stage_ms[i];
     return 0;

@@ -18,6 +18,9 @@
 // form shared with the CPU oracle: acc = fmaf(img, K, acc) in row-major tap order,
 // mag = sqrtf(dx*dx + dy*dy) without contraction, bin = first strict argmax of
 // |fmaf(dx, sin, dy*cos)|.
+#include <cstdlib>
+#include <cstring>
+
 #include "common.h"
 
 namespace lramd {
@@ -29,14 +32,27 @@ constexpr int CW = 72;  // conv region: cols x0-4 .. x0+67, rows y0-2 .. y0+33
 constexpr int CH = 36;
 constexpr int CSTRIPS = CW / 4;
 
+// The 5x5 Gaussian-derivative taps as the host computes them (filter.cpp:72-75) satisfy, bit for bit,
+//   Hx[i][j] = -Hx[i][4-j] = Hx[4-i][j],  Hx[i][2] = +0      Hy[i][j] = Hx[j][i]
+// (the sign enters only through z, and exp() sees the same argument), so six magnitudes describe
+// both kernels.  The kernel keeps them in SGPRs; a negated tap is an FMA source modifier, and the
+// zero taps are skipped: fmaf(v, +0, acc) == acc for every finite v because acc is never -0
+// (it starts at +0 and x + (-x) rounds to +0).
+struct FilterTaps {
+    float k[3][2];    // Hx[i][j] for i = 0..2 (|y| = 2,1,0), j = 0..1 (x = -2,-1)
+    float st[kBins];
+    float ct[kBins];
+};
+
 __global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ img, int w, int h, int stride,
-                                                     FilterConsts fc, float* __restrict__ dx_out,
+                                                     FilterTaps fc, float* __restrict__ dx_out,
                                                      float* __restrict__ dy_out, uint8_t* __restrict__ dmask_out,
                                                      uint64_t* __restrict__ cand, uint32_t* __restrict__ cand_count,
                                                      uint32_t* __restrict__ tile_max) {
     __shared__ __attribute__((aligned(16))) float s_img[IH][IW];
     __shared__ __attribute__((aligned(16))) float s_mag[CH][CW];
-    __shared__ __attribute__((aligned(16))) uint8_t s_bin[CH][CW];
+    __shared__ __attribute__((aligned(16))) uint8_t s_bin[CH][CW];       // bin index (for the peak records)
+    __shared__ __attribute__((aligned(16))) uint8_t s_bit[CH][CW + 8];   // 1 << bin, stored one column to the right
     __shared__ uint32_t s_cnt;
     __shared__ float s_wmax[4];
 
@@ -45,12 +61,27 @@ __global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ i
     const int y0 = blockIdx.y * kTileH;
     const uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;
 
-    for (int i = tid; i < IH * IW; i += 256) {
-        int r = i / IW, c = i - r * IW;
-        int y = y0 - 4 + r, x = x0 - 6 + c;
-        float v = 0.f;
-        if (y >= 0 && y < h && x >= 0 && x < w) v = img[(size_t)y * stride + x];
-        s_img[r][c] = v;
+    // image tile: 20 aligned float4 groups per row (x0-8 .. x0+71); the LDS copy starts at x0-6 so
+    // that the 5x8 conv windows are 16-B aligned, hence each group lands as two 8-B halves
+    const bool in_vec = ((stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(img) & 15) == 0);
+    for (int i = tid; i < IH * 20; i += 256) {
+        const int r = i / 20, m = i - r * 20;
+        const int y = y0 - 4 + r, x = x0 - 8 + 4 * m;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y >= 0 && y < h) {
+            const float* row = img + (size_t)y * stride;
+            if (in_vec && x >= 0 && x + 3 < w) {
+                v = *reinterpret_cast<const float4*>(row + x);
+            } else {
+                if (x >= 0 && x < w) v.x = row[x];
+                if (x + 1 >= 0 && x + 1 < w) v.y = row[x + 1];
+                if (x + 2 >= 0 && x + 2 < w) v.z = row[x + 2];
+                if (x + 3 >= 0 && x + 3 < w) v.w = row[x + 3];
+            }
+        }
+        const int c = 4 * m - 2;
+        if (m > 0) *reinterpret_cast<float2*>(&s_img[r][c]) = make_float2(v.x, v.y);
+        if (m < 19) *reinterpret_cast<float2*>(&s_img[r][c + 2]) = make_float2(v.z, v.w);
     }
     if (tid == 0) s_cnt = 0;
     __syncthreads();
@@ -74,9 +105,16 @@ __global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ i
 #pragma unroll
             for (int i = 0; i < 5; ++i)
 #pragma unroll
-                for (int j = 0; j < 5; ++j) {
-                    ax = fmaf(win[i][j + p], fc.kx[i * 5 + j], ax);
-                    ay = fmaf(win[i][j + p], fc.ky[i * 5 + j], ay);
+                for (int j = 0; j < 5; ++j) {  // row-major tap order, as the oracle
+                    const int ii = i < 3 ? i : 4 - i, jj = j < 3 ? j : 4 - j;
+                    if (j != 2) {
+                        const float kx = fc.k[ii][jj];  // |Hx[i][j]|, sign by column
+                        ax = (j < 2) ? fmaf(win[i][j + p], kx, ax) : fmaf(win[i][j + p], -kx, ax);
+                    }
+                    if (i != 2) {
+                        const float ky = fc.k[jj][ii];  // Hy = Hx^T
+                        ay = (i < 2) ? fmaf(win[i][j + p], ky, ay) : fmaf(win[i][j + p], -ky, ay);
+                    }
                 }
             ddx[p] = ax;
             ddy[p] = ay;
@@ -105,6 +143,7 @@ __global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ i
             }
             s_mag[sr][4 * sc + p] = m;
             s_bin[sr][4 * sc + p] = (uint8_t)bin;
+            s_bit[sr][4 * sc + p + 1] = (uint8_t)(1u << bin);
         }
         // core strips write dx, dy straight from registers
         if (sr >= 2 && sr < CH - 2 && sc >= 1 && sc <= 16 && y < h && xb < w) {
@@ -140,6 +179,17 @@ __global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ i
         }
         const bool row_in = (y >= 2) && (y < h - 2);
         const bool row_border = (y == 0) || (y == h - 1);
+        // dilated-bin mask of the 4 pixels at once: the 3x3 windows span conv cols 4cs+3 .. 4cs+8, i.e. the
+        // two aligned words at s_bit cols 4cs+4 and 4cs+8 of rows cr+1 .. cr+3; byte p of
+        // (W | W>>8 | W>>16) is the OR of bytes p..p+2
+        uint32_t dm4 = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const uint32_t lo = *reinterpret_cast<const uint32_t*>(&s_bit[cr + 1 + i][4 * cs + 4]);
+            const uint32_t hi = *reinterpret_cast<const uint32_t*>(&s_bit[cr + 1 + i][4 * cs + 8]);
+            const uint64_t W = ((uint64_t)hi << 32) | lo;
+            dm4 |= (uint32_t)(W | (W >> 8) | (W >> 16));
+        }
         uint8_t dm[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -151,14 +201,8 @@ __global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ i
                 float mx = colmax[p];
 #pragma unroll
                 for (int j = 1; j < 5; ++j) mx = fmaxf(mx, colmax[p + j]);
-                uint32_t mask = 0;
-                if (!row_border && x != 0 && x != w - 1) {  // binary_dilate leaves a 1-px zero border (filter.cpp:52-61)
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) mask |= 1u << s_bin[cr + 1 + i][4 * cs + 3 + p + j];
-                }
-                dm[p] = (uint8_t)mask;
+                // binary_dilate leaves a 1-px zero border (filter.cpp:52-61)
+                dm[p] = (!row_border && x != 0 && x != w - 1) ? (uint8_t)(dm4 >> (8 * p)) : (uint8_t)0;
                 const bool peak = row_in && (x >= 2) && (x < w - 2) && (center > 0.f) && (center == mx);
                 if (peak) {
                     const uint32_t slot = atomicAdd(&s_cnt, 1u);
@@ -202,8 +246,26 @@ int launch_filter(const float* img, int w, int h, int stride, const FilterConsts
         set_error("launch_filter: image larger than 2^29 pixels is not supported (seed key packs index in 29 bits)");
         return 1;
     }
+    FilterTaps ft;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 2; ++j) ft.k[i][j] = fc.kx[i * 5 + j];
+    // the symmetry the kernel relies on is a property of the host's libm results: verify, never assume
+    for (int i = 0; i < 5; ++i)
+        for (int j = 0; j < 5; ++j) {
+            const int ii = i < 3 ? i : 4 - i, jj = j < 3 ? j : 4 - j;
+            const float ex = (j == 2) ? 0.f : (j < 2 ? ft.k[ii][jj] : -ft.k[ii][jj]);
+            const float ey = (i == 2) ? 0.f : (i < 2 ? ft.k[jj][ii] : -ft.k[jj][ii]);
+            if (!(ex == fc.kx[i * 5 + j]) || !(ey == fc.ky[i * 5 + j])) {
+                set_error("launch_filter: derivative taps are not (anti)symmetric on this host");
+                return 1;
+            }
+        }
+    for (int b = 0; b < kBins; ++b) {
+        ft.st[b] = fc.st[b];
+        ft.ct[b] = fc.ct[b];
+    }
     dim3 grid(tiles_x(w), tiles_y(h));
-    hipLaunchKernelGGL(filter_kernel, grid, dim3(256), 0, s, img, w, h, stride, fc, dx, dy, dmask, cand, cand_count,
+    hipLaunchKernelGGL(filter_kernel, grid, dim3(256), 0, s, img, w, h, stride, ft, dx, dy, dmask, cand, cand_count,
                        tile_max);
     LR_HIP(hipGetLastError());
     return 0;
