@@ -25,7 +25,12 @@ SOURCES = [
 # -fno-slp-vectorize: left alone, clang packs neighbouring scalar f32 FMAs into v_pk_fma_f32, which on gfx950
 # issues slower than the two v_fma_f32 it replaces (MI355X_MICROARCH.md, "price of one filler").
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
-         "-Wno-unused-function", "-fno-slp-vectorize"]
+         "-Wno-unused-function", "-fno-slp-vectorize"] + os.environ.get("LR_EXTRA_FLAGS", "").split()
+
+
+# kernels_filter.hip: inputs are finite by contract (the reference divides/compares them freely as well), so the
+# max-chains need no sNaN quieting: without the IEEE mode bit v_max_f32 is a single instruction.
+PER_FILE_FLAGS = {"kernels_filter.hip": os.environ.get("LR_FILTER_FLAGS", "-fno-honor-nans -mno-amdgpu-ieee").split()}
 
 
 def _hipcc():
@@ -57,7 +62,8 @@ def build(force=False, verbose=True):
     for src in SOURCES:
         obj = os.path.join(objdir, src + ".o")
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        extra = PER_FILE_FLAGS.get(src, [])
+        cmd = [hipcc] + FLAGS + extra + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     failed = False
     for src, p in procs:

@@ -85,13 +85,18 @@ void set_error(const std::string& msg);
 // kernels_filter.hip
 int launch_filter(const float* img, int w, int h, int stride, const FilterConsts& fc, float* dx, float* dy,
                   uint8_t* dmask, uint64_t* cand, uint32_t* cand_count, uint32_t* tile_max, hipStream_t s);
+struct FilterGeom {
+    int n_tiles;   // candidate lists written by the filter (tiles or bands, by kernel variant)
+    int cand_cap;  // slots per list
+};
+FilterGeom filter_geometry(int w, int h);
 inline int tiles_x(int w) { return (w + kTileW - 1) / kTileW; }
 inline int tiles_y(int h) { return (h + kTileH - 1) / kTileH; }
 
 // kernels_seeds.hip
 size_t seeds_temp_bytes(int n_tiles, size_t max_seeds);
 int launch_seed_select(const uint64_t* cand, const uint32_t* cand_count, const uint32_t* tile_max, int n_tiles,
-                       float seed_keep_ratio, float* maxmag, uint32_t* tile_pass, uint32_t* tile_off, uint64_t* keys,
+                       int cand_cap, float seed_keep_ratio, float* maxmag, uint32_t* tile_pass, uint32_t* tile_off, uint64_t* keys,
                        uint32_t* n_seeds, void* temp, size_t temp_bytes, hipStream_t s);
 int launch_seed_sort(uint64_t* keys_in, uint64_t* keys_out, uint32_t n, void* temp, size_t temp_bytes, hipStream_t s);
 int launch_seed_setup(const uint64_t* keys_sorted, uint32_t n, const float* dx, const float* dy, BinTrig trig,

@@ -67,13 +67,14 @@ const std::string& get_error() { return g_error; }
 
 int ctx_ensure_image_capacity(lr_context* c, int w, int h) {
     const size_t npix = (size_t)w * h;
-    const int ntiles = tiles_x(w) * tiles_y(h);
+    const FilterGeom fg = filter_geometry(w, h);
+    const int ntiles = fg.n_tiles;
     if (npix <= c->cap_pix && ntiles <= c->cap_tiles) return 0;
     LR_HIP(hipStreamSynchronize(c->stream));
     const size_t cp = std::max(npix, c->cap_pix);
     const int ct = std::max(ntiles, c->cap_tiles);
     if (dev_alloc(c->d_img, cp) || dev_alloc(c->dx, cp) || dev_alloc(c->dy, cp) || dev_alloc(c->dmask, cp + 16) ||
-        dev_alloc(c->cand, (size_t)ct * kCandPerTile) || dev_alloc(c->cand_count, ct) || dev_alloc(c->tile_max, ct) ||
+        dev_alloc(c->cand, (size_t)ct * std::max(fg.cand_cap, (int)kCandPerTile)) || dev_alloc(c->cand_count, ct) || dev_alloc(c->tile_max, ct) ||
         dev_alloc(c->tile_pass, ct) || dev_alloc(c->tile_off, ct) || dev_alloc(c->keys_a, cp) ||
         dev_alloc(c->keys_b, cp) || dev_alloc(c->seed_idx, cp) || dev_alloc(c->seed_bin, cp) ||
         dev_alloc(c->seed_thr, cp) || dev_alloc(c->seed_size, cp) || dev_alloc(c->label, cp) ||
@@ -222,8 +223,8 @@ int ctx_stage_seeds(lr_context* c) {
         set_error("lr_stage_seeds: run lr_stage_filter first");
         return 1;
     }
-    const int ntiles = tiles_x(c->w) * tiles_y(c->h);
-    if (launch_seed_select(c->cand, c->cand_count, c->tile_max, ntiles, c->seed_keep_ratio, c->maxmag, c->tile_pass,
+    const FilterGeom fg = filter_geometry(c->w, c->h);
+    if (launch_seed_select(c->cand, c->cand_count, c->tile_max, fg.n_tiles, fg.cand_cap, c->seed_keep_ratio, c->maxmag, c->tile_pass,
                            c->tile_off, c->keys_a, c->d_counts, c->temp, c->temp_bytes, c->stream))
         return 1;
     LR_HIP(hipMemcpyAsync(c->h_counts, c->d_counts, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));

@@ -31,14 +31,14 @@ __global__ __launch_bounds__(256) void reduce_max_kernel(const uint32_t* __restr
 // one wave per tile
 __global__ __launch_bounds__(256) void seed_count_kernel(const uint64_t* __restrict__ cand,
                                                          const uint32_t* __restrict__ cand_count, int n_tiles,
-                                                         const float* __restrict__ maxmag, float keep_ratio,
-                                                         uint32_t* __restrict__ tile_pass) {
+                                                         int cand_cap, const float* __restrict__ maxmag,
+                                                         float keep_ratio, uint32_t* __restrict__ tile_pass) {
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (tile >= n_tiles) return;
     const float thr = *maxmag * keep_ratio;
     const uint32_t n = cand_count[tile];
-    const uint64_t* c = cand + (size_t)tile * kCandPerTile;
+    const uint64_t* c = cand + (size_t)tile * cand_cap;
     uint32_t cnt = 0;
     for (uint32_t i = lane; i < n; i += 64) cnt += (__uint_as_float((uint32_t)(c[i] >> 32)) > thr) ? 1u : 0u;
 #pragma unroll
@@ -48,8 +48,8 @@ __global__ __launch_bounds__(256) void seed_count_kernel(const uint64_t* __restr
 
 __global__ __launch_bounds__(256) void seed_write_kernel(const uint64_t* __restrict__ cand,
                                                          const uint32_t* __restrict__ cand_count, int n_tiles,
-                                                         const float* __restrict__ maxmag, float keep_ratio,
-                                                         const uint32_t* __restrict__ tile_pass,
+                                                         int cand_cap, const float* __restrict__ maxmag,
+                                                         float keep_ratio, const uint32_t* __restrict__ tile_pass,
                                                          const uint32_t* __restrict__ tile_off,
                                                          uint64_t* __restrict__ keys, uint32_t* __restrict__ n_seeds) {
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void seed_write_kernel(const uint64_t* __restr
     if (tile >= n_tiles) return;
     const float thr = *maxmag * keep_ratio;
     const uint32_t n = cand_count[tile];
-    const uint64_t* c = cand + (size_t)tile * kCandPerTile;
+    const uint64_t* c = cand + (size_t)tile * cand_cap;
     uint32_t base = tile_off[tile];
     for (uint32_t i0 = 0; i0 < n; i0 += 64) {
         const uint32_t i = i0 + lane;
@@ -105,15 +105,15 @@ size_t seeds_temp_bytes(int n_tiles, size_t max_seeds) {
 }
 
 int launch_seed_select(const uint64_t* cand, const uint32_t* cand_count, const uint32_t* tile_max, int n_tiles,
-                       float seed_keep_ratio, float* maxmag, uint32_t* tile_pass, uint32_t* tile_off, uint64_t* keys,
+                       int cand_cap, float seed_keep_ratio, float* maxmag, uint32_t* tile_pass, uint32_t* tile_off, uint64_t* keys,
                        uint32_t* n_seeds, void* temp, size_t temp_bytes, hipStream_t s) {
     hipLaunchKernelGGL(reduce_max_kernel, dim3(1), dim3(256), 0, s, tile_max, n_tiles, maxmag);
     const int blocks = (n_tiles + 3) / 4;
-    hipLaunchKernelGGL(seed_count_kernel, dim3(blocks), dim3(256), 0, s, cand, cand_count, n_tiles, maxmag,
+    hipLaunchKernelGGL(seed_count_kernel, dim3(blocks), dim3(256), 0, s, cand, cand_count, n_tiles, cand_cap, maxmag,
                        seed_keep_ratio, tile_pass);
     LR_HIP(rocprim::exclusive_scan(temp, temp_bytes, tile_pass, tile_off, 0u, (size_t)n_tiles,
                                    rocprim::plus<uint32_t>(), s));
-    hipLaunchKernelGGL(seed_write_kernel, dim3(blocks), dim3(256), 0, s, cand, cand_count, n_tiles, maxmag,
+    hipLaunchKernelGGL(seed_write_kernel, dim3(blocks), dim3(256), 0, s, cand, cand_count, n_tiles, cand_cap, maxmag,
                        seed_keep_ratio, tile_pass, tile_off, keys, n_seeds);
     LR_HIP(hipGetLastError());
     return 0;
