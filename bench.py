@@ -53,6 +53,17 @@ def make_frames(n, w, h, seed0):
     return out
 
 
+def pmc_traffic(w, h):
+    """HBM bytes per filter launch from the committed PMC pass (4K frame); None for other sizes."""
+    path = os.path.join(ROOT, "profiles", "r01_c_pmc_filter_traffic.txt")
+    if (w, h) != (W4K, H4K) or not os.path.exists(path):
+        return None
+    for line in open(path):
+        if line.startswith("traffic_bytes_per_launch"):
+            return float(line.split()[1])
+    return None
+
+
 def cpu_baseline(frames, w, h, min_length, budget_s=14.0):
     """CPU oracle on a bounded sample of the same workload (kind 'port': the Eigen reference is
     unbuildable here).  Only this leg of bench.py touches oracle/."""
@@ -184,10 +195,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
+    # roofline leg (after the timed region): the filter kernel alone, one launch at a time on one stream, over
+    # the same resident frames, timed with the HIP events the library records around the launch
+    iso = []
+    if rank == 0:
+        c0 = ctxs[0]
+        for lap in range(3):
+            for b in range(B):
+                c0.stage_filter_device(base + b * h * w * 4, w, h)
+                c0.synchronize()
+                if lap > 0:
+                    iso.append(c0.stage_times_partial())
+
     if rank == 0:
         total_px = float(n_gpus) * B * w * h * args.steps
         value = total_px / el / 1e6
-        kdur_ms = float(np.mean(filt_ms)) if filt_ms else float("nan")
+        kdur_ms = float(np.mean(iso)) if iso else float("nan")
         achieved = ALGO_BYTES_PER_PX * w * h / (kdur_ms * 1e-3) / 1e9
         nfr = max(1, len(filt_ms))
         res = {
@@ -213,13 +236,15 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "filter_kernel (fused 5x5 derivative + magnitude + bin + dilated mask + NMS candidates)",
+                "kernel": "filter_lanes_kernel (row-streaming fused 5x5 derivative + magnitude + bin + dilated mask + NMS candidates)",
                 "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": pmc_traffic(w, h),
+                "traffic_source": "profiles/r01_c_pmc_filter_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2.000 calibrated on a 2 GiB read of the same 4 B/lane shape)",
                 "kernel_ms": round(kdur_ms, 5),
+                "kernel_ms_in_pipeline": round(float(np.mean(filt_ms)), 5) if filt_ms else None,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PX * w * h,
             },
             "stage_ms_per_frame": {
