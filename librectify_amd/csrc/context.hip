@@ -100,19 +100,19 @@ static int ensure_flood_buffers(lr_context* c) {
     if (dev_alloc(f.blocked, cs) || dev_alloc(f.count, cs) || dev_alloc(f.flags, cs) || dev_alloc(f.state, cs) ||
         dev_alloc(f.alive, cs) || dev_alloc(f.act_a, cs) || dev_alloc(f.act_b, cs) || dev_alloc(f.ctrl, 16))
         return 1;
-    f.n_slabs = 2048;  // 2048 x 512 KB = 1 GB of the 288 GB: enough for every weak seed of a 4K frame that must walk a long edge
+    f.n_slabs = 512;  // 512 x 2.25 MB = 1.1 GB of the 288 GB; only walks over more than ~190 tiles leave LDS
     if (const char* e = std::getenv("LIBRECTIFY_FLOOD_SLABS")) f.n_slabs = (uint32_t)std::max(1, std::atoi(e));
     f.slab_ring_cap = 1u << 14;  // (tile, entry mask) records, 16 B each
-    f.slab_hash_cap = 1u << 14;  // tile -> foreign-pixel mask records, 16 B each (12 Ki tiles = 786 Ki pixels)
+    f.slab_hash_cap = 1u << 16;  // tile -> (walked, acceptable) records, 32 B each (48 Ki tiles = 3 M pixels)
     {
         uint4* r = (uint4*)f.slab_ring;
         uint4* hsh = (uint4*)f.slab_hash;
-        if (dev_alloc(r, (size_t)f.n_slabs * f.slab_ring_cap) || dev_alloc(hsh, (size_t)f.n_slabs * f.slab_hash_cap))
+        if (dev_alloc(r, (size_t)f.n_slabs * f.slab_ring_cap) || dev_alloc(hsh, (size_t)f.n_slabs * f.slab_hash_cap * 2))
             return 1;
         f.slab_ring = r;
         f.slab_hash = hsh;
     }
-    LR_HIP(hipMemsetAsync(f.slab_hash, 0, (size_t)f.n_slabs * f.slab_hash_cap * 16, c->stream));
+    LR_HIP(hipMemsetAsync(f.slab_hash, 0, (size_t)f.n_slabs * f.slab_hash_cap * 32, c->stream));
     LR_HIP(hipMemsetAsync(f.ctrl, 0, 16 * sizeof(uint32_t), c->stream));
     f.select_temp_bytes = flood_select_temp_bytes((uint32_t)std::min<size_t>(cs, 0xFFFFFFFFu));
     if (f.select_temp) (void)hipFree(f.select_temp);

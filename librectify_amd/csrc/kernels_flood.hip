@@ -143,8 +143,8 @@ namespace {
 // =============================================================================================
 
 constexpr uint32_t kMarkBit = 0x80000000u;
-constexpr int kRingT = 256;  // per-wave LDS frontier ring: (tile, entry mask) records
-constexpr int kHashT = 256;  // per-wave LDS hash: tile -> mask of foreign pixels already walked
+constexpr int kRingT = 128;  // per-wave LDS frontier ring: (tile, entry mask) records
+constexpr int kHashT = 256;  // per-wave LDS tile table: tile -> (pixels walked, pixels acceptable)
 constexpr uint32_t kFlagIncomplete = 1u, kFlagSelfFail = 2u;
 
 struct FloodArgs {
@@ -161,35 +161,47 @@ struct FloodArgs {
     uint32_t* flags;    // per seed
     uint32_t* ctrl;     // kCtrl* words
     uint4* slab_ring;   // n_slabs x slab_ring_cap records {tile, -, mask.lo, mask.hi}
-    uint4* slab_hash;   // n_slabs x slab_hash_cap records {generation, tile+1, mask.lo, mask.hi}
+    uint4* slab_hash;   // n_slabs x slab_hash_cap x 2 records {generation, tile+1, V.lo, V.hi} {A.lo, A.hi, -, -}
     uint32_t n_slabs, slab_ring_cap, slab_hash_cap;  // caps are powers of two
 };
 // words 0..7 are reset every frame; kCtrlGen lives on for the lifetime of the slab memory (hash entries are
 // tagged with it, so a generation must never be reused while old entries are around)
 enum { kCtrlBarrier = 0, kCtrlSlabs = 1, kCtrlNCommit = 3, kCtrlNNext = 4, kCtrlError = 5, kCtrlGen = 8 };
 
+// Frontier records, table entries and ballots are the same in all 64 lanes.  Saying so (readfirstlane) lets the
+// compiler keep them in SGPRs and run the bit-board logic on the scalar unit instead of the vector ALU.
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uni64(uint32_t lo, uint32_t hi) { return ((uint64_t)uni(hi) << 32) | uni(lo); }
+__device__ __forceinline__ uint64_t uni64(uint64_t v) { return uni64((uint32_t)v, (uint32_t)(v >> 32)); }
+
 struct WalkState {
-    uint32_t head, tail, cnt, nforeign;
+    uint32_t head, tail, cnt, ntiles;
     bool blocked;
+    uint32_t steps;  // frontier records popped (diagnostics)
 };
 
 // The walk works on 8x8 pixel tiles, one tile per step, one pixel per lane: the acceptance test of the
 // whole tile is a 64-bit ballot, connectivity inside the tile is a handful of scalar shift/and
 // operations on that mask, and the frontier holds (tile, entry-mask) records instead of pixels.
+// Each wave keeps a private table tile -> (V = pixels it has walked, A = pixels that pass the acceptance
+// test): a record that re-enters a known tile is resolved from the table alone, without touching memory,
+// and walked pixels stamped by lower seeds are remembered there too, so the walk terminates.
 // All store operations below are wave-uniform (every lane performs the same access).
 struct LdsStore {
     uint32_t* rt;   // ring: tile
     uint32_t* rlo;  // ring: entry mask
     uint32_t* rhi;
-    uint32_t* hk;   // hash: tile + 1 (0 = empty)
-    uint32_t* hlo;
-    uint32_t* hhi;
+    uint32_t* hk;   // table: tile + 1 (0 = empty)
+    uint32_t* hv0;  // V
+    uint32_t* hv1;
+    uint32_t* ha0;  // A
+    uint32_t* ha1;
     __device__ uint32_t ring_cap() const { return kRingT; }
     __device__ uint32_t hash_limit() const { return kHashT * 3 / 4; }
     __device__ void get(uint32_t i, uint32_t& tile, uint64_t& m) const {
         const uint32_t j = i & (kRingT - 1);
-        tile = rt[j];
-        m = ((uint64_t)rhi[j] << 32) | rlo[j];
+        tile = uni(rt[j]);
+        m = uni64(rlo[j], rhi[j]);
     }
     __device__ void put(uint32_t i, uint32_t tile, uint64_t m) {
         const uint32_t j = i & (kRingT - 1);
@@ -197,27 +209,32 @@ struct LdsStore {
         rlo[j] = (uint32_t)m;
         rhi[j] = (uint32_t)(m >> 32);
     }
-    __device__ uint64_t lookup(uint32_t tile, uint32_t& slot) const {
+    // returns true if the tile is known; slot = where it is or where it would go
+    __device__ bool lookup(uint32_t tile, uint32_t& slot, uint64_t& V, uint64_t& Am) const {
         const uint32_t key = tile + 1u;
         uint32_t hs = (key * 2654435761u) >> 24;  // 8 bits
         for (int probe = 0; probe < kHashT; ++probe) {
-            const uint32_t cur = hk[hs];
+            const uint32_t cur = uni(hk[hs]);
             if (cur == key) {
                 slot = hs;
-                return ((uint64_t)hhi[hs] << 32) | hlo[hs];
+                V = uni64(hv0[hs], hv1[hs]);
+                Am = uni64(ha0[hs], ha1[hs]);
+                return true;
             }
             if (cur == 0u) break;
             hs = (hs + 1) & (kHashT - 1);
         }
         slot = hs;
-        return 0ull;
+        V = 0ull;
+        Am = 0ull;
+        return false;
     }
-    __device__ bool update(uint32_t slot, uint32_t tile, uint64_t m) {
-        const bool ins = hk[slot] == 0u;
+    __device__ void update(uint32_t slot, uint32_t tile, uint64_t V, uint64_t Am) {
         hk[slot] = tile + 1u;
-        hlo[slot] = (uint32_t)m;
-        hhi[slot] = (uint32_t)(m >> 32);
-        return ins;
+        hv0[slot] = (uint32_t)V;
+        hv1[slot] = (uint32_t)(V >> 32);
+        ha0[slot] = (uint32_t)Am;
+        ha1[slot] = (uint32_t)(Am >> 32);
     }
 };
 
@@ -245,33 +262,65 @@ struct SlabStore {
     }
     __device__ void get(uint32_t i, uint32_t& tile, uint64_t& m) const {
         const uint4 v = ld(&ring[i & (rcap - 1)]);
-        tile = v.x;
-        m = ((uint64_t)v.w << 32) | v.z;
+        tile = uni(v.x);
+        m = uni64(v.z, v.w);
     }
     __device__ void put(uint32_t i, uint32_t tile, uint64_t m) {
         st(&ring[i & (rcap - 1)], make_uint4(tile, 0u, (uint32_t)m, (uint32_t)(m >> 32)));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
-    __device__ uint64_t lookup(uint32_t tile, uint32_t& slot) const {
+    __device__ bool lookup(uint32_t tile, uint32_t& slot, uint64_t& V, uint64_t& Am) const {
         const uint32_t key = tile + 1u;
         uint32_t hs = (key * 2654435761u) & (hcap - 1);
         for (uint32_t probe = 0; probe < hcap; ++probe) {
-            const uint4 v = ld(&hash[hs]);
-            if (v.x != gen) break;  // another generation's record reads as empty
-            if (v.y == key) {
+            const uint4 v = ld(&hash[2 * hs]);
+            if (uni(v.x) != gen) break;  // another generation's record reads as empty
+            if (uni(v.y) == key) {
+                const uint4 a = ld(&hash[2 * hs + 1]);
                 slot = hs;
-                return ((uint64_t)v.w << 32) | v.z;
+                V = uni64(v.z, v.w);
+                Am = uni64(a.x, a.y);
+                return true;
             }
             hs = (hs + 1) & (hcap - 1);
         }
         slot = hs;
-        return 0ull;
+        V = 0ull;
+        Am = 0ull;
+        return false;
     }
-    __device__ bool update(uint32_t slot, uint32_t tile, uint64_t m) {
-        const bool ins = ld(&hash[slot]).x != gen;
-        st(&hash[slot], make_uint4(gen, tile + 1u, (uint32_t)m, (uint32_t)(m >> 32)));
+    __device__ void update(uint32_t slot, uint32_t tile, uint64_t V, uint64_t Am) {
+        st(&hash[2 * slot + 1], make_uint4((uint32_t)Am, (uint32_t)(Am >> 32), 0u, 0u));
+        st(&hash[2 * slot], make_uint4(gen, tile + 1u, (uint32_t)V, (uint32_t)(V >> 32)));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        return ins;
+    }
+};
+
+// Frontier de-duplication: a small direct-mapped table (tile -> ring index of its not-yet-fetched record).
+// A thin ridge re-enters the same tile from several neighbours; merging those entries into the pending
+// record saves a whole step (a memory round trip) per duplicate.
+constexpr int kPend = 64;
+struct Pending {
+    uint32_t* pt;  // tile + 1
+    uint32_t* pi;  // ring index
+    template <class Store>
+    __device__ __forceinline__ void push(Store& S, WalkState& st, uint32_t tile, uint64_t m) {
+        const uint32_t hs = ((tile + 1u) * 2654435761u) >> 26;  // 6 bits
+        const uint32_t idx = uni(pi[hs]);
+        // mergeable iff that record is still beyond the one already prefetched (index st.head)
+        if (uni(pt[hs]) == tile + 1u && (int32_t)(idx - st.head) > 0 && (int32_t)(st.tail - idx) > 0) {
+            uint32_t t2;
+            uint64_t m2;
+            S.get(idx, t2, m2);
+            if (t2 == tile) {
+                S.put(idx, tile, m2 | m);
+                return;
+            }
+        }
+        S.put(st.tail, tile, m);
+        pt[hs] = tile + 1u;
+        pi[hs] = st.tail;
+        st.tail += 1;
     }
 };
 
@@ -283,104 +332,171 @@ __device__ inline uint64_t dilate8(uint64_t r) {
 
 // Walks the footprint of seed k from the state in `st`.  Returns 0 when the walk is complete, 1 when
 // the store ran out; `st` then holds a resumable state.
+// What one lane holds of a frontier record before it is processed.  For a tile the wave already knows, the
+// table answers (V, A) and no memory is touched; otherwise the lane's pixel of the tile is loaded.
+struct TileFetch {
+    uint32_t tile, slot;
+    uint64_t entry, V, Am;
+    size_t q;
+    uint32_t lab;
+    float dx, dy;
+    uint32_t dm;
+    bool known, inside;
+};
+
 template <class Store>
-__device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, float cs, Store& S, WalkState& st,
-                    int lane) {
+__device__ __forceinline__ TileFetch fetch_tile(const FloodArgs& A, const Store& S, uint32_t i, int lr, int lc) {
+    TileFetch f;
+    S.get(i, f.tile, f.entry);
+    const int ty = (int)(f.tile >> 16), tx = (int)(f.tile & 0xFFFFu);  // tile id = ty << 16 | tx
+    const int r = ty * 8 + lr, c = tx * 8 + lc;
+    f.inside = r < A.h && c < A.w;
+    f.q = f.inside ? (size_t)r * A.w + c : 0;
+    f.known = S.lookup(f.tile, f.slot, f.V, f.Am);
+    f.lab = 0u;
+    f.dm = 0u;
+    f.dx = f.dy = 0.f;
+    if (!f.known) {  // wave-uniform
+        f.lab = A.label[f.q];  // only the committed/not-committed split is read from it, and that is stable in a round
+        f.dm = A.dmask[f.q];
+        f.dx = A.dx[f.q];
+        f.dy = A.dy[f.q];
+    }
+    return f;
+}
+
+// Walks the footprint of seed k from the state in `st`.  Returns 0 when the walk is complete, 1 when
+// the store ran out; `st` then holds a resumable state.  The loads of the next frontier record are issued
+// before the current one is processed, so a step costs at most one memory round trip (its atomics).
+template <class Store>
+__device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, float cs, Store& S, Pending& P,
+                    WalkState& st, int lane) {
     const uint32_t mine = kMarkBit | k;
     const int lr = lane >> 3, lc = lane & 7;
     const int tiles_y = (A.h + 7) >> 3;
-    while (st.head != st.tail) {
-        if ((st.tail - st.head) + 8u > S.ring_cap() || st.nforeign + 1u > S.hash_limit()) return 1;
-        uint32_t tile;
-        uint64_t E;
-        S.get(st.head, tile, E);
-        st.head += 1;
-        const int ty = (int)(tile / (uint32_t)A.tiles_x), tx = (int)(tile - (uint32_t)ty * (uint32_t)A.tiles_x);
-        const int r = ty * 8 + lr, c = tx * 8 + lc;
-        const size_t q = (size_t)r * A.w + c;
-        uint32_t lab = 0;
-        bool acc = false;
-        if (r < A.h && c < A.w) {
-            lab = ld_agent(&A.label[q]);
-            if (lab >= kMarkBit && ((A.dmask[q] >> b) & 1)) acc = directional(A.dx[q], A.dy[q], sn, cs) > thr;
-        }
-        const uint64_t Am = __ballot(acc);
-        uint64_t R = E & Am;
-        if (R == 0ull) continue;
-        for (;;) {  // connected closure of the entry pixels inside the tile
-            const uint64_t Rn = dilate8(R) & Am;
-            if (Rn == R) break;
-            R = Rn;
-        }
-        const uint64_t Mine = __ballot(acc && lab == mine);
-        uint32_t slot;
-        const uint64_t VF = S.lookup(tile, slot);
-        const uint64_t New = R & ~(Mine | VF);
-        if (New == 0ull) continue;
-        bool fresh = false, foreign = false;
-        if ((New >> lane) & 1ull) {
-            const uint32_t old = atomicMin(&A.label[q], mine);
-            if (old > mine) {  // free, or stamped by a higher seed that is hereby blocked
-                fresh = true;
-                if (old != kLabelFree) A.blocked[old & ~kMarkBit] = 1u;
-            } else if (old < mine && old >= kMarkBit) {  // a lower active seed reaches this pixel too
+    if (st.head == st.tail) return 0;
+    TileFetch cur = fetch_tile(A, S, st.head, lr, lc);
+    // The stamp of a step (a returning atomicMin) is only needed to tell who else reaches the pixel; the walk
+    // itself continues from every new pixel regardless.  So its result is consumed one step later, and the
+    // atomic's round trip overlaps the next step instead of standing on the critical path.
+    uint32_t prev_old = kLabelFree;
+    bool prev_issued = false;
+    auto settle = [&]() {
+        bool foreign = false;
+        if (prev_issued) {
+            if (prev_old > mine) {  // free, or stamped by a higher seed that is hereby blocked
+                if (prev_old != kLabelFree) A.blocked[prev_old & ~kMarkBit] = 1u;
+            } else if (prev_old < mine && prev_old >= kMarkBit) {  // a lower active seed reaches this pixel too
                 foreign = true;
             }
         }
-        const uint64_t Fr = __ballot(fresh), Fm = __ballot(foreign);
-        if (Fm) {
-            st.blocked = true;
-            if (S.update(slot, tile, VF | Fm)) st.nforeign += 1;
+        if (__ballot(foreign)) st.blocked = true;
+        prev_issued = false;
+    };
+    for (;;) {
+        if ((st.tail - st.head) + 8u > S.ring_cap() || st.ntiles + 2u > S.hash_limit()) {
+            settle();
+            return 1;
         }
-        const uint64_t X = Fr | Fm;  // newly walked pixels: their neighbours outside the tile become entries
-        st.cnt += (uint32_t)__popcll(X);
-        if (X == 0ull) continue;
-        const bool has_l = tx > 0, has_r = tx + 1 < A.tiles_x, has_u = ty > 0, has_d = ty + 1 < tiles_y;
-        {
+        st.head += 1;
+        st.steps += 1;
+        const bool have_next = st.head != st.tail;
+        TileFetch nxt;
+        if (have_next) nxt = fetch_tile(A, S, st.head, lr, lc);
+        const uint32_t tile = cur.tile;
+        const int ty = (int)(tile >> 16), tx = (int)(tile & 0xFFFFu);
+        uint64_t Am = cur.Am;
+        if (!cur.known) {
+            const bool acc = cur.inside && cur.lab >= kMarkBit && ((cur.dm >> b) & 1) &&
+                             directional(cur.dx, cur.dy, sn, cs) > thr;
+            Am = __ballot(acc);
+        }
+        uint64_t R = cur.entry & Am;
+        uint64_t New = 0ull;
+        if (R != 0ull) {
+            for (;;) {  // connected closure of the entry pixels inside the tile
+                const uint64_t Rn = dilate8(R) & Am;
+                if (Rn == R) break;
+                R = Rn;
+            }
+            New = R & ~cur.V;
+        }
+        const bool issue = (New >> lane) & 1ull;
+        uint32_t old = kLabelFree;
+        if (issue) old = atomicMin(&A.label[cur.q], mine);
+        settle();  // the previous step's stamps
+        prev_old = old;
+        prev_issued = issue;
+        if (New != 0ull || !cur.known) {
+            S.update(cur.slot, tile, cur.V | New, Am);
+            if (!cur.known) st.ntiles += 1;
+            if (have_next && nxt.tile == tile) {  // the prefetched record looked this tile up before the update
+                nxt.known = true;
+                nxt.slot = cur.slot;
+                nxt.V = cur.V | New;
+                nxt.Am = Am;
+            } else if (have_next && !cur.known && !nxt.known) {
+                // an insertion may have taken the empty slot the prefetched lookup had reserved: probe again
+                uint64_t v0, a0;
+                (void)S.lookup(nxt.tile, nxt.slot, v0, a0);
+            }
+        }
+        st.cnt += (uint32_t)__popcll(New);
+        if (New != 0ull) {
+            const uint64_t X = New;  // newly walked pixels: their neighbours outside the tile become entries
+            const bool has_l = tx > 0, has_r = tx + 1 < A.tiles_x, has_u = ty > 0, has_d = ty + 1 < tiles_y;
             uint64_t m = (X & 0x8080808080808080ull) >> 7;  // col 7 -> col 0 of the right tile
             m = m | (m << 8) | (m >> 8);
-            if (has_r && m) S.put(st.tail++, tile + 1u, m);
+            if (has_r && m) P.push(S, st, tile + 1u, m);
             m = (X & 0x0101010101010101ull) << 7;  // col 0 -> col 7 of the left tile
             m = m | (m << 8) | (m >> 8);
-            if (has_l && m) S.put(st.tail++, tile - 1u, m);
+            if (has_l && m) P.push(S, st, tile - 1u, m);
             uint64_t t = X >> 56;  // row 7 -> row 0 of the tile below
             t = (t | (t << 1) | (t >> 1)) & 0xFFull;
-            if (has_d && t) S.put(st.tail++, tile + (uint32_t)A.tiles_x, t);
+            if (has_d && t) P.push(S, st, tile + 0x10000u, t);
             t = X & 0xFFull;  // row 0 -> row 7 of the tile above
             t = ((t | (t << 1) | (t >> 1)) & 0xFFull) << 56;
-            if (has_u && t) S.put(st.tail++, tile - (uint32_t)A.tiles_x, t);
-            if (has_d && has_r && (X >> 63)) S.put(st.tail++, tile + (uint32_t)A.tiles_x + 1u, 1ull);
-            if (has_d && has_l && ((X >> 56) & 1ull)) S.put(st.tail++, tile + (uint32_t)A.tiles_x - 1u, 1ull << 7);
-            if (has_u && has_r && ((X >> 7) & 1ull)) S.put(st.tail++, tile - (uint32_t)A.tiles_x + 1u, 1ull << 56);
-            if (has_u && has_l && (X & 1ull)) S.put(st.tail++, tile - (uint32_t)A.tiles_x - 1u, 1ull << 63);
+            if (has_u && t) P.push(S, st, tile - 0x10000u, t);
+            if (has_d && has_r && (X >> 63)) P.push(S, st, tile + 0x10001u, 1ull);
+            if (has_d && has_l && ((X >> 56) & 1ull)) P.push(S, st, tile + 0xFFFFu, 1ull << 7);
+            if (has_u && has_r && ((X >> 7) & 1ull)) P.push(S, st, tile - 0xFFFFu, 1ull << 56);
+            if (has_u && has_l && (X & 1ull)) P.push(S, st, tile - 0x10001u, 1ull << 63);
         }
+        if (st.head == st.tail) {
+            settle();
+            return 0;
+        }
+        cur = have_next ? nxt : fetch_tile(A, S, st.head, lr, lc);
     }
-    return 0;
 }
 
 __global__ __launch_bounds__(256) void flood_explore_kernel(FloodArgs A, BinTrig trig, const uint32_t* __restrict__ act,
                                                             uint32_t n_act) {
     __shared__ uint32_t s_ring[4][3][kRingT];
-    __shared__ uint32_t s_hash[4][3][kHashT];
+    __shared__ uint32_t s_hash[4][5][kHashT];
+    __shared__ uint32_t s_pend[4][2][kPend];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t ai = blockIdx.x * 4 + wv;
+    const uint32_t ai = uni(blockIdx.x * 4 + wv);
     if (ai >= n_act) return;
-    const uint32_t k = act[ai];
-    const int s = A.seed_idx[k];
-    const int b = A.seed_bin[k];
-    const float thr = A.seed_thr[k];
+    const uint32_t k = uni(act[ai]);
+    const int s = (int)uni((uint32_t)A.seed_idx[k]);
+    const int b = (int)uni((uint32_t)A.seed_bin[k]);
+    const float thr = __uint_as_float(uni(__float_as_uint(A.seed_thr[k])));
     const float sn = trig.st[b], cs = trig.ct[b];
     if (A.label[s] < kMarkBit) return;  // claimed by an earlier flood: dead (found again by the compaction)
     if (!(((A.dmask[s] >> b) & 1) && directional(A.dx[s], A.dy[s], sn, cs) > thr)) {
         if (lane == 0) A.flags[k] = kFlagSelfFail;  // flood() accepts nothing, not even the seed
         return;
     }
-    LdsStore L{s_ring[wv][0], s_ring[wv][1], s_ring[wv][2], s_hash[wv][0], s_hash[wv][1], s_hash[wv][2]};
+    LdsStore L{s_ring[wv][0], s_ring[wv][1], s_ring[wv][2], s_hash[wv][0],
+               s_hash[wv][1], s_hash[wv][2], s_hash[wv][3], s_hash[wv][4]};
     for (int i = lane; i < kHashT; i += 64) L.hk[i] = 0u;
+    Pending P{s_pend[wv][0], s_pend[wv][1]};
+    P.pt[lane] = 0u;
     const int sr = s / A.w, sc = s - sr * A.w;
-    WalkState st{0u, 1u, 0u, 0u, false};
-    L.put(0u, (uint32_t)((sr >> 3) * A.tiles_x + (sc >> 3)), 1ull << ((sr & 7) * 8 + (sc & 7)));
-    int rc = walk(A, k, b, thr, sn, cs, L, st, lane);
+    WalkState st{0u, 1u, 0u, 0u, false, 0u};
+    L.put(0u, ((uint32_t)(sr >> 3) << 16) | (uint32_t)(sc >> 3), 1ull << ((sr & 7) * 8 + (sc & 7)));
+    int rc = walk(A, k, b, thr, sn, cs, L, P, st, lane);
     if (rc != 0) {
         // LDS storage exhausted: move the walk to a global slab and carry on
         uint32_t slab = 0;
@@ -390,7 +506,7 @@ __global__ __launch_bounds__(256) void flood_explore_kernel(FloodArgs A, BinTrig
             uint32_t gen = 0;
             if (lane == 0) gen = atomicAdd(&A.ctrl[kCtrlGen], 1u) + 1u;
             gen = (uint32_t)__shfl((int)gen, 0);
-            SlabStore G{A.slab_ring + (size_t)slab * A.slab_ring_cap, A.slab_hash + (size_t)slab * A.slab_hash_cap,
+            SlabStore G{A.slab_ring + (size_t)slab * A.slab_ring_cap, A.slab_hash + (size_t)slab * A.slab_hash_cap * 2,
                         A.slab_ring_cap, A.slab_hash_cap, gen};
             for (uint32_t i = st.head; i != st.tail; ++i) {
                 uint32_t t;
@@ -402,11 +518,12 @@ __global__ __launch_bounds__(256) void flood_explore_kernel(FloodArgs A, BinTrig
                 const uint32_t key = L.hk[i];
                 if (key) {
                     uint32_t slot;
-                    (void)G.lookup(key - 1u, slot);
-                    G.update(slot, key - 1u, ((uint64_t)L.hhi[i] << 32) | L.hlo[i]);
+                    uint64_t v0, a0;
+                    (void)G.lookup(key - 1u, slot, v0, a0);
+                    G.update(slot, key - 1u, ((uint64_t)L.hv1[i] << 32) | L.hv0[i], ((uint64_t)L.ha1[i] << 32) | L.ha0[i]);
                 }
             }
-            rc = walk(A, k, b, thr, sn, cs, G, st, lane);
+            rc = walk(A, k, b, thr, sn, cs, G, P, st, lane);
         }
         if (rc != 0 && lane == 0) {
             A.flags[k] = kFlagIncomplete;
@@ -416,6 +533,7 @@ __global__ __launch_bounds__(256) void flood_explore_kernel(FloodArgs A, BinTrig
     if (lane == 0) {
         A.count[k] = st.cnt;
         if (st.blocked) A.blocked[k] = 1u;
+        A.flags[k] |= st.steps << 8;  // diagnostics only (LIBRECTIFY_FLOOD_DEBUG)
     }
 }
 
@@ -606,7 +724,22 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
         hipLaunchKernelGGL(flood_decide_kernel, dim3((n_act + 255) / 256), dim3(256), 0, s, A, act, n_act, B.state,
                            seed_size);
         if (debug) {
-            std::vector<uint32_t> cnt(n_seeds), blk(n_seeds);
+            std::vector<uint32_t> cnt(n_seeds), blk(n_seeds), flg(n_seeds), actv(n_act);
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(flg.data(), B.flags, n_seeds * sizeof(uint32_t), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(actv.data(), act, n_act * sizeof(uint32_t), hipMemcpyDeviceToHost);
+            {
+                unsigned long long tsteps = 0, tpx = 0;
+                uint32_t mxs = 0, mxk = 0;
+                for (uint32_t i = 0; i < n_act; ++i) {
+                    const uint32_t kk = actv[i], st_ = flg[kk] >> 8;
+                    tsteps += st_;
+                    if (st_ > mxs) { mxs = st_; mxk = kk; }
+                }
+                (void)hipMemcpy(cnt.data(), B.count, n_seeds * sizeof(uint32_t), hipMemcpyDeviceToHost);
+                for (uint32_t i = 0; i < n_act; ++i) tpx += cnt[actv[i]];
+                std::fprintf(stderr, "  this round: %llu px walked in %llu steps; longest walk %u steps (%u px, seed %u)\n", tpx, tsteps, mxs, cnt[mxk], mxk);
+            }
             (void)hipStreamSynchronize(s);
             (void)hipMemcpy(cnt.data(), B.count, n_seeds * sizeof(uint32_t), hipMemcpyDeviceToHost);
             (void)hipMemcpy(blk.data(), B.blocked, n_seeds * sizeof(uint32_t), hipMemcpyDeviceToHost);
@@ -647,7 +780,7 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
     }
     LR_HIP(hipGetLastError());
     if (h_ctrl[kCtrlGen] > 0xF0000000u) {  // generation counter about to wrap: forget every tagged hash entry
-        LR_HIP(hipMemsetAsync(B.slab_hash, 0, (size_t)B.n_slabs * B.slab_hash_cap * 16, s));
+        LR_HIP(hipMemsetAsync(B.slab_hash, 0, (size_t)B.n_slabs * B.slab_hash_cap * 32, s));
         LR_HIP(hipMemsetAsync(B.ctrl + kCtrlGen, 0, sizeof(uint32_t), s));
     }
     *rounds_out = rounds;

@@ -248,6 +248,25 @@ def test_many_frames_through_one_context_stay_exact(L, ctx):
             _assert_lines_equal(lines, first[i])
 
 
+def test_parallel_flood_equals_ordered_flood_at_full_size(L, ctx):
+    """3840x2160: the round-based parallel flood against the single-wave ordered kernel (exact by
+    construction), label image and segment records bit for bit."""
+    from librectify_amd import synth
+
+    img = synth.frame(3840, 2160, 1)
+    out = {}
+    for mode in (0, 1):
+        ctx.set_flood_mode(mode)
+        ctx.stage_filter_host(img)
+        ctx.stage_seeds()
+        ctx.stage_flood()
+        out[mode] = (ctx.download(L.BUF_LABEL), ctx.download(L.BUF_SEED_SIZE), ctx.stage_fit())
+    ctx.set_flood_mode(1)
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    _assert_lines_equal(out[0][2], out[1][2])
+
+
 def test_size_independent_properties_at_full_size(L, ctx):
     """3840x2160 (BASELINE configs[1..2]): properties that need no oracle run."""
     from librectify_amd import synth
