@@ -125,6 +125,20 @@ int lr_ransac_best(lr_context* ctx, const LineSegment* lines_norm, int n, const 
 int lr_estimate_line_pencils(lr_context* ctx, LineSegment* lines, int n, int max_models, float inlier_deg,
                              float garbage_deg, int n_iter, uint64_t seed);
 
+/* ---- PROSAC / Hough weights (opt-in) --------------------------------------------------- */
+/* The reference compiles prosac.h but never instantiates it (ChangeLog.md: "pure RANSAC is used"), so RANSAC
+ * is the default here too.  kind: 0 = RANSAC, 1 = PROSAC with T_N iterations (<= 0: the reference's
+ * niter_RANSAC(0.9, 0.5, 2) = 9, prosac.h:116). */
+void lr_set_estimator(lr_context* ctx, int kind, int prosac_T_N);
+/* LinePencilModel::get_weights (line_pencil.cpp:47-86): 65x65 hemisphere accumulator (LDS, 64-bit integer
+ * atomics), peak direction, inclination^4 per line listed in `indices`. */
+int lr_ht_weights(lr_context* ctx, const LineSegment* lines_norm, int n, const int32_t* indices, int n_idx, float* weights);
+/* PROSAC_Estimator::solve (prosac.h:104-299); trace4 = iterations run, n_star, iteration of the best sample, its inlier count. */
+int lr_prosac_solve(lr_context* ctx, const LineSegment* lines_norm, int n, const int32_t* indices, int n_idx, float tol,
+                    int T_N, uint64_t seed, uint32_t round, float* h3, int32_t* trace4);
+int lr_estimate_line_pencils_prosac(lr_context* ctx, LineSegment* lines, int n, int max_models, float inlier_deg,
+                                    float garbage_deg, int T_N, uint64_t seed);
+
 #ifdef __cplusplus
 }
 #endif

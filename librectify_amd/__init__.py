@@ -68,6 +68,7 @@ EXPORTS = [
     "lr_find_line_segment_groups_host", "lr_find_line_segment_groups_batch_device", "lr_stage_filter",
     "lr_stage_filter_host", "lr_stage_seeds", "lr_stage_flood", "lr_stage_fit", "lr_download", "lr_stage_times",
     "lr_stage_counters", "lr_filter_kernel_ms", "lr_ransac_best", "lr_estimate_line_pencils",
+    "lr_set_estimator", "lr_ht_weights", "lr_prosac_solve", "lr_estimate_line_pencils_prosac",
 ]
 
 _lib = None
@@ -124,6 +125,11 @@ def lib():
         L.lr_filter_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.lr_ransac_best.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         L.lr_estimate_line_pencils.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_uint64]
+        L.lr_set_estimator.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.lr_set_estimator.restype = None
+        L.lr_ht_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.lr_prosac_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.lr_estimate_line_pencils_prosac.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_uint64]
         _lib = L
     return _lib
 
@@ -279,6 +285,29 @@ class Context:
         bi = C.c_int(0)
         _check(lib().lr_ransac_best(self._h, _ptr(lines_norm), len(lines_norm), _ptr(indices), len(indices), tol, n_iter, C.c_uint64(seed), C.c_uint32(rnd), _ptr(bh), C.byref(bs), C.byref(bi)))
         return dict(best_h=bh, score=bs.value, iter=bi.value)
+
+    def set_estimator(self, kind, prosac_T_N=-1):
+        lib().lr_set_estimator(self._h, int(kind), int(prosac_T_N))
+
+    def ht_weights(self, lines_norm, indices):
+        lines_norm = np.ascontiguousarray(lines_norm, LINE_DTYPE)
+        indices = np.ascontiguousarray(indices, np.int32)
+        out = np.zeros(len(indices), np.float32)
+        _check(lib().lr_ht_weights(self._h, _ptr(lines_norm), len(lines_norm), _ptr(indices), len(indices), _ptr(out)))
+        return out
+
+    def prosac_solve(self, lines_norm, indices, tol, T_N=-1, seed=0, rnd=0):
+        lines_norm = np.ascontiguousarray(lines_norm, LINE_DTYPE)
+        indices = np.ascontiguousarray(indices, np.int32)
+        h = np.zeros(3, np.float32)
+        tr = np.zeros(4, np.int32)
+        _check(lib().lr_prosac_solve(self._h, _ptr(lines_norm), len(lines_norm), _ptr(indices), len(indices), tol, T_N, C.c_uint64(seed), C.c_uint32(rnd), _ptr(h), _ptr(tr)))
+        return dict(h=h, iterations=int(tr[0]), n_star=int(tr[1]), best_iter=int(tr[2]), I_N_best=int(tr[3]))
+
+    def estimate_line_pencils_prosac(self, lines, max_models=4, inlier_deg=2.0, garbage_deg=4.0, T_N=-1, seed=0):
+        lines = np.ascontiguousarray(lines, LINE_DTYPE).copy()
+        _check(lib().lr_estimate_line_pencils_prosac(self._h, _ptr(lines), len(lines), max_models, inlier_deg, garbage_deg, T_N, C.c_uint64(seed)))
+        return lines
 
     def estimate_line_pencils(self, lines, max_models=4, inlier_deg=2.0, garbage_deg=4.0, n_iter=10000, seed=0):
         lines = np.ascontiguousarray(lines, LINE_DTYPE).copy()

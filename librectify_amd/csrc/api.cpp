@@ -254,4 +254,43 @@ int lr_estimate_line_pencils(lr_context* ctx, LineSegment* lines, int n, int max
     return 0;
 }
 
+void lr_set_estimator(lr_context* ctx, int kind, int prosac_T_N) {
+    ctx->estimator = kind;
+    ctx->prosac_T_N = prosac_T_N;
+}
+
+int lr_ht_weights(lr_context* ctx, const LineSegment* lines_norm, int n, const int32_t* indices, int n_idx, float* weights) {
+    const PencilModel model(std::vector<LineSegment>(lines_norm, lines_norm + n));
+    std::vector<float> w;
+    if (ctx_ht_weights(ctx, model, std::vector<int>(indices, indices + n_idx), w)) return 1;
+    std::memcpy(weights, w.data(), w.size() * sizeof(float));
+    return 0;
+}
+
+int lr_prosac_solve(lr_context* ctx, const LineSegment* lines_norm, int n, const int32_t* indices, int n_idx, float tol,
+                    int T_N, uint64_t seed, uint32_t round, float* h3, int32_t* trace4) {
+    const PencilModel model(std::vector<LineSegment>(lines_norm, lines_norm + n));
+    Vec3 h;
+    ProsacTrace tr;
+    if (ctx_prosac_solve(ctx, model, std::vector<int>(indices, indices + n_idx), tol, T_N, seed, round, &h, &tr)) return 1;
+    h3[0] = h.x;
+    h3[1] = h.y;
+    h3[2] = h.z;
+    if (trace4) {
+        trace4[0] = tr.iterations;
+        trace4[1] = tr.n_star;
+        trace4[2] = tr.best_iter;
+        trace4[3] = tr.I_N_best;
+    }
+    return 0;
+}
+
+int lr_estimate_line_pencils_prosac(lr_context* ctx, LineSegment* lines, int n, int max_models, float inlier_deg,
+                                    float garbage_deg, int T_N, uint64_t seed) {
+    std::vector<LineSegment> v(lines, lines + n);
+    if (ctx_estimate_line_pencils_prosac(ctx, v, max_models, inlier_deg, garbage_deg, T_N, seed)) return 1;
+    std::memcpy(lines, v.data(), sizeof(LineSegment) * (size_t)n);
+    return 0;
+}
+
 }  // extern "C"

@@ -158,5 +158,9 @@ struct PencilSoA {  // device pointers, n entries each (lines of the current rou
 int launch_ransac_score(PencilSoA m, uint32_t n, float tol, float degeneracy_tol, uint32_t n_iter, uint64_t seed,
                         uint32_t round, float* scores, hipStream_t s);
 int launch_ransac_argmax(const float* scores, uint32_t n_iter, float* best_score, int32_t* best_iter, hipStream_t s);
+int launch_prosac_count(PencilSoA m, uint32_t n, float tol, float degeneracy_tol, const uint32_t* sa,
+                        const uint32_t* sb, uint32_t n_hyp, uint32_t* counts, hipStream_t s);
+int launch_ht_weights(PencilSoA m, uint32_t n, const int32_t* pa, const int32_t* pb, int n_pairs, int ht, float* peak,
+                      float* weights, hipStream_t s);
 
 }  // namespace lramd

@@ -57,6 +57,20 @@ struct lr_context {
     float* d_scores = nullptr;
     float* d_best_score = nullptr;
     int32_t* d_best_iter = nullptr;
+    // PROSAC / Hough weights (opt-in estimator)
+    int32_t* d_pairs = nullptr;   // 2 x ht_pairs
+    int32_t* h_pairs = nullptr;
+    size_t cap_pairs = 0;
+    float* d_peak = nullptr;      // 3 floats
+    float* d_weights = nullptr;   // cap_lines
+    float* h_weights = nullptr;
+    uint32_t* d_samples = nullptr;  // 2 x cap_chunk
+    uint32_t* h_samples = nullptr;
+    uint32_t* d_hcounts = nullptr;  // cap_chunk
+    uint32_t* h_hcounts = nullptr;
+    size_t cap_chunk = 0, cap_wlines = 0;
+    int estimator = 0;            // 0 = RANSAC (reference default), 1 = PROSAC
+    int prosac_T_N = -1;
     // pinned host scalars
     uint32_t* h_counts = nullptr;  // 8 words
     float* h_best = nullptr;       // [0] score, [1] iter (as int bits)
@@ -90,6 +104,14 @@ int ctx_stage_fit(lr_context* c, std::vector<LineSegment>& out);
 int ctx_detect(lr_context* c, const float* d_image, int w, int h, int stride, std::vector<LineSegment>& raw);
 int ctx_ransac_best(lr_context* c, const PencilModel& model, const std::vector<int>& indices, float tol, int n_iter,
                     uint64_t seed, uint32_t round, Vec3* best_h, float* best_score, int* best_iter);
+struct ProsacTrace {
+    int iterations = 0, n_star = 0, best_iter = -1, I_N_best = 0;
+};
+int ctx_ht_weights(lr_context* c, const PencilModel& model, const std::vector<int>& indices, std::vector<float>& weights);
+int ctx_prosac_solve(lr_context* c, const PencilModel& model, const std::vector<int>& indices, float tol, int T_N,
+                     uint64_t seed, uint32_t round, Vec3* h, ProsacTrace* trace);
+int ctx_estimate_line_pencils_prosac(lr_context* c, std::vector<LineSegment>& lines, int max_models, float inlier_deg,
+                                     float garbage_deg, int T_N, uint64_t seed);
 int ctx_estimate_line_pencils(lr_context* c, std::vector<LineSegment>& lines, int max_models, float inlier_deg,
                               float garbage_deg, int n_iter, uint64_t seed);
 int ctx_find_groups_device(lr_context* c, const float* d_image, int w, int h, int stride, float min_length, bool refine,

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <random>
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -184,12 +185,17 @@ void ctx_destroy(lr_context* c) {
                     c->label, c->queue, c->comp_rank, c->comp_seed, c->comp_off, c->cursor, c->px_a, c->px_b,
                     c->scratch_w, c->d_lines, c->temp, c->d_model, c->d_scores, c->d_best_score, c->d_best_iter,
                     c->fb.blocked, c->fb.count, c->fb.flags, c->fb.state, c->fb.alive, c->fb.act_a, c->fb.act_b,
-                    c->fb.ctrl, c->fb.slab_ring, c->fb.slab_hash, c->fb.select_temp};
+                    c->fb.ctrl, c->fb.slab_ring, c->fb.slab_hash, c->fb.select_temp, c->d_pairs, c->d_peak, c->d_weights,
+                    c->d_samples, c->d_hcounts};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->h_model) (void)hipHostFree(c->h_model);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
     if (c->h_best) (void)hipHostFree(c->h_best);
+    if (c->h_pairs) (void)hipHostFree(c->h_pairs);
+    if (c->h_weights) (void)hipHostFree(c->h_weights);
+    if (c->h_samples) (void)hipHostFree(c->h_samples);
+    if (c->h_hcounts) (void)hipHostFree(c->h_hcounts);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
@@ -414,6 +420,274 @@ int ctx_estimate_line_pencils(lr_context* c, std::vector<LineSegment>& lines, in
     return 0;
 }
 
+// ---- PROSAC (opt-in; reference prosac.h, never instantiated there) ---------------------------------
+
+namespace {
+
+int upload_model(lr_context* c, const PencilModel& model, const std::vector<int>& order, PencilSoA* out) {
+    const size_t n = order.size();
+    if (ctx_ensure_ransac_capacity(c, n, 1)) return 1;
+    float* hm = c->h_model;
+    for (size_t j = 0; j < n; ++j) {
+        const int i = order[j];
+        hm[0 * n + j] = model.anchor[i].x;
+        hm[1 * n + j] = model.anchor[i].y;
+        hm[2 * n + j] = model.direction[i].x;
+        hm[3 * n + j] = model.direction[i].y;
+        hm[4 * n + j] = model.length[i];
+        hm[5 * n + j] = model.h[i].x;
+        hm[6 * n + j] = model.h[i].y;
+        hm[7 * n + j] = model.h[i].z;
+    }
+    LR_HIP(hipMemcpyAsync(c->d_model, hm, 8 * n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    *out = PencilSoA{c->d_model + 0 * n, c->d_model + 1 * n, c->d_model + 2 * n, c->d_model + 3 * n,
+                     c->d_model + 4 * n, c->d_model + 5 * n, c->d_model + 6 * n, c->d_model + 7 * n};
+    return 0;
+}
+
+int ensure_prosac_buffers(lr_context* c, size_t n_lines, size_t n_pairs, size_t chunk) {
+    if (n_pairs > c->cap_pairs) {
+        LR_HIP(hipStreamSynchronize(c->stream));
+        if (dev_alloc(c->d_pairs, 2 * n_pairs)) return 1;
+        if (c->h_pairs) (void)hipHostFree(c->h_pairs);
+        LR_HIP(hipHostMalloc((void**)&c->h_pairs, 2 * n_pairs * sizeof(int32_t)));
+        if (!c->d_peak && dev_alloc(c->d_peak, 4)) return 1;
+        c->cap_pairs = n_pairs;
+    }
+    if (n_lines > c->cap_wlines) {
+        LR_HIP(hipStreamSynchronize(c->stream));
+        const size_t cl = std::max<size_t>(n_lines, 4096);
+        if (dev_alloc(c->d_weights, cl)) return 1;
+        if (c->h_weights) (void)hipHostFree(c->h_weights);
+        LR_HIP(hipHostMalloc((void**)&c->h_weights, cl * sizeof(float)));
+        c->cap_wlines = cl;
+    }
+    if (chunk > c->cap_chunk) {
+        LR_HIP(hipStreamSynchronize(c->stream));
+        if (dev_alloc(c->d_samples, 2 * chunk) || dev_alloc(c->d_hcounts, chunk)) return 1;
+        if (c->h_samples) (void)hipHostFree(c->h_samples);
+        if (c->h_hcounts) (void)hipHostFree(c->h_hcounts);
+        LR_HIP(hipHostMalloc((void**)&c->h_samples, 2 * chunk * sizeof(uint32_t)));
+        LR_HIP(hipHostMalloc((void**)&c->h_hcounts, chunk * sizeof(uint32_t)));
+        c->cap_chunk = chunk;
+    }
+    return 0;
+}
+
+// prosac.h:31-55
+int niter_ransac(double p, double epsilon, int s, int Nmax) {
+    if (Nmax == -1) Nmax = INT32_MAX;
+    if (epsilon <= 0.) return 1;
+    const double logarg = -std::exp(s * std::log(1. - epsilon));
+    const double logval = std::log(1. + logarg);
+    const double N = std::log(1. - p) / logval;
+    if (logval < 0. && N < Nmax) return (int)std::ceil(N);
+    return Nmax;
+}
+
+const float kChi2[20] = {INFINITY,   6.6348966f,  5.41189443f, 4.70929225f, 4.21788459f, 3.84145882f, 3.5373846f,
+                         3.28302029f, 3.06490172f, 2.8743734f,  2.70554345f, 2.55422131f, 2.41732093f, 2.29250453f,
+                         2.17795916f, 2.07225086f, 1.97422609f, 1.88294329f, 1.79762406f, 1.71761761f};
+
+inline uint32_t sample_one(uint64_t seed, uint32_t round, uint32_t iter, uint32_t n) {
+    const uint64_t z = splitmix64(seed ^ splitmix64(((uint64_t)round << 32) | iter));
+    return (uint32_t)(((uint64_t)(uint32_t)z * n) >> 32);
+}
+
+// the growth function of PROSAC (prosac.h:150-166): pure bookkeeping, no data
+struct Growth {
+    int t, n, T_n_prime;
+    double T_n;
+    void advance(int n_star, int m) {
+        t = t + 1;
+        if ((t > T_n_prime) && (n < n_star)) {
+            const double T_nplus1 = (T_n * (n + 1)) / (n + 1 - m);
+            n = n + 1;
+            T_n_prime = T_n_prime + (int)std::ceil(T_nplus1 - T_n);
+            T_n = T_nplus1;
+        }
+    }
+};
+
+}  // namespace
+
+// get_weights (line_pencil.cpp:47-86): vote pairs from the host's std::mt19937 (default seed, as the
+// reference), accumulator and peak on the GPU, weights back on the host (positions follow `indices`).
+int ctx_ht_weights(lr_context* c, const PencilModel& model, const std::vector<int>& indices, std::vector<float>& weights) {
+    LR_HIP(hipSetDevice(c->device));
+    const size_t n = indices.size();
+    weights.assign(n, 0.f);
+    if (n == 0) return 0;
+    const int n_pairs = 20000, ht = 65;  // line_pencil.h:26-27
+    if (ensure_prosac_buffers(c, n, (size_t)n_pairs, 1)) return 1;
+    {
+        std::mt19937 rng;
+        std::uniform_int_distribution<int> rand_idx(0, (int)n - 1);
+        for (int i = 0; i < n_pairs; ++i) {
+            c->h_pairs[i] = rand_idx(rng);
+            c->h_pairs[n_pairs + i] = rand_idx(rng);
+        }
+    }
+    PencilSoA m;
+    if (upload_model(c, model, indices, &m)) return 1;
+    LR_HIP(hipMemcpyAsync(c->d_pairs, c->h_pairs, 2 * (size_t)n_pairs * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    if (launch_ht_weights(m, (uint32_t)n, c->d_pairs, c->d_pairs + n_pairs, n_pairs, ht, c->d_peak, c->d_weights, c->stream))
+        return 1;
+    LR_HIP(hipMemcpyAsync(c->h_weights, c->d_weights, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    LR_HIP(hipStreamSynchronize(c->stream));
+    std::copy(c->h_weights, c->h_weights + n, weights.begin());
+    return 0;
+}
+
+// PROSAC_Estimator::solve (prosac.h:104-299).  The sequential loop is replayed on the host exactly as
+// written; only "support of the model" (the inlier count of every sample against all lines) runs on the
+// GPU, for a speculative chunk of upcoming iterations at a time.  The sample of iteration t depends on
+// earlier results only through n_star, which changes when a new best hypothesis appears: the chunk is
+// then cut at that iteration and the rest regenerated, so the outcome equals the sequential run.
+int ctx_prosac_solve(lr_context* c, const PencilModel& model, const std::vector<int>& indices, float tol, int T_N_in,
+                     uint64_t seed, uint32_t round, Vec3* h_out, ProsacTrace* trace) {
+    std::vector<float> weights;
+    if (ctx_ht_weights(c, model, indices, weights)) return 1;
+    const int N = (int)indices.size();
+    std::vector<int> order(N);
+    for (int i = 0; i < N; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return weights[a] > weights[b]; });  // utils.h:36-44
+    std::vector<int> idx(N);
+    for (int i = 0; i < N; ++i) idx[i] = indices[order[i]];
+    const int m = 2;
+    const float eta = 0.05f, beta = 0.01f, psi = 0.02f, p_good = 0.9f, max_outlier = 0.5f;  // prosac.h:62-66
+    const int T_N = T_N_in > 0 ? T_N_in : niter_ransac(p_good, max_outlier, m, -1);
+    float chi2_value;
+    {
+        const float p2 = 2 * psi;
+        chi2_value = kChi2[(int)std::floor(std::max(std::min(p2, 0.2f), 0.01f) * 100)];
+    }
+    auto Imin = [&](int mm, int n) {
+        const double mu = n * beta;
+        const double sigma = std::sqrt(n * beta * (1 - beta));
+        return (int)std::ceil(mm + mu + sigma * std::sqrt(chi2_value));
+    };
+    int n_star = N, I_n_star = 0, I_N_best = 0, k_n_star = T_N, best_iter = -1;
+    const int I_N_min = (int)((1. - max_outlier) * N);
+    Growth g{0, m, 1, (double)T_N};
+    for (int i = 0; i < m; i++) g.T_n *= (double)(g.n - i) / (N - i);
+    Vec3 p_best{0, 0, 0};
+    std::vector<uint8_t> best_inl(N, 0), isInlier(N);
+    PencilSoA soa;
+    if (N >= 2 && upload_model(c, model, idx, &soa)) return 1;
+    size_t chunk = 256;
+    while (N >= 2 && ((I_N_best < I_N_min) || g.t <= k_n_star) && g.t < T_N) {
+        // speculative chunk under "no new best": growth and loop condition then depend on nothing else
+        if (ensure_prosac_buffers(c, (size_t)N, 1, chunk)) return 1;
+        Growth s = g;
+        size_t cnt = 0;
+        while (cnt < chunk && ((I_N_best < I_N_min) || s.t <= k_n_star) && s.t < T_N) {
+            s.advance(n_star, m);
+            uint32_t sa, sb;
+            if (s.t > s.T_n_prime) {
+                sample_pair(seed, round, (uint32_t)s.t, (uint32_t)s.n, sa, sb);
+            } else {
+                sa = sample_one(seed, round, (uint32_t)s.t, (uint32_t)(s.n - 1));
+                sb = (uint32_t)(s.n - 1);  // prosac.h:186 writes n (one past U_n); n-1 is meant
+            }
+            c->h_samples[cnt] = sa;
+            c->h_samples[chunk + cnt] = sb;
+            ++cnt;
+        }
+        LR_HIP(hipMemcpyAsync(c->d_samples, c->h_samples, cnt * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        LR_HIP(hipMemcpyAsync(c->d_samples + chunk, c->h_samples + chunk, cnt * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        if (launch_prosac_count(soa, (uint32_t)N, tol, model.degeneracy_tol, c->d_samples, c->d_samples + chunk,
+                                (uint32_t)cnt, c->d_hcounts, c->stream))
+            return 1;
+        LR_HIP(hipMemcpyAsync(c->h_hcounts, c->d_hcounts, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        LR_HIP(hipStreamSynchronize(c->stream));
+        bool event = false;
+        for (size_t j = 0; j < cnt; ++j) {
+            g.advance(n_star, m);
+            const uint32_t I = c->h_hcounts[j];
+            if (I == 0xFFFFFFFFu) continue;  // degenerate sample
+            if ((int)I > I_N_best) {
+                const int ia = idx[c->h_samples[j]], ib = idx[c->h_samples[chunk + j]];
+                const Vec3 p_t = model.fit(ia, ib);
+                int I_N = 0;
+                for (int i = 0; i < N; ++i) {
+                    isInlier[i] = model.error(p_t, idx[i]) < tol;
+                    I_N += isInlier[i];
+                }
+                I_N_best = I_N;
+                p_best = p_t;
+                best_inl = isInlier;
+                best_iter = g.t;
+                int n_best = N, I_n_best = I_N;
+                double epsilon_n_best = (double)I_n_best / n_best;
+                int n_test, I_n_test;
+                for (n_test = N, I_n_test = I_N; n_test > m; n_test--) {
+                    if ((I_n_test * n_best > I_n_best * n_test) &&
+                        (I_n_test > epsilon_n_best * n_test + std::sqrt(n_test * epsilon_n_best * (1. - epsilon_n_best) * 2.706))) {
+                        if (I_n_test < Imin(m, n_test)) break;
+                        n_best = n_test;
+                        I_n_best = I_n_test;
+                        epsilon_n_best = (double)I_n_best / n_best;
+                    }
+                    I_n_test -= isInlier[n_test - 1];
+                }
+                if (I_n_best * n_star > I_n_star * n_best) {
+                    n_star = n_best;
+                    I_n_star = I_n_best;
+                    k_n_star = niter_ransac(1. - eta, 1. - I_n_star / (double)n_star, m, T_N);
+                }
+                event = true;  // the rest of the chunk was generated under the old n_star / k_n_star
+                break;
+            }
+        }
+        chunk = event ? std::max<size_t>(256, chunk / 2) : std::min<size_t>(chunk * 4, 1u << 16);
+    }
+    if (trace) {
+        trace->iterations = g.t;
+        trace->n_star = n_star;
+        trace->best_iter = best_iter;
+        trace->I_N_best = I_N_best;
+    }
+    std::vector<int> inl;
+    for (int i = 0; i < N; ++i)
+        if (best_inl[i]) inl.push_back(idx[i]);
+    *h_out = model.fit_optimal(inl);
+    return 0;
+}
+
+int ctx_estimate_line_pencils_prosac(lr_context* c, std::vector<LineSegment>& lines, int max_models, float inlier_deg,
+                                     float garbage_deg, int T_N, uint64_t seed) {
+    if (lines.empty()) return 0;
+    const Normalisation nrm = bbox_normalisation(lines);
+    const PencilModel model(normalise(lines, nrm));
+    const float tol = cos_threshold(inlier_deg), garbage_tol = cos_threshold(garbage_deg);
+    const int N = model.size();
+    std::vector<int> inlier_flag(N, -1), garbage_flag(N, 0);
+    int remaining = N, k = 0;
+    while (remaining >= 2 && k < max_models) {
+        std::vector<int> obs;
+        for (int i = 0; i < N; ++i)
+            if (inlier_flag[i] < 0 && garbage_flag[i] == 0) obs.push_back(i);
+        Vec3 h;
+        if (ctx_prosac_solve(c, model, obs, tol, T_N, seed, (uint32_t)k, &h, nullptr)) return 1;
+        int n_in = 0, n_gb = 0;
+        for (int i : obs) {
+            const float e = model.error(h, i);
+            if (e < tol) {
+                inlier_flag[i] = k;
+                ++n_in;
+            } else if (e >= tol && e < garbage_tol) {
+                garbage_flag[i] = 1;
+                ++n_gb;
+            }
+        }
+        remaining -= n_in + n_gb;
+        ++k;
+    }
+    for (int i = 0; i < N; ++i) lines[i].group_id = garbage_flag[i] == 1 ? -1 : inlier_flag[i];
+    return 0;
+}
+
 // find_line_segment_groups (interface.cpp:35-80) on a device-resident image.
 int ctx_find_groups_device(lr_context* c, const float* d_image, int w, int h, int stride, float min_length, bool refine,
                            std::vector<LineSegment>& out) {
@@ -425,8 +699,14 @@ int ctx_find_groups_device(lr_context* c, const float* d_image, int w, int h, in
     std::vector<LineSegment> filtered = filter_lines(raw, min_length);
     if (filtered.empty()) return 0;
     LR_HIP(hipEventRecord(c->ev[5], c->stream));
-    if (ctx_estimate_line_pencils(c, filtered, kMaxModels, kInlierDeg, kGarbageDeg, c->ransac_iters, c->ransac_seed))
+    if (c->estimator == 1) {
+        if (ctx_estimate_line_pencils_prosac(c, filtered, kMaxModels, kInlierDeg, kGarbageDeg, c->prosac_T_N,
+                                             c->ransac_seed))
+            return 1;
+    } else if (ctx_estimate_line_pencils(c, filtered, kMaxModels, kInlierDeg, kGarbageDeg, c->ransac_iters,
+                                         c->ransac_seed)) {
         return 1;
+    }
     LR_HIP(hipEventRecord(c->ev[6], c->stream));
     LR_HIP(hipStreamSynchronize(c->stream));
     float ms = 0.f;

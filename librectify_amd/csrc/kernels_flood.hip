@@ -470,13 +470,15 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
     }
 }
 
-__global__ __launch_bounds__(256) void flood_explore_kernel(FloodArgs A, BinTrig trig, const uint32_t* __restrict__ act,
-                                                            uint32_t n_act) {
-    __shared__ uint32_t s_ring[4][3][kRingT];
-    __shared__ uint32_t s_hash[4][5][kHashT];
-    __shared__ uint32_t s_pend[4][2][kPend];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t ai = uni(blockIdx.x * 4 + wv);
+// One wavefront per workgroup: walks differ in length by three orders of magnitude, and a workgroup keeps its
+// LDS until its longest wave is done.
+__global__ __launch_bounds__(64) void flood_explore_kernel(FloodArgs A, BinTrig trig, const uint32_t* __restrict__ act,
+                                                           uint32_t n_act) {
+    __shared__ uint32_t s_ring[1][3][kRingT];
+    __shared__ uint32_t s_hash[1][5][kHashT];
+    __shared__ uint32_t s_pend[1][2][kPend];
+    const int wv = 0, lane = threadIdx.x & 63;
+    const uint32_t ai = uni(blockIdx.x);
     if (ai >= n_act) return;
     const uint32_t k = uni(act[ai]);
     const int s = (int)uni((uint32_t)A.seed_idx[k]);
@@ -720,7 +722,7 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
         h_ctrl[9] = init[1];
         LR_HIP(hipMemcpyAsync(B.ctrl + kCtrlBarrier, h_ctrl + 8, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
         LR_HIP(hipMemsetAsync(B.ctrl + kCtrlNCommit, 0, 2 * sizeof(uint32_t), s));
-        hipLaunchKernelGGL(flood_explore_kernel, dim3((n_act + 3) / 4), dim3(256), 0, s, A, trig, act, n_act);
+        hipLaunchKernelGGL(flood_explore_kernel, dim3(n_act), dim3(64), 0, s, A, trig, act, n_act);
         hipLaunchKernelGGL(flood_decide_kernel, dim3((n_act + 255) / 256), dim3(256), 0, s, A, act, n_act, B.state,
                            seed_size);
         if (debug) {

@@ -102,7 +102,171 @@ __global__ __launch_bounds__(1024) void ransac_argmax_kernel(const float* __rest
     }
 }
 
+// ---- PROSAC support (reference prosac.h, line_pencil.cpp:47-86; opt-in) ----------
+
+// Inlier COUNT (prosac.h:208-210) of explicit two-line samples over the quality-sorted line table.
+// One wavefront per hypothesis; the count is an integer, so its reduction order is immaterial.
+__global__ __launch_bounds__(256) void prosac_count_kernel(PencilSoA m, uint32_t n, float tol, float degeneracy_tol,
+                                                           const uint32_t* __restrict__ sa,
+                                                           const uint32_t* __restrict__ sb, uint32_t n_hyp,
+                                                           uint32_t* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t hyp = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (hyp >= n_hyp) return;
+    const uint32_t a = sa[hyp], b = sb[hyp];
+    const float hax = m.hx[a], hay = m.hy[a], haz = m.hz[a];
+    const float hbx = m.hx[b], hby = m.hy[b], hbz = m.hz[b];
+    const float ex = hax - hbx, ey = hay - hby, ez = haz - hbz;
+    const float dist = sqrtf((ex * ex + ey * ey) + ez * ez);
+    if (!(dist > degeneracy_tol)) {
+        if (lane == 0) counts[hyp] = 0xFFFFFFFFu;  // sample_check failed: the reference skips the iteration
+        return;
+    }
+    const float px = hay * hbz - haz * hby;
+    const float py = haz * hbx - hax * hbz;
+    const float pz = hax * hby - hay * hbx;
+    const bool ideal = fabsf(pz) < kEps;
+    const float pnx = px / pz, pny = py / pz;
+    uint32_t cnt = 0;
+    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        bool inl = false;
+        if (i < n) {
+            const float vx = ideal ? px : (pnx - m.ax[i]);
+            const float vy = ideal ? py : (pny - m.ay[i]);
+            const float nrm = sqrtf(vx * vx + vy * vy);
+            const float ux = vx / nrm, uy = vy / nrm;
+            const float err = -fabsf(ux * m.dx[i] + uy * m.dy[i]) + 1.0f;
+            inl = err < tol;
+        }
+        cnt += (uint32_t)__popcll(__ballot(inl));
+    }
+    if (lane == 0) counts[hyp] = cnt;
+}
+
+// Hough votes of get_weights on the unit hemisphere: ht x ht accumulator in LDS, 64-bit integer atomics
+// (votes in 2^-20 fixed point, so the result does not depend on arrival order), then the first maximum
+// in column-major order.  Single workgroup: 20 000 votes are nothing.
+constexpr int kHtMax = 65;
+__global__ __launch_bounds__(1024) void ht_votes_kernel(PencilSoA m, const int32_t* __restrict__ pa,
+                                                        const int32_t* __restrict__ pb, int n_pairs, int ht,
+                                                        float* __restrict__ peak /* 3 floats */) {
+    __shared__ unsigned long long acc[kHtMax * kHtMax];
+    __shared__ unsigned long long s_best[16];
+    __shared__ int s_pos[16];
+    const float k = floorf(ht / 2.f), k1 = k - 1;
+    for (int i = threadIdx.x; i < ht * ht; i += 1024) acc[i] = 0ull;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_pairs; i += 1024) {
+        const int a = pa[i], b = pb[i];
+        float x = m.hy[a] * m.hz[b] - m.hz[a] * m.hy[b];
+        float y = m.hz[a] * m.hx[b] - m.hx[a] * m.hz[b];
+        float z = m.hx[a] * m.hy[b] - m.hy[a] * m.hx[b];
+        if (fabsf(x) < 0.0001f && fabsf(y) < 0.0001f && fabsf(z) < 0.0001f) continue;
+        const float zz = (x * x + y * y) + z * z;
+        if (zz > 0.0f) {
+            const float nn = sqrtf(zz);
+            x = x / nn;
+            y = y / nn;
+            z = z / nn;
+        }
+        if (z < 0.f) {
+            x = -x;
+            y = -y;
+        }
+        const int u = (int)roundf(k1 * x + k);
+        const int v = (int)roundf(k1 * y + k);
+        const float vote = m.len[a] + m.len[b];
+        atomicAdd(&acc[u * ht + v], (unsigned long long)(vote * 1048576.0f + 0.5f));
+    }
+    __syncthreads();
+    // first strict maximum in column-major order == maximum value, lowest column-major position
+    unsigned long long bv = 0ull;
+    int bp = 0x7FFFFFFF;
+    for (int i = threadIdx.x; i < ht * ht; i += 1024) {
+        const int u = i / ht, v = i - u * ht;
+        const int pos = v * ht + u;
+        const unsigned long long val = acc[i];
+        if (val > bv || (val == bv && pos < bp)) {
+            bv = val;
+            bp = pos;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned long long ov = __shfl_xor(bv, off);
+        const int op = __shfl_xor(bp, off);
+        if (ov > bv || (ov == bv && op < bp)) {
+            bv = ov;
+            bp = op;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_best[threadIdx.x >> 6] = bv;
+        s_pos[threadIdx.x >> 6] = bp;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (s_best[w] > bv || (s_best[w] == bv && s_pos[w] < bp)) {
+                bv = s_best[w];
+                bp = s_pos[w];
+            }
+        const int max_v = bp / ht, max_u = bp - max_v * ht;
+        float p0 = (max_u - k) / k1, p1 = (max_v - k) / k1;
+        const float pn = sqrtf((p0 * p0 + p1 * p1) + 0.f * 0.f);
+        if (pn > 1.f) {
+            p0 = p0 / pn;
+            p1 = p1 / pn;
+        }
+        peak[0] = p0;
+        peak[1] = p1;
+        peak[2] = sqrtf(1.f - (p0 * p0 + p1 * p1));
+    }
+}
+
+__global__ __launch_bounds__(256) void ht_weights_kernel(PencilSoA m, uint32_t n, const float* __restrict__ peak,
+                                                         float* __restrict__ weights) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float px = peak[0], py = peak[1], pz = peak[2];
+    float vx, vy;
+    if (fabsf(pz) < kEps) {
+        vx = px;
+        vy = py;
+    } else {
+        vx = px / pz - m.ax[i];
+        vy = py / pz - m.ay[i];
+    }
+    const float nrm = sqrtf(vx * vx + vy * vy);
+    const float ux = vx / nrm, uy = vy / nrm;
+    const float inc = fabsf(ux * m.dx[i] + uy * m.dy[i]);
+    const float i2 = inc * inc;
+    weights[i] = i2 * i2;
+}
+
 }  // namespace
+
+int launch_prosac_count(PencilSoA m, uint32_t n, float tol, float degeneracy_tol, const uint32_t* sa,
+                        const uint32_t* sb, uint32_t n_hyp, uint32_t* counts, hipStream_t s) {
+    if (n_hyp == 0) return 0;
+    hipLaunchKernelGGL(prosac_count_kernel, dim3((n_hyp + 3) / 4), dim3(256), 0, s, m, n, tol, degeneracy_tol, sa, sb,
+                       n_hyp, counts);
+    LR_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_ht_weights(PencilSoA m, uint32_t n, const int32_t* pa, const int32_t* pb, int n_pairs, int ht, float* peak,
+                      float* weights, hipStream_t s) {
+    if (ht > kHtMax || ht < 3) {
+        set_error("launch_ht_weights: accumulator size out of range");
+        return 1;
+    }
+    hipLaunchKernelGGL(ht_votes_kernel, dim3(1), dim3(1024), 0, s, m, pa, pb, n_pairs, ht, peak);
+    hipLaunchKernelGGL(ht_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, s, m, n, peak, weights);
+    LR_HIP(hipGetLastError());
+    return 0;
+}
 
 int launch_ransac_score(PencilSoA m, uint32_t n, float tol, float degeneracy_tol, uint32_t n_iter, uint64_t seed,
                         uint32_t round, float* scores, hipStream_t s) {

@@ -718,6 +718,181 @@ V3 ransac_solve(const LinePencilModel& model, const std::vector<int>& indices, f
     return model.fit_optimal(inl);
 }
 
+// ---------------------------------------------------------------------------------------
+// prosac.h — PROSAC_Estimator (compiled header in the reference, never instantiated: ChangeLog.md:1-2;
+// parity unpinned, this restatement is the definition).
+//
+// Canonical deviations, all documented in DESIGN.md:
+//  * samples come from the counter-based generator (as for RANSAC);
+//  * prosac.h:186 writes sample(m-1) = n, one past U_n (and out of range when n == N); the
+//    intended index n-1 is used;
+//  * the Hough votes of get_weights are accumulated in 2^-20 fixed point (order independent),
+//    the vote pairs still come from std::mt19937 default-seeded as in line_pencil.cpp:53-59.
+inline int niter_RANSAC(double p, double epsilon, int s, int Nmax) {  // prosac.h:31-55
+    if (Nmax == -1) Nmax = INT32_MAX;
+    if (epsilon <= 0.) return 1;
+    double logarg = -std::exp(s * std::log(1. - epsilon));
+    double logval = std::log(1. + logarg);
+    double N = std::log(1. - p) / logval;
+    if (logval < 0. && N < Nmax) return (int)std::ceil(N);
+    return Nmax;
+}
+
+static const float chi2_table[20] = {INFINITY,   6.6348966f,  5.41189443f, 4.70929225f, 4.21788459f, 3.84145882f, 3.5373846f,
+                                     3.28302029f, 3.06490172f, 2.8743734f,  2.70554345f, 2.55422131f, 2.41732093f, 2.29250453f,
+                                     2.17795916f, 2.07225086f, 1.97422609f, 1.88294329f, 1.79762406f, 1.71761761f};
+
+struct ProsacParams {
+    float eta = 0.05f, beta = 0.01f, psi = 0.02f, p_good_sample = 0.9f, max_outlier_proportion = 0.5f;
+    int T_N = -1;  // <= 0: niter_RANSAC(p_good_sample, max_outlier_proportion, m, -1) as prosac.h:116 (= 9)
+};
+
+// fixed-point Hough accumulator variant of LinePencilModel::get_weights (line_pencil.cpp:47-86)
+std::vector<float> get_weights_fixed(const LinePencilModel& M, const std::vector<int>& idx) {
+    const int S = M.ht_space_size;
+    float k = std::floor(S / 2.f), k1 = k - 1;
+    std::vector<uint64_t> acc(size_t(S) * S, 0);
+    std::mt19937 rng;
+    std::uniform_int_distribution<int> rand_idx(0, int(idx.size()) - 1);
+    for (int i = 0; i < M.ht_num_hypotheses; ++i) {
+        int a = idx[rand_idx(rng)];
+        int b = idx[rand_idx(rng)];
+        V3 x = cross(M.h[a], M.h[b]);
+        if (std::fabs(x.x) < 0.0001f && std::fabs(x.y) < 0.0001f && std::fabs(x.z) < 0.0001f) continue;
+        x = normalized3(x);
+        if (x.z < 0.f) x = {-x.x, -x.y, -x.z};
+        int u = int(std::round(k1 * x.x + k));
+        int v = int(std::round(k1 * x.y + k));
+        float vote = M.length[a] + M.length[b];
+        acc[size_t(u) * S + v] += uint64_t(vote * 1048576.0f + 0.5f);
+    }
+    int max_u = 0, max_v = 0;
+    uint64_t best = acc[0];
+    for (int v = 0; v < S; ++v)  // column-major first strict max, as Eigen's maxCoeff visitor
+        for (int u = 0; u < S; ++u)
+            if (acc[size_t(u) * S + v] > best) {
+                best = acc[size_t(u) * S + v];
+                max_u = u;
+                max_v = v;
+            }
+    V3 p{(max_u - k) / k1, (max_v - k) / k1, 0.f};
+    float pn = std::sqrt((p.x * p.x + p.y * p.y) + p.z * p.z);
+    if (pn > 1.f) p = {p.x / pn, p.y / pn, p.z / pn};
+    p.z = std::sqrt(1.f - (p.x * p.x + p.y * p.y));
+    std::vector<float> wts(idx.size());
+    for (size_t j = 0; j < idx.size(); ++j) {
+        int i = idx[j];
+        float inc = inclination1(M.anchor[i].x, M.anchor[i].y, M.direction[i].x, M.direction[i].y, p);
+        float i2 = inc * inc;
+        wts[j] = i2 * i2;  // pow(4)
+    }
+    return wts;
+}
+
+// one uniform index out of n, counter based (second word of the pair generator's hash is unused)
+inline uint32_t sample_one(uint64_t seed, uint32_t round, uint32_t iter, uint32_t n) {
+    uint64_t z = splitmix64(seed ^ splitmix64((uint64_t(round) << 32) | iter));
+    return uint32_t((uint64_t(uint32_t(z)) * n) >> 32);
+}
+
+struct ProsacTrace {
+    int iterations = 0, n_star = 0, best_iter = -1, I_N_best = 0;
+};
+
+// prosac.h:104-299
+V3 prosac_solve(const LinePencilModel& model, const std::vector<int>& indices, float tol, const ProsacParams& P,
+                uint64_t seed, uint32_t round, ProsacTrace* trace = nullptr) {
+    std::vector<float> weights = get_weights_fixed(model, indices);
+    std::vector<int> order(indices.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = int(i);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return weights[a] > weights[b]; });  // utils.h:36-44
+    std::vector<int> idx(indices.size());
+    for (size_t i = 0; i < order.size(); ++i) idx[i] = indices[order[i]];
+    const int N = int(idx.size());
+    const int m = 2;
+    const int T_N = P.T_N > 0 ? P.T_N : niter_RANSAC(P.p_good_sample, P.max_outlier_proportion, m, -1);
+    float chi2_value;
+    {
+        float p2 = 2 * P.psi;
+        int ci = int(std::floor(std::max(std::min(p2, 0.2f), 0.01f) * 100));
+        chi2_value = chi2_table[ci];
+    }
+    auto Imin = [&](int mm, int n) {
+        double mu = n * P.beta;
+        double sigma = std::sqrt(n * P.beta * (1 - P.beta));
+        return (int)std::ceil(mm + mu + sigma * std::sqrt(chi2_value));
+    };
+    int n_star = N, I_n_star = 0, I_N_best = 0, t = 0, n = m, T_n_prime = 1, k_n_star = T_N;
+    const int I_N_min = int((1. - P.max_outlier_proportion) * N);
+    double T_n = T_N;
+    for (int i = 0; i < m; i++) T_n *= (double)(n - i) / (N - i);
+    V3 p_best{0, 0, 0};
+    std::vector<uint8_t> best_inl(N, 0);
+    int best_iter = -1;
+    std::vector<uint8_t> isInlier(N);
+    while (((I_N_best < I_N_min) || t <= k_n_star) && t < T_N) {
+        t = t + 1;
+        if ((t > T_n_prime) && (n < n_star)) {
+            double T_nplus1 = (T_n * (n + 1)) / (n + 1 - m);
+            n = n + 1;
+            T_n_prime = T_n_prime + (int)std::ceil(T_nplus1 - T_n);
+            T_n = T_nplus1;
+        }
+        int sa, sb;
+        if (t > T_n_prime) {
+            uint32_t a, b;
+            sample_pair(seed, round, uint32_t(t), uint32_t(n), a, b);
+            sa = int(a);
+            sb = int(b);
+        } else {
+            sa = int(sample_one(seed, round, uint32_t(t), uint32_t(n - 1)));
+            sb = n - 1;
+        }
+        int ia = idx[sa], ib = idx[sb];
+        if (!model.sample_check(ia, ib)) continue;
+        V3 p_t = model.fit(ia, ib);
+        int I_N = 0;
+        for (int i = 0; i < N; ++i) {
+            isInlier[i] = model.error1(p_t, idx[i]) < tol;
+            I_N += isInlier[i];
+        }
+        if (I_N > I_N_best) {
+            I_N_best = I_N;
+            p_best = p_t;
+            best_inl = isInlier;
+            best_iter = t;
+            int n_best = N, I_n_best = I_N;
+            double epsilon_n_best = (double)I_n_best / n_best;
+            int n_test, I_n_test;
+            for (n_test = N, I_n_test = I_N; n_test > m; n_test--) {
+                if ((I_n_test * n_best > I_n_best * n_test) &&
+                    (I_n_test > epsilon_n_best * n_test + std::sqrt(n_test * epsilon_n_best * (1. - epsilon_n_best) * 2.706))) {
+                    if (I_n_test < Imin(m, n_test)) break;
+                    n_best = n_test;
+                    I_n_best = I_n_test;
+                    epsilon_n_best = (double)I_n_best / n_best;
+                }
+                I_n_test -= isInlier[n_test - 1];
+            }
+            if (I_n_best * n_star > I_n_star * n_best) {
+                n_star = n_best;
+                I_n_star = I_n_best;
+                k_n_star = niter_RANSAC(1. - P.eta, 1. - I_n_star / (double)n_star, m, T_N);
+            }
+        }
+    }
+    if (trace) {
+        trace->iterations = t;
+        trace->n_star = n_star;
+        trace->best_iter = best_iter;
+        trace->I_N_best = I_N_best;
+    }
+    std::vector<int> inl;
+    for (int i = 0; i < N; ++i)
+        if (best_inl[i]) inl.push_back(idx[i]);
+    return model.fit_optimal(inl);
+}
+
 // estimator.h:99-145
 std::vector<int> estimate_multiple_structures(const LinePencilModel& model, int max_structures, float tol,
                                               float garbage_tol, int n_iter, uint64_t seed, const ThreadContext& ctx,
@@ -764,6 +939,42 @@ void estimate_line_pencils(std::vector<LineSegment>& lines, int max_models, floa
     LinePencilModel model(lines_norm);
     auto groups = estimate_multiple_structures(model, max_models, inlier_tol, garbage_tol, n_iter, seed, ctx, models_out);
     for (size_t i = 0; i < lines.size(); ++i) lines[i].group_id = groups[i];
+}
+
+// estimate_multiple_structures (estimator.h:99-145) driven by PROSAC instead of RANSAC
+void estimate_line_pencils_prosac(std::vector<LineSegment>& lines, int max_models, float inlier_deg, float garbage_deg,
+                                  const ProsacParams& P, uint64_t seed, std::vector<ProsacTrace>* traces = nullptr) {
+    BBox bb = bounding_box(lines);
+    V2 p = bbox_center(bb);
+    V2 sz = bbox_size(bb);
+    float scale = std::max(sz.x, sz.y);
+    LinePencilModel model(normalize_lines(lines, p, scale));
+    float tol = cos_threshold(inlier_deg), garbage_tol = cos_threshold(garbage_deg);
+    int N = model.size();
+    std::vector<int> inlier_flag(N, -1), garbage_flag(N, 0);
+    int num_observations = N, k = 0;
+    while (num_observations >= 2 && k < max_models) {
+        std::vector<int> obs;
+        for (int i = 0; i < N; ++i)
+            if (inlier_flag[i] < 0 && garbage_flag[i] == 0) obs.push_back(i);
+        ProsacTrace tr;
+        V3 h = prosac_solve(model, obs, tol, P, seed, uint32_t(k), &tr);
+        if (traces) traces->push_back(tr);
+        int n_in = 0, n_gb = 0;
+        for (int i : obs) {
+            float e = model.error1(h, i);
+            if (e < tol) {
+                inlier_flag[i] = k;
+                ++n_in;
+            } else if (e >= tol && e < garbage_tol) {
+                garbage_flag[i] = 1;
+                ++n_gb;
+            }
+        }
+        num_observations -= n_in + n_gb;
+        ++k;
+    }
+    for (int i = 0; i < N; ++i) lines[i].group_id = garbage_flag[i] == 1 ? -1 : inlier_flag[i];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1357,6 +1568,43 @@ int orc_find_line_segment_groups(const float* buffer, int width, int height, int
     }
     return int(filtered.size());
 }
+
+void orc_get_weights_fixed(const LineSegment* lines_norm, int n, const int32_t* indices, int n_idx, float* out) {
+    LinePencilModel model(std::vector<LineSegment>(lines_norm, lines_norm + n));
+    auto w = get_weights_fixed(model, std::vector<int>(indices, indices + n_idx));
+    std::copy(w.begin(), w.end(), out);
+}
+
+// PROSAC over `indices` of the pencil model of already-normalised lines; trace4 = iterations, n_star, best_iter, I_N_best
+void orc_prosac_solve(const LineSegment* lines_norm, int n, const int32_t* indices, int n_idx, float tol, int T_N,
+                      uint64_t seed, uint32_t round, float* h3, int32_t* trace4) {
+    LinePencilModel model(std::vector<LineSegment>(lines_norm, lines_norm + n));
+    ProsacParams P;
+    P.T_N = T_N;
+    ProsacTrace tr;
+    V3 h = prosac_solve(model, std::vector<int>(indices, indices + n_idx), tol, P, seed, round, &tr);
+    h3[0] = h.x;
+    h3[1] = h.y;
+    h3[2] = h.z;
+    if (trace4) {
+        trace4[0] = tr.iterations;
+        trace4[1] = tr.n_star;
+        trace4[2] = tr.best_iter;
+        trace4[3] = tr.I_N_best;
+    }
+}
+
+int orc_estimate_line_pencils_prosac(LineSegment* lines, int n, int max_models, float inlier_deg, float garbage_deg,
+                                     int T_N, uint64_t seed) {
+    std::vector<LineSegment> v(lines, lines + n);
+    ProsacParams P;
+    P.T_N = T_N;
+    estimate_line_pencils_prosac(v, max_models, inlier_deg, garbage_deg, P, seed);
+    std::copy(v.begin(), v.end(), lines);
+    return 0;
+}
+
+int orc_niter_ransac(double p, double eps, int s, int nmax) { return niter_RANSAC(p, eps, s, nmax); }
 
 int orc_max_threads() {
 #ifdef _OPENMP

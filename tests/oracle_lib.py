@@ -233,6 +233,35 @@ def get_weights(lines_norm, indices):
     return out
 
 
+def get_weights_fixed(lines_norm, indices):
+    lines_norm = as_lines(lines_norm)
+    indices = np.ascontiguousarray(indices, np.int32)
+    out = np.zeros(len(indices), np.float32)
+    lib().orc_get_weights_fixed(_p(lines_norm), C.c_int(len(lines_norm)), _p(indices), C.c_int(len(indices)), _p(out))
+    return out
+
+
+def prosac_solve(lines_norm, indices, tol, T_N=-1, seed=0, rnd=0):
+    lines_norm = as_lines(lines_norm)
+    indices = np.ascontiguousarray(indices, np.int32)
+    h = np.zeros(3, np.float32)
+    tr = np.zeros(4, np.int32)
+    lib().orc_prosac_solve(_p(lines_norm), C.c_int(len(lines_norm)), _p(indices), C.c_int(len(indices)), C.c_float(tol), C.c_int(T_N), C.c_uint64(seed), C.c_uint32(rnd), _p(h), _p(tr))
+    return dict(h=h, iterations=int(tr[0]), n_star=int(tr[1]), best_iter=int(tr[2]), I_N_best=int(tr[3]))
+
+
+def estimate_line_pencils_prosac(lines, max_models=4, inlier_deg=2.0, garbage_deg=4.0, T_N=-1, seed=0):
+    lines = as_lines(lines).copy()
+    lib().orc_estimate_line_pencils_prosac(_p(lines), C.c_int(len(lines)), C.c_int(max_models), C.c_float(inlier_deg), C.c_float(garbage_deg), C.c_int(T_N), C.c_uint64(seed))
+    return lines
+
+
+def niter_ransac(p, eps, s, nmax=-1):
+    f = lib().orc_niter_ransac
+    f.restype = C.c_int
+    return f(C.c_double(p), C.c_double(eps), C.c_int(s), C.c_int(nmax))
+
+
 def fit_vanishing_points(lines):
     lines = as_lines(lines)
     ids = np.zeros(64, np.int32)

@@ -187,6 +187,30 @@ def test_ransac_scoring_matches_oracle(L, ctx):
         np.testing.assert_array_equal(a["group_id"], b["group_id"])
 
 
+def test_hough_weights_and_prosac_match_oracle(L, ctx):
+    """Opt-in PROSAC path (prosac.h, line_pencil.cpp:47-86): self-golden against the oracle (the reference never
+    instantiates it).  Includes BASELINE configs[4]'s shape: ~20k segments, 100k hypotheses."""
+    from librectify_amd import synth
+
+    for n, T_N, seed in [(300, -1, 3), (1000, 2000, 42), (20000, 100000, 7)]:
+        segs = synth.random_segments(n, seed)
+        norm, _, _ = O.normalize_lines(segs)
+        idx = np.arange(n, dtype=np.int32)
+        tol = O.cos_threshold(2.0)
+        wr = O.get_weights_fixed(norm, idx)
+        wg = ctx.ht_weights(norm, idx)
+        assert (_bits(wg) != _bits(wr)).sum() == 0
+        ref = O.prosac_solve(norm, idx, tol, T_N, seed=seed)
+        got = ctx.prosac_solve(norm, idx, tol, T_N, seed=seed)
+        for k in ("iterations", "n_star", "best_iter", "I_N_best"):
+            assert got[k] == ref[k], (k, got[k], ref[k])
+        np.testing.assert_array_equal(got["h"], ref["h"])
+    segs = synth.random_segments(1500, 5)
+    a = O.estimate_line_pencils_prosac(segs, T_N=3000, seed=9)
+    b = ctx.estimate_line_pencils_prosac(segs, T_N=3000, seed=9)
+    np.testing.assert_array_equal(a["group_id"], b["group_id"])
+
+
 def test_reference_error_convention_and_strides(L, ctx):
     flat = np.full((64, 80), 0.25, np.float32)
     assert len(L.find_line_segment_groups(flat, 5.0)) == 0  # NULL, *n_lines = 0 (interface.cpp:50-54)
