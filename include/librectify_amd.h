@@ -69,6 +69,13 @@ int lr_find_line_segment_groups_batch_device(lr_context* ctx, const float* d_ima
                                              int num_threads, LineSegment* out, int capacity, int* n_lines,
                                              const RectificationConfig* cfg, ImageTransform* transforms);
 
+/* Minimal device-memory helpers (hipMalloc / hipFree / synchronous hipMemcpy H2D on the context's device). */
+int lr_device_malloc(lr_context* ctx, size_t bytes, void** out);
+int lr_device_free(lr_context* ctx, void* p);
+int lr_memcpy_h2d(lr_context* ctx, void* dst, const void* src, size_t bytes);
+/* Frames kept in flight by the batch call (one host thread + HIP stream + workspace each; default 4). */
+void lr_set_batch_streams(lr_context* ctx, int n);
+
 /* ---- stage API (tests, bench) --------------------------------------------------------- */
 /* Stage 1: fused 5x5 derivative filter + magnitude + direction bin + dilated-bin mask +
  * 5x5 non-max candidates (reference line_detector.cpp:41-49,126-182, filter.cpp:29-98,161-168). */

@@ -68,7 +68,7 @@ EXPORTS = [
     "lr_find_line_segment_groups_host", "lr_find_line_segment_groups_batch_device", "lr_stage_filter",
     "lr_stage_filter_host", "lr_stage_seeds", "lr_stage_flood", "lr_stage_fit", "lr_download", "lr_stage_times",
     "lr_stage_counters", "lr_filter_kernel_ms", "lr_ransac_best", "lr_estimate_line_pencils",
-    "lr_set_estimator", "lr_ht_weights", "lr_prosac_solve", "lr_estimate_line_pencils_prosac",
+    "lr_set_batch_streams", "lr_device_malloc", "lr_device_free", "lr_memcpy_h2d", "lr_set_estimator", "lr_ht_weights", "lr_prosac_solve", "lr_estimate_line_pencils_prosac",
 ]
 
 _lib = None
@@ -125,6 +125,11 @@ def lib():
         L.lr_filter_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.lr_ransac_best.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         L.lr_estimate_line_pencils.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_uint64]
+        L.lr_device_malloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.lr_device_free.argtypes = [C.c_void_p, C.c_void_p]
+        L.lr_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.lr_set_batch_streams.argtypes = [C.c_void_p, C.c_int]
+        L.lr_set_batch_streams.restype = None
         L.lr_set_estimator.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.lr_set_estimator.restype = None
         L.lr_ht_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
@@ -267,8 +272,23 @@ class Context:
         _check(lib().lr_find_line_segment_groups_device(self._h, C.c_void_p(dptr), w, h, stride or w, min_length, int(refine), -1, _ptr(out), cap, C.byref(n)))
         return out[: min(n.value, cap)]
 
-    def find_line_segment_groups_batch_device(self, dptr, image_stride, batch, w, h, min_length, refine=False, capacity=4096, cfg=None):
-        out = np.zeros((batch, capacity), LINE_DTYPE)
+    def device_upload(self, array):
+        """Copies a contiguous numpy array to a fresh device buffer; returns its address (free with device_free)."""
+        a = np.ascontiguousarray(array)
+        p = C.c_void_p()
+        _check(lib().lr_device_malloc(self._h, a.nbytes, C.byref(p)))
+        _check(lib().lr_memcpy_h2d(self._h, p, _ptr(a), a.nbytes))
+        return p.value
+
+    def device_free(self, ptr):
+        _check(lib().lr_device_free(self._h, C.c_void_p(ptr)))
+
+    def set_batch_streams(self, n):
+        lib().lr_set_batch_streams(self._h, int(n))
+
+    def find_line_segment_groups_batch_device(self, dptr, image_stride, batch, w, h, min_length, refine=False, capacity=4096, cfg=None, out=None):
+        if out is None:
+            out = np.zeros((batch, capacity), LINE_DTYPE)
         n = np.zeros(batch, np.int32)
         tf = (ImageTransform * batch)()
         cfg = cfg or RectificationConfig()

@@ -148,20 +148,28 @@ int lr_find_line_segment_groups_batch_device(lr_context* ctx, const float* d_ima
                                              int num_threads, LineSegment* out, int capacity, int* n_lines,
                                              const RectificationConfig* cfg, ImageTransform* transforms) {
     (void)num_threads;
-    for (int b = 0; b < batch; ++b) {
-        std::vector<LineSegment> res;
-        if (ctx_find_groups_device(ctx, d_images + (size_t)b * image_stride, width, height, stride, min_length,
-                                   refine != 0, res))
-            return 1;
-        copy_out(res, out + (size_t)b * capacity, capacity, n_lines ? n_lines + b : nullptr);
-        if (transforms) {
-            const RectificationConfig def;
-            transforms[b] = rectification_transform(res.data(), (int)std::min<size_t>(res.size(), (size_t)capacity),
-                                                    width, height, cfg ? *cfg : def);
-        }
-    }
+    return ctx_find_groups_batch_device(ctx, d_images, image_stride, batch, width, height, stride, min_length,
+                                        refine != 0, out, capacity, n_lines, cfg, transforms);
+}
+
+// minimal device-memory helpers so that C callers (and the tests) need no other runtime binding
+int lr_device_malloc(lr_context* ctx, size_t bytes, void** out) {
+    LR_HIP(hipSetDevice(ctx->device));
+    LR_HIP(hipMalloc(out, bytes));
     return 0;
 }
+int lr_device_free(lr_context* ctx, void* p) {
+    LR_HIP(hipSetDevice(ctx->device));
+    LR_HIP(hipFree(p));
+    return 0;
+}
+int lr_memcpy_h2d(lr_context* ctx, void* dst, const void* src, size_t bytes) {
+    LR_HIP(hipSetDevice(ctx->device));
+    LR_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+void lr_set_batch_streams(lr_context* ctx, int n) { ctx->batch_streams = n < 1 ? 1 : n; }
 
 int lr_stage_filter(lr_context* ctx, const float* d_image, int width, int height, int stride) {
     return ctx_stage_filter(ctx, d_image, width, height, stride);

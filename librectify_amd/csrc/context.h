@@ -69,6 +69,8 @@ struct lr_context {
     uint32_t* d_hcounts = nullptr;  // cap_chunk
     uint32_t* h_hcounts = nullptr;
     size_t cap_chunk = 0, cap_wlines = 0;
+    std::vector<lr_context*> workers;  // extra contexts (own stream + workspace) for frames in flight in batch calls
+    int batch_streams = 4;
     int estimator = 0;            // 0 = RANSAC (reference default), 1 = PROSAC
     int prosac_T_N = -1;
     // pinned host scalars
@@ -116,4 +118,7 @@ int ctx_estimate_line_pencils(lr_context* c, std::vector<LineSegment>& lines, in
                               float garbage_deg, int n_iter, uint64_t seed);
 int ctx_find_groups_device(lr_context* c, const float* d_image, int w, int h, int stride, float min_length, bool refine,
                            std::vector<LineSegment>& out);
+int ctx_find_groups_batch_device(lr_context* c, const float* d_images, size_t image_stride, int batch, int w, int h,
+                                 int stride, float min_length, bool refine, LineSegment* out, int capacity, int* n_lines,
+                                 const RectificationConfig* cfg, ImageTransform* transforms);
 }  // namespace lramd

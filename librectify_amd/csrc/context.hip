@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <random>
+#include <thread>
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
@@ -178,6 +179,8 @@ int ctx_create(int device, lr_context** out) {
 
 void ctx_destroy(lr_context* c) {
     if (!c) return;
+    for (lr_context* wc : c->workers) ctx_destroy(wc);
+    c->workers.clear();
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_img, c->dx, c->dy, c->dmask, c->cand, c->cand_count, c->tile_max, c->tile_pass, c->tile_off,
@@ -715,6 +718,61 @@ int ctx_find_groups_device(lr_context* c, const float* d_image, int w, int h, in
     (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[6]);
     c->stage_ms[LR_T_TOTAL] = ms;
     out.swap(filtered);
+    return 0;
+}
+
+// Batch of independent frames: the stages of one frame are latency-bound (flood rounds,
+// host round trips), so several frames are kept in flight, one host thread + context + HIP stream each.
+int ctx_find_groups_batch_device(lr_context* c, const float* d_images, size_t image_stride, int batch, int w, int h,
+                                 int stride, float min_length, bool refine, LineSegment* out, int capacity, int* n_lines,
+                                 const RectificationConfig* cfg, ImageTransform* transforms) {
+    const int S = std::max(1, std::min(c->batch_streams, batch));
+    while ((int)c->workers.size() < S - 1) {
+        lr_context* wc = nullptr;
+        if (ctx_create(c->device, &wc)) return 1;
+        c->workers.push_back(wc);
+    }
+    std::vector<lr_context*> lanes;
+    lanes.push_back(c);
+    for (int i = 0; i < S - 1; ++i) lanes.push_back(c->workers[i]);
+    for (lr_context* l : lanes) {
+        l->ransac_seed = c->ransac_seed;
+        l->ransac_iters = c->ransac_iters;
+        l->flood_mode = c->flood_mode;
+        l->estimator = c->estimator;
+        l->prosac_T_N = c->prosac_T_N;
+    }
+    std::vector<int> rc(S, 0);
+    std::vector<std::string> err(S);
+    auto work = [&](int si) {
+        lr_context* l = lanes[si];
+        for (int b = si; b < batch; b += S) {
+            std::vector<LineSegment> res;
+            if (ctx_find_groups_device(l, d_images + (size_t)b * image_stride, w, h, stride, min_length, refine, res)) {
+                rc[si] = 1;
+                err[si] = get_error();
+                return;
+            }
+            const int n = (int)res.size();
+            if (n_lines) n_lines[b] = n;
+            if (out && capacity > 0)
+                std::memcpy(out + (size_t)b * capacity, res.data(), sizeof(LineSegment) * (size_t)std::min(n, capacity));
+            if (transforms) {
+                const RectificationConfig def;
+                transforms[b] = rectification_transform(res.data(), std::min(n, capacity > 0 ? capacity : n), w, h,
+                                                        cfg ? *cfg : def);
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int si = 1; si < S; ++si) th.emplace_back(work, si);
+    work(0);
+    for (auto& t : th) t.join();
+    for (int si = 0; si < S; ++si)
+        if (rc[si]) {
+            set_error(err[si]);
+            return 1;
+        }
     return 0;
 }
 

@@ -236,6 +236,25 @@ def test_reference_error_convention_and_strides(L, ctx):
     _assert_lines_equal(got, base)
 
 
+def test_batch_entry_point_matches_single_calls(L, ctx):
+    """lr_find_line_segment_groups_batch_device keeps several frames in flight; results per frame are those of
+    the single-frame call and of the oracle."""
+    w, h = 320, 240
+    from librectify_amd import synth
+
+    frames = [synth.frame(w, h, 50 + i, bars=20) for i in range(7)]
+    d = ctx.device_upload(np.stack(frames))
+    ctx.set_seed(0)
+    ctx.set_batch_streams(3)
+    out, n, tf = ctx.find_line_segment_groups_batch_device(d, w * h, len(frames), w, h, 3.2, capacity=1024)
+    ctx.device_free(d)
+    for i, f in enumerate(frames):
+        ref, _ = O.find_line_segment_groups(f, 3.2, seed=0)
+        _assert_lines_equal(out[i][: n[i]], ref)
+        Tr = O.transform_to_array(O.compute_rectification_transform(ref, w, h))
+        np.testing.assert_array_equal(tf[i].as_array(), Tr)
+
+
 def test_refine_flag_matches_oracle(L, ctx):
     img = FRAMES["320x240"]
     ml = 3.2
