@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ i
 // the 5x5 correlation is computed once per pixel except for the band halo (1.2x instead of the
 // tile kernel's 1.5x).  Same canonical arithmetic, same outputs as filter_kernel above.
 constexpr int kBandCols = 120;
-constexpr int kBandRows = 32;
+constexpr int kBandRows = 30;  // 2160 = 72 x 30: no ragged last band at 4K, 4968 waves = 4.85 per SIMD
 constexpr int kBandSteps = kBandRows + 8;  // image rows y0-4 .. y0+35
 
 // value of the lower / upper neighbour lane as a DPP wavefront shift (a VALU move, not an LDS crossbar
@@ -478,6 +478,13 @@ __device__ __forceinline__ float load_px(const float* __restrict__ img, int stri
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(row) + (unsigned)xcl * 4u);
 }
 
+// Buffer-resource addressing (T8): 32-bit lane byte offset in a VGPR + scalar row byte offset, no per-access
+// 64-bit address arithmetic on the vector ALU.  The descriptors are built once from wave-uniform values.
+using BufRsrc = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ BufRsrc make_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
 __device__ __forceinline__ float load_px_in(const float* __restrict__ img, int stride, int yr, int xcl) {
     const float* __restrict__ row = img + (size_t)yr * stride;
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(row) + (unsigned)xcl * 4u);
@@ -490,11 +497,17 @@ __device__ __forceinline__ void lane_step(Roll1& R, const int t, const float* __
                                           const int stride, const FilterTaps& fc, float* __restrict__ dx_out,
                                           float* __restrict__ dy_out, uint8_t* __restrict__ dmask_out,
                                           uint64_t* __restrict__ cand_band, uint32_t& ncand, float& lmax, const int y0,
-                                          const int x, const int xcl, const int lane, const bool useful) {
+                                          const int x, const int xcl, const int lane, const bool useful,
+                                          const BufRsrc r_img, const BufRsrc r_dx, const BufRsrc r_dy,
+                                          const BufRsrc r_dm) {
     constexpr int K = K10 % 5;
     if (t >= kBandSteps) return;  // wave-uniform (the unrolled loop runs in chunks of ten steps)
     const float cur = R.q[K10];
-    R.q[(K10 + 9) % 10] = INTERIOR ? load_px_in(img, stride, y0 - 4 + t + 9, xcl) : load_px(img, stride, h, y0 - 4 + t + 9, xcl);
+    {
+        const int yy = min(max(y0 - 4 + t + 9, 0), h - 1);  // clamped: see load_px
+        R.q[(K10 + 9) % 10] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                  r_img, (unsigned)xcl * 4u, (unsigned)yy * (unsigned)stride * 4u, 0));
+    }
     const float l1 = from_lower(cur), r1 = from_upper(cur);
     R.win[K][0] = from_lower(l1);
     R.win[K][1] = l1;
@@ -529,11 +542,10 @@ __device__ __forceinline__ void lane_step(Roll1& R, const int t, const float* __
     R.bits[K] = bit;
     const bool in_img = useful && (INTERIOR || x < w);
     if (t >= 6 && t < 6 + kBandRows && (INTERIOR || yc < h)) {  // yc in [y0, y0+32): wave-uniform, compile-time in t
-        float* __restrict__ dxr = dx_out + (size_t)yc * w;
-        float* __restrict__ dyr = dy_out + (size_t)yc * w;
         if (in_img) {
-            *reinterpret_cast<float*>(reinterpret_cast<char*>(dxr) + (unsigned)x * 4u) = vx;
-            *reinterpret_cast<float*>(reinterpret_cast<char*>(dyr) + (unsigned)x * 4u) = vy;
+            const unsigned row = (unsigned)yc * (unsigned)w * 4u;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, vx), r_dx, (unsigned)x * 4u, row, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, vy), r_dy, (unsigned)x * 4u, row, 0);
         }
     }
     if (t < 8) return;  // wave-uniform
@@ -550,9 +562,8 @@ __device__ __forceinline__ void lane_step(Roll1& R, const int t, const float* __
     uint32_t dm = from_lower(v) | v | from_upper(v);
     if (!INTERIOR && (yo == 0 || yo == h - 1 || x == 0 || x == w - 1)) dm = 0;  // binary_dilate's 1-px zero border (filter.cpp:52-61)
     if (in_img) {
-        uint8_t* __restrict__ dmr = dmask_out + (size_t)yo * w;
         lmax = fmaxf(lmax, c);
-        dmr[(unsigned)x] = (uint8_t)dm;
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)dm, r_dm, (unsigned)x, (unsigned)yo * (unsigned)w, 0);
     }
     const bool peak = in_img && (INTERIOR || ((yo >= 2) && (yo < h - 2) && (x >= 2) && (x < w - 2))) && (c > 0.f) && (c == mx);
     const uint64_t m = __ballot(peak);
@@ -595,7 +606,10 @@ __global__ __launch_bounds__(256) void filter_lanes_kernel(const float* __restri
     uint64_t* cand_band = cand + (size_t)band * (kLaneCols * kBandRows);
     uint32_t ncand = 0;
     float lmax = 0.f;
-#define LR_STEP(k, I) lane_step<k, I>(R, t0 + k, img, w, h, stride, fc, dx_out, dy_out, dmask_out, cand_band, ncand, lmax, y0, x, xcl, lane, useful)
+    const uint32_t npx = (uint32_t)w * (uint32_t)h;
+    const BufRsrc r_img = make_rsrc(img, ((uint32_t)(h - 1) * (uint32_t)stride + (uint32_t)w) * 4u);
+    const BufRsrc r_dx = make_rsrc(dx_out, npx * 4u), r_dy = make_rsrc(dy_out, npx * 4u), r_dm = make_rsrc(dmask_out, npx);
+#define LR_STEP(k, I) lane_step<k, I>(R, t0 + k, img, w, h, stride, fc, dx_out, dy_out, dmask_out, cand_band, ncand, lmax, y0, x, xcl, lane, useful, r_img, r_dx, r_dy, r_dm)
     // fully unrolled: across a loop back-edge the compiler can only wait for vmcnt(0), which would expose the
     // latency of every store in flight once per iteration.  (An INTERIOR = true instantiation for bands away
     // from the image border was measured: no gain, twice the code; the kernel is bound by VALU issue.)

@@ -715,6 +715,8 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
     const int pix_blocks = (int)std::min<size_t>((npix + 255) / 256, 4096);
     int rounds = 0;
     static const bool debug = std::getenv("LIBRECTIFY_FLOOD_DEBUG") != nullptr;
+    static const int stage_rounds = std::getenv("LIBRECTIFY_FLOOD_STAGES") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_STAGES")) : 0;  // measured: no gain at 4K (kept as a knob)
+    static const int stage_shift = std::getenv("LIBRECTIFY_FLOOD_STAGE_SHIFT") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_STAGE_SHIFT")) : 3;
     while (n_act > 0) {
         ++rounds;
         const uint32_t init[2] = {0xFFFFFFFFu, 0u};  // barrier, slabs used
@@ -722,8 +724,13 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
         h_ctrl[9] = init[1];
         LR_HIP(hipMemcpyAsync(B.ctrl + kCtrlBarrier, h_ctrl + 8, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
         LR_HIP(hipMemsetAsync(B.ctrl + kCtrlNCommit, 0, 2 * sizeof(uint32_t), s));
-        hipLaunchKernelGGL(flood_explore_kernel, dim3(n_act), dim3(64), 0, s, A, trig, act, n_act);
-        hipLaunchKernelGGL(flood_decide_kernel, dim3((n_act + 255) / 256), dim3(256), 0, s, A, act, n_act, B.state,
+        // Staged start: the first rounds only walk the strongest seeds (the active list is ascending).  Seeds
+        // beyond the window could not commit before the ones inside it anyway, and once the long strong
+        // edges are committed the many weak seeds next to them no longer re-walk those edges.
+        uint32_t n_launch = n_act;
+        if (rounds <= stage_rounds && n_act > 2048u) n_launch = std::max(1024u, n_act >> (stage_shift * (stage_rounds - rounds + 1)));
+        hipLaunchKernelGGL(flood_explore_kernel, dim3(n_launch), dim3(64), 0, s, A, trig, act, n_launch);
+        hipLaunchKernelGGL(flood_decide_kernel, dim3((n_launch + 255) / 256), dim3(256), 0, s, A, act, n_launch, B.state,
                            seed_size);
         if (debug) {
             std::vector<uint32_t> cnt(n_seeds), blk(n_seeds), flg(n_seeds), actv(n_act);
@@ -770,7 +777,7 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
                          n_commit, n_next, h_ctrl[kCtrlBarrier], h_ctrl[kCtrlSlabs]);
         }
         std::swap(act, act_next);
-        const bool progress = n_commit > 0 || n_next < n_act;
+        const bool progress = n_commit > 0 || n_next < n_act || n_launch < n_act;
         n_act = n_next;
         if (n_act > 0 && !progress) {
             // storage exhausted on the lowest active seed: finish in order (always exact)
