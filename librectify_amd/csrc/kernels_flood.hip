@@ -196,6 +196,8 @@ struct LdsStore {
     uint32_t* hv1;
     uint32_t* ha0;  // A
     uint32_t* ha1;
+    uint32_t* hr0;  // acceptable pixels of the 36-pixel ring around the tile (lane order, see ring_xy)
+    uint32_t* hr1;
     __device__ uint32_t ring_cap() const { return kRingT; }
     __device__ uint32_t hash_limit() const { return kHashT * 3 / 4; }
     __device__ void get(uint32_t i, uint32_t& tile, uint64_t& m) const {
@@ -210,7 +212,7 @@ struct LdsStore {
         rhi[j] = (uint32_t)(m >> 32);
     }
     // returns true if the tile is known; slot = where it is or where it would go
-    __device__ bool lookup(uint32_t tile, uint32_t& slot, uint64_t& V, uint64_t& Am) const {
+    __device__ bool lookup(uint32_t tile, uint32_t& slot, uint64_t& V, uint64_t& Am, uint64_t& Rg) const {
         const uint32_t key = tile + 1u;
         uint32_t hs = (key * 2654435761u) >> 24;  // 8 bits
         for (int probe = 0; probe < kHashT; ++probe) {
@@ -219,6 +221,7 @@ struct LdsStore {
                 slot = hs;
                 V = uni64(hv0[hs], hv1[hs]);
                 Am = uni64(ha0[hs], ha1[hs]);
+                Rg = uni64(hr0[hs], hr1[hs]);
                 return true;
             }
             if (cur == 0u) break;
@@ -227,14 +230,17 @@ struct LdsStore {
         slot = hs;
         V = 0ull;
         Am = 0ull;
+        Rg = 0ull;
         return false;
     }
-    __device__ void update(uint32_t slot, uint32_t tile, uint64_t V, uint64_t Am) {
+    __device__ void update(uint32_t slot, uint32_t tile, uint64_t V, uint64_t Am, uint64_t Rg) {
         hk[slot] = tile + 1u;
         hv0[slot] = (uint32_t)V;
         hv1[slot] = (uint32_t)(V >> 32);
         ha0[slot] = (uint32_t)Am;
         ha1[slot] = (uint32_t)(Am >> 32);
+        hr0[slot] = (uint32_t)Rg;
+        hr1[slot] = (uint32_t)(Rg >> 32);
     }
 };
 
@@ -269,7 +275,7 @@ struct SlabStore {
         st(&ring[i & (rcap - 1)], make_uint4(tile, 0u, (uint32_t)m, (uint32_t)(m >> 32)));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
-    __device__ bool lookup(uint32_t tile, uint32_t& slot, uint64_t& V, uint64_t& Am) const {
+    __device__ bool lookup(uint32_t tile, uint32_t& slot, uint64_t& V, uint64_t& Am, uint64_t& Rg) const {
         const uint32_t key = tile + 1u;
         uint32_t hs = (key * 2654435761u) & (hcap - 1);
         for (uint32_t probe = 0; probe < hcap; ++probe) {
@@ -280,6 +286,7 @@ struct SlabStore {
                 slot = hs;
                 V = uni64(v.z, v.w);
                 Am = uni64(a.x, a.y);
+                Rg = uni64(a.z, a.w);
                 return true;
             }
             hs = (hs + 1) & (hcap - 1);
@@ -287,10 +294,11 @@ struct SlabStore {
         slot = hs;
         V = 0ull;
         Am = 0ull;
+        Rg = 0ull;
         return false;
     }
-    __device__ void update(uint32_t slot, uint32_t tile, uint64_t V, uint64_t Am) {
-        st(&hash[2 * slot + 1], make_uint4((uint32_t)Am, (uint32_t)(Am >> 32), 0u, 0u));
+    __device__ void update(uint32_t slot, uint32_t tile, uint64_t V, uint64_t Am, uint64_t Rg) {
+        st(&hash[2 * slot + 1], make_uint4((uint32_t)Am, (uint32_t)(Am >> 32), (uint32_t)Rg, (uint32_t)(Rg >> 32)));
         st(&hash[2 * slot], make_uint4(gen, tile + 1u, (uint32_t)V, (uint32_t)(V >> 32)));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
@@ -332,35 +340,75 @@ __device__ inline uint64_t dilate8(uint64_t r) {
 
 // Walks the footprint of seed k from the state in `st`.  Returns 0 when the walk is complete, 1 when
 // the store ran out; `st` then holds a resumable state.
+// The 36 pixels around an 8x8 tile, one per lane 0..35: lanes 0-7 the row above (x = 0..7), 8-15 the row below,
+// 16-23 the column to the left (y = 0..7), 24-31 the column to the right, 32-35 the corners (-1,-1) (8,-1)
+// (-1,8) (8,8).  A record is pushed to a neighbour tile only for ring pixels that are themselves acceptable and
+// touch a newly walked pixel, so no step is spent on a tile that nothing can enter.
+__device__ __forceinline__ void ring_xy(int lane, int& rx, int& ry) {
+    const int g = lane >> 3, i = lane & 7;
+    rx = (g == 0 || g == 1) ? i : (g == 2 ? -1 : (g == 3 ? 8 : ((i & 1) ? 8 : -1)));
+    ry = (g == 0) ? -1 : (g == 1 ? 8 : ((g == 2 || g == 3) ? i : ((i & 2) ? 8 : -1)));
+}
+// in-tile pixels (bit = y*8+x) 8-adjacent to this lane's ring pixel
+__device__ __forceinline__ uint64_t ring_adjacency(int lane) {
+    if (lane >= 36) return 0ull;
+    int rx, ry;
+    ring_xy(lane, rx, ry);
+    uint64_t m = 0ull;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int x = rx + dx, y = ry + dy;
+            if (x >= 0 && x < 8 && y >= 0 && y < 8) m |= 1ull << (y * 8 + x);
+        }
+    return m;
+}
+// bit y of b -> bit 8*y (a byte's bits spread down a bit-board column)
+__device__ __forceinline__ uint64_t spread_col(uint64_t b) {
+    b = (b | (b << 28)) & 0x0000000F0000000Full;
+    b = (b | (b << 14)) & 0x0003000300030003ull;
+    b = (b | (b << 7)) & 0x0101010101010101ull;
+    return b;
+}
+
 // What one lane holds of a frontier record before it is processed.  For a tile the wave already knows, the
-// table answers (V, A) and no memory is touched; otherwise the lane's pixel of the tile is loaded.
+// table answers (V, A, ring) and no memory is touched; otherwise the lane's pixel of the tile and its pixel of
+// the surrounding ring are loaded.
 struct TileFetch {
     uint32_t tile, slot;
-    uint64_t entry, V, Am;
+    uint64_t entry, V, Am, Rg;
     size_t q;
-    uint32_t lab;
-    float dx, dy;
-    uint32_t dm;
-    bool known, inside;
+    uint32_t lab, rlab;
+    float dx, dy, rdx, rdy;
+    uint32_t dm, rdm;
+    bool known, inside, rinside;
 };
 
 template <class Store>
-__device__ __forceinline__ TileFetch fetch_tile(const FloodArgs& A, const Store& S, uint32_t i, int lr, int lc) {
+__device__ __forceinline__ TileFetch fetch_tile(const FloodArgs& A, const Store& S, uint32_t i, int lr, int lc,
+                                                int rx, int ry, bool ring_lane) {
     TileFetch f;
     S.get(i, f.tile, f.entry);
     const int ty = (int)(f.tile >> 16), tx = (int)(f.tile & 0xFFFFu);  // tile id = ty << 16 | tx
     const int r = ty * 8 + lr, c = tx * 8 + lc;
     f.inside = r < A.h && c < A.w;
     f.q = f.inside ? (size_t)r * A.w + c : 0;
-    f.known = S.lookup(f.tile, f.slot, f.V, f.Am);
-    f.lab = 0u;
-    f.dm = 0u;
-    f.dx = f.dy = 0.f;
+    f.known = S.lookup(f.tile, f.slot, f.V, f.Am, f.Rg);
+    f.lab = f.rlab = 0u;
+    f.dm = f.rdm = 0u;
+    f.dx = f.dy = f.rdx = f.rdy = 0.f;
+    f.rinside = false;
     if (!f.known) {  // wave-uniform
         f.lab = A.label[f.q];  // only the committed/not-committed split is read from it, and that is stable in a round
         f.dm = A.dmask[f.q];
         f.dx = A.dx[f.q];
         f.dy = A.dy[f.q];
+        const int rr = ty * 8 + ry, rc = tx * 8 + rx;
+        f.rinside = ring_lane && rr >= 0 && rr < A.h && rc >= 0 && rc < A.w;
+        const size_t rq = f.rinside ? (size_t)rr * A.w + rc : 0;
+        f.rlab = A.label[rq];
+        f.rdm = A.dmask[rq];
+        f.rdx = A.dx[rq];
+        f.rdy = A.dy[rq];
     }
     return f;
 }
@@ -373,9 +421,12 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
                     WalkState& st, int lane) {
     const uint32_t mine = kMarkBit | k;
     const int lr = lane >> 3, lc = lane & 7;
-    const int tiles_y = (A.h + 7) >> 3;
+    int rx, ry;
+    ring_xy(lane, rx, ry);
+    const bool ring_lane = lane < 36;
+    const uint64_t adj = ring_adjacency(lane);
     if (st.head == st.tail) return 0;
-    TileFetch cur = fetch_tile(A, S, st.head, lr, lc);
+    TileFetch cur = fetch_tile(A, S, st.head, lr, lc, rx, ry, ring_lane);
     // The stamp of a step (a returning atomicMin) is only needed to tell who else reaches the pixel; the walk
     // itself continues from every new pixel regardless.  So its result is consumed one step later, and the
     // atomic's round trip overlaps the next step instead of standing on the critical path.
@@ -402,14 +453,16 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
         st.steps += 1;
         const bool have_next = st.head != st.tail;
         TileFetch nxt;
-        if (have_next) nxt = fetch_tile(A, S, st.head, lr, lc);
+        if (have_next) nxt = fetch_tile(A, S, st.head, lr, lc, rx, ry, ring_lane);
         const uint32_t tile = cur.tile;
-        const int ty = (int)(tile >> 16), tx = (int)(tile & 0xFFFFu);
-        uint64_t Am = cur.Am;
+        uint64_t Am = cur.Am, Rg = cur.Rg;
         if (!cur.known) {
             const bool acc = cur.inside && cur.lab >= kMarkBit && ((cur.dm >> b) & 1) &&
                              directional(cur.dx, cur.dy, sn, cs) > thr;
             Am = __ballot(acc);
+            const bool racc = cur.rinside && cur.rlab >= kMarkBit && ((cur.rdm >> b) & 1) &&
+                              directional(cur.rdx, cur.rdy, sn, cs) > thr;
+            Rg = __ballot(racc);
         }
         uint64_t R = cur.entry & Am;
         uint64_t New = 0ull;
@@ -428,45 +481,41 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
         prev_old = old;
         prev_issued = issue;
         if (New != 0ull || !cur.known) {
-            S.update(cur.slot, tile, cur.V | New, Am);
+            S.update(cur.slot, tile, cur.V | New, Am, Rg);
             if (!cur.known) st.ntiles += 1;
             if (have_next && nxt.tile == tile) {  // the prefetched record looked this tile up before the update
                 nxt.known = true;
                 nxt.slot = cur.slot;
                 nxt.V = cur.V | New;
                 nxt.Am = Am;
+                nxt.Rg = Rg;
             } else if (have_next && !cur.known && !nxt.known) {
                 // an insertion may have taken the empty slot the prefetched lookup had reserved: probe again
-                uint64_t v0, a0;
-                (void)S.lookup(nxt.tile, nxt.slot, v0, a0);
+                uint64_t v0, a0, r0;
+                (void)S.lookup(nxt.tile, nxt.slot, v0, a0, r0);
             }
         }
         st.cnt += (uint32_t)__popcll(New);
         if (New != 0ull) {
-            const uint64_t X = New;  // newly walked pixels: their neighbours outside the tile become entries
-            const bool has_l = tx > 0, has_r = tx + 1 < A.tiles_x, has_u = ty > 0, has_d = ty + 1 < tiles_y;
-            uint64_t m = (X & 0x8080808080808080ull) >> 7;  // col 7 -> col 0 of the right tile
-            m = m | (m << 8) | (m >> 8);
-            if (has_r && m) P.push(S, st, tile + 1u, m);
-            m = (X & 0x0101010101010101ull) << 7;  // col 0 -> col 7 of the left tile
-            m = m | (m << 8) | (m >> 8);
-            if (has_l && m) P.push(S, st, tile - 1u, m);
-            uint64_t t = X >> 56;  // row 7 -> row 0 of the tile below
-            t = (t | (t << 1) | (t >> 1)) & 0xFFull;
-            if (has_d && t) P.push(S, st, tile + 0x10000u, t);
-            t = X & 0xFFull;  // row 0 -> row 7 of the tile above
-            t = ((t | (t << 1) | (t >> 1)) & 0xFFull) << 56;
-            if (has_u && t) P.push(S, st, tile - 0x10000u, t);
-            if (has_d && has_r && (X >> 63)) P.push(S, st, tile + 0x10001u, 1ull);
-            if (has_d && has_l && ((X >> 56) & 1ull)) P.push(S, st, tile + 0xFFFFu, 1ull << 7);
-            if (has_u && has_r && ((X >> 7) & 1ull)) P.push(S, st, tile - 0xFFFFu, 1ull << 56);
-            if (has_u && has_l && (X & 1ull)) P.push(S, st, tile - 0x10001u, 1ull << 63);
+            // ring pixels that are acceptable and touch a newly walked pixel become entries of their own tiles
+            const uint64_t H = __ballot(((Rg >> lane) & 1ull) && (New & adj) != 0ull);
+            if (H != 0ull) {
+                const uint64_t up = H & 0xFFull, dn = (H >> 8) & 0xFFull, lf = (H >> 16) & 0xFFull, rt = (H >> 24) & 0xFFull;
+                if (up) P.push(S, st, tile - 0x10000u, up << 56);          // (x,-1) -> pixel (x,7) of the tile above
+                if (dn) P.push(S, st, tile + 0x10000u, dn);                // (x,8)  -> pixel (x,0) of the tile below
+                if (lf) P.push(S, st, tile - 1u, spread_col(lf) << 7);     // (-1,y) -> pixel (7,y) of the left tile
+                if (rt) P.push(S, st, tile + 1u, spread_col(rt));          // (8,y)  -> pixel (0,y) of the right tile
+                if ((H >> 32) & 1ull) P.push(S, st, tile - 0x10001u, 1ull << 63);
+                if ((H >> 33) & 1ull) P.push(S, st, tile - 0xFFFFu, 1ull << 56);
+                if ((H >> 34) & 1ull) P.push(S, st, tile + 0xFFFFu, 1ull << 7);
+                if ((H >> 35) & 1ull) P.push(S, st, tile + 0x10001u, 1ull);
+            }
         }
         if (st.head == st.tail) {
             settle();
             return 0;
         }
-        cur = have_next ? nxt : fetch_tile(A, S, st.head, lr, lc);
+        cur = have_next ? nxt : fetch_tile(A, S, st.head, lr, lc, rx, ry, ring_lane);
     }
 }
 
@@ -475,7 +524,7 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
 __global__ __launch_bounds__(64) void flood_explore_kernel(FloodArgs A, BinTrig trig, const uint32_t* __restrict__ act,
                                                            uint32_t n_act) {
     __shared__ uint32_t s_ring[1][3][kRingT];
-    __shared__ uint32_t s_hash[1][5][kHashT];
+    __shared__ uint32_t s_hash[1][7][kHashT];
     __shared__ uint32_t s_pend[1][2][kPend];
     const int wv = 0, lane = threadIdx.x & 63;
     const uint32_t ai = uni(blockIdx.x);
@@ -490,8 +539,8 @@ __global__ __launch_bounds__(64) void flood_explore_kernel(FloodArgs A, BinTrig 
         if (lane == 0) A.flags[k] = kFlagSelfFail;  // flood() accepts nothing, not even the seed
         return;
     }
-    LdsStore L{s_ring[wv][0], s_ring[wv][1], s_ring[wv][2], s_hash[wv][0],
-               s_hash[wv][1], s_hash[wv][2], s_hash[wv][3], s_hash[wv][4]};
+    LdsStore L{s_ring[wv][0], s_ring[wv][1], s_ring[wv][2], s_hash[wv][0], s_hash[wv][1],
+               s_hash[wv][2], s_hash[wv][3], s_hash[wv][4], s_hash[wv][5], s_hash[wv][6]};
     for (int i = lane; i < kHashT; i += 64) L.hk[i] = 0u;
     Pending P{s_pend[wv][0], s_pend[wv][1]};
     P.pt[lane] = 0u;
@@ -520,9 +569,10 @@ __global__ __launch_bounds__(64) void flood_explore_kernel(FloodArgs A, BinTrig 
                 const uint32_t key = L.hk[i];
                 if (key) {
                     uint32_t slot;
-                    uint64_t v0, a0;
-                    (void)G.lookup(key - 1u, slot, v0, a0);
-                    G.update(slot, key - 1u, ((uint64_t)L.hv1[i] << 32) | L.hv0[i], ((uint64_t)L.ha1[i] << 32) | L.ha0[i]);
+                    uint64_t v0, a0, r0;
+                    (void)G.lookup(key - 1u, slot, v0, a0, r0);
+                    G.update(slot, key - 1u, ((uint64_t)L.hv1[i] << 32) | L.hv0[i], ((uint64_t)L.ha1[i] << 32) | L.ha0[i],
+                             ((uint64_t)L.hr1[i] << 32) | L.hr0[i]);
                 }
             }
             rc = walk(A, k, b, thr, sn, cs, G, P, st, lane);
