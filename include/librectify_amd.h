@@ -132,6 +132,10 @@ int lr_ransac_best(lr_context* ctx, const LineSegment* lines_norm, int n, const 
 int lr_estimate_line_pencils(lr_context* ctx, LineSegment* lines, int n, int max_models, float inlier_deg,
                              float garbage_deg, int n_iter, uint64_t seed);
 
+/* postprocess_lines_segments (line_detector.cpp:332-444), what refine=true runs: merges collinear neighbours.
+ * `out` must hold n records; the O(n^2) pair test runs on the GPU for n >= 2048. */
+int lr_refine_lines(lr_context* ctx, const LineSegment* in, int n, LineSegment* out, int* n_out);
+
 /* ---- PROSAC / Hough weights (opt-in) --------------------------------------------------- */
 /* The reference compiles prosac.h but never instantiates it (ChangeLog.md: "pure RANSAC is used"), so RANSAC
  * is the default here too.  kind: 0 = RANSAC, 1 = PROSAC with T_N iterations (<= 0: the reference's

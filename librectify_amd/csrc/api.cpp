@@ -262,6 +262,14 @@ int lr_estimate_line_pencils(lr_context* ctx, LineSegment* lines, int n, int max
     return 0;
 }
 
+int lr_refine_lines(lr_context* ctx, const LineSegment* in, int n, LineSegment* out, int* n_out) {
+    std::vector<LineSegment> v(in, in + n);
+    if (ctx_refine(ctx, v)) return 1;
+    std::memcpy(out, v.data(), v.size() * sizeof(LineSegment));
+    *n_out = (int)v.size();
+    return 0;
+}
+
 void lr_set_estimator(lr_context* ctx, int kind, int prosac_T_N) {
     ctx->estimator = kind;
     ctx->prosac_T_N = prosac_T_N;

@@ -691,6 +691,45 @@ int ctx_estimate_line_pencils_prosac(lr_context* c, std::vector<LineSegment>& li
     return 0;
 }
 
+// postprocess_lines_segments (line_detector.cpp:332-444): pair test on the GPU for large n, graph walk and
+// merges on the host.
+int ctx_refine(lr_context* c, std::vector<LineSegment>& lines) {
+    const size_t n = lines.size();
+    if (n < 2048) {
+        lines = refine_lines(lines);
+        return 0;
+    }
+    LR_HIP(hipSetDevice(c->device));
+    std::vector<float> table;
+    refine_segment_table(lines, table);
+    float* d_table = nullptr;
+    uint2* d_edges = nullptr;
+    size_t cap = 16 * n;
+    std::vector<std::pair<uint32_t, uint32_t>> edges;
+    LR_HIP(hipMalloc((void**)&d_table, table.size() * sizeof(float)));
+    LR_HIP(hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    for (;;) {
+        LR_HIP(hipMalloc((void**)&d_edges, cap * sizeof(uint2)));
+        LR_HIP(hipMemsetAsync(c->d_counts + 8, 0, sizeof(uint32_t), c->stream));
+        if (launch_refine_pairs(d_table, (uint32_t)n, d_edges, c->d_counts + 8, (uint32_t)std::min<size_t>(cap, 0xFFFFFFFFu), c->stream)) return 1;
+        LR_HIP(hipMemcpyAsync(c->h_counts + 8, c->d_counts + 8, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        LR_HIP(hipStreamSynchronize(c->stream));
+        const size_t ne = c->h_counts[8];
+        if (ne <= cap) {
+            edges.resize(ne);
+            static_assert(sizeof(std::pair<uint32_t, uint32_t>) == sizeof(uint2), "edge layout");
+            LR_HIP(hipMemcpy(edges.data(), d_edges, ne * sizeof(uint2), hipMemcpyDeviceToHost));
+            (void)hipFree(d_edges);
+            break;
+        }
+        (void)hipFree(d_edges);
+        cap = ne;  // the kernel counted every edge: exactly enough next time
+    }
+    (void)hipFree(d_table);
+    lines = refine_lines_from_edges(lines, edges);
+    return 0;
+}
+
 // find_line_segment_groups (interface.cpp:35-80) on a device-resident image.
 int ctx_find_groups_device(lr_context* c, const float* d_image, int w, int h, int stride, float min_length, bool refine,
                            std::vector<LineSegment>& out) {
@@ -698,7 +737,7 @@ int ctx_find_groups_device(lr_context* c, const float* d_image, int w, int h, in
     std::vector<LineSegment> raw;
     if (ctx_detect(c, d_image, w, h, stride, raw)) return 1;
     if (raw.size() < 2) return 0;
-    if (refine) raw = refine_lines(raw);
+    if (refine && ctx_refine(c, raw)) return 1;
     std::vector<LineSegment> filtered = filter_lines(raw, min_length);
     if (filtered.empty()) return 0;
     LR_HIP(hipEventRecord(c->ev[5], c->stream));

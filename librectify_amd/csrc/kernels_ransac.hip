@@ -245,7 +245,61 @@ __global__ __launch_bounds__(256) void ht_weights_kernel(PencilSoA m, uint32_t n
     weights[i] = i2 * i2;
 }
 
+// ---- refine: pairwise merge test (reference line_detector.cpp:353-400) ---------------------------------
+// One thread per (i, j > i) pair inside a 64 x 64 tile of the pair matrix; segment data of the tile's rows and
+// columns is staged in LDS.  Emits the edges (i, j) of the merge graph; the (tiny) graph walk and the merges
+// stay on the host.  Same float operations, in the same order, as the host loop in vp_host.cpp.
+struct RefineSeg {
+    float x1, y1, x2, y2, dx, dy, len;  // d = unit direction, n = (-dy, dx)
+};
+
+__global__ __launch_bounds__(256) void refine_pairs_kernel(const RefineSeg* __restrict__ seg, uint32_t n,
+                                                           uint2* __restrict__ edges, uint32_t* __restrict__ n_edges,
+                                                           uint32_t cap) {
+    __shared__ RefineSeg si[64], sj[64];
+    const uint32_t bi = blockIdx.y, bj = blockIdx.x;
+    if (bj < bi) return;  // only the upper triangle (whole block)
+    const uint32_t i0 = bi * 64, j0 = bj * 64;
+    for (uint32_t t = threadIdx.x; t < 128; t += 256) {
+        const uint32_t idx = (t < 64) ? i0 + t : j0 + (t - 64);
+        RefineSeg v{0, 0, 0, 0, 0, 0, 1};
+        if (idx < n) v = seg[idx];
+        if (t < 64) si[t] = v; else sj[t - 64] = v;
+    }
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < 64 * 64; p += 256) {
+        const uint32_t a = p >> 6, b = p & 63;
+        const uint32_t i = i0 + a, j = j0 + b;
+        if (i >= n || j >= n || j <= i) continue;
+        const RefineSeg A = si[a], B = sj[b];
+        if (fabsf(A.dx * B.dx + A.dy * B.dy) < 0.99) continue;  // cos(max angular difference); double literal as the reference
+        const bool i_short = A.len < B.len;
+        const RefineSeg R = i_short ? B : A;  // frame of the longer one
+        const RefineSeg O = i_short ? A : B;
+        const float nx = -R.dy, ny = R.dx;
+        const float ax = O.x1 - R.x1, ay = O.y1 - R.y1, bx = O.x2 - R.x1, by = O.y2 - R.y1;
+        const float w00 = (ax * R.dx + ay * R.dy) / R.len, w01 = (ax * nx + ay * ny) / R.len;
+        const float w10 = (bx * R.dx + by * R.dy) / R.len, w11 = (bx * nx + by * ny) / R.len;
+        if (fmaxf(fabsf(w01), fabsf(w11)) < 0.02) {
+            const bool any_gt = (w00 > -0.5) || (w10 > -0.5);
+            const bool any_lt = (w00 < 1.5) || (w10 < 1.5);
+            if (any_gt && any_lt) {
+                const uint32_t slot = atomicAdd(n_edges, 1u);
+                if (slot < cap) edges[slot] = make_uint2(i, j);
+            }
+        }
+    }
+}
+
 }  // namespace
+
+int launch_refine_pairs(const void* seg, uint32_t n, void* edges, uint32_t* n_edges, uint32_t cap, hipStream_t s) {
+    const uint32_t nb = (n + 63) / 64;
+    hipLaunchKernelGGL(refine_pairs_kernel, dim3(nb, nb), dim3(256), 0, s, (const RefineSeg*)seg, n, (uint2*)edges,
+                       n_edges, cap);
+    LR_HIP(hipGetLastError());
+    return 0;
+}
 
 int launch_prosac_count(PencilSoA m, uint32_t n, float tol, float degeneracy_tol, const uint32_t* sa,
                         const uint32_t* sb, uint32_t n_hyp, uint32_t* counts, hipStream_t s) {

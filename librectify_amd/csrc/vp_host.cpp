@@ -359,8 +359,65 @@ std::vector<LineSegment> filter_lines(const std::vector<LineSegment>& lines, flo
     return out;
 }
 
-// line_detector.cpp:254-444.  O(n^2) pair test on the host for now (SURVEY.md §8f-1 ranks the GPU
-// version "next"); the merge graph walk reproduces the reference's forward-only BFS (:293).
+// graph_components + dfs + merge_lines (line_detector.cpp:254-329,409-443): forward-only BFS over the edges
+// i -> j (j > i), label = first vertex, one merged segment per label in ascending label order.
+static std::vector<LineSegment> merge_graph(const std::vector<LineSegment>& lines, const std::vector<std::vector<int>>& adj) {
+    const int n = (int)lines.size();
+    std::vector<uint8_t> visited(n, 0);
+    std::vector<int> comp(n, 0);
+    for (int v = 0; v < n; ++v) {
+        if (visited[v]) continue;
+        std::queue<int> nodes;
+        nodes.push(v);
+        while (!nodes.empty()) {
+            const int u = nodes.front();
+            nodes.pop();
+            visited[u] = 1;
+            comp[u] = v;
+            for (int t : adj[u])
+                if (!visited[t]) nodes.push(t);
+        }
+    }
+    // members per label in ascending index order, labels in ascending order (what the reference's
+    // std::set walk + linear scans produce, without their O(n * labels) cost)
+    std::vector<std::vector<int>> members(n);
+    for (int j = 0; j < n; ++j) members[comp[j]].push_back(j);
+    std::vector<LineSegment> res;
+    for (int lbl = 0; lbl < n; ++lbl) {
+        if (members[lbl].empty()) continue;
+        std::vector<const LineSegment*> grp;
+        for (int j : members[lbl]) grp.push_back(&lines[j]);
+        if (grp.size() == 1) {
+            res.push_back(*grp[0]);
+            continue;
+        }
+        // merge_lines (:254-274): endpoints weighted by length*weight
+        const size_t m = 2 * grp.size();
+        std::vector<float> xr(m), xc(m), W(m);
+        float wsum = 0.f, lsum = 0.f;
+        for (size_t i = 0; i < grp.size(); ++i) {
+            const LineSegment& ln = *grp[i];
+            const float l = segment_length(ln);
+            const float wt = l * ln.weight;
+            xr[2 * i] = ln.y1;
+            xc[2 * i] = ln.x1;
+            xr[2 * i + 1] = ln.y2;
+            xc[2 * i + 1] = ln.x2;
+            W[2 * i] = wt;
+            W[2 * i + 1] = wt;
+            wsum = wsum + wt;
+            lsum = lsum + l;
+        }
+        LineSegment merged = fit_line_host(xr, xc, W);
+        merged.weight = wsum / lsum;
+        res.push_back(merged);
+    }
+    return res;
+}
+
+
+// line_detector.cpp:254-444 with the O(n^2) pair test on the host (used for small n; context.hip switches to
+// refine_pairs_kernel for large n); the merge graph walk reproduces the reference's forward-only BFS (:293).
 std::vector<LineSegment> refine_lines(const std::vector<LineSegment>& lines) {
     const int n = (int)lines.size();
     std::vector<Vec2> d(n), nv(n);
@@ -394,54 +451,30 @@ std::vector<LineSegment> refine_lines(const std::vector<LineSegment>& lines) {
             }
         }
     }
-    std::vector<uint8_t> visited(n, 0);
-    std::vector<int> comp(n, 0);
-    for (int v = 0; v < n; ++v) {
-        if (visited[v]) continue;
-        std::queue<int> nodes;
-        nodes.push(v);
-        while (!nodes.empty()) {
-            const int u = nodes.front();
-            nodes.pop();
-            visited[u] = 1;
-            comp[u] = v;
-            for (int t : adj[u])
-                if (!visited[t]) nodes.push(t);
-        }
+    return merge_graph(lines, adj);
+}
+
+void refine_segment_table(const std::vector<LineSegment>& lines, std::vector<float>& t) {
+    const size_t n = lines.size();
+    t.resize(7 * n);
+    for (size_t i = 0; i < n; ++i) {
+        const float dx = lines[i].x2 - lines[i].x1, dy = lines[i].y2 - lines[i].y1;
+        const float l = std::sqrt(dx * dx + dy * dy);
+        t[7 * i + 0] = lines[i].x1;
+        t[7 * i + 1] = lines[i].y1;
+        t[7 * i + 2] = lines[i].x2;
+        t[7 * i + 3] = lines[i].y2;
+        t[7 * i + 4] = dx / l;
+        t[7 * i + 5] = dy / l;
+        t[7 * i + 6] = l;
     }
-    std::set<int> labels(comp.begin(), comp.end());
-    std::vector<LineSegment> res;
-    res.reserve(labels.size());
-    for (int lbl : labels) {
-        std::vector<const LineSegment*> grp;
-        for (int j = 0; j < n; ++j)
-            if (comp[j] == lbl) grp.push_back(&lines[j]);
-        if (grp.size() == 1) {
-            res.push_back(*grp[0]);
-            continue;
-        }
-        // merge_lines (:254-274): endpoints weighted by length*weight
-        const size_t m = 2 * grp.size();
-        std::vector<float> xr(m), xc(m), W(m);
-        float wsum = 0.f, lsum = 0.f;
-        for (size_t i = 0; i < grp.size(); ++i) {
-            const LineSegment& ln = *grp[i];
-            const float l = segment_length(ln);
-            const float wt = l * ln.weight;
-            xr[2 * i] = ln.y1;
-            xc[2 * i] = ln.x1;
-            xr[2 * i + 1] = ln.y2;
-            xc[2 * i + 1] = ln.x2;
-            W[2 * i] = wt;
-            W[2 * i + 1] = wt;
-            wsum = wsum + wt;
-            lsum = lsum + l;
-        }
-        LineSegment merged = fit_line_host(xr, xc, W);
-        merged.weight = wsum / lsum;
-        res.push_back(merged);
-    }
-    return res;
+}
+
+std::vector<LineSegment> refine_lines_from_edges(const std::vector<LineSegment>& lines,
+                                                 const std::vector<std::pair<uint32_t, uint32_t>>& edges) {
+    std::vector<std::vector<int>> adj(lines.size());
+    for (const auto& e : edges) adj[e.first].push_back((int)e.second);
+    return merge_graph(lines, adj);
 }
 
 std::map<int, Vec3> fit_vanishing_points(const std::vector<LineSegment>& lines) {

@@ -51,6 +51,11 @@ float segment_length(const LineSegment& l);
 
 std::vector<LineSegment> filter_lines(const std::vector<LineSegment>& lines, float min_length);  // interface.cpp:26-32
 std::vector<LineSegment> refine_lines(const std::vector<LineSegment>& lines);  // line_detector.cpp:332-444
+// same, with the merge-graph edges (i < j) already computed (by the GPU pair kernel)
+std::vector<LineSegment> refine_lines_from_edges(const std::vector<LineSegment>& lines,
+                                                 const std::vector<std::pair<uint32_t, uint32_t>>& edges);
+// per-segment record of the pair test: {x1, y1, x2, y2, unit dx, unit dy, length}
+void refine_segment_table(const std::vector<LineSegment>& lines, std::vector<float>& table7);
 
 std::map<int, Vec3> fit_vanishing_points(const std::vector<LineSegment>& lines);  // transform.cpp:52-81
 Vec3 fit_single_vanishing_point(const std::vector<LineSegment>& lines, int g);    // transform.cpp:24-47

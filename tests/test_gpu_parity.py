@@ -310,6 +310,20 @@ def test_parallel_flood_equals_ordered_flood_at_full_size(L, ctx):
     _assert_lines_equal(out[0][2], out[1][2])
 
 
+def test_refine_pair_kernel_matches_oracle(L, ctx):
+    """postprocess_lines_segments on raw detector output: small n takes the host loop, n >= 2048 the GPU pair
+    kernel; both against the oracle (self-golden: the reference pins nothing for refine)."""
+    from librectify_amd import synth
+
+    for w, h, seed in [(320, 240, 13), (1920, 1080, 1000)]:
+        raw = O.find_line_segments(synth.frame(w, h, seed), want_label=False)["lines"]
+        assert (len(raw) >= 2048) == (w > 1000)
+        ref = O.refine_lines(raw)
+        got = ctx.refine_lines(raw)
+        _assert_lines_equal(got, ref)
+        assert len(got) < len(raw)
+
+
 def test_size_independent_properties_at_full_size(L, ctx):
     """3840x2160 (BASELINE configs[1..2]): properties that need no oracle run."""
     from librectify_amd import synth
