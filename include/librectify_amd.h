@@ -132,6 +132,11 @@ int lr_ransac_best(lr_context* ctx, const LineSegment* lines_norm, int n, const 
 int lr_estimate_line_pencils(lr_context* ctx, LineSegment* lines, int n, int max_models, float inlier_deg,
                              float garbage_deg, int n_iter, uint64_t seed);
 
+/* Diamond-space ("cascaded Hough") accumulator, opt-in: what reference cht.h:13-24 describes (its cht.cpp is an
+ * uncompiled sketch).  d x d accumulator (8 <= d <= 128) of length-weighted line polylines, kept in LDS with integer
+ * atomics; returns the de-normalised vanishing point of the strongest pencil (z = 0: ideal point) and, if acc_out is
+ * not NULL, the d*d 64-bit accumulator. */
+int lr_cht_vanishing_point(lr_context* ctx, const LineSegment* lines, int n, int d, Point* vp, uint64_t* acc_out);
 /* postprocess_lines_segments (line_detector.cpp:332-444), what refine=true runs: merges collinear neighbours.
  * `out` must hold n records; the O(n^2) pair test runs on the GPU for n >= 2048. */
 int lr_refine_lines(lr_context* ctx, const LineSegment* in, int n, LineSegment* out, int* n_out);

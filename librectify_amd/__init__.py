@@ -68,7 +68,7 @@ EXPORTS = [
     "lr_find_line_segment_groups_host", "lr_find_line_segment_groups_batch_device", "lr_stage_filter",
     "lr_stage_filter_host", "lr_stage_seeds", "lr_stage_flood", "lr_stage_fit", "lr_download", "lr_stage_times",
     "lr_stage_counters", "lr_filter_kernel_ms", "lr_ransac_best", "lr_estimate_line_pencils",
-    "lr_set_batch_streams", "lr_device_malloc", "lr_device_free", "lr_memcpy_h2d", "lr_refine_lines", "lr_set_estimator", "lr_ht_weights", "lr_prosac_solve", "lr_estimate_line_pencils_prosac",
+    "lr_set_batch_streams", "lr_device_malloc", "lr_device_free", "lr_memcpy_h2d", "lr_cht_vanishing_point", "lr_refine_lines", "lr_set_estimator", "lr_ht_weights", "lr_prosac_solve", "lr_estimate_line_pencils_prosac",
 ]
 
 _lib = None
@@ -130,6 +130,7 @@ def lib():
         L.lr_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.lr_set_batch_streams.argtypes = [C.c_void_p, C.c_int]
         L.lr_set_batch_streams.restype = None
+        L.lr_cht_vanishing_point.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Point), C.c_void_p]
         L.lr_refine_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
         L.lr_set_estimator.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.lr_set_estimator.restype = None
@@ -306,6 +307,13 @@ class Context:
         bi = C.c_int(0)
         _check(lib().lr_ransac_best(self._h, _ptr(lines_norm), len(lines_norm), _ptr(indices), len(indices), tol, n_iter, C.c_uint64(seed), C.c_uint32(rnd), _ptr(bh), C.byref(bs), C.byref(bi)))
         return dict(best_h=bh, score=bs.value, iter=bi.value)
+
+    def cht_vanishing_point(self, lines, d=128):
+        lines = np.ascontiguousarray(lines, LINE_DTYPE)
+        vp = Point()
+        acc = np.zeros((d, d), np.uint64)
+        _check(lib().lr_cht_vanishing_point(self._h, _ptr(lines), len(lines), d, C.byref(vp), _ptr(acc)))
+        return np.array([vp.x, vp.y, vp.z], np.float32), acc
 
     def refine_lines(self, lines):
         lines = np.ascontiguousarray(lines, LINE_DTYPE)

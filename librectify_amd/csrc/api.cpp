@@ -262,6 +262,15 @@ int lr_estimate_line_pencils(lr_context* ctx, LineSegment* lines, int n, int max
     return 0;
 }
 
+int lr_cht_vanishing_point(lr_context* ctx, const LineSegment* lines, int n, int d, Point* vp, uint64_t* acc_out) {
+    Vec3 p;
+    std::vector<uint64_t> acc;
+    if (ctx_cht_vanishing_point(ctx, std::vector<LineSegment>(lines, lines + n), d, &p, acc_out ? &acc : nullptr)) return 1;
+    *vp = Point{p.x, p.y, p.z};
+    if (acc_out) std::memcpy(acc_out, acc.data(), acc.size() * sizeof(uint64_t));
+    return 0;
+}
+
 int lr_refine_lines(lr_context* ctx, const LineSegment* in, int n, LineSegment* out, int* n_out) {
     std::vector<LineSegment> v(in, in + n);
     if (ctx_refine(ctx, v)) return 1;

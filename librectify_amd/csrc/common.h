@@ -158,6 +158,7 @@ struct PencilSoA {  // device pointers, n entries each (lines of the current rou
 int launch_ransac_score(PencilSoA m, uint32_t n, float tol, float degeneracy_tol, uint32_t n_iter, uint64_t seed,
                         uint32_t round, float* scores, hipStream_t s);
 int launch_ransac_argmax(const float* scores, uint32_t n_iter, float* best_score, int32_t* best_iter, hipStream_t s);
+int launch_cht_accumulate(PencilSoA m, uint32_t n, int d, unsigned long long* acc, hipStream_t s);
 // refine: seg = n records of 7 floats {x1,y1,x2,y2,dx,dy,len}; edges = pairs of uint32 (i<j); *n_edges may exceed cap
 int launch_refine_pairs(const void* seg, uint32_t n, void* edges, uint32_t* n_edges, uint32_t cap, hipStream_t s);
 int launch_prosac_count(PencilSoA m, uint32_t n, float tol, float degeneracy_tol, const uint32_t* sa,

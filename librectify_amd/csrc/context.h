@@ -116,6 +116,8 @@ int ctx_estimate_line_pencils_prosac(lr_context* c, std::vector<LineSegment>& li
                                      float garbage_deg, int T_N, uint64_t seed);
 int ctx_estimate_line_pencils(lr_context* c, std::vector<LineSegment>& lines, int max_models, float inlier_deg,
                               float garbage_deg, int n_iter, uint64_t seed);
+int ctx_cht_vanishing_point(lr_context* c, const std::vector<LineSegment>& lines, int d, Vec3* vp,
+                            std::vector<uint64_t>* acc_out);
 int ctx_refine(lr_context* c, std::vector<LineSegment>& lines);
 int ctx_find_groups_device(lr_context* c, const float* d_image, int w, int h, int stride, float min_length, bool refine,
                            std::vector<LineSegment>& out);

@@ -691,6 +691,42 @@ int ctx_estimate_line_pencils_prosac(lr_context* c, std::vector<LineSegment>& li
     return 0;
 }
 
+// Diamond-space accumulator (opt-in; cht.h:13-24): de-normalised vanishing point of the strongest pencil.
+int ctx_cht_vanishing_point(lr_context* c, const std::vector<LineSegment>& lines, int d, Vec3* vp,
+                            std::vector<uint64_t>* acc_out) {
+    LR_HIP(hipSetDevice(c->device));
+    const Normalisation nrm = bbox_normalisation(lines);
+    const PencilModel model(normalise(lines, nrm));
+    std::vector<int> all(model.size());
+    for (int i = 0; i < model.size(); ++i) all[i] = i;
+    PencilSoA soa;
+    if (upload_model(c, model, all, &soa)) return 1;
+    unsigned long long* d_acc = nullptr;
+    LR_HIP(hipMalloc((void**)&d_acc, (size_t)d * d * sizeof(unsigned long long)));
+    if (launch_cht_accumulate(soa, (uint32_t)model.size(), d, d_acc, c->stream)) return 1;
+    std::vector<uint64_t> acc((size_t)d * d);
+    LR_HIP(hipStreamSynchronize(c->stream));
+    LR_HIP(hipMemcpy(acc.data(), d_acc, acc.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    (void)hipFree(d_acc);
+    size_t best = 0;
+    for (size_t i = 1; i < acc.size(); ++i)
+        if (acc[i] > acc[best]) best = i;
+    const int iy = (int)(best / d), ix = (int)(best % d);
+    const float u = (float)ix / (float)(d - 1) * 2.f - 1.f, v = (float)iy / (float)(d - 1) * 2.f - 1.f;
+    const float su = u >= 0.f ? 1.f : -1.f, sv = v >= 0.f ? 1.f : -1.f;
+    Vec3 p{v, su * u + sv * v - 1.f, u};
+    if (std::fabs(p.z) < kEps) {
+        p.z = 0.f;
+    } else {
+        p = {p.x / p.z, p.y / p.z, 1.f};
+        p.x = nrm.scale * p.x + nrm.center.x;
+        p.y = nrm.scale * p.y + nrm.center.y;
+    }
+    *vp = p;
+    if (acc_out) acc_out->swap(acc);
+    return 0;
+}
+
 // postprocess_lines_segments (line_detector.cpp:332-444): pair test on the GPU for large n, graph walk and
 // merges on the host.
 int ctx_refine(lr_context* c, std::vector<LineSegment>& lines) {

@@ -291,7 +291,71 @@ __global__ __launch_bounds__(256) void refine_pairs_kernel(const RefineSeg* __re
     }
 }
 
+// ---- diamond-space (cascaded Hough) accumulator, opt-in (reference cht.h:13-24, cht.cpp: an uncompiled sketch) --
+// One thread per line; each workgroup keeps a d x d accumulator of 32-bit fixed-point votes in LDS (d <= 128:
+// 64 KB) and flushes it into the global 64-bit accumulator with integer atomics, so the result is independent
+// of scheduling.  Formulas and rasterisation: see the oracle's cht_accumulate.
+__device__ inline float sgn1(float x) { return x >= 0.f ? 1.f : -1.f; }
+constexpr int kChtMax = 128;
+constexpr int kChtLinesPerBlock = 4096;  // keeps every LDS cell below 2^32 (<= 6 votes of < 2^17 per line)
+
+__global__ __launch_bounds__(256) void cht_accumulate_kernel(PencilSoA m, uint32_t n, int d,
+                                                             unsigned long long* __restrict__ acc) {
+    extern __shared__ uint32_t s_acc[];
+    for (int i = threadIdx.x; i < d * d; i += 256) s_acc[i] = 0u;
+    __syncthreads();
+    const float sc = (float)(d - 1);
+    const uint32_t lo = blockIdx.x * kChtLinesPerBlock;
+    const uint32_t hi = min(n, lo + kChtLinesPerBlock);
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const float a = m.hx[i], b = m.hy[i], c = m.hz[i];
+        const float al = sgn1(a * b), be = sgn1(b * c), ga = sgn1(a * c);
+        const float d1 = c + ga * a, d2 = c + be * b, d3 = a + al * b;
+        float px[4], py[4];
+        bool ok[4];
+        ok[0] = ok[3] = d1 != 0.f;
+        ok[1] = d2 != 0.f;
+        ok[2] = d3 != 0.f;
+        px[0] = al * a / d1;   py[0] = -al * c / d1;
+        px[1] = b / d2;        py[1] = 0.f;
+        px[2] = 0.f;           py[2] = b / d3;
+        px[3] = -al * a / d1;  py[3] = al * c / d1;
+        const uint32_t vote = (uint32_t)(m.len[i] * 65536.0f + 0.5f);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            if (!ok[s] || !ok[s + 1]) continue;
+            const float x0 = roundf((px[s] + 1.f) * 0.5f * sc), y0 = roundf((py[s] + 1.f) * 0.5f * sc);
+            const float x1 = roundf((px[s + 1] + 1.f) * 0.5f * sc), y1 = roundf((py[s + 1] + 1.f) * 0.5f * sc);
+            if (!(x0 >= 0.f && x0 <= sc && y0 >= 0.f && y0 <= sc && x1 >= 0.f && x1 <= sc && y1 >= 0.f && y1 <= sc)) continue;
+            const int steps = (int)roundf(fmaxf(fabsf(x1 - x0), fabsf(y1 - y0))) + 1;
+            const float sx = steps > 1 ? (x1 - x0) / (float)(steps - 1) : 0.f;
+            const float sy = steps > 1 ? (y1 - y0) / (float)(steps - 1) : 0.f;
+            for (int j = 0; j < steps; ++j) {
+                const int xi = (int)roundf(x0 + (float)j * sx), yi = (int)roundf(y0 + (float)j * sy);
+                atomicAdd(&s_acc[yi * d + xi], vote);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < d * d; i += 256) {
+        const uint32_t v = s_acc[i];
+        if (v) atomicAdd(&acc[i], (unsigned long long)v);
+    }
+}
+
 }  // namespace
+
+int launch_cht_accumulate(PencilSoA m, uint32_t n, int d, unsigned long long* acc, hipStream_t s) {
+    if (d < 8 || d > kChtMax) {
+        set_error("launch_cht_accumulate: accumulator size must be in [8, 128]");
+        return 1;
+    }
+    LR_HIP(hipMemsetAsync(acc, 0, (size_t)d * d * sizeof(unsigned long long), s));
+    const uint32_t blocks = (n + kChtLinesPerBlock - 1) / kChtLinesPerBlock;
+    hipLaunchKernelGGL(cht_accumulate_kernel, dim3(blocks ? blocks : 1), dim3(256), (size_t)d * d * sizeof(uint32_t), s, m, n, d, acc);
+    LR_HIP(hipGetLastError());
+    return 0;
+}
 
 int launch_refine_pairs(const void* seg, uint32_t n, void* edges, uint32_t* n_edges, uint32_t cap, hipStream_t s) {
     const uint32_t nb = (n + 63) / 64;

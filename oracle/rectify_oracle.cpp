@@ -941,6 +941,60 @@ void estimate_line_pencils(std::vector<LineSegment>& lines, int max_models, floa
     for (size_t i = 0; i < lines.size(); ++i) lines[i].group_id = groups[i];
 }
 
+// ---------------------------------------------------------------------------------------
+// cht.{h,cpp} — diamond-space ("cascaded Hough") vanishing point accumulator.  The reference's version is an
+// uncompiled sketch (insert() uses undeclared names, argmax() is empty: SURVEY.md §0.1), so this follows what
+// cht.h:13-24 says it should do, with the published diamond-space mapping (Dubska & Herout 2013):
+//   line (a,b,c) -> polyline through  [alpha*a/(c+gamma*a), -alpha*c/(c+gamma*a)]  [b/(c+beta*b), 0]
+//                   [0, b/(a+alpha*b)]  [-alpha*a/(c+gamma*a), alpha*c/(c+gamma*a)],
+//   alpha = sgn(ab), beta = sgn(bc), gamma = sgn(ac), sgn(0) = +1;  accumulator cell (u,v) in [-1,1]^2 maps back
+//   to the point [v, sgn(u)u + sgn(v)v - 1, u].
+// Rasterisation as accumulate_lines (cht.cpp:163-197): steps = round(max|d|)+1, positions lo + j*(hi-lo)/(steps-1),
+// rounded; votes are line lengths in 2^-16 fixed point (cht.cpp:194 ignores the weights; cht.h:18 wants them).
+// Parity unpinned; validated on synthetic pencils with known vanishing points.
+inline float sgn1(float x) { return x >= 0.f ? 1.f : -1.f; }
+
+void cht_accumulate(const LinePencilModel& M, int d, std::vector<uint64_t>& acc) {
+    acc.assign(size_t(d) * d, 0);
+    const float sc = float(d - 1);
+    for (int i = 0; i < M.size(); ++i) {
+        const float a = M.h[i].x, b = M.h[i].y, c = M.h[i].z;
+        const float al = sgn1(a * b), be = sgn1(b * c), ga = sgn1(a * c);
+        const float d1 = c + ga * a, d2 = c + be * b, d3 = a + al * b;
+        float px[4], py[4];
+        bool ok[4];
+        ok[0] = ok[3] = d1 != 0.f;
+        ok[1] = d2 != 0.f;
+        ok[2] = d3 != 0.f;
+        px[0] = al * a / d1;   py[0] = -al * c / d1;
+        px[1] = b / d2;        py[1] = 0.f;
+        px[2] = 0.f;           py[2] = b / d3;
+        px[3] = -al * a / d1;  py[3] = al * c / d1;
+        const uint64_t vote = uint64_t(M.length[i] * 65536.0f + 0.5f);
+        for (int s = 0; s < 3; ++s) {
+            if (!ok[s] || !ok[s + 1]) continue;
+            const float x0 = std::round((px[s] + 1.f) * 0.5f * sc), y0 = std::round((py[s] + 1.f) * 0.5f * sc);
+            const float x1 = std::round((px[s + 1] + 1.f) * 0.5f * sc), y1 = std::round((py[s + 1] + 1.f) * 0.5f * sc);
+            if (!(x0 >= 0.f && x0 <= sc && y0 >= 0.f && y0 <= sc && x1 >= 0.f && x1 <= sc && y1 >= 0.f && y1 <= sc)) continue;
+            const int steps = int(std::round(std::max(std::fabs(x1 - x0), std::fabs(y1 - y0)))) + 1;
+            const float sx = steps > 1 ? (x1 - x0) / float(steps - 1) : 0.f, sy = steps > 1 ? (y1 - y0) / float(steps - 1) : 0.f;
+            for (int j = 0; j < steps; ++j) {
+                const int xi = int(std::round(x0 + float(j) * sx)), yi = int(std::round(y0 + float(j) * sy));
+                acc[size_t(yi) * d + xi] += vote;
+            }
+        }
+    }
+}
+
+V3 cht_peak(const std::vector<uint64_t>& acc, int d) {
+    size_t best = 0;
+    for (size_t i = 1; i < acc.size(); ++i)
+        if (acc[i] > acc[best]) best = i;  // first maximum in row-major order
+    const int iy = int(best / d), ix = int(best % d);
+    const float u = float(ix) / float(d - 1) * 2.f - 1.f, v = float(iy) / float(d - 1) * 2.f - 1.f;
+    return {v, sgn1(u) * u + sgn1(v) * v - 1.f, u};
+}
+
 // estimate_multiple_structures (estimator.h:99-145) driven by PROSAC instead of RANSAC
 void estimate_line_pencils_prosac(std::vector<LineSegment>& lines, int max_models, float inlier_deg, float garbage_deg,
                                   const ProsacParams& P, uint64_t seed, std::vector<ProsacTrace>* traces = nullptr) {
@@ -1602,6 +1656,27 @@ int orc_estimate_line_pencils_prosac(LineSegment* lines, int n, int max_models, 
     estimate_line_pencils_prosac(v, max_models, inlier_deg, garbage_deg, P, seed);
     std::copy(v.begin(), v.end(), lines);
     return 0;
+}
+
+// lines in image coordinates; returns the de-normalised vanishing point (z = 0 for an ideal point) and, optionally, the accumulator
+void orc_cht_vanishing_point(const LineSegment* lines, int n, int d, float* vp3, uint64_t* acc_out) {
+    std::vector<LineSegment> v(lines, lines + n);
+    BBox bb = bounding_box(v);
+    V2 c = bbox_center(bb);
+    V2 sz = bbox_size(bb);
+    float scale = std::max(sz.x, sz.y);
+    LinePencilModel model(normalize_lines(v, c, scale));
+    std::vector<uint64_t> acc;
+    cht_accumulate(model, d, acc);
+    if (acc_out) std::copy(acc.begin(), acc.end(), acc_out);
+    V3 p = normalize_point(cht_peak(acc, d));
+    if (p.z > 0) {
+        p.x = scale * p.x + c.x;
+        p.y = scale * p.y + c.y;
+    }
+    vp3[0] = p.x;
+    vp3[1] = p.y;
+    vp3[2] = p.z;
 }
 
 int orc_niter_ransac(double p, double eps, int s, int nmax) { return niter_RANSAC(p, eps, s, nmax); }

@@ -256,6 +256,14 @@ def estimate_line_pencils_prosac(lines, max_models=4, inlier_deg=2.0, garbage_de
     return lines
 
 
+def cht_vanishing_point(lines, d=128):
+    lines = as_lines(lines)
+    vp = np.zeros(3, np.float32)
+    acc = np.zeros((d, d), np.uint64)
+    lib().orc_cht_vanishing_point(_p(lines), C.c_int(len(lines)), C.c_int(d), _p(vp), _p(acc))
+    return vp, acc
+
+
 def niter_ransac(p, eps, s, nmax=-1):
     f = lib().orc_niter_ransac
     f.restype = C.c_int

@@ -310,6 +310,44 @@ def test_parallel_flood_equals_ordered_flood_at_full_size(L, ctx):
     _assert_lines_equal(out[0][2], out[1][2])
 
 
+def _pencil(vp, n_on, n_off, seed):
+    rng = np.random.RandomState(seed)
+    rows = []
+    for i in range(n_on + n_off):
+        c = rng.uniform(50, 950, 2)
+        if i < n_on:
+            d = np.array(vp) - c
+            d /= np.linalg.norm(d)
+            a = rng.normal(0, 0.002)
+            d = np.array([d[0] * np.cos(a) - d[1] * np.sin(a), d[0] * np.sin(a) + d[1] * np.cos(a)])
+        else:
+            t = rng.uniform(0, np.pi)
+            d = np.array([np.cos(t), np.sin(t)])
+        ln = rng.uniform(30, 120)
+        p1, p2 = c - d * ln / 2, c + d * ln / 2
+        rows.append([p1[0], p1[1], p2[0], p2[1], 1, 0, -1])
+    return O.lines_from_rows(np.array(rows))
+
+
+def test_diamond_space_accumulator(L, ctx):
+    """Opt-in cascaded-Hough estimator (reference cht.h:13-24; its cht.cpp is an uncompiled sketch, so parity is
+    unpinned): the LDS accumulator equals the oracle's cell for cell, and known vanishing points of synthetic
+    pencils are recovered to the accumulator's angular resolution."""
+    centre = np.array([500.0, 500.0])
+    for vp, seed in [((1800.0, 420.0), 1), ((-900.0, 300.0), 2), ((520.0, -4000.0), 3), ((500.0, 380.0), 4)]:
+        for n_on, n_off in [(260, 140), (3000, 6000)]:  # the second case spans several workgroups
+            lines = _pencil(vp, n_on, n_off, seed)
+            ref_vp, ref_acc = O.cht_vanishing_point(lines, 128)
+            got_vp, got_acc = ctx.cht_vanishing_point(lines, 128)
+            np.testing.assert_array_equal(got_acc, ref_acc)
+            np.testing.assert_array_equal(got_vp, ref_vp)
+            a = np.array(vp) - centre
+            b = got_vp[:2] - centre if got_vp[2] != 0 else got_vp[:2]
+            cosang = abs(np.dot(a, b)) / (np.linalg.norm(a) * np.linalg.norm(b))
+            near = got_vp[2] != 0 and np.linalg.norm(got_vp[:2] - np.array(vp)) < 25.0  # a finite VP close to the frame
+            assert near or cosang > np.cos(np.radians(3.0)), (vp, got_vp)
+
+
 def test_refine_pair_kernel_matches_oracle(L, ctx):
     """postprocess_lines_segments on raw detector output: small n takes the host loop, n >= 2048 the GPU pair
     kernel; both against the oracle (self-golden: the reference pins nothing for refine)."""
