@@ -627,25 +627,35 @@ __global__ __launch_bounds__(256) void flood_commit_pixels_kernel(uint32_t* __re
 __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, const uint32_t* __restrict__ act,
                                                               uint32_t n_act, uint8_t* __restrict__ state,
                                                               int32_t* __restrict__ seed_size,
-                                                              uint8_t* __restrict__ alive) {
+                                                              uint32_t* __restrict__ act_next) {
     const uint32_t ai = blockIdx.x * 256 + threadIdx.x;
-    if (ai >= n_act) return;
-    const uint32_t k = act[ai];
-    uint8_t a = 0;
-    if (state[k] == 1) {
-        state[k] = 2;
-    } else if (state[k] == 0) {
-        if (A.label[A.seed_idx[k]] < kMarkBit) {  // its pixel now belongs to a committed flood: skipped forever
+    bool a = false;
+    uint32_t k = 0;
+    if (ai < n_act) {
+        k = act[ai];
+        if (state[k] == 1) {
             state[k] = 2;
-            seed_size[k] = 0;
-        } else {
-            a = 1;
-            A.blocked[k] = 0u;
-            A.count[k] = 0u;
-            A.flags[k] = 0u;
+        } else if (state[k] == 0) {
+            if (A.label[A.seed_idx[k]] < kMarkBit) {  // its pixel now belongs to a committed flood: skipped forever
+                state[k] = 2;
+                seed_size[k] = 0;
+            } else {
+                a = true;
+                A.blocked[k] = 0u;
+                A.count[k] = 0u;
+                A.flags[k] = 0u;
+            }
         }
     }
-    alive[k] = a;
+    // next round's active list: one atomic per wavefront; the order of the list does not matter
+    const uint64_t m = __ballot(a);
+    if (m) {
+        const int lane = threadIdx.x & 63;
+        uint32_t base = 0;
+        if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&A.ctrl[kCtrlNNext], (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, __ffsll((long long)m) - 1);
+        if (a) act_next[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = k;
+    }
 }
 
 __global__ __launch_bounds__(256) void flood_init_seeds_kernel(uint32_t n_seeds, uint32_t* __restrict__ act,
@@ -778,7 +788,7 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
         // beyond the window could not commit before the ones inside it anyway, and once the long strong
         // edges are committed the many weak seeds next to them no longer re-walk those edges.
         uint32_t n_launch = n_act;
-        if (rounds <= stage_rounds && n_act > 2048u) n_launch = std::max(1024u, n_act >> (stage_shift * (stage_rounds - rounds + 1)));
+        if (rounds == 1 && stage_rounds > 0 && n_act > 2048u) n_launch = std::max(1024u, n_act >> stage_shift);  // only round 1: its list is still in ascending order
         hipLaunchKernelGGL(flood_explore_kernel, dim3(n_launch), dim3(64), 0, s, A, trig, act, n_launch);
         hipLaunchKernelGGL(flood_decide_kernel, dim3((n_launch + 255) / 256), dim3(256), 0, s, A, act, n_launch, B.state,
                            seed_size);
@@ -814,10 +824,7 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
         }
         hipLaunchKernelGGL(flood_commit_pixels_kernel, dim3(pix_blocks), dim3(256), 0, s, label, npix, B.state);
         hipLaunchKernelGGL(flood_survivors_kernel, dim3((n_act + 255) / 256), dim3(256), 0, s, A, act, n_act, B.state,
-                           seed_size, B.alive);
-        size_t tb = B.select_temp_bytes;
-        LR_HIP(rocprim::select(B.select_temp, tb, rocprim::counting_iterator<uint32_t>(0), B.alive, act_next,
-                               B.ctrl + kCtrlNNext, (size_t)n_seeds, s));
+                           seed_size, act_next);
         LR_HIP(hipMemcpyAsync(h_ctrl, B.ctrl, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         LR_HIP(hipStreamSynchronize(s));
         const uint32_t n_commit = h_ctrl[kCtrlNCommit];
@@ -830,7 +837,13 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
         const bool progress = n_commit > 0 || n_next < n_act || n_launch < n_act;
         n_act = n_next;
         if (n_act > 0 && !progress) {
-            // storage exhausted on the lowest active seed: finish in order (always exact)
+            // storage exhausted on the lowest active seed: finish in order (always exact); the list is unordered
+            {
+                std::vector<uint32_t> tmp(n_act);
+                LR_HIP(hipMemcpy(tmp.data(), act, n_act * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                std::sort(tmp.begin(), tmp.end());
+                LR_HIP(hipMemcpy(act, tmp.data(), n_act * sizeof(uint32_t), hipMemcpyHostToDevice));
+            }
             hipLaunchKernelGGL(flood_ordered_tail_kernel, dim3(1), dim3(64), 0, s, dx, dy, dmask, w, seed_idx, seed_bin,
                                seed_thr, act, n_act, trig, label, seed_size, queue);
             ++rounds;
