@@ -116,14 +116,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
-    n_gpus = world if world > 1 else 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # rehearsal hooks for a one-GPU box: LR_BENCH_BACKEND=gloo LR_BENCH_SINGLE_DEVICE=1 runs N ranks on device 0 with
+    # the gather over gloo (RCCL refuses two ranks on one device); the driver's real runs use neither
+    backend = os.environ.get("LR_BENCH_BACKEND", "nccl")
+    if os.environ.get("LR_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    torch.cuda.set_device(local_rank)  # before the process group: RCCL binds each rank to its current device
     dev = torch.device("cuda", local_rank)
+    cdev = dev if backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    n_gpus = world if world > 1 else 1
 
     w, h, B = args.width, args.height, args.frames
     min_length = float(max(w, h)) / 100.0  # autorectify.cpp:134
@@ -161,7 +171,7 @@ def main():
             filt_ms.append(float(t[L.T_FILTER_KERNEL]))
             stage_acc[:] += t
         if world > 1:  # the path's one exchange step: gather the per-frame results over RCCL
-            D.gather_results([out[b][: n_lines[b]] for b in range(B)], tforms, B * world, device=dev)
+            D.gather_results([out[b][: n_lines[b]] for b in range(B)], tforms, B * world, device=cdev)
 
     for _ in range(args.warmup):
         step(False)
@@ -180,7 +190,7 @@ def main():
     fence()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        t = torch.tensor([el], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
