@@ -78,6 +78,7 @@ typedef float InputPixelType;
 typedef struct LineSegment LineSegment;
 typedef struct ImageTransform ImageTransform;
 typedef struct Point Point;
+typedef struct RectificationConfig RectificationConfig;
 #endif
 
 /*
