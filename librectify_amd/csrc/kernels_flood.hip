@@ -332,6 +332,79 @@ struct Pending {
     }
 };
 
+// bit y of b -> bit 8*y (a byte's bits spread down a bit-board column)
+__device__ __forceinline__ uint64_t spread_col(uint64_t b) {
+    b = (b | (b << 28)) & 0x0000000F0000000Full;
+    b = (b | (b << 14)) & 0x0003000300030003ull;
+    b = (b | (b << 7)) & 0x0101010101010101ull;
+    return b;
+}
+
+// All (up to eight) neighbour records of a step at once, one direction per lane 0..7 (LDS store only): the
+// per-direction entry masks are cut out of the ring-hit ballot H with lane-parallel arithmetic, the pending table
+// is probed by the eight lanes together and new records are appended with one ballot.  Replaces eight scalar
+// pushes (the longest stretch of wave-uniform, one-lane-at-a-time code of a step).
+__device__ __forceinline__ void push8(LdsStore& S, Pending& P, WalkState& st, uint32_t tile, uint64_t H, int lane) {
+    const int d = lane & 7;
+    const bool dl = lane < 8;
+    // direction d: 0 up, 1 down, 2 left, 3 right, 4 up-left, 5 up-right, 6 down-left, 7 down-right
+    const uint32_t off = (d == 0) ? 0xFFFF0000u : (d == 1) ? 0x00010000u : (d == 2) ? 0xFFFFFFFFu : (d == 3) ? 1u
+                       : (d == 4) ? 0xFFFEFFFFu : (d == 5) ? 0xFFFF0001u : (d == 6) ? 0x0000FFFFu : 0x00010001u;
+    const uint32_t nt = tile + off;
+    const uint64_t byte = (H >> (8 * (d & 3))) & 0xFFull;
+    const uint64_t bit = (H >> (32 + (d & 3))) & 1ull;
+    uint64_t E;
+    if (d == 0) E = byte << 56;
+    else if (d == 1) E = byte;
+    else if (d == 2) E = spread_col(byte) << 7;
+    else if (d == 3) E = spread_col(byte);
+    else if (d == 4) E = bit << 63;
+    else if (d == 5) E = bit << 56;
+    else if (d == 6) E = bit << 7;
+    else E = bit;
+    const bool active = dl && E != 0ull;
+    bool fresh = active;
+    const uint32_t hs = ((nt + 1u) * 2654435761u) >> 26;
+    if (active) {
+        const uint32_t idx = P.pi[hs];
+        // mergeable iff that record is still beyond the one already prefetched (index st.head)
+        if (P.pt[hs] == nt + 1u && (int32_t)(idx - st.head) > 0 && (int32_t)(st.tail - idx) > 0) {
+            const uint32_t j = idx & (kRingT - 1);
+            if (S.rt[j] == nt) {
+                S.rlo[j] |= (uint32_t)E;
+                S.rhi[j] |= (uint32_t)(E >> 32);
+                fresh = false;
+            }
+        }
+    }
+    const uint64_t mf = __ballot(fresh);
+    if (fresh) {
+        const uint32_t pos = st.tail + (uint32_t)__popcll(mf & ((1ull << lane) - 1ull));
+        const uint32_t j = pos & (kRingT - 1);
+        S.rt[j] = nt;
+        S.rlo[j] = (uint32_t)E;
+        S.rhi[j] = (uint32_t)(E >> 32);
+        P.pt[hs] = nt + 1u;
+        P.pi[hs] = pos;
+    }
+    st.tail += (uint32_t)__popcll(mf);
+}
+
+// scalar form (global slab store)
+template <class Store>
+__device__ __forceinline__ void push8(Store& S, Pending& P, WalkState& st, uint32_t tile, uint64_t H, int lane) {
+    (void)lane;
+    const uint64_t up = H & 0xFFull, dn = (H >> 8) & 0xFFull, lf = (H >> 16) & 0xFFull, rt = (H >> 24) & 0xFFull;
+    if (up) P.push(S, st, tile - 0x10000u, up << 56);          // (x,-1) -> pixel (x,7) of the tile above
+    if (dn) P.push(S, st, tile + 0x10000u, dn);                // (x,8)  -> pixel (x,0) of the tile below
+    if (lf) P.push(S, st, tile - 1u, spread_col(lf) << 7);     // (-1,y) -> pixel (7,y) of the left tile
+    if (rt) P.push(S, st, tile + 1u, spread_col(rt));          // (8,y)  -> pixel (0,y) of the right tile
+    if ((H >> 32) & 1ull) P.push(S, st, tile - 0x10001u, 1ull << 63);
+    if ((H >> 33) & 1ull) P.push(S, st, tile - 0xFFFFu, 1ull << 56);
+    if ((H >> 34) & 1ull) P.push(S, st, tile + 0xFFFFu, 1ull << 7);
+    if ((H >> 35) & 1ull) P.push(S, st, tile + 0x10001u, 1ull);
+}
+
 // 8-neighbour dilation of a bit-board (bit = row*8 + col) restricted to the tile
 __device__ inline uint64_t dilate8(uint64_t r) {
     const uint64_t hz = r | ((r << 1) & 0xFEFEFEFEFEFEFEFEull) | ((r >> 1) & 0x7F7F7F7F7F7F7F7Full);
@@ -362,14 +435,6 @@ __device__ __forceinline__ uint64_t ring_adjacency(int lane) {
         }
     return m;
 }
-// bit y of b -> bit 8*y (a byte's bits spread down a bit-board column)
-__device__ __forceinline__ uint64_t spread_col(uint64_t b) {
-    b = (b | (b << 28)) & 0x0000000F0000000Full;
-    b = (b | (b << 14)) & 0x0003000300030003ull;
-    b = (b | (b << 7)) & 0x0101010101010101ull;
-    return b;
-}
-
 // What one lane holds of a frontier record before it is processed.  For a tile the wave already knows, the
 // table answers (V, A, ring) and no memory is touched; otherwise the lane's pixel of the tile and its pixel of
 // the surrounding ring are loaded.
@@ -499,17 +564,7 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
         if (New != 0ull) {
             // ring pixels that are acceptable and touch a newly walked pixel become entries of their own tiles
             const uint64_t H = __ballot(((Rg >> lane) & 1ull) && (New & adj) != 0ull);
-            if (H != 0ull) {
-                const uint64_t up = H & 0xFFull, dn = (H >> 8) & 0xFFull, lf = (H >> 16) & 0xFFull, rt = (H >> 24) & 0xFFull;
-                if (up) P.push(S, st, tile - 0x10000u, up << 56);          // (x,-1) -> pixel (x,7) of the tile above
-                if (dn) P.push(S, st, tile + 0x10000u, dn);                // (x,8)  -> pixel (x,0) of the tile below
-                if (lf) P.push(S, st, tile - 1u, spread_col(lf) << 7);     // (-1,y) -> pixel (7,y) of the left tile
-                if (rt) P.push(S, st, tile + 1u, spread_col(rt));          // (8,y)  -> pixel (0,y) of the right tile
-                if ((H >> 32) & 1ull) P.push(S, st, tile - 0x10001u, 1ull << 63);
-                if ((H >> 33) & 1ull) P.push(S, st, tile - 0xFFFFu, 1ull << 56);
-                if ((H >> 34) & 1ull) P.push(S, st, tile + 0xFFFFu, 1ull << 7);
-                if ((H >> 35) & 1ull) P.push(S, st, tile + 0x10001u, 1ull);
-            }
+            if (H != 0ull) push8(S, P, st, tile, H, lane);
         }
         if (st.head == st.tail) {
             settle();
