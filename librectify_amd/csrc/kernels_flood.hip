@@ -362,6 +362,24 @@ __device__ __forceinline__ void push8(LdsStore& S, Pending& P, WalkState& st, ui
     else if (d == 5) E = bit << 56;
     else if (d == 6) E = bit << 7;
     else E = bit;
+    // A neighbour the wave already knows needs a record only for entry pixels it has not walked yet: every walked
+    // set V is a union of whole in-tile components, so entries inside V could add nothing.  This drops the record
+    // back into the tile a step came from (about half of all records otherwise).
+    bool searching = dl && E != 0ull;
+    uint32_t ts = ((nt + 1u) * 2654435761u) >> 24;
+    for (int probe = 0; probe < kHashT && __ballot(searching) != 0ull; ++probe) {
+        if (searching) {
+            const uint32_t c = S.hk[ts];
+            if (c == nt + 1u) {
+                E &= ~(((uint64_t)S.hv1[ts] << 32) | S.hv0[ts]);
+                searching = false;
+            } else if (c == 0u) {
+                searching = false;
+            } else {
+                ts = (ts + 1) & (kHashT - 1);
+            }
+        }
+    }
     const bool active = dl && E != 0ull;
     bool fresh = active;
     const uint32_t hs = ((nt + 1u) * 2654435761u) >> 26;
@@ -395,14 +413,20 @@ template <class Store>
 __device__ __forceinline__ void push8(Store& S, Pending& P, WalkState& st, uint32_t tile, uint64_t H, int lane) {
     (void)lane;
     const uint64_t up = H & 0xFFull, dn = (H >> 8) & 0xFFull, lf = (H >> 16) & 0xFFull, rt = (H >> 24) & 0xFFull;
-    if (up) P.push(S, st, tile - 0x10000u, up << 56);          // (x,-1) -> pixel (x,7) of the tile above
-    if (dn) P.push(S, st, tile + 0x10000u, dn);                // (x,8)  -> pixel (x,0) of the tile below
-    if (lf) P.push(S, st, tile - 1u, spread_col(lf) << 7);     // (-1,y) -> pixel (7,y) of the left tile
-    if (rt) P.push(S, st, tile + 1u, spread_col(rt));          // (8,y)  -> pixel (0,y) of the right tile
-    if ((H >> 32) & 1ull) P.push(S, st, tile - 0x10001u, 1ull << 63);
-    if ((H >> 33) & 1ull) P.push(S, st, tile - 0xFFFFu, 1ull << 56);
-    if ((H >> 34) & 1ull) P.push(S, st, tile + 0xFFFFu, 1ull << 7);
-    if ((H >> 35) & 1ull) P.push(S, st, tile + 0x10001u, 1ull);
+    auto send = [&](uint32_t nt, uint64_t E) {  // same filter as the LDS form: skip entries the neighbour has walked
+        uint32_t slot;
+        uint64_t V, Am, Rg;
+        if (S.lookup(nt, slot, V, Am, Rg)) E &= ~V;
+        if (E != 0ull) P.push(S, st, nt, E);
+    };
+    if (up) send(tile - 0x10000u, up << 56);          // (x,-1) -> pixel (x,7) of the tile above
+    if (dn) send(tile + 0x10000u, dn);                // (x,8)  -> pixel (x,0) of the tile below
+    if (lf) send(tile - 1u, spread_col(lf) << 7);     // (-1,y) -> pixel (7,y) of the left tile
+    if (rt) send(tile + 1u, spread_col(rt));          // (8,y)  -> pixel (0,y) of the right tile
+    if ((H >> 32) & 1ull) send(tile - 0x10001u, 1ull << 63);
+    if ((H >> 33) & 1ull) send(tile - 0xFFFFu, 1ull << 56);
+    if ((H >> 34) & 1ull) send(tile + 0xFFFFu, 1ull << 7);
+    if ((H >> 35) & 1ull) send(tile + 0x10001u, 1ull);
 }
 
 // 8-neighbour dilation of a bit-board (bit = row*8 + col) restricted to the tile
