@@ -188,6 +188,7 @@ struct WalkState {
 // and walked pixels stamped by lower seeds are remembered there too, so the walk terminates.
 // All store operations below are wave-uniform (every lane performs the same access).
 struct LdsStore {
+    static constexpr bool kDeferStamps = true;
     uint32_t* rt;   // ring: tile
     uint32_t* rlo;  // ring: entry mask
     uint32_t* rhi;
@@ -198,6 +199,8 @@ struct LdsStore {
     uint32_t* ha1;
     uint32_t* hr0;  // acceptable pixels of the 36-pixel ring around the tile (lane order, see ring_xy)
     uint32_t* hr1;
+    uint8_t* ord;   // table slots in order of insertion (what stamp_footprint walks)
+    __device__ void note_new(uint32_t i, uint32_t slot) { ord[i] = (uint8_t)slot; }
     __device__ uint32_t ring_cap() const { return kRingT; }
     __device__ uint32_t hash_limit() const { return kHashT * 3 / 4; }
     __device__ void get(uint32_t i, uint32_t& tile, uint64_t& m) const {
@@ -245,6 +248,8 @@ struct LdsStore {
 };
 
 struct SlabStore {
+    static constexpr bool kDeferStamps = false;
+    __device__ void note_new(uint32_t, uint32_t) {}
     uint4* ring;
     uint4* hash;
     uint32_t rcap, hcap, gen;
@@ -503,8 +508,14 @@ __device__ __forceinline__ TileFetch fetch_tile(const FloodArgs& A, const Store&
 }
 
 // Walks the footprint of seed k from the state in `st`.  Returns 0 when the walk is complete, 1 when
-// the store ran out; `st` then holds a resumable state.  The loads of the next frontier record are issued
-// before the current one is processed, so a step costs at most one memory round trip (its atomics).
+// the store ran out; `st` then holds a resumable state.
+//
+// A step is: acceptance ballots of the tile (from the loads issued when its record was popped), connected
+// closure of the entry pixels, table update, records for the neighbours, pop of the next record and issue of
+// its loads.  Stamping is not part of the dependent chain tile -> neighbour tile: which seeds meet on a pixel
+// does not depend on when the stamps land within a round, so the LDS store only remembers the walked pixels (V)
+// and stamps them all at the end (stamp_footprint), with many atomics in flight at once.  The slab store
+// stamps as it goes.
 template <class Store>
 __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, float cs, Store& S, Pending& P,
                     WalkState& st, int lane) {
@@ -515,34 +526,11 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
     const bool ring_lane = lane < 36;
     const uint64_t adj = ring_adjacency(lane);
     if (st.head == st.tail) return 0;
+    if ((st.tail - st.head) + 8u > S.ring_cap() || st.ntiles + 2u > S.hash_limit()) return 1;
     TileFetch cur = fetch_tile(A, S, st.head, lr, lc, rx, ry, ring_lane);
-    // The stamp of a step (a returning atomicMin) is only needed to tell who else reaches the pixel; the walk
-    // itself continues from every new pixel regardless.  So its result is consumed one step later, and the
-    // atomic's round trip overlaps the next step instead of standing on the critical path.
-    uint32_t prev_old = kLabelFree;
-    bool prev_issued = false;
-    auto settle = [&]() {
-        bool foreign = false;
-        if (prev_issued) {
-            if (prev_old > mine) {  // free, or stamped by a higher seed that is hereby blocked
-                if (prev_old != kLabelFree) A.blocked[prev_old & ~kMarkBit] = 1u;
-            } else if (prev_old < mine && prev_old >= kMarkBit) {  // a lower active seed reaches this pixel too
-                foreign = true;
-            }
-        }
-        if (__ballot(foreign)) st.blocked = true;
-        prev_issued = false;
-    };
     for (;;) {
-        if ((st.tail - st.head) + 8u > S.ring_cap() || st.ntiles + 2u > S.hash_limit()) {
-            settle();
-            return 1;
-        }
         st.head += 1;
         st.steps += 1;
-        const bool have_next = st.head != st.tail;
-        TileFetch nxt;
-        if (have_next) nxt = fetch_tile(A, S, st.head, lr, lc, rx, ry, ring_lane);
         const uint32_t tile = cur.tile;
         uint64_t Am = cur.Am, Rg = cur.Rg;
         if (!cur.known) {
@@ -563,48 +551,81 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
             }
             New = R & ~cur.V;
         }
-        const bool issue = (New >> lane) & 1ull;
-        uint32_t old = kLabelFree;
-        if (issue) old = atomicMin(&A.label[cur.q], mine);
-        settle();  // the previous step's stamps
-        prev_old = old;
-        prev_issued = issue;
         if (New != 0ull || !cur.known) {
             S.update(cur.slot, tile, cur.V | New, Am, Rg);
-            if (!cur.known) st.ntiles += 1;
-            if (have_next && nxt.tile == tile) {  // the prefetched record looked this tile up before the update
-                nxt.known = true;
-                nxt.slot = cur.slot;
-                nxt.V = cur.V | New;
-                nxt.Am = Am;
-                nxt.Rg = Rg;
-            } else if (have_next && !cur.known && !nxt.known) {
-                // an insertion may have taken the empty slot the prefetched lookup had reserved: probe again
-                uint64_t v0, a0, r0;
-                (void)S.lookup(nxt.tile, nxt.slot, v0, a0, r0);
+            if (!cur.known) {
+                S.note_new(st.ntiles, cur.slot);
+                st.ntiles += 1;
             }
         }
         st.cnt += (uint32_t)__popcll(New);
         if (New != 0ull) {
+            if constexpr (!Store::kDeferStamps) {
+                uint32_t old = kLabelFree;
+                const bool issue = (New >> lane) & 1ull;
+                if (issue) old = atomicMin(&A.label[cur.q], mine);
+                bool foreign = false;
+                if (old > mine) {  // free, or stamped by a higher seed that is hereby blocked
+                    if (old != kLabelFree) A.blocked[old & ~kMarkBit] = 1u;
+                } else if (old < mine && old >= kMarkBit) {  // a lower active seed reaches this pixel too
+                    foreign = true;
+                }
+                if (__ballot(foreign)) st.blocked = true;
+            }
             // ring pixels that are acceptable and touch a newly walked pixel become entries of their own tiles
             const uint64_t H = __ballot(((Rg >> lane) & 1ull) && (New & adj) != 0ull);
             if (H != 0ull) push8(S, P, st, tile, H, lane);
         }
-        if (st.head == st.tail) {
-            settle();
-            return 0;
-        }
-        cur = have_next ? nxt : fetch_tile(A, S, st.head, lr, lc, rx, ry, ring_lane);
+        if (st.head == st.tail) return 0;
+        if ((st.tail - st.head) + 8u > S.ring_cap() || st.ntiles + 2u > S.hash_limit()) return 1;
+        cur = fetch_tile(A, S, st.head, lr, lc, rx, ry, ring_lane);
     }
+}
+
+// Stamps every pixel the LDS walk has covered: atomicMin(label, MARK|k) on each, eight tiles' worth in flight
+// before the first result is looked at.  A lower stamp found means a lower active seed reaches the pixel (this
+// seed is blocked); a higher stamp replaced means that seed is blocked.
+__device__ __forceinline__ void stamp_footprint(const FloodArgs& A, uint32_t k, const LdsStore& S, WalkState& st,
+                                                int lane) {
+    const uint32_t mine = kMarkBit | k;
+    const int lr = lane >> 3, lc = lane & 7;
+    bool foreign = false;
+    for (uint32_t i0 = 0; i0 < st.ntiles; i0 += 8) {
+        uint32_t old[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            old[j] = kLabelFree;
+            const uint32_t i = i0 + (uint32_t)j;
+            if (i < st.ntiles) {
+                const uint32_t slot = S.ord[i];
+                const uint32_t tile = S.hk[slot] - 1u;
+                const uint64_t V = ((uint64_t)S.hv1[slot] << 32) | S.hv0[slot];
+                if ((V >> lane) & 1ull) {
+                    const size_t q = (size_t)((tile >> 16) * 8 + lr) * A.w + ((tile & 0xFFFFu) * 8 + lc);
+                    old[j] = atomicMin(&A.label[q], mine);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (old[j] > mine) {
+                if (old[j] != kLabelFree) A.blocked[old[j] & ~kMarkBit] = 1u;
+            } else if (old[j] < mine && old[j] >= kMarkBit) {
+                foreign = true;
+            }
+        }
+    }
+    if (__ballot(foreign)) st.blocked = true;
 }
 
 // One wavefront per workgroup: walks differ in length by three orders of magnitude, and a workgroup keeps its
 // LDS until its longest wave is done.
-__global__ __launch_bounds__(64) void flood_explore_kernel(FloodArgs A, BinTrig trig, const uint32_t* __restrict__ act,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void flood_explore_kernel(FloodArgs A, BinTrig trig, const uint32_t* __restrict__ act,
                                                            uint32_t n_act) {
     __shared__ uint32_t s_ring[1][3][kRingT];
     __shared__ uint32_t s_hash[1][7][kHashT];
     __shared__ uint32_t s_pend[1][2][kPend];
+    __shared__ uint8_t s_ord[1][kHashT];
     const int wv = 0, lane = threadIdx.x & 63;
     const uint32_t ai = uni(blockIdx.x);
     if (ai >= n_act) return;
@@ -619,7 +640,7 @@ __global__ __launch_bounds__(64) void flood_explore_kernel(FloodArgs A, BinTrig 
         return;
     }
     LdsStore L{s_ring[wv][0], s_ring[wv][1], s_ring[wv][2], s_hash[wv][0], s_hash[wv][1],
-               s_hash[wv][2], s_hash[wv][3], s_hash[wv][4], s_hash[wv][5], s_hash[wv][6]};
+               s_hash[wv][2], s_hash[wv][3], s_hash[wv][4], s_hash[wv][5], s_hash[wv][6], s_ord[wv]};
     for (int i = lane; i < kHashT; i += 64) L.hk[i] = 0u;
     Pending P{s_pend[wv][0], s_pend[wv][1]};
     P.pt[lane] = 0u;
@@ -627,6 +648,7 @@ __global__ __launch_bounds__(64) void flood_explore_kernel(FloodArgs A, BinTrig 
     WalkState st{0u, 1u, 0u, 0u, false, 0u};
     L.put(0u, ((uint32_t)(sr >> 3) << 16) | (uint32_t)(sc >> 3), 1ull << ((sr & 7) * 8 + (sc & 7)));
     int rc = walk(A, k, b, thr, sn, cs, L, P, st, lane);
+    stamp_footprint(A, k, L, st, lane);
     if (rc != 0) {
         // LDS storage exhausted: move the walk to a global slab and carry on
         uint32_t slab = 0;
