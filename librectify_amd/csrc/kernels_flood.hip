@@ -236,6 +236,11 @@ struct LdsStore {
         Rg = 0ull;
         return false;
     }
+    __device__ void values(uint32_t slot, uint64_t& V, uint64_t& Am, uint64_t& Rg) const {
+        V = uni64(hv0[slot], hv1[slot]);
+        Am = uni64(ha0[slot], ha1[slot]);
+        Rg = uni64(hr0[slot], hr1[slot]);
+    }
     __device__ void update(uint32_t slot, uint32_t tile, uint64_t V, uint64_t Am, uint64_t Rg) {
         hk[slot] = tile + 1u;
         hv0[slot] = (uint32_t)V;
@@ -302,6 +307,12 @@ struct SlabStore {
         Rg = 0ull;
         return false;
     }
+    __device__ void values(uint32_t slot, uint64_t& V, uint64_t& Am, uint64_t& Rg) const {
+        const uint4 v = ld(&hash[2 * slot]), a = ld(&hash[2 * slot + 1]);
+        V = uni64(v.z, v.w);
+        Am = uni64(a.x, a.y);
+        Rg = uni64(a.z, a.w);
+    }
     __device__ void update(uint32_t slot, uint32_t tile, uint64_t V, uint64_t Am, uint64_t Rg) {
         st(&hash[2 * slot + 1], make_uint4((uint32_t)Am, (uint32_t)(Am >> 32), (uint32_t)Rg, (uint32_t)(Rg >> 32)));
         st(&hash[2 * slot], make_uint4(gen, tile + 1u, (uint32_t)V, (uint32_t)(V >> 32)));
@@ -320,8 +331,8 @@ struct Pending {
     __device__ __forceinline__ void push(Store& S, WalkState& st, uint32_t tile, uint64_t m) {
         const uint32_t hs = ((tile + 1u) * 2654435761u) >> 26;  // 6 bits
         const uint32_t idx = uni(pi[hs]);
-        // mergeable iff that record is still beyond the one already prefetched (index st.head)
-        if (uni(pt[hs]) == tile + 1u && (int32_t)(idx - st.head) > 0 && (int32_t)(st.tail - idx) > 0) {
+        // mergeable iff that record is still in the frontier (ring index in [head, tail))
+        if (uni(pt[hs]) == tile + 1u && (int32_t)(idx - st.head) >= 0 && (int32_t)(st.tail - idx) > 0) {
             uint32_t t2;
             uint64_t m2;
             S.get(idx, t2, m2);
@@ -345,61 +356,88 @@ __device__ __forceinline__ uint64_t spread_col(uint64_t b) {
     return b;
 }
 
-// All (up to eight) neighbour records of a step at once, one direction per lane 0..7 (LDS store only): the
-// per-direction entry masks are cut out of the ring-hit ballot H with lane-parallel arithmetic, the pending table
-// is probed by the eight lanes together and new records are appended with one ballot.  Replaces eight scalar
-// pushes (the longest stretch of wave-uniform, one-lane-at-a-time code of a step).
-__device__ __forceinline__ void push8(LdsStore& S, Pending& P, WalkState& st, uint32_t tile, uint64_t H, int lane) {
+// Per-lane constants of push8 (direction d = lane & 7: 0 up, 1 down, 2 left, 3 right, 4 up-left, 5 up-right,
+// 6 down-left, 7 down-right), computed once per walk.
+struct PushLane {
+    uint32_t off;    // neighbour tile id - tile id
+    uint32_t shamt;  // where the direction's bits sit in the ring-hit ballot
+    uint32_t msk;    // 0xFF for an edge, 1 for a corner
+    uint32_t sh;     // shift of the (spread) bits into the neighbour's bit-board
+    bool spread;     // left/right edges: the byte runs down a column
+    bool dl;         // lane carries a direction
+};
+__device__ __forceinline__ PushLane push_lane(int lane) {
     const int d = lane & 7;
-    const bool dl = lane < 8;
-    // direction d: 0 up, 1 down, 2 left, 3 right, 4 up-left, 5 up-right, 6 down-left, 7 down-right
-    const uint32_t off = (d == 0) ? 0xFFFF0000u : (d == 1) ? 0x00010000u : (d == 2) ? 0xFFFFFFFFu : (d == 3) ? 1u
-                       : (d == 4) ? 0xFFFEFFFFu : (d == 5) ? 0xFFFF0001u : (d == 6) ? 0x0000FFFFu : 0x00010001u;
-    const uint32_t nt = tile + off;
-    const uint64_t byte = (H >> (8 * (d & 3))) & 0xFFull;
-    const uint64_t bit = (H >> (32 + (d & 3))) & 1ull;
-    uint64_t E;
-    if (d == 0) E = byte << 56;
-    else if (d == 1) E = byte;
-    else if (d == 2) E = spread_col(byte) << 7;
-    else if (d == 3) E = spread_col(byte);
-    else if (d == 4) E = bit << 63;
-    else if (d == 5) E = bit << 56;
-    else if (d == 6) E = bit << 7;
-    else E = bit;
+    const int dy = (d < 2) ? (d == 0 ? -1 : 1) : (d < 4 ? 0 : (d < 6 ? -1 : 1));
+    const int dx = (d < 2) ? 0 : ((d & 1) ? 1 : -1);
+    PushLane c;
+    c.off = (uint32_t)(dy * 0x10000 + dx);
+    c.shamt = (d < 4) ? 8u * (uint32_t)d : 32u + (uint32_t)(d - 4);
+    c.msk = (d < 4) ? 0xFFu : 1u;
+    c.sh = (uint32_t)((0x0007383F00070038ull >> (8 * d)) & 0xFFull);  // 56 0 7 0 63 56 7 0
+    c.spread = d == 2 || d == 3;
+    c.dl = lane < 8;
+    // keep them in registers: recomputing the selects inside the walk loop costs more than four VGPRs
+    asm volatile("" : "+v"(c.off), "+v"(c.shamt), "+v"(c.msk), "+v"(c.sh));
+    return c;
+}
+
+// The first record a step appended, handed to the next step in registers when the frontier was empty before
+// (a walk along a line: the chain tile -> neighbour tile then never waits for the ring or the table).
+struct Forward {
+    bool valid;
+    uint32_t tile, slot;
+    uint64_t entry;
+    bool known;
+};
+
+// All (up to eight) neighbour records of a step at once, one direction per lane 0..7 (LDS store only): the
+// per-direction entry masks are cut out of the ring-hit ballot H with lane-parallel arithmetic; the tile table
+// (is the neighbour known, and what of it is walked) and the pending table are read by the eight lanes in one
+// LDS round trip, and new records are appended with one ballot.
+__device__ __forceinline__ void push8(LdsStore& S, Pending& P, WalkState& st, uint32_t tile, uint64_t H, int lane,
+                                      const PushLane& c, Forward& fw) {
+    const uint32_t nt = tile + c.off;
+    const uint32_t key = nt + 1u;
+    const uint64_t src = (H >> c.shamt) & (uint64_t)c.msk;
+    uint64_t E = (c.spread ? spread_col(src) : src) << c.sh;
+    uint32_t ts = (key * 2654435761u) >> 24;
+    const uint32_t hs = (key * 2654435761u) >> 26;
+    // one round trip: first probe of the tile table with its walked set, and the pending entry
+    uint32_t hk0 = S.hk[ts];
+    uint32_t v0 = S.hv0[ts], v1 = S.hv1[ts];
+    const uint32_t pt = P.pt[hs], pi = P.pi[hs];
+    const bool want = c.dl && E != 0ull;
+    bool found = hk0 == key;
+    bool searching = want && !found && hk0 != 0u;
+    for (int probe = 1; probe < kHashT && __ballot(searching) != 0ull; ++probe) {  // collisions: rare
+        if (searching) {
+            ts = (ts + 1) & (kHashT - 1);
+            hk0 = S.hk[ts];
+            if (hk0 == key) {
+                v0 = S.hv0[ts];
+                v1 = S.hv1[ts];
+                found = true;
+                searching = false;
+            } else if (hk0 == 0u) {
+                searching = false;
+            }
+        }
+    }
     // A neighbour the wave already knows needs a record only for entry pixels it has not walked yet: every walked
     // set V is a union of whole in-tile components, so entries inside V could add nothing.  This drops the record
     // back into the tile a step came from (about half of all records otherwise).
-    bool searching = dl && E != 0ull;
-    uint32_t ts = ((nt + 1u) * 2654435761u) >> 24;
-    for (int probe = 0; probe < kHashT && __ballot(searching) != 0ull; ++probe) {
-        if (searching) {
-            const uint32_t c = S.hk[ts];
-            if (c == nt + 1u) {
-                E &= ~(((uint64_t)S.hv1[ts] << 32) | S.hv0[ts]);
-                searching = false;
-            } else if (c == 0u) {
-                searching = false;
-            } else {
-                ts = (ts + 1) & (kHashT - 1);
-            }
-        }
+    if (found) E &= ~(((uint64_t)v1 << 32) | v0);
+    const bool active = want && E != 0ull;
+    // A record of the same tile that is still in the frontier (ring index in [head, tail)) takes the entries: the
+    // pending entry was written with that record, and a ring slot is not reused while its index is in the window.
+    const bool merge = active && pt == key && (int32_t)(pi - st.head) >= 0 && (int32_t)(st.tail - pi) > 0;
+    if (merge) {
+        const uint32_t j = pi & (kRingT - 1);
+        atomicOr(&S.rlo[j], (uint32_t)E);
+        atomicOr(&S.rhi[j], (uint32_t)(E >> 32));
     }
-    const bool active = dl && E != 0ull;
-    bool fresh = active;
-    const uint32_t hs = ((nt + 1u) * 2654435761u) >> 26;
-    if (active) {
-        const uint32_t idx = P.pi[hs];
-        // mergeable iff that record is still beyond the one already prefetched (index st.head)
-        if (P.pt[hs] == nt + 1u && (int32_t)(idx - st.head) > 0 && (int32_t)(st.tail - idx) > 0) {
-            const uint32_t j = idx & (kRingT - 1);
-            if (S.rt[j] == nt) {
-                S.rlo[j] |= (uint32_t)E;
-                S.rhi[j] |= (uint32_t)(E >> 32);
-                fresh = false;
-            }
-        }
-    }
+    const bool fresh = active && !merge;
     const uint64_t mf = __ballot(fresh);
     if (fresh) {
         const uint32_t pos = st.tail + (uint32_t)__popcll(mf & ((1ull << lane) - 1ull));
@@ -407,16 +445,28 @@ __device__ __forceinline__ void push8(LdsStore& S, Pending& P, WalkState& st, ui
         S.rt[j] = nt;
         S.rlo[j] = (uint32_t)E;
         S.rhi[j] = (uint32_t)(E >> 32);
-        P.pt[hs] = nt + 1u;
+        P.pt[hs] = key;
         P.pi[hs] = pos;
+    }
+    if (mf != 0ull) {
+        const int f = __builtin_ctzll(mf);  // the lane whose record went to index st.tail
+        fw.valid = true;
+        fw.tile = (uint32_t)__builtin_amdgcn_readlane((int)nt, f);
+        fw.slot = (uint32_t)__builtin_amdgcn_readlane((int)ts, f);
+        fw.entry = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(E >> 32), f) << 32) |
+                   (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)E, f);
+        fw.known = (__ballot(found) >> f) & 1ull;
     }
     st.tail += (uint32_t)__popcll(mf);
 }
 
 // scalar form (global slab store)
 template <class Store>
-__device__ __forceinline__ void push8(Store& S, Pending& P, WalkState& st, uint32_t tile, uint64_t H, int lane) {
+__device__ __forceinline__ void push8(Store& S, Pending& P, WalkState& st, uint32_t tile, uint64_t H, int lane,
+                                      const PushLane& c, Forward& fw) {
     (void)lane;
+    (void)c;
+    (void)fw;
     const uint64_t up = H & 0xFFull, dn = (H >> 8) & 0xFFull, lf = (H >> 16) & 0xFFull, rt = (H >> 24) & 0xFFull;
     auto send = [&](uint32_t nt, uint64_t E) {  // same filter as the LDS form: skip entries the neighbour has walked
         uint32_t slot;
@@ -440,8 +490,6 @@ __device__ inline uint64_t dilate8(uint64_t r) {
     return hz | (hz << 8) | (hz >> 8);
 }
 
-// Walks the footprint of seed k from the state in `st`.  Returns 0 when the walk is complete, 1 when
-// the store ran out; `st` then holds a resumable state.
 // The 36 pixels around an 8x8 tile, one per lane 0..35: lanes 0-7 the row above (x = 0..7), 8-15 the row below,
 // 16-23 the column to the left (y = 0..7), 24-31 the column to the right, 32-35 the corners (-1,-1) (8,-1)
 // (-1,8) (8,8).  A record is pushed to a neighbour tile only for ring pixels that are themselves acceptable and
@@ -477,16 +525,26 @@ struct TileFetch {
     bool known, inside, rinside;
 };
 
+// `fw` (when valid) is the record at ring index i as the previous step's push8 left it in registers.
 template <class Store>
 __device__ __forceinline__ TileFetch fetch_tile(const FloodArgs& A, const Store& S, uint32_t i, int lr, int lc,
-                                                int rx, int ry, bool ring_lane) {
+                                                int rx, int ry, bool ring_lane, const Forward& fw) {
     TileFetch f;
-    S.get(i, f.tile, f.entry);
+    if (fw.valid) {
+        f.tile = fw.tile;
+        f.entry = fw.entry;
+        f.slot = fw.slot;
+        f.known = fw.known;
+        f.V = f.Am = f.Rg = 0ull;
+        if (f.known) S.values(f.slot, f.V, f.Am, f.Rg);
+    } else {
+        S.get(i, f.tile, f.entry);
+        f.known = S.lookup(f.tile, f.slot, f.V, f.Am, f.Rg);
+    }
     const int ty = (int)(f.tile >> 16), tx = (int)(f.tile & 0xFFFFu);  // tile id = ty << 16 | tx
     const int r = ty * 8 + lr, c = tx * 8 + lc;
     f.inside = r < A.h && c < A.w;
     f.q = f.inside ? (size_t)r * A.w + c : 0;
-    f.known = S.lookup(f.tile, f.slot, f.V, f.Am, f.Rg);
     f.lab = f.rlab = 0u;
     f.dm = f.rdm = 0u;
     f.dx = f.dy = f.rdx = f.rdy = 0.f;
@@ -527,7 +585,10 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
     const uint64_t adj = ring_adjacency(lane);
     if (st.head == st.tail) return 0;
     if ((st.tail - st.head) + 8u > S.ring_cap() || st.ntiles + 2u > S.hash_limit()) return 1;
-    TileFetch cur = fetch_tile(A, S, st.head, lr, lc, rx, ry, ring_lane);
+    const PushLane pc = push_lane(lane);
+    Forward fw;
+    fw.valid = false;
+    TileFetch cur = fetch_tile(A, S, st.head, lr, lc, rx, ry, ring_lane, fw);
     for (;;) {
         st.head += 1;
         st.steps += 1;
@@ -559,6 +620,8 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
             }
         }
         st.cnt += (uint32_t)__popcll(New);
+        fw.valid = false;
+        const bool was_empty = st.head == st.tail;  // then the first record appended now is the next one popped
         if (New != 0ull) {
             if constexpr (!Store::kDeferStamps) {
                 uint32_t old = kLabelFree;
@@ -574,11 +637,12 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
             }
             // ring pixels that are acceptable and touch a newly walked pixel become entries of their own tiles
             const uint64_t H = __ballot(((Rg >> lane) & 1ull) && (New & adj) != 0ull);
-            if (H != 0ull) push8(S, P, st, tile, H, lane);
+            if (H != 0ull) push8(S, P, st, tile, H, lane, pc, fw);
         }
+        fw.valid = fw.valid && was_empty;
         if (st.head == st.tail) return 0;
         if ((st.tail - st.head) + 8u > S.ring_cap() || st.ntiles + 2u > S.hash_limit()) return 1;
-        cur = fetch_tile(A, S, st.head, lr, lc, rx, ry, ring_lane);
+        cur = fetch_tile(A, S, st.head, lr, lc, rx, ry, ring_lane, fw);
     }
 }
 
