@@ -146,6 +146,7 @@ constexpr uint32_t kMarkBit = 0x80000000u;
 constexpr int kRingT = 128;  // per-wave LDS frontier ring: (tile, entry mask) records
 constexpr int kHashT = 256;  // per-wave LDS tile table: tile -> (pixels walked, pixels acceptable)
 constexpr uint32_t kFlagIncomplete = 1u, kFlagSelfFail = 2u;
+constexpr uint32_t kMaxSteps = 1u << 22;  // safety net of the walk loop: more records than an 8K frame has tile visits
 
 struct FloodArgs {
     const float* dx;
@@ -164,9 +165,23 @@ struct FloodArgs {
     uint4* slab_hash;   // n_slabs x slab_hash_cap x 2 records {generation, tile+1, V.lo, V.hi} {A.lo, A.hi, -, -}
     uint32_t n_slabs, slab_ring_cap, slab_hash_cap;  // caps are powers of two
 };
-// words 0..7 are reset every frame; kCtrlGen lives on for the lifetime of the slab memory (hash entries are
-// tagged with it, so a generation must never be reused while old entries are around)
-enum { kCtrlBarrier = 0, kCtrlSlabs = 1, kCtrlNCommit = 3, kCtrlNNext = 4, kCtrlError = 5, kCtrlGen = 8 };
+// All words but kCtrlGen are set up by flood_init_seeds_kernel every frame; kCtrlGen lives on for the lifetime of
+// the slab memory (hash entries are tagged with it, so a generation must never be reused while old entries are
+// around).  The rounds schedule themselves from these words: the host enqueues a batch of rounds blindly and
+// looks at the block once per batch.
+enum {
+    kCtrlBarrier = 0,  // lowest seed whose walk ran out of storage this round
+    kCtrlSlabs = 1,    // slabs handed out this round
+    kCtrlNAct = 2,     // length of the current active list (0: nothing left to do)
+    kCtrlNCommit = 3,  // seeds committed this round
+    kCtrlNNext = 4,    // length of the next active list (being appended)
+    kCtrlError = 5,
+    kCtrlWork = 6,     // (unused)
+    kCtrlRounds = 7,   // rounds that had work
+    kCtrlGen = 8,
+    kCtrlStall = 9,    // a round made no progress: kCtrlNRemain seeds are left for the ordered tail
+    kCtrlNRemain = 10,
+};
 
 // Frontier records, table entries and ballots are the same in all 64 lanes.  Saying so (readfirstlane) lets the
 // compiler keep them in SGPRs and run the bit-board logic on the scalar unit instead of the vector ALU.
@@ -642,6 +657,7 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
         fw.valid = fw.valid && was_empty;
         if (st.head == st.tail) return 0;
         if ((st.tail - st.head) + 8u > S.ring_cap() || st.ntiles + 2u > S.hash_limit()) return 1;
+        if (st.steps > kMaxSteps) return 1;  // never reached by a terminating walk; treated like exhausted storage
         cur = fetch_tile(A, S, st.head, lr, lc, rx, ry, ring_lane, fw);
     }
 }
@@ -682,18 +698,9 @@ __device__ __forceinline__ void stamp_footprint(const FloodArgs& A, uint32_t k, 
     if (__ballot(foreign)) st.blocked = true;
 }
 
-// One wavefront per workgroup: walks differ in length by three orders of magnitude, and a workgroup keeps its
-// LDS until its longest wave is done.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void flood_explore_kernel(FloodArgs A, BinTrig trig, const uint32_t* __restrict__ act,
-                                                           uint32_t n_act) {
-    __shared__ uint32_t s_ring[1][3][kRingT];
-    __shared__ uint32_t s_hash[1][7][kHashT];
-    __shared__ uint32_t s_pend[1][2][kPend];
-    __shared__ uint8_t s_ord[1][kHashT];
-    const int wv = 0, lane = threadIdx.x & 63;
-    const uint32_t ai = uni(blockIdx.x);
-    if (ai >= n_act) return;
-    const uint32_t k = uni(act[ai]);
+// One seed's exploration by one wavefront (see walk).
+__device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& trig, uint32_t k, LdsStore& L, Pending& P,
+                                             int lane) {
     const int s = (int)uni((uint32_t)A.seed_idx[k]);
     const int b = (int)uni((uint32_t)A.seed_bin[k]);
     const float thr = __uint_as_float(uni(__float_as_uint(A.seed_thr[k])));
@@ -703,10 +710,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
         if (lane == 0) A.flags[k] = kFlagSelfFail;  // flood() accepts nothing, not even the seed
         return;
     }
-    LdsStore L{s_ring[wv][0], s_ring[wv][1], s_ring[wv][2], s_hash[wv][0], s_hash[wv][1],
-               s_hash[wv][2], s_hash[wv][3], s_hash[wv][4], s_hash[wv][5], s_hash[wv][6], s_ord[wv]};
     for (int i = lane; i < kHashT; i += 64) L.hk[i] = 0u;
-    Pending P{s_pend[wv][0], s_pend[wv][1]};
     P.pt[lane] = 0u;
     const int sr = s / A.w, sc = s - sr * A.w;
     WalkState st{0u, 1u, 0u, 0u, false, 0u};
@@ -754,29 +758,51 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     }
 }
 
+// One wavefront per workgroup (walks differ in length by three orders of magnitude, and a workgroup keeps its
+// LDS until its longest wave is done), one seed per wavefront.  The grid covers the frame's seed count; the
+// length of the round's active list is read from the control block, so the host need not know it (workgroups
+// beyond the list leave at once).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void flood_explore_kernel(
+    FloodArgs A, BinTrig trig, const uint32_t* __restrict__ act) {
+    __shared__ uint32_t s_ring[3][kRingT];
+    __shared__ uint32_t s_hash[7][kHashT];
+    __shared__ uint32_t s_pend[2][kPend];
+    __shared__ uint8_t s_ord[kHashT];
+    const int lane = threadIdx.x & 63;
+    const uint32_t ai = uni(blockIdx.x);
+    if (ai >= uni(A.ctrl[kCtrlNAct])) return;
+    LdsStore L{s_ring[0], s_ring[1], s_ring[2], s_hash[0], s_hash[1], s_hash[2],
+               s_hash[3], s_hash[4], s_hash[5], s_hash[6], s_ord};
+    Pending P{s_pend[0], s_pend[1]};
+    explore_seed(A, trig, uni(act[ai]), L, P, lane);
+}
+
 // state: 0 = active, 1 = committed in this round, 2 = finished earlier / dead
-__global__ __launch_bounds__(256) void flood_decide_kernel(FloodArgs A, const uint32_t* __restrict__ act, uint32_t n_act,
+__global__ __launch_bounds__(256) void flood_decide_kernel(FloodArgs A, const uint32_t* __restrict__ act,
                                                            uint8_t* __restrict__ state, int32_t* __restrict__ seed_size) {
-    const uint32_t ai = blockIdx.x * 256 + threadIdx.x;
-    if (ai >= n_act) return;
-    const uint32_t k = act[ai];
-    const uint32_t fl = A.flags[k];
-    if (fl & kFlagSelfFail) {
-        state[k] = 2;
-        seed_size[k] = 0;
-        return;
-    }
+    const uint32_t n_act = A.ctrl[kCtrlNAct];
     const uint32_t barrier = A.ctrl[kCtrlBarrier];
-    const bool walked = A.count[k] > 0u;
-    if (walked && A.blocked[k] == 0u && !(fl & kFlagIncomplete) && k < barrier) {
-        state[k] = 1;
-        seed_size[k] = (int32_t)A.count[k];
-        atomicAdd(&A.ctrl[kCtrlNCommit], 1u);
+    for (uint32_t ai = blockIdx.x * 256 + threadIdx.x; ai < n_act; ai += gridDim.x * 256) {
+        const uint32_t k = act[ai];
+        const uint32_t fl = A.flags[k];
+        if (fl & kFlagSelfFail) {
+            state[k] = 2;
+            seed_size[k] = 0;
+            continue;
+        }
+        const bool walked = A.count[k] > 0u;
+        if (walked && A.blocked[k] == 0u && !(fl & kFlagIncomplete) && k < barrier) {
+            state[k] = 1;
+            seed_size[k] = (int32_t)A.count[k];
+            atomicAdd(&A.ctrl[kCtrlNCommit], 1u);
+        }
     }
 }
 
 __global__ __launch_bounds__(256) void flood_commit_pixels_kernel(uint32_t* __restrict__ label, size_t npix,
-                                                                  const uint8_t* __restrict__ state) {
+                                                                  const uint8_t* __restrict__ state,
+                                                                  const uint32_t* __restrict__ ctrl) {
+    if (ctrl[kCtrlNAct] == 0u) return;  // a round enqueued past the end
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t step = (size_t)gridDim.x * 256;
     for (; i < npix; i += step) {
@@ -788,46 +814,80 @@ __global__ __launch_bounds__(256) void flood_commit_pixels_kernel(uint32_t* __re
     }
 }
 
-// After the commit: which seeds go on to the next round?  alive[k] = 1 for still-active seeds.
+// After the commit: which seeds go on to the next round?
 __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, const uint32_t* __restrict__ act,
-                                                              uint32_t n_act, uint8_t* __restrict__ state,
+                                                              uint8_t* __restrict__ state,
                                                               int32_t* __restrict__ seed_size,
                                                               uint32_t* __restrict__ act_next) {
-    const uint32_t ai = blockIdx.x * 256 + threadIdx.x;
-    bool a = false;
-    uint32_t k = 0;
-    if (ai < n_act) {
-        k = act[ai];
-        if (state[k] == 1) {
-            state[k] = 2;
-        } else if (state[k] == 0) {
-            if (A.label[A.seed_idx[k]] < kMarkBit) {  // its pixel now belongs to a committed flood: skipped forever
+    const uint32_t n_act = A.ctrl[kCtrlNAct];
+    const uint32_t n_pad = (n_act + 255u) & ~255u;  // whole wavefronts take part in the ballots
+    for (uint32_t ai = blockIdx.x * 256 + threadIdx.x; ai < n_pad; ai += gridDim.x * 256) {
+        bool a = false;
+        uint32_t k = 0;
+        if (ai < n_act) {
+            k = act[ai];
+            if (state[k] == 1) {
                 state[k] = 2;
-                seed_size[k] = 0;
-            } else {
-                a = true;
-                A.blocked[k] = 0u;
-                A.count[k] = 0u;
-                A.flags[k] = 0u;
+            } else if (state[k] == 0) {
+                if (A.label[A.seed_idx[k]] < kMarkBit) {  // its pixel now belongs to a committed flood: skipped forever
+                    state[k] = 2;
+                    seed_size[k] = 0;
+                } else {
+                    a = true;
+                    A.blocked[k] = 0u;
+                    A.count[k] = 0u;
+                    A.flags[k] = 0u;
+                }
             }
         }
+        // next round's active list: one atomic per wavefront; the order of the list does not matter
+        const uint64_t m = __ballot(a);
+        if (m) {
+            const int lane = threadIdx.x & 63;
+            uint32_t base = 0;
+            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&A.ctrl[kCtrlNNext], (uint32_t)__popcll(m));
+            base = (uint32_t)__shfl((int)base, __ffsll((long long)m) - 1);
+            if (a) act_next[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = k;
+        }
     }
-    // next round's active list: one atomic per wavefront; the order of the list does not matter
-    const uint64_t m = __ballot(a);
-    if (m) {
-        const int lane = threadIdx.x & 63;
-        uint32_t base = 0;
-        if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&A.ctrl[kCtrlNNext], (uint32_t)__popcll(m));
-        base = (uint32_t)__shfl((int)base, __ffsll((long long)m) - 1);
-        if (a) act_next[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = k;
-    }
+}
+
+// End of a round (one thread): the next list becomes the current one.  A round without progress (possible only
+// when storage ran out on the lowest active seed) stops the rounds and leaves the rest to the ordered tail.
+__global__ void flood_advance_kernel(uint32_t* __restrict__ ctrl) {
+    const uint32_t n_act = ctrl[kCtrlNAct];
+    if (n_act == 0u) return;
+    const uint32_t n_next = ctrl[kCtrlNNext];
+    const bool progress = ctrl[kCtrlNCommit] > 0u || n_next < n_act;
+    ctrl[kCtrlRounds] += 1u;
+    ctrl[kCtrlNRemain] = n_next;
+    if (!progress) ctrl[kCtrlStall] = 1u;
+    ctrl[kCtrlNAct] = progress ? n_next : 0u;
+    ctrl[kCtrlNNext] = 0u;
+    ctrl[kCtrlNCommit] = 0u;
+    ctrl[kCtrlWork] = 0u;
+    ctrl[kCtrlBarrier] = 0xFFFFFFFFu;
+    ctrl[kCtrlSlabs] = 0u;
 }
 
 __global__ __launch_bounds__(256) void flood_init_seeds_kernel(uint32_t n_seeds, uint32_t* __restrict__ act,
                                                                uint8_t* __restrict__ state, uint8_t* __restrict__ alive,
                                                                uint32_t* __restrict__ blocked, uint32_t* __restrict__ count,
-                                                               uint32_t* __restrict__ flags, int32_t* __restrict__ seed_size) {
+                                                               uint32_t* __restrict__ flags, int32_t* __restrict__ seed_size,
+                                                               uint32_t* __restrict__ ctrl) {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k == 0u) {
+        ctrl[kCtrlBarrier] = 0xFFFFFFFFu;
+        ctrl[kCtrlSlabs] = 0u;
+        ctrl[kCtrlNAct] = n_seeds;
+        ctrl[kCtrlNCommit] = 0u;
+        ctrl[kCtrlNNext] = 0u;
+        ctrl[kCtrlError] = 0u;
+        ctrl[kCtrlWork] = 0u;
+        ctrl[kCtrlRounds] = 0u;
+        ctrl[kCtrlStall] = 0u;
+        ctrl[kCtrlNRemain] = n_seeds;
+    }
     if (k >= n_seeds) return;
     act[k] = k;
     state[k] = 0;
@@ -903,6 +963,37 @@ size_t flood_select_temp_bytes(uint32_t max_seeds) {
     return b + 256;
 }
 
+// LIBRECTIFY_FLOOD_DEBUG: what the round's exploration did (synchronises; rounds are then enqueued one at a time)
+static void flood_debug_round(const FloodBuffers& B, uint32_t n_seeds, const uint32_t* act, hipStream_t s) {
+    uint32_t ctrl[16];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(ctrl, B.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost);
+    const uint32_t n_act = ctrl[kCtrlNAct];
+    if (n_act == 0) return;
+    std::vector<uint32_t> cnt(n_seeds), blk(n_seeds), flg(n_seeds), actv(n_act);
+    (void)hipMemcpy(flg.data(), B.flags, n_seeds * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(actv.data(), act, n_act * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(cnt.data(), B.count, n_seeds * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(blk.data(), B.blocked, n_seeds * sizeof(uint32_t), hipMemcpyDeviceToHost);
+    unsigned long long tsteps = 0, tpx = 0;
+    uint32_t mxs = 0, mxk = 0, nb = 0;
+    for (uint32_t i = 0; i < n_act; ++i) {
+        const uint32_t kk = actv[i], st_ = flg[kk] >> 8;
+        tsteps += st_;
+        tpx += cnt[kk];
+        nb += blk[kk] != 0;
+        if (st_ > mxs) {
+            mxs = st_;
+            mxk = kk;
+        }
+    }
+    std::fprintf(stderr,
+                 "flood round %u: active %u, %llu px walked in %llu steps, longest walk %u steps (%u px, seed %u), "
+                 "blocked %u, committed %u, barrier %u, slabs %u\n",
+                 ctrl[kCtrlRounds] + 1, n_act, tpx, tsteps, mxs, cnt[mxk], mxk, nb, ctrl[kCtrlNCommit], ctrl[kCtrlBarrier],
+                 ctrl[kCtrlSlabs]);
+}
+
 int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, const uint8_t* dmask, int w, int h,
                    const int32_t* seed_idx, const int32_t* seed_bin, const float* seed_thr, uint32_t n_seeds,
                    BinTrig trig, uint32_t* label, int32_t* seed_size, int32_t* queue, uint32_t* h_ctrl, int* rounds_out,
@@ -931,89 +1022,50 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
     A.slab_ring_cap = B.slab_ring_cap;
     A.slab_hash_cap = B.slab_hash_cap;
 
-    uint32_t* act = B.act_a;
-    uint32_t* act_next = B.act_b;
-    uint32_t n_act = n_seeds;
-    hipLaunchKernelGGL(flood_init_seeds_kernel, dim3((n_seeds + 255) / 256), dim3(256), 0, s, n_seeds, act, B.state,
-                       B.alive, B.blocked, B.count, B.flags, seed_size);
-    LR_HIP(hipMemsetAsync(B.ctrl, 0, 8 * sizeof(uint32_t), s));
+    uint32_t* lists[2] = {B.act_a, B.act_b};
+    hipLaunchKernelGGL(flood_init_seeds_kernel, dim3((n_seeds + 255) / 256), dim3(256), 0, s, n_seeds, lists[0], B.state,
+                       B.alive, B.blocked, B.count, B.flags, seed_size, B.ctrl);
     const int pix_blocks = (int)std::min<size_t>((npix + 255) / 256, 4096);
-    int rounds = 0;
+    const int seed_blocks = (int)std::min<uint32_t>((n_seeds + 255) / 256, 256);
     static const bool debug = std::getenv("LIBRECTIFY_FLOOD_DEBUG") != nullptr;
-    static const int stage_rounds = std::getenv("LIBRECTIFY_FLOOD_STAGES") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_STAGES")) : 0;  // measured: no gain at 4K (kept as a knob)
-    static const int stage_shift = std::getenv("LIBRECTIFY_FLOOD_STAGE_SHIFT") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_STAGE_SHIFT")) : 3;
-    while (n_act > 0) {
-        ++rounds;
-        const uint32_t init[2] = {0xFFFFFFFFu, 0u};  // barrier, slabs used
-        h_ctrl[8] = init[0];
-        h_ctrl[9] = init[1];
-        LR_HIP(hipMemcpyAsync(B.ctrl + kCtrlBarrier, h_ctrl + 8, 2 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-        LR_HIP(hipMemsetAsync(B.ctrl + kCtrlNCommit, 0, 2 * sizeof(uint32_t), s));
-        // Staged start: the first rounds only walk the strongest seeds (the active list is ascending).  Seeds
-        // beyond the window could not commit before the ones inside it anyway, and once the long strong
-        // edges are committed the many weak seeds next to them no longer re-walk those edges.
-        uint32_t n_launch = n_act;
-        if (rounds == 1 && stage_rounds > 0 && n_act > 2048u) n_launch = std::max(1024u, n_act >> stage_shift);  // only round 1: its list is still in ascending order
-        hipLaunchKernelGGL(flood_explore_kernel, dim3(n_launch), dim3(64), 0, s, A, trig, act, n_launch);
-        hipLaunchKernelGGL(flood_decide_kernel, dim3((n_launch + 255) / 256), dim3(256), 0, s, A, act, n_launch, B.state,
-                           seed_size);
-        if (debug) {
-            std::vector<uint32_t> cnt(n_seeds), blk(n_seeds), flg(n_seeds), actv(n_act);
-            (void)hipStreamSynchronize(s);
-            (void)hipMemcpy(flg.data(), B.flags, n_seeds * sizeof(uint32_t), hipMemcpyDeviceToHost);
-            (void)hipMemcpy(actv.data(), act, n_act * sizeof(uint32_t), hipMemcpyDeviceToHost);
-            {
-                unsigned long long tsteps = 0, tpx = 0;
-                uint32_t mxs = 0, mxk = 0;
-                for (uint32_t i = 0; i < n_act; ++i) {
-                    const uint32_t kk = actv[i], st_ = flg[kk] >> 8;
-                    tsteps += st_;
-                    if (st_ > mxs) { mxs = st_; mxk = kk; }
-                }
-                (void)hipMemcpy(cnt.data(), B.count, n_seeds * sizeof(uint32_t), hipMemcpyDeviceToHost);
-                for (uint32_t i = 0; i < n_act; ++i) tpx += cnt[actv[i]];
-                std::fprintf(stderr, "  this round: %llu px walked in %llu steps; longest walk %u steps (%u px, seed %u)\n", tpx, tsteps, mxs, cnt[mxk], mxk);
-            }
-            (void)hipStreamSynchronize(s);
-            (void)hipMemcpy(cnt.data(), B.count, n_seeds * sizeof(uint32_t), hipMemcpyDeviceToHost);
-            (void)hipMemcpy(blk.data(), B.blocked, n_seeds * sizeof(uint32_t), hipMemcpyDeviceToHost);
-            unsigned long long tot = 0, totb = 0;
-            uint32_t mx = 0, big = 0, nb = 0;
-            for (uint32_t i = 0; i < n_seeds; ++i) {
-                tot += cnt[i];
-                if (blk[i]) { totb += cnt[i]; ++nb; }
-                mx = std::max(mx, cnt[i]);
-                big += cnt[i] > 768;
-            }
-            std::fprintf(stderr, "  visits %llu (blocked seeds: %llu over %u seeds) max %u, >768: %u\n", tot, totb, nb, mx, big);
+    // Rounds are enqueued blindly, a batch at a time: their kernels read the list length from the control block,
+    // and a round enqueued past the end does nothing.  Typical frames finish within the first batch, i.e. with one
+    // host synchronisation for the whole flood.
+    int enqueued = 0;
+    for (;;) {
+        const int batch = debug ? 1 : (enqueued == 0 ? 6 : 3);
+        for (int r = 0; r < batch; ++r, ++enqueued) {
+            uint32_t* act = lists[enqueued & 1];
+            uint32_t* act_next = lists[(enqueued + 1) & 1];
+            hipLaunchKernelGGL(flood_explore_kernel, dim3(n_seeds), dim3(64), 0, s, A, trig, act);
+            hipLaunchKernelGGL(flood_decide_kernel, dim3(seed_blocks), dim3(256), 0, s, A, act, B.state, seed_size);
+            if (debug) flood_debug_round(B, n_seeds, act, s);
+            hipLaunchKernelGGL(flood_commit_pixels_kernel, dim3(pix_blocks), dim3(256), 0, s, label, npix, B.state, B.ctrl);
+            hipLaunchKernelGGL(flood_survivors_kernel, dim3(seed_blocks), dim3(256), 0, s, A, act, B.state, seed_size,
+                               act_next);
+            hipLaunchKernelGGL(flood_advance_kernel, dim3(1), dim3(1), 0, s, B.ctrl);
         }
-        hipLaunchKernelGGL(flood_commit_pixels_kernel, dim3(pix_blocks), dim3(256), 0, s, label, npix, B.state);
-        hipLaunchKernelGGL(flood_survivors_kernel, dim3((n_act + 255) / 256), dim3(256), 0, s, A, act, n_act, B.state,
-                           seed_size, act_next);
         LR_HIP(hipMemcpyAsync(h_ctrl, B.ctrl, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         LR_HIP(hipStreamSynchronize(s));
-        const uint32_t n_commit = h_ctrl[kCtrlNCommit];
-        const uint32_t n_next = h_ctrl[kCtrlNNext];
-        if (debug) {
-            std::fprintf(stderr, "flood round %d: active %u committed %u next %u barrier %u slabs %u\n", rounds, n_act,
-                         n_commit, n_next, h_ctrl[kCtrlBarrier], h_ctrl[kCtrlSlabs]);
+        if (debug)
+            std::fprintf(stderr, "flood after %d rounds enqueued: %u done, active %u, remain %u, stall %u\n", enqueued,
+                         h_ctrl[kCtrlRounds], h_ctrl[kCtrlNAct], h_ctrl[kCtrlNRemain], h_ctrl[kCtrlStall]);
+        if (h_ctrl[kCtrlNAct] == 0u) break;
+    }
+    int rounds = (int)h_ctrl[kCtrlRounds];
+    if (h_ctrl[kCtrlStall] != 0u && h_ctrl[kCtrlNRemain] > 0u) {
+        // storage exhausted on the lowest active seed: finish in order (always exact); the list is unordered
+        const uint32_t n_rem = h_ctrl[kCtrlNRemain];
+        uint32_t* act = lists[rounds & 1];  // what the last round with work appended to
+        {
+            std::vector<uint32_t> tmp(n_rem);
+            LR_HIP(hipMemcpy(tmp.data(), act, n_rem * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            std::sort(tmp.begin(), tmp.end());
+            LR_HIP(hipMemcpy(act, tmp.data(), n_rem * sizeof(uint32_t), hipMemcpyHostToDevice));
         }
-        std::swap(act, act_next);
-        const bool progress = n_commit > 0 || n_next < n_act || n_launch < n_act;
-        n_act = n_next;
-        if (n_act > 0 && !progress) {
-            // storage exhausted on the lowest active seed: finish in order (always exact); the list is unordered
-            {
-                std::vector<uint32_t> tmp(n_act);
-                LR_HIP(hipMemcpy(tmp.data(), act, n_act * sizeof(uint32_t), hipMemcpyDeviceToHost));
-                std::sort(tmp.begin(), tmp.end());
-                LR_HIP(hipMemcpy(act, tmp.data(), n_act * sizeof(uint32_t), hipMemcpyHostToDevice));
-            }
-            hipLaunchKernelGGL(flood_ordered_tail_kernel, dim3(1), dim3(64), 0, s, dx, dy, dmask, w, seed_idx, seed_bin,
-                               seed_thr, act, n_act, trig, label, seed_size, queue);
-            ++rounds;
-            n_act = 0;
-        }
+        hipLaunchKernelGGL(flood_ordered_tail_kernel, dim3(1), dim3(64), 0, s, dx, dy, dmask, w, seed_idx, seed_bin,
+                           seed_thr, act, n_rem, trig, label, seed_size, queue);
+        ++rounds;
     }
     LR_HIP(hipGetLastError());
     if (h_ctrl[kCtrlGen] > 0xF0000000u) {  // generation counter about to wrap: forget every tagged hash entry
