@@ -17,86 +17,143 @@ namespace {
 
 constexpr uint32_t kNoComp = 0xFFFFFFFFu;
 
-// Single-workgroup scan over the seeds: rank and pixel offset of every kept flood.
-__global__ __launch_bounds__(1024) void component_offsets_kernel(const int32_t* __restrict__ seed_size,
-                                                                 uint32_t n_seeds, int min_size,
-                                                                 uint32_t* __restrict__ comp_rank,
-                                                                 uint32_t* __restrict__ comp_seed,
-                                                                 uint32_t* __restrict__ comp_off,
-                                                                 uint32_t* __restrict__ totals) {
-    __shared__ uint32_t s_cnt[16], s_px[16];
-    __shared__ uint32_t s_carry_cnt, s_carry_px;
+// Rank and pixel offset of every kept flood, in seed order: a two-level scan.  Workgroup b owns seeds
+// [b * kOffChunk, (b + 1) * kOffChunk), eight consecutive seeds per thread.  First kernel: per-chunk totals.
+// Second kernel: every workgroup adds up the totals of the chunks before it and scans its own chunk.
+constexpr int kOffPer = 8;
+constexpr uint32_t kOffChunk = 256 * kOffPer;
+
+__device__ __forceinline__ void chunk_counts(const int32_t* __restrict__ seed_size, uint32_t n_seeds, int min_size,
+                                             uint32_t k0, int (&sz)[kOffPer], uint32_t& c, uint32_t& p) {
+    c = p = 0;
+#pragma unroll
+    for (int j = 0; j < kOffPer; ++j) {
+        sz[j] = (k0 + j < n_seeds) ? seed_size[k0 + j] : 0;
+        if (sz[j] > min_size) {
+            c += 1u;
+            p += (uint32_t)sz[j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void component_sums_kernel(const int32_t* __restrict__ seed_size, uint32_t n_seeds,
+                                                             int min_size, uint2* __restrict__ chunk_tot) {
+    __shared__ uint32_t s_c[4], s_p[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) {
-        s_carry_cnt = 0;
-        s_carry_px = 0;
+    int sz[kOffPer];
+    uint32_t c, p;
+    chunk_counts(seed_size, n_seeds, min_size, blockIdx.x * kOffChunk + (uint32_t)tid * kOffPer, sz, c, p);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        c += (uint32_t)__shfl_xor((int)c, off);
+        p += (uint32_t)__shfl_xor((int)p, off);
+    }
+    if (lane == 0) {
+        s_c[wv] = c;
+        s_p[wv] = p;
     }
     __syncthreads();
-    for (uint32_t base = 0; base < n_seeds; base += 1024) {
-        const uint32_t k = base + tid;
-        const int sz = (k < n_seeds) ? seed_size[k] : 0;
-        const bool keep = sz > min_size;
-        uint32_t c = keep ? 1u : 0u, p = keep ? (uint32_t)sz : 0u;
-        // inclusive scan inside the wave
-        uint32_t ic = c, ip = p;
+    if (tid == 0) chunk_tot[blockIdx.x] = make_uint2(s_c[0] + s_c[1] + s_c[2] + s_c[3], s_p[0] + s_p[1] + s_p[2] + s_p[3]);
+}
+
+__global__ __launch_bounds__(256) void component_offsets_kernel(const int32_t* __restrict__ seed_size,
+                                                                uint32_t n_seeds, int min_size,
+                                                                const uint2* __restrict__ chunk_tot,
+                                                                uint32_t* __restrict__ comp_rank,
+                                                                uint32_t* __restrict__ comp_seed,
+                                                                uint32_t* __restrict__ comp_off,
+                                                                uint32_t* __restrict__ totals) {
+    __shared__ uint32_t s_c[4], s_p[4], s_cc[4], s_cp[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // totals of the chunks before this one
+    uint32_t cc = 0, cp = 0;
+    for (uint32_t i = (uint32_t)tid; i < blockIdx.x; i += 256) {
+        const uint2 t = chunk_tot[i];
+        cc += t.x;
+        cp += t.y;
+    }
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t tc = (uint32_t)__shfl_up((int)ic, off);
-            const uint32_t tp = (uint32_t)__shfl_up((int)ip, off);
-            if (lane >= off) {
-                ic += tc;
-                ip += tp;
-            }
+    for (int off = 32; off >= 1; off >>= 1) {
+        cc += (uint32_t)__shfl_xor((int)cc, off);
+        cp += (uint32_t)__shfl_xor((int)cp, off);
+    }
+    const uint32_t k0 = blockIdx.x * kOffChunk + (uint32_t)tid * kOffPer;
+    int sz[kOffPer];
+    uint32_t c, p;
+    chunk_counts(seed_size, n_seeds, min_size, k0, sz, c, p);
+    uint32_t ic = c, ip = p;  // inclusive scan inside the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t tc = (uint32_t)__shfl_up((int)ic, off);
+        const uint32_t tp = (uint32_t)__shfl_up((int)ip, off);
+        if (lane >= off) {
+            ic += tc;
+            ip += tp;
         }
-        if (lane == 63) {
-            s_cnt[wv] = ic;
-            s_px[wv] = ip;
-        }
-        __syncthreads();
-        uint32_t wc = 0, wp = 0;
-        for (int i = 0; i < wv; ++i) {
-            wc += s_cnt[i];
-            wp += s_px[i];
-        }
-        const uint32_t carry_c = s_carry_cnt, carry_p = s_carry_px;
-        const uint32_t rank = carry_c + wc + ic - c;
-        const uint32_t off_px = carry_p + wp + ip - p;
+    }
+    if (lane == 63) {
+        s_c[wv] = ic;
+        s_p[wv] = ip;
+    }
+    if (lane == 0) {
+        s_cc[wv] = cc;
+        s_cp[wv] = cp;
+    }
+    __syncthreads();
+    uint32_t rank = s_cc[0] + s_cc[1] + s_cc[2] + s_cc[3] + ic - c;
+    uint32_t off_px = s_cp[0] + s_cp[1] + s_cp[2] + s_cp[3] + ip - p;
+    for (int i = 0; i < wv; ++i) {
+        rank += s_c[i];
+        off_px += s_p[i];
+    }
+#pragma unroll
+    for (int j = 0; j < kOffPer; ++j) {
+        const uint32_t k = k0 + j;
         if (k < n_seeds) {
+            const bool keep = sz[j] > min_size;
             comp_rank[k] = keep ? rank : kNoComp;
             if (keep) {
                 comp_seed[rank] = k;
                 comp_off[rank] = off_px;
+                rank += 1u;
+                off_px += (uint32_t)sz[j];
             }
         }
-        __syncthreads();
-        if (tid == 1023) {
-            s_carry_cnt = carry_c + wc + ic;
-            s_carry_px = carry_p + wp + ip;
-        }
-        __syncthreads();
     }
-    if (tid == 0) {
-        totals[0] = s_carry_cnt;
-        totals[1] = s_carry_px;
-        comp_off[s_carry_cnt] = s_carry_px;
+    if (blockIdx.x == gridDim.x - 1 && tid == 255) {  // the last thread of the last chunk ends on the grand totals
+        totals[0] = rank;
+        totals[1] = off_px;
+        comp_off[rank] = off_px;
     }
 }
 
+// Pixels of kept floods go to their component's slice of `px` (any order: the segmented sort follows).  Lanes of
+// a wavefront that hold the same component (neighbours along a row mostly do) take their slots with ONE atomic:
+// per-pixel atomics on the cursor of a 3000-pixel component would queue up behind each other in L2.
 __global__ __launch_bounds__(256) void component_scatter_kernel(const uint32_t* __restrict__ label, size_t npix,
                                                                 const uint32_t* __restrict__ comp_rank,
                                                                 const uint32_t* __restrict__ comp_off,
                                                                 uint32_t* __restrict__ cursor,
                                                                 uint32_t* __restrict__ px) {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const size_t step = (size_t)gridDim.x * 256;
-    for (; i < npix; i += step) {
-        const uint32_t l = label[i];
-        if (l != kLabelFree) {
-            const uint32_t r = comp_rank[l];
-            if (r != kNoComp) {
-                const uint32_t pos = comp_off[r] + atomicAdd(&cursor[r], 1u);
-                px[pos] = (uint32_t)i;
-            }
+    const size_t n_pad = (npix + 255) / 256 * 256;  // whole wavefronts take part in the ballots
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_pad; i += step) {
+        uint32_t r = kNoComp;
+        if (i < npix) {
+            const uint32_t l = label[i];
+            if (l != kLabelFree) r = comp_rank[l];
+        }
+        uint64_t todo = __ballot(r != kNoComp);
+        while (todo != 0ull) {
+            const int leader = __builtin_ctzll(todo);
+            const uint32_t rl = (uint32_t)__builtin_amdgcn_readlane((int)r, leader);
+            const uint64_t same = __ballot(r == rl) & todo;
+            uint32_t base = 0;
+            if (lane == leader) base = comp_off[rl] + atomicAdd(&cursor[rl], (uint32_t)__popcll(same));
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+            if ((same >> lane) & 1ull) px[base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = (uint32_t)i;
+            todo &= ~same;
         }
     }
 }
@@ -230,10 +287,12 @@ size_t fit_temp_bytes(size_t max_pixels, uint32_t max_segments) {
 int launch_component_offsets(const int32_t* seed_size, uint32_t n_seeds, int min_size, uint32_t* comp_rank,
                              uint32_t* comp_seed, uint32_t* comp_off, uint32_t* totals, void* temp, size_t temp_bytes,
                              hipStream_t s) {
-    (void)temp;
-    (void)temp_bytes;
-    hipLaunchKernelGGL(component_offsets_kernel, dim3(1), dim3(1024), 0, s, seed_size, n_seeds, min_size, comp_rank,
-                       comp_seed, comp_off, totals);
+    const uint32_t chunks = (n_seeds + kOffChunk - 1) / kOffChunk;
+    if (chunks == 0 || temp_bytes < chunks * sizeof(uint2)) return 1;
+    uint2* chunk_tot = static_cast<uint2*>(temp);
+    hipLaunchKernelGGL(component_sums_kernel, dim3(chunks), dim3(256), 0, s, seed_size, n_seeds, min_size, chunk_tot);
+    hipLaunchKernelGGL(component_offsets_kernel, dim3(chunks), dim3(256), 0, s, seed_size, n_seeds, min_size, chunk_tot,
+                       comp_rank, comp_seed, comp_off, totals);
     LR_HIP(hipGetLastError());
     return 0;
 }
