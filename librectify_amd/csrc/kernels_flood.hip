@@ -527,6 +527,17 @@ __device__ __forceinline__ uint64_t ring_adjacency(int lane) {
         }
     return m;
 }
+// pixels of the tile (bit = y*8+x) that are 8-adjacent to this lane's pixel, and the pixel itself
+__device__ __forceinline__ uint64_t tile_neighbours(int lane) {
+    const int lr = lane >> 3, lc = lane & 7;
+    uint64_t m = 0ull;
+    for (int dy = -1; dy <= 1; ++dy)
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int x = lc + dx, y = lr + dy;
+            if (x >= 0 && x < 8 && y >= 0 && y < 8) m |= 1ull << (y * 8 + x);
+        }
+    return m;
+}
 // What one lane holds of a frontier record before it is processed.  For a tile the wave already knows, the
 // table answers (V, A, ring) and no memory is touched; otherwise the lane's pixel of the tile and its pixel of
 // the surrounding ring are loaded.
@@ -598,6 +609,8 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
     ring_xy(lane, rx, ry);
     const bool ring_lane = lane < 36;
     const uint64_t adj = ring_adjacency(lane);
+    uint64_t nbr = tile_neighbours(lane);
+    asm volatile("" : "+v"(nbr));  // a per-lane constant: keep it in registers
     if (st.head == st.tail) return 0;
     if ((st.tail - st.head) + 8u > S.ring_cap() || st.ntiles + 2u > S.hash_limit()) return 1;
     const PushLane pc = push_lane(lane);
@@ -620,8 +633,12 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
         uint64_t R = cur.entry & Am;
         uint64_t New = 0ull;
         if (R != 0ull) {
-            for (;;) {  // connected closure of the entry pixels inside the tile
-                const uint64_t Rn = dilate8(R) & Am;
+            // Connected closure of the entry pixels inside the tile.  One iteration is dilate8(R) & Am, evaluated
+            // with a pixel per lane (an acceptable pixel joins when its 3x3 neighbourhood meets R): three vector
+            // instructions instead of sixteen on the scalar unit, which the rest of the step keeps busy.
+            const uint64_t reach = ((Am >> lane) & 1ull) ? nbr : 0ull;
+            for (;;) {
+                const uint64_t Rn = __ballot((R & reach) != 0ull);
                 if (Rn == R) break;
                 R = Rn;
             }
