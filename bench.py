@@ -99,12 +99,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=8, help="distinct frames per rank per step")
+    ap.add_argument("--frames", type=int, default=32, help="distinct frames per rank per step")
     ap.add_argument("--width", type=int, default=W4K)
     ap.add_argument("--height", type=int, default=H4K)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flood-mode", type=int, default=None)
-    ap.add_argument("--streams", type=int, default=8, help="frames in flight per GPU (one context + HIP stream + host thread each)")
+    ap.add_argument("--streams", type=int, default=16, help="frames in flight per GPU (one context + HIP stream + host thread each)")
     args = ap.parse_args()
 
     import torch

@@ -123,6 +123,11 @@ struct FloodBuffers {
     uint32_t n_slabs = 0, slab_ring_cap = 0, slab_hash_cap = 0;
     void* select_temp = nullptr;
     size_t select_temp_bytes = 0;
+    // Staged start of the rounds: the first round walks the strongest n_seeds >> win_first_shift seeds (0 = all),
+    // the window grows by << win_growth per round.  Fewer pixels are walked in total (weak seeds on an edge that a
+    // strong seed takes die unwalked) at the price of one or two more rounds: better throughput with many frames
+    // in flight, worse latency for a single frame.
+    int win_first_shift = 0, win_growth = 2;
 };
 size_t flood_select_temp_bytes(uint32_t max_seeds);
 // Runs all rounds (synchronises the stream once per round).  h_ctrl: >= 16 words of pinned host memory.

@@ -265,6 +265,7 @@ int ctx_stage_flood(lr_context* c) {
         FloodBuffers fbuf = c->fb;
         if (c->flood_mode == 2) fbuf.n_slabs = 0;  // test hooks: exercise the exhausted-storage paths
         if (c->flood_mode == 3) fbuf.n_slabs = 2;
+        if (c->flood_staged) fbuf.win_first_shift = 3;
         if (flood_parallel(fbuf, c->dx, c->dy, c->dmask, c->w, c->h, c->seed_idx, c->seed_bin, c->seed_thr,
                            c->n_seeds, c->trig, c->label, c->seed_size, c->queue, c->h_counts + 16, &c->flood_rounds,
                            c->stream))
@@ -814,6 +815,7 @@ int ctx_find_groups_batch_device(lr_context* c, const float* d_images, size_t im
         l->ransac_seed = c->ransac_seed;
         l->ransac_iters = c->ransac_iters;
         l->flood_mode = c->flood_mode;
+        l->flood_staged = S > 1;
         l->estimator = c->estimator;
         l->prosac_T_N = c->prosac_T_N;
     }
@@ -843,6 +845,7 @@ int ctx_find_groups_batch_device(lr_context* c, const float* d_images, size_t im
     for (int si = 1; si < S; ++si) th.emplace_back(work, si);
     work(0);
     for (auto& t : th) t.join();
+    c->flood_staged = false;  // the caller's context goes back to the latency-oriented single-frame setting
     for (int si = 0; si < S; ++si)
         if (rc[si]) {
             set_error(err[si]);

@@ -164,6 +164,7 @@ struct FloodArgs {
     uint4* slab_ring;   // n_slabs x slab_ring_cap records {tile, -, mask.lo, mask.hi}
     uint4* slab_hash;   // n_slabs x slab_hash_cap x 2 records {generation, tile+1, V.lo, V.hi} {A.lo, A.hi, -, -}
     uint32_t n_slabs, slab_ring_cap, slab_hash_cap;  // caps are powers of two
+    uint32_t n_seeds, win_first, win_shift;          // staged start (see kCtrlWindow)
 };
 // All words but kCtrlGen are set up by flood_init_seeds_kernel every frame; kCtrlGen lives on for the lifetime of
 // the slab memory (hash entries are tagged with it, so a generation must never be reused while old entries are
@@ -181,6 +182,11 @@ enum {
     kCtrlGen = 8,
     kCtrlStall = 9,    // a round made no progress: kCtrlNRemain seeds are left for the ordered tail
     kCtrlNRemain = 10,
+    // Staged start: a round only walks seeds below this index (all lower active seeds are then walked too, so a
+    // commit is as valid as in a full round); it grows by << win_shift per round up to the seed count.  Seeds are
+    // ordered by strength, and most weak seeds sit on an edge that a strong seed's flood takes: they die without
+    // ever having walked it.
+    kCtrlWindow = 11,
 };
 
 // Frontier records, table entries and ballots are the same in all 64 lanes.  Saying so (readfirstlane) lets the
@@ -791,7 +797,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     LdsStore L{s_ring[0], s_ring[1], s_ring[2], s_hash[0], s_hash[1], s_hash[2],
                s_hash[3], s_hash[4], s_hash[5], s_hash[6], s_ord};
     Pending P{s_pend[0], s_pend[1]};
-    explore_seed(A, trig, uni(act[ai]), L, P, lane);
+    const uint32_t k = uni(act[ai]);
+    if (k >= uni(A.ctrl[kCtrlWindow])) return;  // not yet in the staged window: stays active, walks in a later round
+    explore_seed(A, trig, k, L, P, lane);
 }
 
 // state: 0 = active, 1 = committed in this round, 2 = finished earlier / dead
@@ -871,11 +879,14 @@ __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, const
 
 // End of a round (one thread): the next list becomes the current one.  A round without progress (possible only
 // when storage ran out on the lowest active seed) stops the rounds and leaves the rest to the ordered tail.
-__global__ void flood_advance_kernel(uint32_t* __restrict__ ctrl) {
+__global__ void flood_advance_kernel(uint32_t* __restrict__ ctrl, uint32_t n_seeds, uint32_t win_shift) {
     const uint32_t n_act = ctrl[kCtrlNAct];
     if (n_act == 0u) return;
     const uint32_t n_next = ctrl[kCtrlNNext];
-    const bool progress = ctrl[kCtrlNCommit] > 0u || n_next < n_act;
+    const uint32_t window = ctrl[kCtrlWindow];
+    const bool progress = ctrl[kCtrlNCommit] > 0u || n_next < n_act || window < n_seeds;
+    const unsigned long long grown = (unsigned long long)window << win_shift;
+    ctrl[kCtrlWindow] = grown < n_seeds ? (uint32_t)grown : n_seeds;
     ctrl[kCtrlRounds] += 1u;
     ctrl[kCtrlNRemain] = n_next;
     if (!progress) ctrl[kCtrlStall] = 1u;
@@ -891,9 +902,10 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(uint32_t n_seeds,
                                                                uint8_t* __restrict__ state, uint8_t* __restrict__ alive,
                                                                uint32_t* __restrict__ blocked, uint32_t* __restrict__ count,
                                                                uint32_t* __restrict__ flags, int32_t* __restrict__ seed_size,
-                                                               uint32_t* __restrict__ ctrl) {
+                                                               uint32_t* __restrict__ ctrl, uint32_t win_first) {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k == 0u) {
+        ctrl[kCtrlWindow] = win_first;
         ctrl[kCtrlBarrier] = 0xFFFFFFFFu;
         ctrl[kCtrlSlabs] = 0u;
         ctrl[kCtrlNAct] = n_seeds;
@@ -1039,9 +1051,21 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
     A.slab_ring_cap = B.slab_ring_cap;
     A.slab_hash_cap = B.slab_hash_cap;
 
+    // staged start (FloodBuffers::win_*); LIBRECTIFY_FLOOD_WINDOW="<first shift>,<growth shift>" overrides
+    static const char* win_env = std::getenv("LIBRECTIFY_FLOOD_WINDOW");
+    int win_first_shift = B.win_first_shift, win_growth = B.win_growth;
+    if (win_env) {
+        win_first_shift = std::atoi(win_env);
+        const char* c = std::strchr(win_env, ',');
+        if (c) win_growth = std::max(1, std::atoi(c + 1));
+    }
+    A.n_seeds = n_seeds;
+    A.win_first = win_first_shift > 0 ? std::max(1024u, n_seeds >> win_first_shift) : n_seeds;
+    if (A.win_first > n_seeds) A.win_first = n_seeds;
+    A.win_shift = (uint32_t)win_growth;
     uint32_t* lists[2] = {B.act_a, B.act_b};
     hipLaunchKernelGGL(flood_init_seeds_kernel, dim3((n_seeds + 255) / 256), dim3(256), 0, s, n_seeds, lists[0], B.state,
-                       B.alive, B.blocked, B.count, B.flags, seed_size, B.ctrl);
+                       B.alive, B.blocked, B.count, B.flags, seed_size, B.ctrl, A.win_first);
     const int pix_blocks = (int)std::min<size_t>((npix + 255) / 256, 4096);
     const int seed_blocks = (int)std::min<uint32_t>((n_seeds + 255) / 256, 256);
     static const bool debug = std::getenv("LIBRECTIFY_FLOOD_DEBUG") != nullptr;
@@ -1060,7 +1084,7 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
             hipLaunchKernelGGL(flood_commit_pixels_kernel, dim3(pix_blocks), dim3(256), 0, s, label, npix, B.state, B.ctrl);
             hipLaunchKernelGGL(flood_survivors_kernel, dim3(seed_blocks), dim3(256), 0, s, A, act, B.state, seed_size,
                                act_next);
-            hipLaunchKernelGGL(flood_advance_kernel, dim3(1), dim3(1), 0, s, B.ctrl);
+            hipLaunchKernelGGL(flood_advance_kernel, dim3(1), dim3(1), 0, s, B.ctrl, n_seeds, A.win_shift);
         }
         LR_HIP(hipMemcpyAsync(h_ctrl, B.ctrl, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         LR_HIP(hipStreamSynchronize(s));
