@@ -728,8 +728,12 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
     const int b = (int)uni((uint32_t)A.seed_bin[k]);
     const float thr = __uint_as_float(uni(__float_as_uint(A.seed_thr[k])));
     const float sn = trig.st[b], cs = trig.ct[b];
-    if (A.label[s] < kMarkBit) return;  // claimed by an earlier flood: dead (found again by the compaction)
-    if (!(((A.dmask[s] >> b) & 1) && directional(A.dx[s], A.dy[s], sn, cs) > thr)) {
+    // the four values at the seed pixel in one round trip (most seeds of a late round end right here)
+    const uint32_t seed_label = A.label[s];
+    const uint32_t seed_mask = A.dmask[s];
+    const float seed_dx = A.dx[s], seed_dy = A.dy[s];
+    if (seed_label < kMarkBit) return;  // claimed by an earlier flood: dead (found again by the compaction)
+    if (!(((seed_mask >> b) & 1) && directional(seed_dx, seed_dy, sn, cs) > thr)) {
         if (lane == 0) A.flags[k] = kFlagSelfFail;  // flood() accepts nothing, not even the seed
         return;
     }
@@ -792,13 +796,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     __shared__ uint32_t s_pend[2][kPend];
     __shared__ uint8_t s_ord[kHashT];
     const int lane = threadIdx.x & 63;
+    // list length, staged window and list entry are independent loads: one round trip, then the tests
     const uint32_t ai = uni(blockIdx.x);
-    if (ai >= uni(A.ctrl[kCtrlNAct])) return;
+    const uint32_t n_act = uni(A.ctrl[kCtrlNAct]), window = uni(A.ctrl[kCtrlWindow]);
+    const uint32_t k = uni(act[ai]);  // within the list's capacity for every workgroup of the grid
+    if (ai >= n_act || k >= window) return;  // past the list, or not yet in the staged window (stays active)
     LdsStore L{s_ring[0], s_ring[1], s_ring[2], s_hash[0], s_hash[1], s_hash[2],
                s_hash[3], s_hash[4], s_hash[5], s_hash[6], s_ord};
     Pending P{s_pend[0], s_pend[1]};
-    const uint32_t k = uni(act[ai]);
-    if (k >= uni(A.ctrl[kCtrlWindow])) return;  // not yet in the staged window: stays active, walks in a later round
     explore_seed(A, trig, k, L, P, lane);
 }
 
