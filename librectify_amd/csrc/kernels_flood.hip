@@ -1079,7 +1079,7 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
     // host synchronisation for the whole flood.
     int enqueued = 0;
     for (;;) {
-        const int batch = debug ? 1 : (enqueued == 0 ? 6 : 3);
+        const int batch = debug ? 1 : (enqueued == 0 ? (A.win_first < n_seeds ? 7 : 6) : 3);
         for (int r = 0; r < batch; ++r, ++enqueued) {
             uint32_t* act = lists[enqueued & 1];
             uint32_t* act_next = lists[(enqueued + 1) & 1];
