@@ -118,6 +118,7 @@ struct FloodBuffers {
     uint32_t* act_a = nullptr;
     uint32_t* act_b = nullptr;
     uint32_t* ctrl = nullptr;       // 16 words
+    uint32_t* big_list = nullptr;   // 1024 seeds: this round's hand-over to the second storage tier
     void* slab_ring = nullptr;  // n_slabs x slab_ring_cap 16-byte records
     void* slab_hash = nullptr;  // n_slabs x slab_hash_cap 16-byte records
     uint32_t n_slabs = 0, slab_ring_cap = 0, slab_hash_cap = 0;

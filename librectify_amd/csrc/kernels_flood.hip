@@ -143,8 +143,12 @@ namespace {
 // =============================================================================================
 
 constexpr uint32_t kMarkBit = 0x80000000u;
-constexpr int kRingT = 128;  // per-wave LDS frontier ring: (tile, entry mask) records
-constexpr int kHashT = 256;  // per-wave LDS tile table: tile -> (pixels walked, pixels acceptable)
+// Per-wave LDS storage of a walk, two tiers: every seed starts with a 128-record frontier ring and a 256-tile table
+// (9.5 KB: 16 walks per CU); the few walks that outgrow it (edges over ~1500 px) start again in a workgroup with a
+// 1024-record ring and a 2048-tile table (72 KB: 2 per CU) before the global slabs are the last resort.
+constexpr int kRingT = 128, kHashT = 256;
+constexpr int kRingBig = 1024, kHashBig = 2048;
+constexpr uint32_t kBigCap = 1024;  // seeds per round that can move to the second tier
 constexpr uint32_t kFlagIncomplete = 1u, kFlagSelfFail = 2u;
 constexpr uint32_t kMaxSteps = 1u << 22;  // safety net of the walk loop: more records than an 8K frame has tile visits
 
@@ -187,6 +191,7 @@ enum {
     // ordered by strength, and most weak seeds sit on an edge that a strong seed's flood takes: they die without
     // ever having walked it.
     kCtrlWindow = 11,
+    kCtrlNBig = 12,  // seeds handed to the second storage tier this round
 };
 
 // Frontier records, table entries and ballots are the same in all 64 lanes.  Saying so (readfirstlane) lets the
@@ -208,8 +213,11 @@ struct WalkState {
 // test): a record that re-enters a known tile is resolved from the table alone, without touching memory,
 // and walked pixels stamped by lower seeds are remembered there too, so the walk terminates.
 // All store operations below are wave-uniform (every lane performs the same access).
-struct LdsStore {
+template <int kRing, int kHash, typename OrdT>
+struct LdsStoreT {
     static constexpr bool kDeferStamps = true;
+    static constexpr int kRingN = kRing, kHashN = kHash;
+    static constexpr int kHashShift = 32 - __builtin_ctz((unsigned)kHash);
     uint32_t* rt;   // ring: tile
     uint32_t* rlo;  // ring: entry mask
     uint32_t* rhi;
@@ -220,17 +228,17 @@ struct LdsStore {
     uint32_t* ha1;
     uint32_t* hr0;  // acceptable pixels of the 36-pixel ring around the tile (lane order, see ring_xy)
     uint32_t* hr1;
-    uint8_t* ord;   // table slots in order of insertion (what stamp_footprint walks)
-    __device__ void note_new(uint32_t i, uint32_t slot) { ord[i] = (uint8_t)slot; }
-    __device__ uint32_t ring_cap() const { return kRingT; }
-    __device__ uint32_t hash_limit() const { return kHashT * 3 / 4; }
+    OrdT* ord;      // table slots in order of insertion (what stamp_footprint walks)
+    __device__ void note_new(uint32_t i, uint32_t slot) { ord[i] = (OrdT)slot; }
+    __device__ uint32_t ring_cap() const { return kRing; }
+    __device__ uint32_t hash_limit() const { return kHash * 3 / 4; }
     __device__ void get(uint32_t i, uint32_t& tile, uint64_t& m) const {
-        const uint32_t j = i & (kRingT - 1);
+        const uint32_t j = i & (kRing - 1);
         tile = uni(rt[j]);
         m = uni64(rlo[j], rhi[j]);
     }
     __device__ void put(uint32_t i, uint32_t tile, uint64_t m) {
-        const uint32_t j = i & (kRingT - 1);
+        const uint32_t j = i & (kRing - 1);
         rt[j] = tile;
         rlo[j] = (uint32_t)m;
         rhi[j] = (uint32_t)(m >> 32);
@@ -238,8 +246,8 @@ struct LdsStore {
     // returns true if the tile is known; slot = where it is or where it would go
     __device__ bool lookup(uint32_t tile, uint32_t& slot, uint64_t& V, uint64_t& Am, uint64_t& Rg) const {
         const uint32_t key = tile + 1u;
-        uint32_t hs = (key * 2654435761u) >> 24;  // 8 bits
-        for (int probe = 0; probe < kHashT; ++probe) {
+        uint32_t hs = (key * 2654435761u) >> kHashShift;
+        for (int probe = 0; probe < kHash; ++probe) {
             const uint32_t cur = uni(hk[hs]);
             if (cur == key) {
                 slot = hs;
@@ -249,7 +257,7 @@ struct LdsStore {
                 return true;
             }
             if (cur == 0u) break;
-            hs = (hs + 1) & (kHashT - 1);
+            hs = (hs + 1) & (kHash - 1);
         }
         slot = hs;
         V = 0ull;
@@ -272,6 +280,9 @@ struct LdsStore {
         hr1[slot] = (uint32_t)(Rg >> 32);
     }
 };
+
+using LdsStore = LdsStoreT<kRingT, kHashT, uint8_t>;
+using LdsStoreBig = LdsStoreT<kRingBig, kHashBig, uint16_t>;
 
 struct SlabStore {
     static constexpr bool kDeferStamps = false;
@@ -416,13 +427,14 @@ struct Forward {
 // per-direction entry masks are cut out of the ring-hit ballot H with lane-parallel arithmetic; the tile table
 // (is the neighbour known, and what of it is walked) and the pending table are read by the eight lanes in one
 // LDS round trip, and new records are appended with one ballot.
-__device__ __forceinline__ void push8(LdsStore& S, Pending& P, WalkState& st, uint32_t tile, uint64_t H, int lane,
-                                      const PushLane& c, Forward& fw) {
+template <int kRing, int kHash, typename OrdT>
+__device__ __forceinline__ void push8(LdsStoreT<kRing, kHash, OrdT>& S, Pending& P, WalkState& st, uint32_t tile,
+                                      uint64_t H, int lane, const PushLane& c, Forward& fw) {
     const uint32_t nt = tile + c.off;
     const uint32_t key = nt + 1u;
     const uint64_t src = (H >> c.shamt) & (uint64_t)c.msk;
     uint64_t E = (c.spread ? spread_col(src) : src) << c.sh;
-    uint32_t ts = (key * 2654435761u) >> 24;
+    uint32_t ts = (key * 2654435761u) >> LdsStoreT<kRing, kHash, OrdT>::kHashShift;
     const uint32_t hs = (key * 2654435761u) >> 26;
     // one round trip: first probe of the tile table with its walked set, and the pending entry
     uint32_t hk0 = S.hk[ts];
@@ -431,9 +443,9 @@ __device__ __forceinline__ void push8(LdsStore& S, Pending& P, WalkState& st, ui
     const bool want = c.dl && E != 0ull;
     bool found = hk0 == key;
     bool searching = want && !found && hk0 != 0u;
-    for (int probe = 1; probe < kHashT && __ballot(searching) != 0ull; ++probe) {  // collisions: rare
+    for (int probe = 1; probe < kHash && __ballot(searching) != 0ull; ++probe) {  // collisions: rare
         if (searching) {
-            ts = (ts + 1) & (kHashT - 1);
+            ts = (ts + 1) & (kHash - 1);
             hk0 = S.hk[ts];
             if (hk0 == key) {
                 v0 = S.hv0[ts];
@@ -454,7 +466,7 @@ __device__ __forceinline__ void push8(LdsStore& S, Pending& P, WalkState& st, ui
     // pending entry was written with that record, and a ring slot is not reused while its index is in the window.
     const bool merge = active && pt == key && (int32_t)(pi - st.head) >= 0 && (int32_t)(st.tail - pi) > 0;
     if (merge) {
-        const uint32_t j = pi & (kRingT - 1);
+        const uint32_t j = pi & (kRing - 1);
         atomicOr(&S.rlo[j], (uint32_t)E);
         atomicOr(&S.rhi[j], (uint32_t)(E >> 32));
     }
@@ -462,7 +474,7 @@ __device__ __forceinline__ void push8(LdsStore& S, Pending& P, WalkState& st, ui
     const uint64_t mf = __ballot(fresh);
     if (fresh) {
         const uint32_t pos = st.tail + (uint32_t)__popcll(mf & ((1ull << lane) - 1ull));
-        const uint32_t j = pos & (kRingT - 1);
+        const uint32_t j = pos & (kRing - 1);
         S.rt[j] = nt;
         S.rlo[j] = (uint32_t)E;
         S.rhi[j] = (uint32_t)(E >> 32);
@@ -482,8 +494,7 @@ __device__ __forceinline__ void push8(LdsStore& S, Pending& P, WalkState& st, ui
 }
 
 // scalar form (global slab store)
-template <class Store>
-__device__ __forceinline__ void push8(Store& S, Pending& P, WalkState& st, uint32_t tile, uint64_t H, int lane,
+__device__ __forceinline__ void push8(SlabStore& S, Pending& P, WalkState& st, uint32_t tile, uint64_t H, int lane,
                                       const PushLane& c, Forward& fw) {
     (void)lane;
     (void)c;
@@ -688,7 +699,8 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
 // Stamps every pixel the LDS walk has covered: atomicMin(label, MARK|k) on each, eight tiles' worth in flight
 // before the first result is looked at.  A lower stamp found means a lower active seed reaches the pixel (this
 // seed is blocked); a higher stamp replaced means that seed is blocked.
-__device__ __forceinline__ void stamp_footprint(const FloodArgs& A, uint32_t k, const LdsStore& S, WalkState& st,
+template <class Lds>
+__device__ __forceinline__ void stamp_footprint(const FloodArgs& A, uint32_t k, const Lds& S, WalkState& st,
                                                 int lane) {
     const uint32_t mine = kMarkBit | k;
     const int lr = lane >> 3, lc = lane & 7;
@@ -721,9 +733,11 @@ __device__ __forceinline__ void stamp_footprint(const FloodArgs& A, uint32_t k, 
     if (__ballot(foreign)) st.blocked = true;
 }
 
-// One seed's exploration by one wavefront (see walk).
-__device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& trig, uint32_t k, LdsStore& L, Pending& P,
-                                             int lane) {
+// One seed's exploration by one wavefront (see walk).  kFirstTier: a walk that outgrows the store is handed to the
+// second tier (big_list) instead of going on in a slab.
+template <class Lds, bool kFirstTier>
+__device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& trig, uint32_t k, Lds& L, Pending& P,
+                                             uint32_t* __restrict__ big_list, int lane) {
     const int s = (int)uni((uint32_t)A.seed_idx[k]);
     const int b = (int)uni((uint32_t)A.seed_bin[k]);
     const float thr = __uint_as_float(uni(__float_as_uint(A.seed_thr[k])));
@@ -737,12 +751,23 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
         if (lane == 0) A.flags[k] = kFlagSelfFail;  // flood() accepts nothing, not even the seed
         return;
     }
-    for (int i = lane; i < kHashT; i += 64) L.hk[i] = 0u;
+    for (int i = lane; i < Lds::kHashN; i += 64) L.hk[i] = 0u;
     P.pt[lane] = 0u;
     const int sr = s / A.w, sc = s - sr * A.w;
     WalkState st{0u, 1u, 0u, 0u, false, 0u};
     L.put(0u, ((uint32_t)(sr >> 3) << 16) | (uint32_t)(sc >> 3), 1ull << ((sr & 7) * 8 + (sc & 7)));
     int rc = walk(A, k, b, thr, sn, cs, L, P, st, lane);
+    if (kFirstTier && rc != 0) {
+        // outgrew the first tier: start again in the second (nothing is stamped yet, so nothing to undo)
+        uint32_t pos = 0;
+        if (lane == 0) pos = atomicAdd(&A.ctrl[kCtrlNBig], 1u);
+        pos = (uint32_t)__shfl((int)pos, 0);
+        if (pos < kBigCap) {
+            if (lane == 0) big_list[pos] = k;
+            return;
+        }
+        // second tier full this round: carry on in a slab from the state reached
+    }
     stamp_footprint(A, k, L, st, lane);
     if (rc != 0) {
         // LDS storage exhausted: move the walk to a global slab and carry on
@@ -761,7 +786,7 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
                 L.get(i, t, m);
                 G.put(i, t, m);
             }
-            for (int i = 0; i < kHashT; ++i) {
+            for (int i = 0; i < Lds::kHashN; ++i) {
                 const uint32_t key = L.hk[i];
                 if (key) {
                     uint32_t slot;
@@ -790,7 +815,7 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
 // length of the round's active list is read from the control block, so the host need not know it (workgroups
 // beyond the list leave at once).
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void flood_explore_kernel(
-    FloodArgs A, BinTrig trig, const uint32_t* __restrict__ act) {
+    FloodArgs A, BinTrig trig, const uint32_t* __restrict__ act, uint32_t* __restrict__ big_list) {
     __shared__ uint32_t s_ring[3][kRingT];
     __shared__ uint32_t s_hash[7][kHashT];
     __shared__ uint32_t s_pend[2][kPend];
@@ -804,7 +829,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     LdsStore L{s_ring[0], s_ring[1], s_ring[2], s_hash[0], s_hash[1], s_hash[2],
                s_hash[3], s_hash[4], s_hash[5], s_hash[6], s_ord};
     Pending P{s_pend[0], s_pend[1]};
-    explore_seed(A, trig, k, L, P, lane);
+    explore_seed<LdsStore, true>(A, trig, k, L, P, big_list, lane);
+}
+
+// Second storage tier: the same walk from the start with a 1024-record ring and a 2048-tile table (dynamic LDS,
+// kBigLdsBytes), for the seeds the first tier handed over this round.
+constexpr size_t kBigLdsBytes = (size_t)(3 * kRingBig + 7 * kHashBig + 2 * kPend) * 4 + (size_t)kHashBig * 2;
+__global__ __launch_bounds__(64) void flood_explore_big_kernel(FloodArgs A, BinTrig trig,
+                                                               uint32_t* __restrict__ big_list) {
+    extern __shared__ uint32_t s_big[];
+    const int lane = threadIdx.x & 63;
+    const uint32_t ai = uni(blockIdx.x);
+    const uint32_t n_big = uni(A.ctrl[kCtrlNBig]);
+    if (ai >= (n_big < kBigCap ? n_big : kBigCap)) return;
+    const uint32_t k = uni(big_list[ai]);
+    uint32_t* ring = s_big;
+    uint32_t* hash = ring + 3 * kRingBig;
+    uint32_t* pend = hash + 7 * kHashBig;
+    uint16_t* ord = reinterpret_cast<uint16_t*>(pend + 2 * kPend);
+    LdsStoreBig L{ring, ring + kRingBig, ring + 2 * kRingBig, hash, hash + kHashBig, hash + 2 * kHashBig,
+                  hash + 3 * kHashBig, hash + 4 * kHashBig, hash + 5 * kHashBig, hash + 6 * kHashBig, ord};
+    Pending P{pend, pend + kPend};
+    explore_seed<LdsStoreBig, false>(A, trig, k, L, P, big_list, lane);
 }
 
 // state: 0 = active, 1 = committed in this round, 2 = finished earlier / dead
@@ -901,6 +947,7 @@ __global__ void flood_advance_kernel(uint32_t* __restrict__ ctrl, uint32_t n_see
     ctrl[kCtrlWork] = 0u;
     ctrl[kCtrlBarrier] = 0xFFFFFFFFu;
     ctrl[kCtrlSlabs] = 0u;
+    ctrl[kCtrlNBig] = 0u;
 }
 
 __global__ __launch_bounds__(256) void flood_init_seeds_kernel(uint32_t n_seeds, uint32_t* __restrict__ act,
@@ -911,6 +958,7 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(uint32_t n_seeds,
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k == 0u) {
         ctrl[kCtrlWindow] = win_first;
+        ctrl[kCtrlNBig] = 0u;
         ctrl[kCtrlBarrier] = 0xFFFFFFFFu;
         ctrl[kCtrlSlabs] = 0u;
         ctrl[kCtrlNAct] = n_seeds;
@@ -1068,6 +1116,14 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
     A.win_first = win_first_shift > 0 ? std::max(1024u, n_seeds >> win_first_shift) : n_seeds;
     if (A.win_first > n_seeds) A.win_first = n_seeds;
     A.win_shift = (uint32_t)win_growth;
+    static const bool big_ok = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(flood_explore_big_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigLdsBytes) == hipSuccess;
+    }();
+    if (!big_ok) {
+        set_error("flood: cannot reserve the second-tier LDS");
+        return 1;
+    }
     uint32_t* lists[2] = {B.act_a, B.act_b};
     hipLaunchKernelGGL(flood_init_seeds_kernel, dim3((n_seeds + 255) / 256), dim3(256), 0, s, n_seeds, lists[0], B.state,
                        B.alive, B.blocked, B.count, B.flags, seed_size, B.ctrl, A.win_first);
@@ -1083,7 +1139,9 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
         for (int r = 0; r < batch; ++r, ++enqueued) {
             uint32_t* act = lists[enqueued & 1];
             uint32_t* act_next = lists[(enqueued + 1) & 1];
-            hipLaunchKernelGGL(flood_explore_kernel, dim3(n_seeds), dim3(64), 0, s, A, trig, act);
+            hipLaunchKernelGGL(flood_explore_kernel, dim3(n_seeds), dim3(64), 0, s, A, trig, act, B.big_list);
+            hipLaunchKernelGGL(flood_explore_big_kernel, dim3(std::min<uint32_t>(n_seeds, kBigCap)), dim3(64),
+                               kBigLdsBytes, s, A, trig, B.big_list);
             hipLaunchKernelGGL(flood_decide_kernel, dim3(seed_blocks), dim3(256), 0, s, A, act, B.state, seed_size);
             if (debug) flood_debug_round(B, n_seeds, act, s);
             hipLaunchKernelGGL(flood_commit_pixels_kernel, dim3(pix_blocks), dim3(256), 0, s, label, npix, B.state, B.ctrl);
