@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--width", type=int, default=W4K)
     ap.add_argument("--height", type=int, default=H4K)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="run only the roofline leg (the filter kernel alone): the command profiled for "
+                         "profiles/*_kernel_stats_roofline_leg.csv, where rocprofv3's average must agree with kernel_ms")
     ap.add_argument("--flood-mode", type=int, default=None)
     ap.add_argument("--streams", type=int, default=16, help="frames in flight per GPU (one context + HIP stream + host thread each)")
     args = ap.parse_args()
@@ -173,6 +176,9 @@ def main():
         if world > 1:  # the path's one exchange step: gather the per-frame results over RCCL
             D.gather_results([out[b][: n_lines[b]] for b in range(B)], tforms, B * world, device=cdev)
 
+    if args.roofline_only:
+        args.steps = args.warmup = 0
+        args.no_cpu_baseline = True
     for _ in range(args.warmup):
         step(False)
 
@@ -208,18 +214,18 @@ def main():
 
     if rank == 0:
         total_px = float(n_gpus) * B * w * h * args.steps
-        value = total_px / el / 1e6
+        value = total_px / el / 1e6 if args.steps > 0 else None
         kdur_ms = float(np.mean(iso)) if iso else float("nan")
         achieved = ALGO_BYTES_PER_PX * w * h / (kdur_ms * 1e-3) / 1e9
         nfr = max(1, len(filt_ms))
         res = {
             "metric": "Mpix/s end-to-end (detect+VP) on 4K frames",
-            "value": round(value, 3),
+            "value": round(value, 3) if value is not None else None,
             "unit": "Mpix/s",
             "n_gpus": n_gpus,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(el / args.steps * 1e3, 4),
+            "ms_per_step": round(el / max(1, args.steps) * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
