@@ -169,6 +169,7 @@ struct FloodArgs {
     uint4* slab_hash;   // n_slabs x slab_hash_cap x 2 records {generation, tile+1, V.lo, V.hi} {A.lo, A.hi, -, -}
     uint32_t n_slabs, slab_ring_cap, slab_hash_cap;  // caps are powers of two
     uint32_t n_seeds, win_first, win_shift;          // staged start (see kCtrlWindow)
+    uint32_t from_end;                               // explore the active list from its end (see flood_explore_kernel)
 };
 // All words but kCtrlGen are set up by flood_init_seeds_kernel every frame; kCtrlGen lives on for the lifetime of
 // the slab memory (hash entries are tagged with it, so a generation must never be reused while old entries are
@@ -824,8 +825,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     // list length, staged window and list entry are independent loads: one round trip, then the tests
     const uint32_t ai = uni(blockIdx.x);
     const uint32_t n_act = uni(A.ctrl[kCtrlNAct]), window = uni(A.ctrl[kCtrlWindow]);
-    const uint32_t k = uni(act[ai]);  // within the list's capacity for every workgroup of the grid
-    if (ai >= n_act || k >= window) return;  // past the list, or not yet in the staged window (stays active)
+    if (ai >= n_act) return;  // past the list
+    // The list is walked from its end: the first round's list is in seed order, strongest first, and the longest
+    // walks belong to the weak seeds at its end (low thresholds, large footprints).  Started first, they run
+    // alongside the mass of short walks instead of after it.
+    const uint32_t k = uni(act[A.from_end ? n_act - 1u - ai : ai]);
+    if (k >= window) return;  // not yet in the staged window (stays active)
     LdsStore L{s_ring[0], s_ring[1], s_ring[2], s_hash[0], s_hash[1], s_hash[2],
                s_hash[3], s_hash[4], s_hash[5], s_hash[6], s_ord};
     Pending P{s_pend[0], s_pend[1]};
@@ -1116,6 +1121,8 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
     A.win_first = win_first_shift > 0 ? std::max(1024u, n_seeds >> win_first_shift) : n_seeds;
     if (A.win_first > n_seeds) A.win_first = n_seeds;
     A.win_shift = (uint32_t)win_growth;
+    static const int order_env = std::getenv("LIBRECTIFY_FLOOD_ORDER") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_ORDER")) : -1;
+    A.from_end = order_env >= 0 ? (uint32_t)order_env : 1u;
     static const bool big_ok = [] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(flood_explore_big_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigLdsBytes) == hipSuccess;
