@@ -114,7 +114,6 @@ struct FloodBuffers {
     uint32_t* count = nullptr;
     uint32_t* flags = nullptr;
     uint8_t* state = nullptr;
-    uint8_t* alive = nullptr;
     uint32_t* act_a = nullptr;
     uint32_t* act_b = nullptr;
     uint32_t* ctrl = nullptr;       // 16 words
@@ -122,16 +121,14 @@ struct FloodBuffers {
     void* slab_ring = nullptr;  // n_slabs x slab_ring_cap 16-byte records
     void* slab_hash = nullptr;  // n_slabs x slab_hash_cap 16-byte records
     uint32_t n_slabs = 0, slab_ring_cap = 0, slab_hash_cap = 0;
-    void* select_temp = nullptr;
-    size_t select_temp_bytes = 0;
     // Staged start of the rounds: the first round walks the strongest n_seeds >> win_first_shift seeds (0 = all),
     // the window grows by << win_growth per round.  Fewer pixels are walked in total (weak seeds on an edge that a
     // strong seed takes die unwalked) at the price of one or two more rounds: better throughput with many frames
     // in flight, worse latency for a single frame.
     int win_first_shift = 0, win_growth = 2;
 };
-size_t flood_select_temp_bytes(uint32_t max_seeds);
-// Runs all rounds (synchronises the stream once per round).  h_ctrl: >= 16 words of pinned host memory.
+// Runs all rounds (enqueued in batches; one stream synchronisation per batch, normally one per flood).
+// h_ctrl: >= 16 words of pinned host memory.
 int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, const uint8_t* dmask, int w, int h,
                    const int32_t* seed_idx, const int32_t* seed_bin, const float* seed_thr, uint32_t n_seeds,
                    BinTrig trig, uint32_t* label, int32_t* seed_size, int32_t* queue, uint32_t* h_ctrl, int* rounds_out,

@@ -100,7 +100,7 @@ static int ensure_flood_buffers(lr_context* c) {
     LR_HIP(hipStreamSynchronize(c->stream));
     const size_t cs = c->cap_pix;
     if (dev_alloc(f.blocked, cs) || dev_alloc(f.count, cs) || dev_alloc(f.flags, cs) || dev_alloc(f.state, cs) ||
-        dev_alloc(f.alive, cs) || dev_alloc(f.act_a, cs) || dev_alloc(f.act_b, cs) || dev_alloc(f.ctrl, 16) || dev_alloc(f.big_list, 1024))
+        dev_alloc(f.act_a, cs) || dev_alloc(f.act_b, cs) || dev_alloc(f.ctrl, 16) || dev_alloc(f.big_list, 1024))
         return 1;
     f.n_slabs = 512;  // 512 x 2.25 MB = 1.1 GB of the 288 GB; only walks over more than ~190 tiles leave LDS
     if (const char* e = std::getenv("LIBRECTIFY_FLOOD_SLABS")) f.n_slabs = (uint32_t)std::max(1, std::atoi(e));
@@ -116,10 +116,6 @@ static int ensure_flood_buffers(lr_context* c) {
     }
     LR_HIP(hipMemsetAsync(f.slab_hash, 0, (size_t)f.n_slabs * f.slab_hash_cap * 32, c->stream));
     LR_HIP(hipMemsetAsync(f.ctrl, 0, 16 * sizeof(uint32_t), c->stream));
-    f.select_temp_bytes = flood_select_temp_bytes((uint32_t)std::min<size_t>(cs, 0xFFFFFFFFu));
-    if (f.select_temp) (void)hipFree(f.select_temp);
-    f.select_temp = nullptr;
-    LR_HIP(hipMalloc(&f.select_temp, f.select_temp_bytes));
     c->fb_cap_seeds = cs;
     return 0;
 }
@@ -187,8 +183,8 @@ void ctx_destroy(lr_context* c) {
                     c->maxmag, c->keys_a, c->keys_b, c->d_counts, c->seed_idx, c->seed_bin, c->seed_thr, c->seed_size,
                     c->label, c->queue, c->comp_rank, c->comp_seed, c->comp_off, c->cursor, c->px_a, c->px_b,
                     c->scratch_w, c->d_lines, c->temp, c->d_model, c->d_scores, c->d_best_score, c->d_best_iter,
-                    c->fb.blocked, c->fb.count, c->fb.flags, c->fb.state, c->fb.alive, c->fb.act_a, c->fb.act_b,
-                    c->fb.ctrl, c->fb.big_list, c->fb.slab_ring, c->fb.slab_hash, c->fb.select_temp, c->d_pairs, c->d_peak, c->d_weights,
+                    c->fb.blocked, c->fb.count, c->fb.flags, c->fb.state, c->fb.act_a, c->fb.act_b,
+                    c->fb.ctrl, c->fb.big_list, c->fb.slab_ring, c->fb.slab_hash, c->d_pairs, c->d_peak, c->d_weights,
                     c->d_samples, c->d_hcounts};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);

@@ -182,7 +182,6 @@ enum {
     kCtrlNCommit = 3,  // seeds committed this round
     kCtrlNNext = 4,    // length of the next active list (being appended)
     kCtrlError = 5,
-    kCtrlWork = 6,     // (unused)
     kCtrlRounds = 7,   // rounds that had work
     kCtrlGen = 8,
     kCtrlStall = 9,    // a round made no progress: kCtrlNRemain seeds are left for the ordered tail
@@ -517,12 +516,6 @@ __device__ __forceinline__ void push8(SlabStore& S, Pending& P, WalkState& st, u
     if ((H >> 35) & 1ull) send(tile + 0x10001u, 1ull);
 }
 
-// 8-neighbour dilation of a bit-board (bit = row*8 + col) restricted to the tile
-__device__ inline uint64_t dilate8(uint64_t r) {
-    const uint64_t hz = r | ((r << 1) & 0xFEFEFEFEFEFEFEFEull) | ((r >> 1) & 0x7F7F7F7F7F7F7F7Full);
-    return hz | (hz << 8) | (hz >> 8);
-}
-
 // The 36 pixels around an 8x8 tile, one per lane 0..35: lanes 0-7 the row above (x = 0..7), 8-15 the row below,
 // 16-23 the column to the left (y = 0..7), 24-31 the column to the right, 32-35 the corners (-1,-1) (8,-1)
 // (-1,8) (8,8).  A record is pushed to a neighbour tile only for ring pixels that are themselves acceptable and
@@ -651,7 +644,7 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
         uint64_t R = cur.entry & Am;
         uint64_t New = 0ull;
         if (R != 0ull) {
-            // Connected closure of the entry pixels inside the tile.  One iteration is dilate8(R) & Am, evaluated
+            // Connected closure of the entry pixels inside the tile.  One iteration is "8-neighbour dilation of R, restricted to Am", evaluated
             // with a pixel per lane (an acceptable pixel joins when its 3x3 neighbourhood meets R): three vector
             // instructions instead of sixteen on the scalar unit, which the rest of the step keeps busy.
             const uint64_t reach = ((Am >> lane) & 1ull) ? nbr : 0ull;
@@ -949,14 +942,13 @@ __global__ void flood_advance_kernel(uint32_t* __restrict__ ctrl, uint32_t n_see
     ctrl[kCtrlNAct] = progress ? n_next : 0u;
     ctrl[kCtrlNNext] = 0u;
     ctrl[kCtrlNCommit] = 0u;
-    ctrl[kCtrlWork] = 0u;
     ctrl[kCtrlBarrier] = 0xFFFFFFFFu;
     ctrl[kCtrlSlabs] = 0u;
     ctrl[kCtrlNBig] = 0u;
 }
 
 __global__ __launch_bounds__(256) void flood_init_seeds_kernel(uint32_t n_seeds, uint32_t* __restrict__ act,
-                                                               uint8_t* __restrict__ state, uint8_t* __restrict__ alive,
+                                                               uint8_t* __restrict__ state,
                                                                uint32_t* __restrict__ blocked, uint32_t* __restrict__ count,
                                                                uint32_t* __restrict__ flags, int32_t* __restrict__ seed_size,
                                                                uint32_t* __restrict__ ctrl, uint32_t win_first) {
@@ -970,7 +962,6 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(uint32_t n_seeds,
         ctrl[kCtrlNCommit] = 0u;
         ctrl[kCtrlNNext] = 0u;
         ctrl[kCtrlError] = 0u;
-        ctrl[kCtrlWork] = 0u;
         ctrl[kCtrlRounds] = 0u;
         ctrl[kCtrlStall] = 0u;
         ctrl[kCtrlNRemain] = n_seeds;
@@ -978,7 +969,6 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(uint32_t n_seeds,
     if (k >= n_seeds) return;
     act[k] = k;
     state[k] = 0;
-    alive[k] = 0;
     blocked[k] = 0u;
     count[k] = 0u;
     flags[k] = 0u;
@@ -1042,13 +1032,6 @@ __global__ __launch_bounds__(64) void flood_ordered_tail_kernel(const float* __r
 }  // namespace
 
 // ---- host side of the rounds ------------------------------------------------------------------
-
-size_t flood_select_temp_bytes(uint32_t max_seeds) {
-    size_t b = 0;
-    (void)rocprim::select(nullptr, b, rocprim::counting_iterator<uint32_t>(0), (const uint8_t*)nullptr,
-                          (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)max_seeds);
-    return b + 256;
-}
 
 // LIBRECTIFY_FLOOD_DEBUG: what the round's exploration did (synchronises; rounds are then enqueued one at a time)
 static void flood_debug_round(const FloodBuffers& B, uint32_t n_seeds, const uint32_t* act, hipStream_t s) {
@@ -1133,7 +1116,7 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
     }
     uint32_t* lists[2] = {B.act_a, B.act_b};
     hipLaunchKernelGGL(flood_init_seeds_kernel, dim3((n_seeds + 255) / 256), dim3(256), 0, s, n_seeds, lists[0], B.state,
-                       B.alive, B.blocked, B.count, B.flags, seed_size, B.ctrl, A.win_first);
+                       B.blocked, B.count, B.flags, seed_size, B.ctrl, A.win_first);
     const int pix_blocks = (int)std::min<size_t>((npix + 255) / 256, 4096);
     const int seed_blocks = (int)std::min<uint32_t>((n_seeds + 255) / 256, 256);
     static const bool debug = std::getenv("LIBRECTIFY_FLOOD_DEBUG") != nullptr;
