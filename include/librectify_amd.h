@@ -44,7 +44,8 @@ void lr_set_ransac_seed(lr_context* ctx, uint64_t seed);
 /* RANSAC iterations per model (reference config.h:36 RANSAC_MAX_ITER = 10000). */
 void lr_set_ransac_iterations(lr_context* ctx, int n_iter);
 /* Flood implementation: 0 = ordered single-wave (simple, slow), 1 = parallel rounds (default);
- * 2 / 3 = parallel rounds with no / two overflow slabs (test hooks for the exhausted-storage paths).
+ * 2 / 3 / 4 = test hooks: parallel rounds without the second LDS storage tier and with no / two / all overflow
+ * slabs (exhausted-storage and slab paths; lr_stage_counters tells which storage a frame used).
  * All modes give identical results. */
 void lr_set_flood_mode(lr_context* ctx, int mode);
 int lr_device_count(void);
@@ -118,7 +119,9 @@ int lr_stage_times(lr_context* ctx, float* ms, int count);
 /* Duration (ms) of the last fused filter kernel alone (HIP events around its launch); valid right after
  * lr_stage_filter*, without running the later stages. */
 int lr_filter_kernel_ms(lr_context* ctx, float* ms);
-/* Extra counters of the last call: [0] seeds, [1] components, [2] flood rounds, [3] labelled pixels. */
+/* Extra counters of the last call: [0] seeds, [1] components, [2] flood rounds, [3] labelled pixels, and how the
+ * flood's walks were stored: [4] seeds that moved to the second LDS tier, [5] global slabs used, [6] seeds finished by
+ * the ordered single-wave tail (storage exhausted). */
 int lr_stage_counters(lr_context* ctx, int64_t* out, int count);
 
 /* ---- RANSAC --------------------------------------------------------------------------- */

@@ -247,9 +247,10 @@ class Context:
         return ms.value
 
     def stage_counters(self):
-        c = np.zeros(4, np.int64)
-        _check(lib().lr_stage_counters(self._h, _ptr(c), 4))
-        return dict(seeds=int(c[0]), components=int(c[1]), flood_rounds=int(c[2]), labelled_px=int(c[3]))
+        c = np.zeros(7, np.int64)
+        _check(lib().lr_stage_counters(self._h, _ptr(c), 7))
+        return dict(seeds=int(c[0]), components=int(c[1]), flood_rounds=int(c[2]), labelled_px=int(c[3]),
+                    second_tier_seeds=int(c[4]), slabs=int(c[5]), ordered_tail_seeds=int(c[6]))
 
     # ---- full path ----
     def find_line_segment_groups(self, img, min_length, refine=False, num_threads=-1, capacity=None):

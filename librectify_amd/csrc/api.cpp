@@ -233,8 +233,10 @@ int lr_stage_times(lr_context* ctx, float* ms, int count) {
 }
 
 int lr_stage_counters(lr_context* ctx, int64_t* out, int count) {
-    const int64_t v[4] = {(int64_t)ctx->n_seeds, (int64_t)ctx->n_comp, (int64_t)ctx->flood_rounds, (int64_t)ctx->n_px};
-    for (int i = 0; i < count && i < 4; ++i) out[i] = v[i];
+    const int64_t v[7] = {(int64_t)ctx->n_seeds,        (int64_t)ctx->n_comp,         (int64_t)ctx->flood_rounds,
+                          (int64_t)ctx->n_px,           (int64_t)ctx->flood_tiers[0], (int64_t)ctx->flood_tiers[1],
+                          (int64_t)ctx->flood_tiers[2]};
+    for (int i = 0; i < count && i < 7; ++i) out[i] = v[i];
     return 0;
 }
 

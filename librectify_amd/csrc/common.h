@@ -117,7 +117,7 @@ struct FloodBuffers {
     uint32_t* act_a = nullptr;
     uint32_t* act_b = nullptr;
     uint32_t* ctrl = nullptr;       // 16 words
-    uint32_t* big_list = nullptr;   // 1024 seeds: this round's hand-over to the second storage tier
+    uint32_t* big_list = nullptr;   // 8192 seeds: this round's hand-over to the second storage tier
     void* slab_ring = nullptr;  // n_slabs x slab_ring_cap 16-byte records
     void* slab_hash = nullptr;  // n_slabs x slab_hash_cap 16-byte records
     uint32_t n_slabs = 0, slab_ring_cap = 0, slab_hash_cap = 0;
@@ -126,12 +126,14 @@ struct FloodBuffers {
     // strong seed takes die unwalked) at the price of one or two more rounds: better throughput with many frames
     // in flight, worse latency for a single frame.
     int win_first_shift = 0, win_growth = 2;
+    bool second_tier = true;  // test hook: without it every walk that outgrows the first tier goes to a slab
 };
 // Runs all rounds (enqueued in batches; one stream synchronisation per batch, normally one per flood).
 // h_ctrl: >= 16 words of pinned host memory.
 int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, const uint8_t* dmask, int w, int h,
                    const int32_t* seed_idx, const int32_t* seed_bin, const float* seed_thr, uint32_t n_seeds,
                    BinTrig trig, uint32_t* label, int32_t* seed_size, int32_t* queue, uint32_t* h_ctrl, int* rounds_out,
+                   uint32_t* tiers_out /* [3]: seeds moved to the second tier, slabs used, seeds left to the ordered tail */,
                    hipStream_t s);
 
 // kernels_fit.hip

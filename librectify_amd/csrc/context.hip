@@ -100,9 +100,9 @@ static int ensure_flood_buffers(lr_context* c) {
     LR_HIP(hipStreamSynchronize(c->stream));
     const size_t cs = c->cap_pix;
     if (dev_alloc(f.blocked, cs) || dev_alloc(f.count, cs) || dev_alloc(f.flags, cs) || dev_alloc(f.state, cs) ||
-        dev_alloc(f.act_a, cs) || dev_alloc(f.act_b, cs) || dev_alloc(f.ctrl, 16) || dev_alloc(f.big_list, 1024))
+        dev_alloc(f.act_a, cs) || dev_alloc(f.act_b, cs) || dev_alloc(f.ctrl, 16) || dev_alloc(f.big_list, 8192))
         return 1;
-    f.n_slabs = 512;  // 512 x 2.25 MB = 1.1 GB of the 288 GB; only walks over more than ~190 tiles leave LDS
+    f.n_slabs = 128;  // 128 x 2.25 MB = 288 MB; only walks over ~1500 tiles (both LDS tiers outgrown) get here
     if (const char* e = std::getenv("LIBRECTIFY_FLOOD_SLABS")) f.n_slabs = (uint32_t)std::max(1, std::atoi(e));
     f.slab_ring_cap = 1u << 14;  // (tile, entry mask) records, 16 B each
     f.slab_hash_cap = 1u << 16;  // tile -> (walked, acceptable) records, 32 B each (48 Ki tiles = 3 M pixels)
@@ -259,12 +259,15 @@ int ctx_stage_flood(lr_context* c) {
     } else {
         if (ensure_flood_buffers(c)) return 1;
         FloodBuffers fbuf = c->fb;
-        if (c->flood_mode == 2) fbuf.n_slabs = 0;  // test hooks: exercise the exhausted-storage paths
+        // test hooks: 2 and 3 exercise the slab and exhausted-storage paths (no second LDS tier, no / two slabs),
+        // 4 the slab path with the full pool
+        if (c->flood_mode >= 2) fbuf.second_tier = false;
+        if (c->flood_mode == 2) fbuf.n_slabs = 0;
         if (c->flood_mode == 3) fbuf.n_slabs = 2;
         if (c->flood_staged) fbuf.win_first_shift = 3;
         if (flood_parallel(fbuf, c->dx, c->dy, c->dmask, c->w, c->h, c->seed_idx, c->seed_bin, c->seed_thr,
                            c->n_seeds, c->trig, c->label, c->seed_size, c->queue, c->h_counts + 16, &c->flood_rounds,
-                           c->stream))
+                           c->flood_tiers, c->stream))
             return 1;
     }
     LR_HIP(hipEventRecord(c->ev[3], c->stream));

@@ -148,7 +148,7 @@ constexpr uint32_t kMarkBit = 0x80000000u;
 // 1024-record ring and a 2048-tile table (72 KB: 2 per CU) before the global slabs are the last resort.
 constexpr int kRingT = 128, kHashT = 256;
 constexpr int kRingBig = 1024, kHashBig = 2048;
-constexpr uint32_t kBigCap = 1024;  // seeds per round that can move to the second tier
+constexpr uint32_t kBigCap = 8192;  // seeds per round that can move to the second tier (FloodBuffers::big_list)
 constexpr uint32_t kFlagIncomplete = 1u, kFlagSelfFail = 2u;
 constexpr uint32_t kMaxSteps = 1u << 22;  // safety net of the walk loop: more records than an 8K frame has tile visits
 
@@ -170,6 +170,7 @@ struct FloodArgs {
     uint32_t n_slabs, slab_ring_cap, slab_hash_cap;  // caps are powers of two
     uint32_t n_seeds, win_first, win_shift;          // staged start (see kCtrlWindow)
     uint32_t from_end;                               // explore the active list from its end (see flood_explore_kernel)
+    uint32_t big_cap;                                // seeds per round the second tier takes (0: tier switched off)
 };
 // All words but kCtrlGen are set up by flood_init_seeds_kernel every frame; kCtrlGen lives on for the lifetime of
 // the slab memory (hash entries are tagged with it, so a generation must never be reused while old entries are
@@ -192,6 +193,8 @@ enum {
     // ever having walked it.
     kCtrlWindow = 11,
     kCtrlNBig = 12,  // seeds handed to the second storage tier this round
+    kCtrlBigTotal = 13,   // ... over the frame (diagnostics: lr_stage_counters)
+    kCtrlSlabTotal = 14,  // slabs handed out over the frame
 };
 
 // Frontier records, table entries and ballots are the same in all 64 lanes.  Saying so (readfirstlane) lets the
@@ -751,13 +754,16 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
     WalkState st{0u, 1u, 0u, 0u, false, 0u};
     L.put(0u, ((uint32_t)(sr >> 3) << 16) | (uint32_t)(sc >> 3), 1ull << ((sr & 7) * 8 + (sc & 7)));
     int rc = walk(A, k, b, thr, sn, cs, L, P, st, lane);
-    if (kFirstTier && rc != 0) {
+    if (kFirstTier && rc != 0 && A.big_cap != 0u) {
         // outgrew the first tier: start again in the second (nothing is stamped yet, so nothing to undo)
         uint32_t pos = 0;
         if (lane == 0) pos = atomicAdd(&A.ctrl[kCtrlNBig], 1u);
         pos = (uint32_t)__shfl((int)pos, 0);
-        if (pos < kBigCap) {
-            if (lane == 0) big_list[pos] = k;
+        if (pos < A.big_cap) {
+            if (lane == 0) {
+                big_list[pos] = k;
+                atomicAdd(&A.ctrl[kCtrlBigTotal], 1u);
+            }
             return;
         }
         // second tier full this round: carry on in a slab from the state reached
@@ -770,6 +776,7 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
         slab = (uint32_t)__shfl((int)slab, 0);
         if (slab < A.n_slabs) {
             uint32_t gen = 0;
+            if (lane == 0) atomicAdd(&A.ctrl[kCtrlSlabTotal], 1u);
             if (lane == 0) gen = atomicAdd(&A.ctrl[kCtrlGen], 1u) + 1u;
             gen = (uint32_t)__shfl((int)gen, 0);
             SlabStore G{A.slab_ring + (size_t)slab * A.slab_ring_cap, A.slab_hash + (size_t)slab * A.slab_hash_cap * 2,
@@ -839,7 +846,7 @@ __global__ __launch_bounds__(64) void flood_explore_big_kernel(FloodArgs A, BinT
     const int lane = threadIdx.x & 63;
     const uint32_t ai = uni(blockIdx.x);
     const uint32_t n_big = uni(A.ctrl[kCtrlNBig]);
-    if (ai >= (n_big < kBigCap ? n_big : kBigCap)) return;
+    if (ai >= (n_big < A.big_cap ? n_big : A.big_cap)) return;
     const uint32_t k = uni(big_list[ai]);
     uint32_t* ring = s_big;
     uint32_t* hash = ring + 3 * kRingBig;
@@ -956,6 +963,8 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(uint32_t n_seeds,
     if (k == 0u) {
         ctrl[kCtrlWindow] = win_first;
         ctrl[kCtrlNBig] = 0u;
+        ctrl[kCtrlBigTotal] = 0u;
+        ctrl[kCtrlSlabTotal] = 0u;
         ctrl[kCtrlBarrier] = 0xFFFFFFFFu;
         ctrl[kCtrlSlabs] = 0u;
         ctrl[kCtrlNAct] = n_seeds;
@@ -1067,7 +1076,7 @@ static void flood_debug_round(const FloodBuffers& B, uint32_t n_seeds, const uin
 int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, const uint8_t* dmask, int w, int h,
                    const int32_t* seed_idx, const int32_t* seed_bin, const float* seed_thr, uint32_t n_seeds,
                    BinTrig trig, uint32_t* label, int32_t* seed_size, int32_t* queue, uint32_t* h_ctrl, int* rounds_out,
-                   hipStream_t s) {
+                   uint32_t* tiers_out, hipStream_t s) {
     *rounds_out = 0;
     if (n_seeds == 0) return 0;
     const size_t npix = (size_t)w * h;
@@ -1106,6 +1115,7 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
     A.win_shift = (uint32_t)win_growth;
     static const int order_env = std::getenv("LIBRECTIFY_FLOOD_ORDER") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_ORDER")) : -1;
     A.from_end = order_env >= 0 ? (uint32_t)order_env : 1u;
+    A.big_cap = B.second_tier ? kBigCap : 0u;
     static const bool big_ok = [] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(flood_explore_big_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigLdsBytes) == hipSuccess;
@@ -1167,6 +1177,11 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
         LR_HIP(hipMemsetAsync(B.ctrl + kCtrlGen, 0, sizeof(uint32_t), s));
     }
     *rounds_out = rounds;
+    if (tiers_out) {
+        tiers_out[0] = h_ctrl[kCtrlBigTotal];
+        tiers_out[1] = h_ctrl[kCtrlSlabTotal];
+        tiers_out[2] = (h_ctrl[kCtrlStall] != 0u && h_ctrl[kCtrlNRemain] > 0u) ? h_ctrl[kCtrlNRemain] : 0u;
+    }
     return 0;
 }
 

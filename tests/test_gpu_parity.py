@@ -329,6 +329,47 @@ def test_staged_rounds_of_a_batch_equal_the_single_frame_call_at_full_size(L, ct
         _assert_lines_equal(out[i][: n[i]], single[i])
 
 
+def _long_bars(W, H, seed, K=14):
+    """Bars across most of the frame: edges of well over 1500 px, i.e. walks that outgrow the first storage tier."""
+    from librectify_amd import synth
+
+    rng = np.random.RandomState(seed)
+    img = np.full((H, W), 0.5, np.float64)
+    yy, xx = np.mgrid[0:H, 0:W]
+    for _ in range(K):
+        c = np.array([rng.uniform(0.4, 0.6) * W, rng.uniform(0.1, 0.9) * H])
+        ang = rng.uniform(-0.08, 0.08)
+        d = np.array([np.cos(ang), np.sin(ang)])
+        nrm = np.array([-d[1], d[0]])
+        px, py = xx - c[0], yy - c[1]
+        m = (np.abs(px * d[0] + py * d[1]) <= rng.uniform(0.6, 0.95) * W / 2) & (np.abs(px * nrm[0] + py * nrm[1]) <= rng.uniform(3, 9))
+        img[m] += rng.uniform(0.1, 0.4) * (1 if rng.rand() < 0.5 else -1)
+    img = synth._gauss_blur(np.clip(img, 0, 1), 1.0) + rng.normal(0, 0.005, size=img.shape)
+    return img.astype(np.float32)
+
+
+def test_every_storage_tier_of_the_flood_is_exact_on_long_edges(L, ctx):
+    """2560x480 with edges of 1500-2400 px against the oracle: default (walks restart in the second LDS tier), mode 4
+    (no second tier: they carry on in global slabs, and when the pool runs out the ordered tail finishes), mode 3 (two
+    slabs), mode 2 (no slab at all).  The counters prove that each path was really taken."""
+    img = _long_bars(2560, 480, 5)
+    ref = O.find_line_segments(img)
+    used = {}
+    for mode in (1, 4, 3, 2):
+        ctx.set_flood_mode(mode)
+        ctx.stage_filter_host(img)
+        ctx.stage_seeds()
+        ctx.stage_flood()
+        used[mode] = ctx.stage_counters()
+        np.testing.assert_array_equal(ctx.download(L.BUF_LABEL), ref["label"])
+        _assert_lines_equal(ctx.stage_fit(), ref["lines"])
+    ctx.set_flood_mode(1)
+    assert used[1]["second_tier_seeds"] > 0 and used[1]["ordered_tail_seeds"] == 0
+    assert used[4]["second_tier_seeds"] == 0 and used[4]["slabs"] > 2
+    assert used[3]["ordered_tail_seeds"] > 0
+    assert used[2]["slabs"] == 0 and used[2]["ordered_tail_seeds"] > 0
+
+
 def _pencil(vp, n_on, n_off, seed):
     rng = np.random.RandomState(seed)
     rows = []
