@@ -169,6 +169,7 @@ struct FloodArgs {
     uint4* slab_hash;   // n_slabs x slab_hash_cap x 2 records {generation, tile+1, V.lo, V.hi} {A.lo, A.hi, -, -}
     uint32_t n_slabs, slab_ring_cap, slab_hash_cap;  // caps are powers of two
     uint32_t n_seeds, win_first, win_shift;          // staged start (see kCtrlWindow)
+    uint32_t win_hold;                               // the window stops here until no seed below it is active
     uint32_t from_end;                               // explore the active list from its end (see flood_explore_kernel)
     uint32_t big_cap;                                // seeds per round the second tier takes (0: tier switched off)
 };
@@ -182,7 +183,7 @@ enum {
     kCtrlNAct = 2,     // length of the current active list (0: nothing left to do)
     kCtrlNCommit = 3,  // seeds committed this round
     kCtrlNNext = 4,    // length of the next active list (being appended)
-    kCtrlError = 5,
+    kCtrlPhase = 5,    // hold-back of the weakest seeds: 0 not engaged, 1 holding, 2 released (see flood_advance_kernel)
     kCtrlRounds = 7,   // rounds that had work
     kCtrlGen = 8,
     kCtrlStall = 9,    // a round made no progress: kCtrlNRemain seeds are left for the ordered tail
@@ -195,6 +196,7 @@ enum {
     kCtrlNBig = 12,  // seeds handed to the second storage tier this round
     kCtrlBigTotal = 13,   // ... over the frame (diagnostics: lr_stage_counters)
     kCtrlSlabTotal = 14,  // slabs handed out over the frame
+    kCtrlBelow = 15,      // active seeds below the window after this round (the window opens fully when none is left)
 };
 
 // Frontier records, table entries and ballots are the same in all 64 lanes.  Saying so (readfirstlane) lets the
@@ -902,6 +904,7 @@ __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, const
                                                               uint32_t* __restrict__ act_next) {
     const uint32_t n_act = A.ctrl[kCtrlNAct];
     const uint32_t n_pad = (n_act + 255u) & ~255u;  // whole wavefronts take part in the ballots
+    const uint32_t window = A.ctrl[kCtrlWindow];
     for (uint32_t ai = blockIdx.x * 256 + threadIdx.x; ai < n_pad; ai += gridDim.x * 256) {
         bool a = false;
         uint32_t k = 0;
@@ -929,20 +932,41 @@ __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, const
             if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&A.ctrl[kCtrlNNext], (uint32_t)__popcll(m));
             base = (uint32_t)__shfl((int)base, __ffsll((long long)m) - 1);
             if (a) act_next[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = k;
+            const uint64_t mb = __ballot(a && k < window);
+            if (mb != 0ull && lane == __ffsll((long long)m) - 1) atomicAdd(&A.ctrl[kCtrlBelow], (uint32_t)__popcll(mb));
         }
     }
 }
 
 // End of a round (one thread): the next list becomes the current one.  A round without progress (possible only
 // when storage ran out on the lowest active seed) stops the rounds and leaves the rest to the ordered tail.
-__global__ void flood_advance_kernel(uint32_t* __restrict__ ctrl, uint32_t n_seeds, uint32_t win_shift) {
+__global__ void flood_advance_kernel(uint32_t* __restrict__ ctrl, uint32_t n_seeds, uint32_t win_shift,
+                                     uint32_t win_hold) {
     const uint32_t n_act = ctrl[kCtrlNAct];
     if (n_act == 0u) return;
     const uint32_t n_next = ctrl[kCtrlNNext];
     const uint32_t window = ctrl[kCtrlWindow];
     const bool progress = ctrl[kCtrlNCommit] > 0u || n_next < n_act || window < n_seeds;
-    const unsigned long long grown = (unsigned long long)window << win_shift;
-    ctrl[kCtrlWindow] = grown < n_seeds ? (uint32_t)grown : n_seeds;
+    // Window of the next round.  Staged start: it grows by << win_shift up to the seed count.  Hold-back: once a
+    // full round has shown walks that outgrow the first storage tier (a frame with long edges or large smooth
+    // regions: the weakest seeds, with the lowest thresholds, own the largest footprints and stay blocked for most
+    // of the rounds, re-walking them every time), the window drops to win_hold and the weakest seeds wait until every
+    // seed below it is resolved; then it opens for good.  Any prefix of the seed order is a valid window.
+    unsigned long long grown = (unsigned long long)window << win_shift;
+    if (grown > n_seeds) grown = n_seeds;
+    const uint32_t phase = ctrl[kCtrlPhase];
+    if (phase == 0u && window >= n_seeds && win_hold < n_seeds && ctrl[kCtrlBigTotal] > 0u && n_next > 0u) {
+        grown = win_hold;
+        ctrl[kCtrlPhase] = 1u;
+    } else if (phase == 1u) {
+        grown = window;
+        if (ctrl[kCtrlBelow] == 0u) {
+            grown = n_seeds;
+            ctrl[kCtrlPhase] = 2u;
+        }
+    }
+    ctrl[kCtrlWindow] = (uint32_t)grown;
+    ctrl[kCtrlBelow] = 0u;
     ctrl[kCtrlRounds] += 1u;
     ctrl[kCtrlNRemain] = n_next;
     if (!progress) ctrl[kCtrlStall] = 1u;
@@ -962,6 +986,7 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(uint32_t n_seeds,
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k == 0u) {
         ctrl[kCtrlWindow] = win_first;
+        ctrl[kCtrlBelow] = 0u;
         ctrl[kCtrlNBig] = 0u;
         ctrl[kCtrlBigTotal] = 0u;
         ctrl[kCtrlSlabTotal] = 0u;
@@ -970,7 +995,7 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(uint32_t n_seeds,
         ctrl[kCtrlNAct] = n_seeds;
         ctrl[kCtrlNCommit] = 0u;
         ctrl[kCtrlNNext] = 0u;
-        ctrl[kCtrlError] = 0u;
+        ctrl[kCtrlPhase] = 0u;
         ctrl[kCtrlRounds] = 0u;
         ctrl[kCtrlStall] = 0u;
         ctrl[kCtrlNRemain] = n_seeds;
@@ -1113,6 +1138,10 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
     A.win_first = win_first_shift > 0 ? std::max(1024u, n_seeds >> win_first_shift) : n_seeds;
     if (A.win_first > n_seeds) A.win_first = n_seeds;
     A.win_shift = (uint32_t)win_growth;
+    static const int hold_env = std::getenv("LIBRECTIFY_FLOOD_HOLD") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_HOLD")) : -1;
+    const int hold_pct = hold_env >= 0 ? hold_env : B.win_hold_pct;
+    A.win_hold = hold_pct > 0 && hold_pct < 100 ? (uint32_t)((unsigned long long)n_seeds * hold_pct / 100) : n_seeds;
+    if (A.win_hold < 1024u) A.win_hold = n_seeds;  // not worth another phase
     static const int order_env = std::getenv("LIBRECTIFY_FLOOD_ORDER") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_ORDER")) : -1;
     A.from_end = order_env >= 0 ? (uint32_t)order_env : 1u;
     A.big_cap = B.second_tier ? kBigCap : 0u;
@@ -1147,7 +1176,7 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
             hipLaunchKernelGGL(flood_commit_pixels_kernel, dim3(pix_blocks), dim3(256), 0, s, label, npix, B.state, B.ctrl);
             hipLaunchKernelGGL(flood_survivors_kernel, dim3(seed_blocks), dim3(256), 0, s, A, act, B.state, seed_size,
                                act_next);
-            hipLaunchKernelGGL(flood_advance_kernel, dim3(1), dim3(1), 0, s, B.ctrl, n_seeds, A.win_shift);
+            hipLaunchKernelGGL(flood_advance_kernel, dim3(1), dim3(1), 0, s, B.ctrl, n_seeds, A.win_shift, A.win_hold);
         }
         LR_HIP(hipMemcpyAsync(h_ctrl, B.ctrl, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         LR_HIP(hipStreamSynchronize(s));
