@@ -370,6 +370,23 @@ def test_every_storage_tier_of_the_flood_is_exact_on_long_edges(L, ctx):
     assert used[2]["slabs"] == 0 and used[2]["ordered_tail_seeds"] > 0
 
 
+def test_natural_image_at_4k_matches_the_oracle(L, ctx):
+    """The reference's doc image upsampled to 3840x2160 (cubic spline): 53 760 seeds, walks of over a thousand tiles,
+    second storage tier and the hold-back of the weakest seeds all in play; full path against the oracle."""
+    import scipy.ndimage as ndi
+
+    g = np.load(os.path.join(G, "doc_image_gray.npy")).astype(np.float32) / np.float32(256.0)
+    w, h = 3840, 2160
+    img = np.ascontiguousarray(ndi.zoom(g, (h / g.shape[0], w / g.shape[1]), order=3).astype(np.float32)[:h, :w])
+    assert img.shape == (h, w)
+    ctx.set_seed(0)
+    got = ctx.find_line_segment_groups(img, max(w, h) / 100.0)
+    used = ctx.stage_counters()
+    ref, _ = O.find_line_segment_groups(img, max(w, h) / 100.0, seed=0)
+    _assert_lines_equal(got, ref)
+    assert len(got) > 300 and used["second_tier_seeds"] > 0 and used["ordered_tail_seeds"] == 0
+
+
 def _pencil(vp, n_on, n_off, seed):
     rng = np.random.RandomState(seed)
     rows = []
