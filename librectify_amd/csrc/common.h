@@ -114,6 +114,7 @@ struct FloodBuffers {
     uint32_t* count = nullptr;
     uint32_t* flags = nullptr;
     uint8_t* state = nullptr;
+    uint8_t* tier = nullptr;        // per seed: 1 = its walk outgrew the first storage tier in an earlier round
     uint32_t* act_a = nullptr;
     uint32_t* act_b = nullptr;
     uint32_t* ctrl = nullptr;       // 16 words

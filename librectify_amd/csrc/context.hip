@@ -99,7 +99,7 @@ static int ensure_flood_buffers(lr_context* c) {
     if (c->fb_cap_seeds >= c->cap_pix && f.slab_ring) return 0;
     LR_HIP(hipStreamSynchronize(c->stream));
     const size_t cs = c->cap_pix;
-    if (dev_alloc(f.blocked, cs) || dev_alloc(f.count, cs) || dev_alloc(f.flags, cs) || dev_alloc(f.state, cs) ||
+    if (dev_alloc(f.blocked, cs) || dev_alloc(f.count, cs) || dev_alloc(f.flags, cs) || dev_alloc(f.state, cs) || dev_alloc(f.tier, cs) ||
         dev_alloc(f.act_a, cs) || dev_alloc(f.act_b, cs) || dev_alloc(f.ctrl, 16) || dev_alloc(f.big_list, 8192))
         return 1;
     f.n_slabs = 128;  // 128 x 2.25 MB = 288 MB; only walks over ~1500 tiles (both LDS tiers outgrown) get here
@@ -183,7 +183,7 @@ void ctx_destroy(lr_context* c) {
                     c->maxmag, c->keys_a, c->keys_b, c->d_counts, c->seed_idx, c->seed_bin, c->seed_thr, c->seed_size,
                     c->label, c->queue, c->comp_rank, c->comp_seed, c->comp_off, c->cursor, c->px_a, c->px_b,
                     c->scratch_w, c->d_lines, c->temp, c->d_model, c->d_scores, c->d_best_score, c->d_best_iter,
-                    c->fb.blocked, c->fb.count, c->fb.flags, c->fb.state, c->fb.act_a, c->fb.act_b,
+                    c->fb.blocked, c->fb.count, c->fb.flags, c->fb.state, c->fb.tier, c->fb.act_a, c->fb.act_b,
                     c->fb.ctrl, c->fb.big_list, c->fb.slab_ring, c->fb.slab_hash, c->d_pairs, c->d_peak, c->d_weights,
                     c->d_samples, c->d_hcounts};
     for (void* p : ptrs)

@@ -164,6 +164,7 @@ struct FloodArgs {
     uint32_t* blocked;  // per seed
     uint32_t* count;    // per seed: pixels walked this round
     uint32_t* flags;    // per seed
+    uint8_t* tier;      // per seed, kept across rounds: 1 = go to the second storage tier at once
     uint32_t* ctrl;     // kCtrl* words
     uint4* slab_ring;   // n_slabs x slab_ring_cap records {tile, -, mask.lo, mask.hi}
     uint4* slab_hash;   // n_slabs x slab_hash_cap x 2 records {generation, tile+1, V.lo, V.hi} {A.lo, A.hi, -, -}
@@ -750,12 +751,18 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
         if (lane == 0) A.flags[k] = kFlagSelfFail;  // flood() accepts nothing, not even the seed
         return;
     }
-    for (int i = lane; i < Lds::kHashN; i += 64) L.hk[i] = 0u;
-    P.pt[lane] = 0u;
-    const int sr = s / A.w, sc = s - sr * A.w;
     WalkState st{0u, 1u, 0u, 0u, false, 0u};
-    L.put(0u, ((uint32_t)(sr >> 3) << 16) | (uint32_t)(sc >> 3), 1ull << ((sr & 7) * 8 + (sc & 7)));
-    int rc = walk(A, k, b, thr, sn, cs, L, P, st, lane);
+    int rc = 1;
+    // a walk that outgrew the first tier in an earlier round does not try it again (footprints only shrink, but
+    // rarely below 190 tiles from above 1500 px)
+    const bool skip_first = kFirstTier && A.big_cap != 0u && uni((uint32_t)A.tier[k]) != 0u;
+    if (!skip_first) {
+        for (int i = lane; i < Lds::kHashN; i += 64) L.hk[i] = 0u;
+        P.pt[lane] = 0u;
+        const int sr = s / A.w, sc = s - sr * A.w;
+        L.put(0u, ((uint32_t)(sr >> 3) << 16) | (uint32_t)(sc >> 3), 1ull << ((sr & 7) * 8 + (sc & 7)));
+        rc = walk(A, k, b, thr, sn, cs, L, P, st, lane);
+    }
     if (kFirstTier && rc != 0 && A.big_cap != 0u) {
         // outgrew the first tier: start again in the second (nothing is stamped yet, so nothing to undo)
         uint32_t pos = 0;
@@ -764,9 +771,17 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
         if (pos < A.big_cap) {
             if (lane == 0) {
                 big_list[pos] = k;
+                A.tier[k] = 1;
                 atomicAdd(&A.ctrl[kCtrlBigTotal], 1u);
             }
             return;
+        }
+        if (skip_first) {  // no room in the second tier this round: walk in the first after all, then a slab
+            for (int i = lane; i < Lds::kHashN; i += 64) L.hk[i] = 0u;
+            P.pt[lane] = 0u;
+            const int sr = s / A.w, sc = s - sr * A.w;
+            L.put(0u, ((uint32_t)(sr >> 3) << 16) | (uint32_t)(sc >> 3), 1ull << ((sr & 7) * 8 + (sc & 7)));
+            rc = walk(A, k, b, thr, sn, cs, L, P, st, lane);
         }
         // second tier full this round: carry on in a slab from the state reached
     }
@@ -979,7 +994,7 @@ __global__ void flood_advance_kernel(uint32_t* __restrict__ ctrl, uint32_t n_see
 }
 
 __global__ __launch_bounds__(256) void flood_init_seeds_kernel(uint32_t n_seeds, uint32_t* __restrict__ act,
-                                                               uint8_t* __restrict__ state,
+                                                               uint8_t* __restrict__ state, uint8_t* __restrict__ tier,
                                                                uint32_t* __restrict__ blocked, uint32_t* __restrict__ count,
                                                                uint32_t* __restrict__ flags, int32_t* __restrict__ seed_size,
                                                                uint32_t* __restrict__ ctrl, uint32_t win_first) {
@@ -1003,6 +1018,7 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(uint32_t n_seeds,
     if (k >= n_seeds) return;
     act[k] = k;
     state[k] = 0;
+    tier[k] = 0;
     blocked[k] = 0u;
     count[k] = 0u;
     flags[k] = 0u;
@@ -1119,6 +1135,7 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
     A.blocked = B.blocked;
     A.count = B.count;
     A.flags = B.flags;
+    A.tier = B.tier;
     A.ctrl = B.ctrl;
     A.slab_ring = (uint4*)B.slab_ring;
     A.slab_hash = (uint4*)B.slab_hash;
@@ -1155,7 +1172,7 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
     }
     uint32_t* lists[2] = {B.act_a, B.act_b};
     hipLaunchKernelGGL(flood_init_seeds_kernel, dim3((n_seeds + 255) / 256), dim3(256), 0, s, n_seeds, lists[0], B.state,
-                       B.blocked, B.count, B.flags, seed_size, B.ctrl, A.win_first);
+                       B.tier, B.blocked, B.count, B.flags, seed_size, B.ctrl, A.win_first);
     const int pix_blocks = (int)std::min<size_t>((npix + 255) / 256, 4096);
     const int seed_blocks = (int)std::min<uint32_t>((n_seeds + 255) / 256, 256);
     static const bool debug = std::getenv("LIBRECTIFY_FLOOD_DEBUG") != nullptr;
