@@ -569,9 +569,25 @@ struct TileFetch {
 };
 
 // `fw` (when valid) is the record at ring index i as the previous step's push8 left it in registers.
+// element `idx` of a uniform array through a 32-bit byte offset (global_load with scalar base + vector offset)
+__device__ __forceinline__ uint32_t ld32(const uint32_t* p, uint32_t idx) {
+    return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(p) + (idx << 2));
+}
+__device__ __forceinline__ float ldf(const float* p, uint32_t idx) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p) + (idx << 2));
+}
+__device__ __forceinline__ uint32_t ld8(const uint8_t* p, uint32_t idx) { return p[idx]; }
+
+// per-lane constants of the address computation: offset of the lane's pixel from the tile's first pixel, and of its
+// ring pixel (may be negative: wraps modulo 2^32 and comes out right after the add)
+struct LaneGeom {
+    uint32_t off, roff;
+};
+
 template <class Store>
 __device__ __forceinline__ TileFetch fetch_tile(const FloodArgs& A, const Store& S, uint32_t i, int lr, int lc,
-                                                int rx, int ry, bool ring_lane, const Forward& fw) {
+                                                int rx, int ry, bool ring_lane, const Forward& fw,
+                                                const LaneGeom& G) {
     TileFetch f;
     if (fw.valid) {
         f.tile = fw.tile;
@@ -584,26 +600,30 @@ __device__ __forceinline__ TileFetch fetch_tile(const FloodArgs& A, const Store&
         S.get(i, f.tile, f.entry);
         f.known = S.lookup(f.tile, f.slot, f.V, f.Am, f.Rg);
     }
+    // Addresses: the tile's first pixel is a wave-uniform index (scalar unit), the lane's place in the tile and in
+    // the ring around it are per-lane constants of the walk (G.off, G.roff): one 32-bit add per pixel, and the loads
+    // take a uniform base with a 32-bit byte offset (frames have fewer than 2^29 pixels: launch_filter checks).
     const int ty = (int)(f.tile >> 16), tx = (int)(f.tile & 0xFFFFu);  // tile id = ty << 16 | tx
-    const int r = ty * 8 + lr, c = tx * 8 + lc;
-    f.inside = r < A.h && c < A.w;
-    f.q = f.inside ? (size_t)r * A.w + c : 0;
+    const uint32_t base = (uint32_t)(ty * 8) * (uint32_t)A.w + (uint32_t)(tx * 8);
+    f.inside = (ty * 8 + lr) < A.h && (tx * 8 + lc) < A.w;
+    const uint32_t q = f.inside ? base + G.off : 0u;
+    f.q = q;
     f.lab = f.rlab = 0u;
     f.dm = f.rdm = 0u;
     f.dx = f.dy = f.rdx = f.rdy = 0.f;
     f.rinside = false;
     if (!f.known) {  // wave-uniform
-        f.lab = A.label[f.q];  // only the committed/not-committed split is read from it, and that is stable in a round
-        f.dm = A.dmask[f.q];
-        f.dx = A.dx[f.q];
-        f.dy = A.dy[f.q];
+        f.lab = ld32(A.label, q);  // only the committed/not-committed split is read from it, and that is stable in a round
+        f.dm = ld8(A.dmask, q);
+        f.dx = ldf(A.dx, q);
+        f.dy = ldf(A.dy, q);
         const int rr = ty * 8 + ry, rc = tx * 8 + rx;
         f.rinside = ring_lane && rr >= 0 && rr < A.h && rc >= 0 && rc < A.w;
-        const size_t rq = f.rinside ? (size_t)rr * A.w + rc : 0;
-        f.rlab = A.label[rq];
-        f.rdm = A.dmask[rq];
-        f.rdx = A.dx[rq];
-        f.rdy = A.dy[rq];
+        const uint32_t rq = f.rinside ? base + G.roff : 0u;
+        f.rlab = ld32(A.label, rq);
+        f.rdm = ld8(A.dmask, rq);
+        f.rdx = ldf(A.dx, rq);
+        f.rdy = ldf(A.dy, rq);
     }
     return f;
 }
@@ -633,7 +653,11 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
     const PushLane pc = push_lane(lane);
     Forward fw;
     fw.valid = false;
-    TileFetch cur = fetch_tile(A, S, st.head, lr, lc, rx, ry, ring_lane, fw);
+    LaneGeom G;
+    G.off = (uint32_t)(lr * A.w + lc);
+    G.roff = (uint32_t)(ry * A.w + rx);
+    asm volatile("" : "+v"(G.off), "+v"(G.roff));
+    TileFetch cur = fetch_tile(A, S, st.head, lr, lc, rx, ry, ring_lane, fw, G);
     for (;;) {
         st.head += 1;
         st.steps += 1;
@@ -692,7 +716,7 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
         if (st.head == st.tail) return 0;
         if ((st.tail - st.head) + 8u > S.ring_cap() || st.ntiles + 2u > S.hash_limit()) return 1;
         if (st.steps > kMaxSteps) return 1;  // never reached by a terminating walk; treated like exhausted storage
-        cur = fetch_tile(A, S, st.head, lr, lc, rx, ry, ring_lane, fw);
+        cur = fetch_tile(A, S, st.head, lr, lc, rx, ry, ring_lane, fw, G);
     }
 }
 
