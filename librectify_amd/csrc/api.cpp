@@ -117,7 +117,10 @@ int lr_synchronize(lr_context* ctx) {
 }
 void lr_set_ransac_seed(lr_context* ctx, uint64_t seed) { ctx->ransac_seed = seed; }
 void lr_set_ransac_iterations(lr_context* ctx, int n_iter) { ctx->ransac_iters = n_iter; }
-void lr_set_flood_mode(lr_context* ctx, int mode) { ctx->flood_mode = mode; }
+void lr_set_flood_mode(lr_context* ctx, int mode) {
+    ctx->flood_mode = mode;
+    ctx->flood_big_hint = true;  // forget what the previous frame needed
+}
 int lr_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -262,6 +262,7 @@ int ctx_stage_flood(lr_context* c) {
         // test hooks: 2 and 3 exercise the slab and exhausted-storage paths (no second LDS tier, no / two slabs),
         // 4 the slab path with the full pool
         if (c->flood_mode >= 2) fbuf.second_tier = false;
+        fbuf.second_tier_from_start = c->flood_big_hint;
         if (c->flood_mode == 2) fbuf.n_slabs = 0;
         if (c->flood_mode == 3) fbuf.n_slabs = 2;
         if (c->flood_staged) fbuf.win_first_shift = 3;
@@ -269,6 +270,7 @@ int ctx_stage_flood(lr_context* c) {
                            c->n_seeds, c->trig, c->label, c->seed_size, c->queue, c->h_counts + 16, &c->flood_rounds,
                            c->flood_tiers, c->stream))
             return 1;
+        c->flood_big_hint = c->flood_tiers[0] > 0 || c->flood_tiers[1] > 0;
     }
     LR_HIP(hipEventRecord(c->ev[3], c->stream));
     c->stage_valid[2] = true;

@@ -1185,7 +1185,8 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
     if (A.win_hold < 1024u) A.win_hold = n_seeds;  // not worth another phase
     static const int order_env = std::getenv("LIBRECTIFY_FLOOD_ORDER") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_ORDER")) : -1;
     A.from_end = order_env >= 0 ? (uint32_t)order_env : 1u;
-    A.big_cap = B.second_tier ? kBigCap : 0u;
+    bool use_big = B.second_tier && B.second_tier_from_start;
+    A.big_cap = use_big ? kBigCap : 0u;
     static const bool big_ok = [] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(flood_explore_big_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigLdsBytes) == hipSuccess;
@@ -1210,8 +1211,9 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
             uint32_t* act = lists[enqueued & 1];
             uint32_t* act_next = lists[(enqueued + 1) & 1];
             hipLaunchKernelGGL(flood_explore_kernel, dim3(n_seeds), dim3(64), 0, s, A, trig, act, B.big_list);
-            hipLaunchKernelGGL(flood_explore_big_kernel, dim3(std::min<uint32_t>(n_seeds, kBigCap)), dim3(64),
-                               kBigLdsBytes, s, A, trig, B.big_list);
+            if (use_big)
+                hipLaunchKernelGGL(flood_explore_big_kernel, dim3(std::min<uint32_t>(n_seeds, kBigCap)), dim3(64),
+                                   kBigLdsBytes, s, A, trig, B.big_list);
             hipLaunchKernelGGL(flood_decide_kernel, dim3(seed_blocks), dim3(256), 0, s, A, act, B.state, seed_size);
             if (debug) flood_debug_round(B, n_seeds, act, s);
             hipLaunchKernelGGL(flood_commit_pixels_kernel, dim3(pix_blocks), dim3(256), 0, s, label, npix, B.state, B.ctrl);
@@ -1225,6 +1227,10 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
             std::fprintf(stderr, "flood after %d rounds enqueued: %u done, active %u, remain %u, stall %u\n", enqueued,
                          h_ctrl[kCtrlRounds], h_ctrl[kCtrlNAct], h_ctrl[kCtrlNRemain], h_ctrl[kCtrlStall]);
         if (h_ctrl[kCtrlNAct] == 0u) break;
+        if (!use_big && B.second_tier && h_ctrl[kCtrlSlabTotal] > 0u) {  // long walks after all: second tier from now on
+            use_big = true;
+            A.big_cap = kBigCap;
+        }
     }
     int rounds = (int)h_ctrl[kCtrlRounds];
     if (h_ctrl[kCtrlStall] != 0u && h_ctrl[kCtrlNRemain] > 0u) {

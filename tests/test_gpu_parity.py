@@ -380,11 +380,17 @@ def test_natural_image_at_4k_matches_the_oracle(L, ctx):
     img = np.ascontiguousarray(ndi.zoom(g, (h / g.shape[0], w / g.shape[1]), order=3).astype(np.float32)[:h, :w])
     assert img.shape == (h, w)
     ctx.set_seed(0)
+    ctx.set_flood_mode(1)  # also forgets what the previous frame's walks needed: the second tier is on from round one
     got = ctx.find_line_segment_groups(img, max(w, h) / 100.0)
     used = ctx.stage_counters()
     ref, _ = O.find_line_segment_groups(img, max(w, h) / 100.0, seed=0)
     _assert_lines_equal(got, ref)
     assert len(got) > 300 and used["second_tier_seeds"] > 0 and used["ordered_tail_seeds"] == 0
+    # a frame without long walks in between: the next flood starts without the second tier and turns it on itself
+    ctx.find_line_segment_groups(FRAMES["320x240"], 3.2)
+    got2 = ctx.find_line_segment_groups(img, max(w, h) / 100.0)
+    _assert_lines_equal(got2, ref)
+    assert ctx.stage_counters()["slabs"] > 0
 
 
 def _pencil(vp, n_on, n_off, seed):
