@@ -123,13 +123,13 @@ namespace {
 // seed k is the connected set around it in {response_k > thr_k} minus everything claimed by
 // seeds < k.  Rounds evaluate that recursion for many seeds at once:
 //
-//   explore  every active seed walks its WHOLE reachable set w.r.t. the labels committed so far
-//            (its "footprint", a superset of its final flood) and stamps each pixel with
-//            atomicMin(label, MARK|k).  A seed that meets a lower stamp, or whose stamp is
-//            overwritten by a lower seed, is "blocked": a lower active seed can reach one of
-//            its pixels, so its flood is not decided yet.  Footprints are never truncated
-//            at other seeds' stamps; pixels stamped lower than k are tracked in a private hash
-//            set so that the walk still terminates.
+//   explore  every active seed below the round's window (a prefix of the seed order; usually all of them) walks
+//            its WHOLE reachable set w.r.t. the labels committed so far (its "footprint", a superset of its final
+//            flood), records it per 8x8 tile in a private table and, at the end of the walk, stamps each pixel
+//            with atomicMin(label, MARK|k).  A seed that finds a lower stamp, or whose stamp is overwritten by a
+//            lower seed, is "blocked": a lower active seed can reach one of its pixels, so its flood is not
+//            decided yet.  Footprints are never truncated at other seeds' stamps (a truncated walk would hide an
+//            overlap from a third seed).
 //   decide   unblocked seeds have footprints disjoint from every lower active footprint, so
 //            their footprint IS their final flood: commit.  If some seed could not finish its
 //            walk (private storage exhausted) only seeds below the lowest such seed commit.
@@ -770,7 +770,7 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
     const uint32_t seed_label = A.label[s];
     const uint32_t seed_mask = A.dmask[s];
     const float seed_dx = A.dx[s], seed_dy = A.dy[s];
-    if (seed_label < kMarkBit) return;  // claimed by an earlier flood: dead (found again by the compaction)
+    if (seed_label < kMarkBit) return;  // claimed by an earlier flood: dead (the survivors pass takes it off the list)
     if (!(((seed_mask >> b) & 1) && directional(seed_dx, seed_dy, sn, cs) > thr)) {
         if (lane == 0) A.flags[k] = kFlagSelfFail;  // flood() accepts nothing, not even the seed
         return;
