@@ -120,6 +120,7 @@ void lr_set_ransac_iterations(lr_context* ctx, int n_iter) { ctx->ransac_iters =
 void lr_set_flood_mode(lr_context* ctx, int mode) {
     ctx->flood_mode = mode;
     ctx->flood_big_hint = true;  // forget what the previous frame needed
+    ctx->flood_hold_hint = false;
 }
 int lr_device_count(void) {
     int n = 0;

@@ -137,13 +137,17 @@ struct FloodBuffers {
     // context's previous frame needed it (or there was none), and turns it on at the next look at the control block
     // once a walk has had to go to a slab.
     bool second_tier_from_start = true;
+    // Likewise the hold-back: if the context's previous frame engaged it, this frame starts with it (a round of very
+    // long walks saved); otherwise it engages after the first full round that shows such walks.
+    bool hold_from_start = false;
 };
 // Runs all rounds (enqueued in batches; one stream synchronisation per batch, normally one per flood).
 // h_ctrl: >= 16 words of pinned host memory.
 int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, const uint8_t* dmask, int w, int h,
                    const int32_t* seed_idx, const int32_t* seed_bin, const float* seed_thr, uint32_t n_seeds,
                    BinTrig trig, uint32_t* label, int32_t* seed_size, int32_t* queue, uint32_t* h_ctrl, int* rounds_out,
-                   uint32_t* tiers_out /* [3]: seeds moved to the second tier, slabs used, seeds left to the ordered tail */,
+                   uint32_t* tiers_out /* [4]: seeds moved to the second tier, slabs used, seeds left to the ordered tail,
+                                          hold-back engaged */,
                    hipStream_t s);
 
 // kernels_fit.hip

@@ -89,7 +89,8 @@ struct lr_context {
     int ransac_iters = lramd::kRansacMaxIter;
     int flood_mode = 1;
     bool flood_big_hint = true;  // did the last frame's walks outgrow the first storage tier? (none yet: assume so)
-    uint32_t flood_tiers[3] = {0, 0, 0};  // last flood: seeds in the second tier, slabs used, seeds of the ordered tail
+    bool flood_hold_hint = false;  // did the last frame hold its weakest seeds back?
+    uint32_t flood_tiers[4] = {0, 0, 0, 0};  // last flood: seeds in the second tier, slabs used, seeds of the ordered tail
     bool flood_staged = false;  // set on the lanes of a batch call (throughput over latency)
     hipEvent_t ev[16] = {};
     float stage_ms[LR_T_COUNT] = {};

@@ -263,6 +263,7 @@ int ctx_stage_flood(lr_context* c) {
         // 4 the slab path with the full pool
         if (c->flood_mode >= 2) fbuf.second_tier = false;
         fbuf.second_tier_from_start = c->flood_big_hint;
+        fbuf.hold_from_start = c->flood_hold_hint;
         if (c->flood_mode == 2) fbuf.n_slabs = 0;
         if (c->flood_mode == 3) fbuf.n_slabs = 2;
         if (c->flood_staged) fbuf.win_first_shift = 3;
@@ -271,6 +272,7 @@ int ctx_stage_flood(lr_context* c) {
                            c->flood_tiers, c->stream))
             return 1;
         c->flood_big_hint = c->flood_tiers[0] > 0 || c->flood_tiers[1] > 0;
+        c->flood_hold_hint = c->flood_tiers[3] != 0;
     }
     LR_HIP(hipEventRecord(c->ev[3], c->stream));
     c->stage_valid[2] = true;

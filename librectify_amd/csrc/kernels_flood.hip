@@ -998,10 +998,14 @@ __global__ void flood_advance_kernel(uint32_t* __restrict__ ctrl, uint32_t n_see
         grown = win_hold;
         ctrl[kCtrlPhase] = 1u;
     } else if (phase == 1u) {
-        grown = window;
-        if (ctrl[kCtrlBelow] == 0u) {
-            grown = n_seeds;
-            ctrl[kCtrlPhase] = 2u;
+        if (window < win_hold) {  // (a staged start that began below the hold line keeps growing up to it)
+            if (grown > win_hold) grown = win_hold;
+        } else {
+            grown = window;
+            if (ctrl[kCtrlBelow] == 0u) {
+                grown = n_seeds;
+                ctrl[kCtrlPhase] = 2u;
+            }
         }
     }
     ctrl[kCtrlWindow] = (uint32_t)grown;
@@ -1021,7 +1025,8 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(uint32_t n_seeds,
                                                                uint8_t* __restrict__ state, uint8_t* __restrict__ tier,
                                                                uint32_t* __restrict__ blocked, uint32_t* __restrict__ count,
                                                                uint32_t* __restrict__ flags, int32_t* __restrict__ seed_size,
-                                                               uint32_t* __restrict__ ctrl, uint32_t win_first) {
+                                                               uint32_t* __restrict__ ctrl, uint32_t win_first,
+                                                               uint32_t phase) {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k == 0u) {
         ctrl[kCtrlWindow] = win_first;
@@ -1034,7 +1039,7 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(uint32_t n_seeds,
         ctrl[kCtrlNAct] = n_seeds;
         ctrl[kCtrlNCommit] = 0u;
         ctrl[kCtrlNNext] = 0u;
-        ctrl[kCtrlPhase] = 0u;
+        ctrl[kCtrlPhase] = phase;
         ctrl[kCtrlRounds] = 0u;
         ctrl[kCtrlStall] = 0u;
         ctrl[kCtrlNRemain] = n_seeds;
@@ -1183,6 +1188,8 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
     const int hold_pct = hold_env >= 0 ? hold_env : B.win_hold_pct;
     A.win_hold = hold_pct > 0 && hold_pct < 100 ? (uint32_t)((unsigned long long)n_seeds * hold_pct / 100) : n_seeds;
     if (A.win_hold < 1024u) A.win_hold = n_seeds;  // not worth another phase
+    const bool hold_now = B.hold_from_start && A.win_hold < n_seeds;
+    if (hold_now && A.win_first > A.win_hold) A.win_first = A.win_hold;
     static const int order_env = std::getenv("LIBRECTIFY_FLOOD_ORDER") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_ORDER")) : -1;
     A.from_end = order_env >= 0 ? (uint32_t)order_env : 1u;
     bool use_big = B.second_tier && B.second_tier_from_start;
@@ -1197,7 +1204,7 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
     }
     uint32_t* lists[2] = {B.act_a, B.act_b};
     hipLaunchKernelGGL(flood_init_seeds_kernel, dim3((n_seeds + 255) / 256), dim3(256), 0, s, n_seeds, lists[0], B.state,
-                       B.tier, B.blocked, B.count, B.flags, seed_size, B.ctrl, A.win_first);
+                       B.tier, B.blocked, B.count, B.flags, seed_size, B.ctrl, A.win_first, hold_now ? 1u : 0u);
     const int pix_blocks = (int)std::min<size_t>((npix + 255) / 256, 4096);
     const int seed_blocks = (int)std::min<uint32_t>((n_seeds + 255) / 256, 256);
     static const bool debug = std::getenv("LIBRECTIFY_FLOOD_DEBUG") != nullptr;
@@ -1257,6 +1264,7 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
         tiers_out[0] = h_ctrl[kCtrlBigTotal];
         tiers_out[1] = h_ctrl[kCtrlSlabTotal];
         tiers_out[2] = (h_ctrl[kCtrlStall] != 0u && h_ctrl[kCtrlNRemain] > 0u) ? h_ctrl[kCtrlNRemain] : 0u;
+        tiers_out[3] = h_ctrl[kCtrlPhase];
     }
     return 0;
 }
