@@ -236,6 +236,29 @@ def test_reference_error_convention_and_strides(L, ctx):
     _assert_lines_equal(got, base)
 
 
+def test_degenerate_shapes_and_values(L, ctx):
+    """Smallest legal frame, one-tile-wide strips, frames below the filter size, and non-finite pixels: the oracle's
+    answer where it has one, and in every case a clean return (no hang, no fault, context usable afterwards)."""
+    from librectify_amd import synth
+
+    for w, h, seed in [(5, 5, 1), (6, 9, 2), (8, 600, 3), (700, 7, 4), (64, 64, 5)]:
+        img = synth.frame(w, h, seed, bars=3)
+        ref, _ = O.find_line_segment_groups(img, 2.0, seed=0)
+        _assert_lines_equal(ctx.find_line_segment_groups(img, 2.0), ref)
+    with pytest.raises(Exception):
+        ctx.find_line_segment_groups(np.zeros((4, 40), np.float32), 2.0)  # smaller than the 5x5 filter: an error, said loudly
+    img = synth.frame(320, 240, 13, bars=24).copy()
+    img[50:60, 70:90] = np.nan
+    img[100, 100] = np.inf
+    img[150, 200:210] = -np.inf
+    got = ctx.find_line_segment_groups(img, 3.2)  # the reference has no defined answer here: only "returns"
+    assert got.dtype == L.LINE_DTYPE
+    clean = FRAMES["320x240"]
+    ref, _ = O.find_line_segment_groups(clean, 3.2, seed=0)
+    ctx.set_seed(0)
+    _assert_lines_equal(ctx.find_line_segment_groups(clean, 3.2), ref)
+
+
 def test_batch_entry_point_matches_single_calls(L, ctx):
     """lr_find_line_segment_groups_batch_device keeps several frames in flight; results per frame are those of
     the single-frame call and of the oracle."""
