@@ -140,6 +140,7 @@ struct FloodBuffers {
     // Likewise the hold-back: if the context's previous frame engaged it, this frame starts with it (a round of very
     // long walks saved); otherwise it engages after the first full round that shows such walks.
     bool hold_from_start = false;
+    uint32_t big_cap_override = 0;  // test hook: seeds per round the second tier takes (0 = the default, 8192)
 };
 // Runs all rounds (enqueued in batches; one stream synchronisation per batch, normally one per flood).
 // h_ctrl: >= 16 words of pinned host memory.

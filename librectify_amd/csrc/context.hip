@@ -260,12 +260,16 @@ int ctx_stage_flood(lr_context* c) {
         if (ensure_flood_buffers(c)) return 1;
         FloodBuffers fbuf = c->fb;
         // test hooks: 2 and 3 exercise the slab and exhausted-storage paths (no second LDS tier, no / two slabs),
-        // 4 the slab path with the full pool
-        if (c->flood_mode >= 2) fbuf.second_tier = false;
+        // 4 the slab path with the full pool, 5 a stall during the hold-back
+        if (c->flood_mode >= 2 && c->flood_mode <= 4) fbuf.second_tier = false;
         fbuf.second_tier_from_start = c->flood_big_hint;
         fbuf.hold_from_start = c->flood_hold_hint;
         if (c->flood_mode == 2) fbuf.n_slabs = 0;
         if (c->flood_mode == 3) fbuf.n_slabs = 2;
+        if (c->flood_mode == 5) {  // second tier with room for one seed per round and no slab: the rounds stall while
+            fbuf.n_slabs = 0;      // the weakest seeds are held back, and must still hand over to the ordered tail
+            fbuf.big_cap_override = 1;
+        }
         if (c->flood_staged) fbuf.win_first_shift = 3;
         if (flood_parallel(fbuf, c->dx, c->dy, c->dmask, c->w, c->h, c->seed_idx, c->seed_bin, c->seed_thr,
                            c->n_seeds, c->trig, c->label, c->seed_size, c->queue, c->h_counts + 16, &c->flood_rounds,

@@ -985,7 +985,8 @@ __global__ void flood_advance_kernel(uint32_t* __restrict__ ctrl, uint32_t n_see
     if (n_act == 0u) return;
     const uint32_t n_next = ctrl[kCtrlNNext];
     const uint32_t window = ctrl[kCtrlWindow];
-    const bool progress = ctrl[kCtrlNCommit] > 0u || n_next < n_act || window < n_seeds;
+    const bool moved = ctrl[kCtrlNCommit] > 0u || n_next < n_act;
+    const bool progress = moved || window < n_seeds;
     // Window of the next round.  Staged start: it grows by << win_shift up to the seed count.  Hold-back: once a
     // full round has shown walks that outgrow the first storage tier (a frame with long edges or large smooth
     // regions: the weakest seeds, with the lowest thresholds, own the largest footprints and stay blocked for most
@@ -1001,8 +1002,10 @@ __global__ void flood_advance_kernel(uint32_t* __restrict__ ctrl, uint32_t n_see
         if (window < win_hold) {  // (a staged start that began below the hold line keeps growing up to it)
             if (grown > win_hold) grown = win_hold;
         } else {
+            // released when nothing below the line is active any more -- or when a round moved nothing (storage ran
+            // out on the lowest active seed): the full window lets the next round detect the stall
             grown = window;
-            if (ctrl[kCtrlBelow] == 0u) {
+            if (ctrl[kCtrlBelow] == 0u || !moved) {
                 grown = n_seeds;
                 ctrl[kCtrlPhase] = 2u;
             }
@@ -1193,7 +1196,8 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
     static const int order_env = std::getenv("LIBRECTIFY_FLOOD_ORDER") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_ORDER")) : -1;
     A.from_end = order_env >= 0 ? (uint32_t)order_env : 1u;
     bool use_big = B.second_tier && B.second_tier_from_start;
-    A.big_cap = use_big ? kBigCap : 0u;
+    const uint32_t big_cap = B.big_cap_override ? B.big_cap_override : kBigCap;
+    A.big_cap = use_big ? big_cap : 0u;
     static const bool big_ok = [] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(flood_explore_big_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigLdsBytes) == hipSuccess;
@@ -1236,7 +1240,7 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
         if (h_ctrl[kCtrlNAct] == 0u) break;
         if (!use_big && B.second_tier && h_ctrl[kCtrlSlabTotal] > 0u) {  // long walks after all: second tier from now on
             use_big = true;
-            A.big_cap = kBigCap;
+            A.big_cap = big_cap;
         }
     }
     int rounds = (int)h_ctrl[kCtrlRounds];

@@ -378,7 +378,7 @@ def test_every_storage_tier_of_the_flood_is_exact_on_long_edges(L, ctx):
     img = _long_bars(2560, 480, 5)
     ref = O.find_line_segments(img)
     used = {}
-    for mode in (1, 4, 3, 2):
+    for mode in (1, 4, 3, 2, 5):
         ctx.set_flood_mode(mode)
         ctx.stage_filter_host(img)
         ctx.stage_seeds()
@@ -391,6 +391,7 @@ def test_every_storage_tier_of_the_flood_is_exact_on_long_edges(L, ctx):
     assert used[4]["second_tier_seeds"] == 0 and used[4]["slabs"] > 2
     assert used[3]["ordered_tail_seeds"] > 0
     assert used[2]["slabs"] == 0 and used[2]["ordered_tail_seeds"] > 0
+    assert used[5]["second_tier_seeds"] > 0 and used[5]["slabs"] == 0 and used[5]["ordered_tail_seeds"] > 0
 
 
 def test_natural_image_at_4k_matches_the_oracle(L, ctx):
