@@ -55,7 +55,7 @@ def make_frames(n, w, h, seed0):
 
 def pmc_traffic(w, h):
     """HBM bytes per filter launch from the committed PMC pass (4K frame); None for other sizes."""
-    path = os.path.join(ROOT, "profiles", "r01_c_pmc_filter_traffic.txt")
+    path = os.path.join(ROOT, "profiles", "r01_f_pmc_filter_traffic.txt")
     if (w, h) != (W4K, H4K) or not os.path.exists(path):
         return None
     for line in open(path):
@@ -247,7 +247,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": pmc_traffic(w, h),
-                "traffic_source": "profiles/r01_c_pmc_filter_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2.000 calibrated on a 2 GiB read of the same 4 B/lane shape)",
+                "traffic_source": "profiles/r01_f_pmc_filter_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2.000 calibrated on a 2 GiB read of the same 4 B/lane shape)",
                 "kernel_ms": round(kdur_ms, 5),
                 "kernel_ms_in_pipeline": round(float(np.mean(filt_ms)), 5) if filt_ms else None,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PX * w * h,
