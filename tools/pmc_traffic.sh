@@ -10,6 +10,7 @@ v=[float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if kern in r["Kern
 print(sum(v)/len(v))
 PY
 }
+test -x tools/ubench/read_calib || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/ubench/read_calib tools/ubench/read_calib.hip
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/cal_f -- tools/ubench/read_calib > /dev/null 2>&1
 CAL=$(rd gpurun_out/cal_f read4 FETCH_SIZE)
 LAPS=2 NFRAMES=10 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/flt_f -- python3 tools/bench_filter.py > /dev/null 2>&1
