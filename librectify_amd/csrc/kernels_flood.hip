@@ -1002,10 +1002,12 @@ __global__ void flood_advance_kernel(uint32_t* __restrict__ ctrl, uint32_t n_see
         if (window < win_hold) {  // (a staged start that began below the hold line keeps growing up to it)
             if (grown > win_hold) grown = win_hold;
         } else {
-            // released when nothing below the line is active any more -- or when a round moved nothing (storage ran
-            // out on the lowest active seed): the full window lets the next round detect the stall
+            // released when (next to) nothing below the line is active any more: the last few seeds there are a chain
+            // of small dependent floods, one round each, that need not keep everybody else waiting -- or when a round
+            // moved nothing (storage ran out on the lowest active seed): the full window lets the next round detect
+            // the stall
             grown = window;
-            if (ctrl[kCtrlBelow] == 0u || !moved) {
+            if (ctrl[kCtrlBelow] <= 64u || !moved) {
                 grown = n_seeds;
                 ctrl[kCtrlPhase] = 2u;
             }
