@@ -185,6 +185,7 @@ enum {
     kCtrlNCommit = 3,  // seeds committed this round
     kCtrlNNext = 4,    // length of the next active list (being appended)
     kCtrlPhase = 5,    // hold-back of the weakest seeds: 0 not engaged, 1 holding, 2 released (see flood_advance_kernel)
+    kCtrlDone = 6,     // workgroups of the survivors pass that have finished (the last one closes the round)
     kCtrlRounds = 7,   // rounds that had work
     kCtrlGen = 8,
     kCtrlStall = 9,    // a round made no progress: kCtrlNRemain seeds are left for the ordered tail
@@ -936,6 +937,54 @@ __global__ __launch_bounds__(256) void flood_commit_pixels_kernel(uint32_t* __re
     }
 }
 
+// End of a round (one thread: the last workgroup of the survivors pass): the next list becomes the current one.  A round without progress (possible only
+// when storage ran out on the lowest active seed) stops the rounds and leaves the rest to the ordered tail.
+__device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t n_seeds, uint32_t win_shift, uint32_t win_hold) {
+    const uint32_t n_act = ld_agent(&ctrl[kCtrlNAct]);
+    if (n_act == 0u) return;
+    const uint32_t n_next = ld_agent(&ctrl[kCtrlNNext]);
+    const uint32_t window = ld_agent(&ctrl[kCtrlWindow]);
+    const bool moved = ld_agent(&ctrl[kCtrlNCommit]) > 0u || n_next < n_act;
+    const bool progress = moved || window < n_seeds;
+    // Window of the next round.  Staged start: it grows by << win_shift up to the seed count.  Hold-back: once a
+    // full round has shown walks that outgrow the first storage tier (a frame with long edges or large smooth
+    // regions: the weakest seeds, with the lowest thresholds, own the largest footprints and stay blocked for most
+    // of the rounds, re-walking them every time), the window drops to win_hold and the weakest seeds wait until every
+    // seed below it is resolved; then it opens for good.  Any prefix of the seed order is a valid window.
+    unsigned long long grown = (unsigned long long)window << win_shift;
+    if (grown > n_seeds) grown = n_seeds;
+    const uint32_t phase = ld_agent(&ctrl[kCtrlPhase]);
+    if (phase == 0u && window >= n_seeds && win_hold < n_seeds && ld_agent(&ctrl[kCtrlBigTotal]) > 0u && n_next > 0u) {
+        grown = win_hold;
+        ctrl[kCtrlPhase] = 1u;
+    } else if (phase == 1u) {
+        if (window < win_hold) {  // (a staged start that began below the hold line keeps growing up to it)
+            if (grown > win_hold) grown = win_hold;
+        } else {
+            // released when (next to) nothing below the line is active any more: the last few seeds there are a chain
+            // of small dependent floods, one round each, that need not keep everybody else waiting -- or when a round
+            // moved nothing (storage ran out on the lowest active seed): the full window lets the next round detect
+            // the stall
+            grown = window;
+            if (ld_agent(&ctrl[kCtrlBelow]) <= 64u || !moved) {
+                grown = n_seeds;
+                ctrl[kCtrlPhase] = 2u;
+            }
+        }
+    }
+    ctrl[kCtrlWindow] = (uint32_t)grown;
+    ctrl[kCtrlBelow] = 0u;
+    ctrl[kCtrlRounds] = ld_agent(&ctrl[kCtrlRounds]) + 1u;
+    ctrl[kCtrlNRemain] = n_next;
+    if (!progress) ctrl[kCtrlStall] = 1u;
+    ctrl[kCtrlNAct] = progress ? n_next : 0u;
+    ctrl[kCtrlNNext] = 0u;
+    ctrl[kCtrlNCommit] = 0u;
+    ctrl[kCtrlBarrier] = 0xFFFFFFFFu;
+    ctrl[kCtrlSlabs] = 0u;
+    ctrl[kCtrlNBig] = 0u;
+}
+
 // After the commit: which seeds go on to the next round?
 __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, const uint32_t* __restrict__ act,
                                                               uint8_t* __restrict__ state,
@@ -975,55 +1024,17 @@ __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, const
             if (mb != 0ull && lane == __ffsll((long long)m) - 1) atomicAdd(&A.ctrl[kCtrlBelow], (uint32_t)__popcll(mb));
         }
     }
-}
-
-// End of a round (one thread): the next list becomes the current one.  A round without progress (possible only
-// when storage ran out on the lowest active seed) stops the rounds and leaves the rest to the ordered tail.
-__global__ void flood_advance_kernel(uint32_t* __restrict__ ctrl, uint32_t n_seeds, uint32_t win_shift,
-                                     uint32_t win_hold) {
-    const uint32_t n_act = ctrl[kCtrlNAct];
-    if (n_act == 0u) return;
-    const uint32_t n_next = ctrl[kCtrlNNext];
-    const uint32_t window = ctrl[kCtrlWindow];
-    const bool moved = ctrl[kCtrlNCommit] > 0u || n_next < n_act;
-    const bool progress = moved || window < n_seeds;
-    // Window of the next round.  Staged start: it grows by << win_shift up to the seed count.  Hold-back: once a
-    // full round has shown walks that outgrow the first storage tier (a frame with long edges or large smooth
-    // regions: the weakest seeds, with the lowest thresholds, own the largest footprints and stay blocked for most
-    // of the rounds, re-walking them every time), the window drops to win_hold and the weakest seeds wait until every
-    // seed below it is resolved; then it opens for good.  Any prefix of the seed order is a valid window.
-    unsigned long long grown = (unsigned long long)window << win_shift;
-    if (grown > n_seeds) grown = n_seeds;
-    const uint32_t phase = ctrl[kCtrlPhase];
-    if (phase == 0u && window >= n_seeds && win_hold < n_seeds && ctrl[kCtrlBigTotal] > 0u && n_next > 0u) {
-        grown = win_hold;
-        ctrl[kCtrlPhase] = 1u;
-    } else if (phase == 1u) {
-        if (window < win_hold) {  // (a staged start that began below the hold line keeps growing up to it)
-            if (grown > win_hold) grown = win_hold;
-        } else {
-            // released when (next to) nothing below the line is active any more: the last few seeds there are a chain
-            // of small dependent floods, one round each, that need not keep everybody else waiting -- or when a round
-            // moved nothing (storage ran out on the lowest active seed): the full window lets the next round detect
-            // the stall
-            grown = window;
-            if (ctrl[kCtrlBelow] <= 64u || !moved) {
-                grown = n_seeds;
-                ctrl[kCtrlPhase] = 2u;
-            }
+    // the workgroup that finishes last closes the round (every other one has read the control block and added its
+    // counts by then)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&A.ctrl[kCtrlDone], 1u) == gridDim.x - 1u) {
+            __threadfence();
+            A.ctrl[kCtrlDone] = 0u;
+            flood_advance(A.ctrl, A.n_seeds, A.win_shift, A.win_hold);
         }
     }
-    ctrl[kCtrlWindow] = (uint32_t)grown;
-    ctrl[kCtrlBelow] = 0u;
-    ctrl[kCtrlRounds] += 1u;
-    ctrl[kCtrlNRemain] = n_next;
-    if (!progress) ctrl[kCtrlStall] = 1u;
-    ctrl[kCtrlNAct] = progress ? n_next : 0u;
-    ctrl[kCtrlNNext] = 0u;
-    ctrl[kCtrlNCommit] = 0u;
-    ctrl[kCtrlBarrier] = 0xFFFFFFFFu;
-    ctrl[kCtrlSlabs] = 0u;
-    ctrl[kCtrlNBig] = 0u;
 }
 
 __global__ __launch_bounds__(256) void flood_init_seeds_kernel(uint32_t n_seeds, uint32_t* __restrict__ act,
@@ -1035,6 +1046,7 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(uint32_t n_seeds,
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k == 0u) {
         ctrl[kCtrlWindow] = win_first;
+        ctrl[kCtrlDone] = 0u;
         ctrl[kCtrlBelow] = 0u;
         ctrl[kCtrlNBig] = 0u;
         ctrl[kCtrlBigTotal] = 0u;
@@ -1232,7 +1244,6 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
             hipLaunchKernelGGL(flood_commit_pixels_kernel, dim3(pix_blocks), dim3(256), 0, s, label, npix, B.state, B.ctrl);
             hipLaunchKernelGGL(flood_survivors_kernel, dim3(seed_blocks), dim3(256), 0, s, A, act, B.state, seed_size,
                                act_next);
-            hipLaunchKernelGGL(flood_advance_kernel, dim3(1), dim3(1), 0, s, B.ctrl, n_seeds, A.win_shift, A.win_hold);
         }
         LR_HIP(hipMemcpyAsync(h_ctrl, B.ctrl, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         LR_HIP(hipStreamSynchronize(s));
