@@ -563,7 +563,6 @@ struct TileFetch {
     uint32_t tile, slot;
     uint64_t entry, V, Am, Rg;
     size_t q;
-    uint32_t lab, rlab;
     float dx, dy, rdx, rdy;
     uint32_t dm, rdm;
     bool known, inside, rinside;
@@ -609,19 +608,18 @@ __device__ __forceinline__ TileFetch fetch_tile(const FloodArgs& A, const Store&
     f.inside = (ty * 8 + lr) < A.h && (tx * 8 + lc) < A.w;
     const uint32_t q = f.inside ? base + G.off : 0u;
     f.q = q;
-    f.lab = f.rlab = 0u;
     f.dm = f.rdm = 0u;
     f.dx = f.dy = f.rdx = f.rdy = 0.f;
     f.rinside = false;
     if (!f.known) {  // wave-uniform
-        f.lab = ld32(A.label, q);  // only the committed/not-committed split is read from it, and that is stable in a round
+        // (no label load: the commit pass clears the direction mask of every pixel it commits, so "not claimed by
+        // an earlier flood" is part of the mask test)
         f.dm = ld8(A.dmask, q);
         f.dx = ldf(A.dx, q);
         f.dy = ldf(A.dy, q);
         const int rr = ty * 8 + ry, rc = tx * 8 + rx;
         f.rinside = ring_lane && rr >= 0 && rr < A.h && rc >= 0 && rc < A.w;
         const uint32_t rq = f.rinside ? base + G.roff : 0u;
-        f.rlab = ld32(A.label, rq);
         f.rdm = ld8(A.dmask, rq);
         f.rdx = ldf(A.dx, rq);
         f.rdy = ldf(A.dy, rq);
@@ -665,10 +663,10 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
         const uint32_t tile = cur.tile;
         uint64_t Am = cur.Am, Rg = cur.Rg;
         if (!cur.known) {
-            const bool acc = cur.inside && cur.lab >= kMarkBit && ((cur.dm >> b) & 1) &&
+            const bool acc = cur.inside && ((cur.dm >> b) & 1) &&
                              directional(cur.dx, cur.dy, sn, cs) > thr;
             Am = __ballot(acc);
-            const bool racc = cur.rinside && cur.rlab >= kMarkBit && ((cur.rdm >> b) & 1) &&
+            const bool racc = cur.rinside && ((cur.rdm >> b) & 1) &&
                               directional(cur.rdx, cur.rdy, sn, cs) > thr;
             Rg = __ballot(racc);
         }
@@ -922,9 +920,12 @@ __global__ __launch_bounds__(256) void flood_decide_kernel(FloodArgs A, const ui
     }
 }
 
+// Stamps of committed seeds become labels, all other stamps are erased.  A committed pixel also loses its direction
+// mask: the walks then reject it on the mask alone and never load the label image (a quarter of their gathers).
 __global__ __launch_bounds__(256) void flood_commit_pixels_kernel(uint32_t* __restrict__ label, size_t npix,
                                                                   const uint8_t* __restrict__ state,
-                                                                  const uint32_t* __restrict__ ctrl) {
+                                                                  const uint32_t* __restrict__ ctrl,
+                                                                  uint8_t* __restrict__ dmask) {
     if (ctrl[kCtrlNAct] == 0u) return;  // a round enqueued past the end
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t step = (size_t)gridDim.x * 256;
@@ -932,7 +933,9 @@ __global__ __launch_bounds__(256) void flood_commit_pixels_kernel(uint32_t* __re
         const uint32_t v = label[i];
         if (v >= kMarkBit && v != kLabelFree) {
             const uint32_t k = v & ~kMarkBit;
-            label[i] = (state[k] == 1) ? k : kLabelFree;
+            const bool committed = state[k] == 1;
+            label[i] = committed ? k : kLabelFree;
+            if (committed) dmask[i] = 0;
         }
     }
 }
@@ -1241,7 +1244,8 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
                                    kBigLdsBytes, s, A, trig, B.big_list);
             hipLaunchKernelGGL(flood_decide_kernel, dim3(seed_blocks), dim3(256), 0, s, A, act, B.state, seed_size);
             if (debug) flood_debug_round(B, n_seeds, act, s);
-            hipLaunchKernelGGL(flood_commit_pixels_kernel, dim3(pix_blocks), dim3(256), 0, s, label, npix, B.state, B.ctrl);
+            hipLaunchKernelGGL(flood_commit_pixels_kernel, dim3(pix_blocks), dim3(256), 0, s, label, npix, B.state, B.ctrl,
+                               const_cast<uint8_t*>(dmask));
             hipLaunchKernelGGL(flood_survivors_kernel, dim3(seed_blocks), dim3(256), 0, s, A, act, B.state, seed_size,
                                act_next);
         }
