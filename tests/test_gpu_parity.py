@@ -259,6 +259,25 @@ def test_degenerate_shapes_and_values(L, ctx):
     _assert_lines_equal(ctx.find_line_segment_groups(clean, 3.2), ref)
 
 
+def test_random_small_frames_match_the_oracle(L, ctx):
+    """Forty seeded frames of random size (5..140 on a side, so most tiles are ragged), bar count, contrast and noise
+    level, noiseless ones with exact ties among them: label image and segment records against the oracle."""
+    from librectify_amd import synth
+
+    rng = np.random.RandomState(2024)
+    for t in range(40):
+        w, h = int(rng.randint(5, 141)), int(rng.randint(5, 141))
+        img = synth.frame(w, h, 3000 + t, bars=int(rng.randint(1, 9)), noise=[0.0, 0.002, 0.01][t % 3])
+        if t % 7 == 0:
+            img = np.round(img * 16) / np.float32(16)  # few grey levels: plateaus, equal magnitudes, equal responses
+        ref = O.find_line_segments(img.astype(np.float32))
+        ctx.stage_filter_host(img.astype(np.float32))
+        assert ctx.stage_seeds() == ref["n_seeds"], (t, w, h)
+        ctx.stage_flood()
+        np.testing.assert_array_equal(ctx.download(L.BUF_LABEL), ref["label"], err_msg="frame %d (%dx%d)" % (t, w, h))
+        _assert_lines_equal(ctx.stage_fit(), ref["lines"])
+
+
 def test_batch_entry_point_matches_single_calls(L, ctx):
     """lr_find_line_segment_groups_batch_device keeps several frames in flight; results per frame are those of
     the single-frame call and of the oracle."""
