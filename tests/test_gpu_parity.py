@@ -276,6 +276,12 @@ def test_random_small_frames_match_the_oracle(L, ctx):
         ctx.stage_flood()
         np.testing.assert_array_equal(ctx.download(L.BUF_LABEL), ref["label"], err_msg="frame %d (%dx%d)" % (t, w, h))
         _assert_lines_equal(ctx.stage_fit(), ref["lines"])
+        if t % 4 == 1:  # every fourth frame through the whole path: filter_lines, grouping, refine on and off
+            ml = max(2.0, max(w, h) / 50.0)
+            for refine in (False, True):
+                full, _ = O.find_line_segment_groups(img.astype(np.float32), ml, refine=refine, seed=0)
+                ctx.set_seed(0)
+                _assert_lines_equal(ctx.find_line_segment_groups(img.astype(np.float32), ml, refine=refine), full)
 
 
 def test_batch_entry_point_matches_single_calls(L, ctx):
