@@ -3,16 +3,28 @@
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
 torch.distributed.run with one rank per GPU.  One step = one pass of the hot path
-(find_line_segment_groups + compute_rectification_transform) over this rank's batch of
-`--frames` distinct synthetic 3840x2160 frames, already resident in HBM.  Frames are
-independent, so ranks shard them with no data-path collective (weak scaling: per-GPU work is
+(find_line_segment_groups + compute_rectification_transform) over this rank's batch
+of `--frames` distinct synthetic 3840x2160 frames.
+
+`value` is measured FROM HOST POINTERS: the timed call is lr_find_line_segment_groups_batch_host on
+frames in ordinary (pageable) host memory, so the upload of every frame (pinned staging + H2D) and the
+download of its results are inside the timed region, as in the reference's only entry point
+(interface.cpp:46, image.cpp:11-19).  The same workload on page-locked host frames and on frames already
+resident in HBM is measured in short extra legs and reported under other keys, never as `value`.
+Frames are independent, so ranks shard them with no data-path collective (weak scaling: per-GPU work is
 fixed); the only exchange is the final gather of the per-frame results over RCCL.
 
 Rank 0 prints ONE JSON line carrying, besides the contract's keys:
   roofline     — the fused filter kernel (HBM-bound): algorithmic 18 B/px over the
-                 kernel's mean duration, measured with HIP events on the library's own stream;
-  cpu_baseline — the CPU oracle (a restatement of the reference; the Eigen reference itself
-                 cannot be built here) timed on a bounded sample of the same workload.
+                 kernel's mean duration, measured with HIP events on the library's own stream; and the
+                 same with the bytes the kernel really moves (PMC pass under profiles/);
+  cpu_baseline — the CPU oracle (a restatement of the reference; the Eigen reference itself cannot be
+                 built here) timed on a bounded sample of the same workload, threaded and serial;
+  ransac_hypotheses_per_s — BASELINE metric (ii) at N = 1 000 / 10 000 and N = 20 000 / 100 000;
+  config4_batch1080 — BASELINE configs[3]: 512 frames 1920x1080 sharded over the ranks (strong scaling),
+                 host pointers, one gather.
+
+`--config batch1080` makes that last workload the timed one (512 frames over N ranks, "scaling": "strong").
 """
 import argparse
 import json
@@ -28,14 +40,16 @@ sys.path.insert(0, ROOT)
 W4K, H4K = 3840, 2160
 ALGO_BYTES_PER_PX = 18.0  # 4 read + 12 (dx,dy,mag) + 1 (bin) + 1 (peak candidate)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PMC_FILE = os.path.join("profiles", "r02_pmc_filter_traffic.txt")
 
 
-def make_frames(n, w, h, seed0):
-    """n distinct frames: two generated, the rest flips of them (cheap, same statistics)."""
+def make_frames(n, w, h, seed0, bases=2, out=None):
+    """n distinct frames: `bases` generated, the rest flips / rolls of them (cheap, same statistics).
+    Written into `out` ([n, h, w] float32) if given."""
     from librectify_amd import synth
 
-    base = [synth.frame(w, h, seed0 + i) for i in range(min(n, 2))]
-    out = []
+    base = [synth.frame(w, h, seed0 + i) for i in range(min(n, bases))]
+    res = out if out is not None else np.empty((n, h, w), np.float32)
     for i in range(n):
         b = base[i % len(base)]
         k = i // len(base)
@@ -49,13 +63,13 @@ def make_frames(n, w, h, seed0):
             f = b[::-1, ::-1]
         else:
             f = np.roll(b, 97 * k, axis=1)
-        out.append(np.ascontiguousarray(f))
-    return out
+        res[i] = f
+    return res
 
 
 def pmc_traffic(w, h):
     """HBM bytes per filter launch from the committed PMC pass (4K frame); None for other sizes."""
-    path = os.path.join(ROOT, "profiles", "r01_f_pmc_filter_traffic.txt")
+    path = os.path.join(ROOT, PMC_FILE)
     if (w, h) != (W4K, H4K) or not os.path.exists(path):
         return None
     for line in open(path):
@@ -64,34 +78,76 @@ def pmc_traffic(w, h):
     return None
 
 
-def cpu_baseline(frames, w, h, min_length, budget_s=14.0):
+def cpu_baseline(frames, w, h, min_length, budget_s=12.0):
     """CPU oracle on a bounded sample of the same workload (kind 'port': the Eigen reference is
-    unbuildable here).  Only this leg of bench.py touches oracle/."""
+    unbuildable here).  Only this leg of bench.py touches oracle/.  Two settings, as BASELINE.md §2 asks:
+    all host cores (`value`) and the reference's serial mode num_threads = -1."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
 
-    cores = O.max_threads()
-    done = 0
-    t0 = time.perf_counter()
-    stage = np.zeros(7)
-    while True:
-        img = frames[done % len(frames)]
-        lines, times = O.find_line_segment_groups(img, min_length, num_threads=cores, seed=0)
-        O.compute_rectification_transform(lines, w, h)
-        stage += times
-        done += 1
+    names = ["gradients", "directions", "seeds", "components", "fitting", "ransac", "total"]
+
+    def leg(threads, budget, max_frames):
+        done = 0
+        t0 = time.perf_counter()
+        stage = np.zeros(7)
+        while True:
+            img = frames[done % len(frames)]
+            lines, times = O.find_line_segment_groups(img, min_length, num_threads=threads, seed=0)
+            O.compute_rectification_transform(lines, w, h)
+            stage += times
+            done += 1
+            if time.perf_counter() - t0 >= budget or done >= max_frames:
+                break
         el = time.perf_counter() - t0
-        if el >= budget_s or done >= 16:
-            break
-    el = time.perf_counter() - t0
+        return done, el, {k: round(float(v) / done, 2) for k, v in zip(names, stage)}
+
+    cores = O.max_threads()
+    done, el, stage = leg(cores, budget_s, 16)
+    sdone, sel, sstage = leg(-1, budget_s * 0.6, 4)
     return {
         "value": round(done * w * h / el / 1e6, 3),
         "unit": "Mpix/s",
         "cores": int(cores),
         "kind": "port",
         "sample": "%d frame(s) %dx%d, oracle find_line_segment_groups+compute_rectification_transform, %d OpenMP threads, %.1f s" % (done, w, h, cores, el),
-        "stage_ms_per_frame": {k: round(float(v) / done, 2) for k, v in zip(["gradients", "directions", "seeds", "components", "fitting", "ransac", "total"], stage)},
+        "stage_ms_per_frame": stage,
+        "serial": {
+            "value": round(sdone * w * h / sel / 1e6, 3),
+            "unit": "Mpix/s",
+            "cores": 1,
+            "sample": "%d frame(s), num_threads = -1 (the reference's serial mode, threading.h:24-27), %.1f s" % (sdone, sel),
+            "stage_ms_per_frame": sstage,
+        },
     }
+
+
+def ransac_rates(ctx):
+    """BASELINE metric (ii): hypotheses scored against all N lines per second, through lr_ransac_best (upload of the
+    pencil table, scoring kernel, argmax, one synchronisation: what one peeling round costs)."""
+    import librectify_amd as L
+    from librectify_amd import synth
+
+    out = {}
+    for n, n_iter in [(1000, 10000), (20000, 100000)]:
+        lines = np.ascontiguousarray(synth.random_segments(n, 42), L.LINE_DTYPE)
+        xs = np.concatenate([lines["x1"], lines["x2"]])
+        ys = np.concatenate([lines["y1"], lines["y2"]])
+        cx, cy = xs.min() + 0.5 * (xs.max() - xs.min()), ys.min() + 0.5 * (ys.max() - ys.min())
+        sc = max(xs.max() - xs.min(), ys.max() - ys.min())
+        norm = lines.copy()
+        for a, c0 in (("x1", cx), ("x2", cx), ("y1", cy), ("y2", cy)):
+            norm[a] = (lines[a] - np.float32(c0)) / np.float32(sc)
+        idx = np.arange(n, dtype=np.int32)
+        tol = float(np.float32(1.0) - np.float32(np.cos(np.float32(2.0) / np.float32(180.0) * np.float32(np.pi))))
+        ctx.ransac_best(norm, idx, tol, n_iter, 42)
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.ransac_best(norm, idx, tol, n_iter, 42)
+        dt = (time.perf_counter() - t0) / reps
+        out["N%d_hyp%d" % (n, n_iter)] = {"hypotheses_per_s": round(n_iter / dt, 1), "line_evaluations_per_s": round(n_iter / dt * n, 1), "ms_per_solve": round(dt * 1e3, 4)}
+    return out
 
 
 def main():
@@ -99,15 +155,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=32, help="distinct frames per rank per step")
-    ap.add_argument("--width", type=int, default=W4K)
-    ap.add_argument("--height", type=int, default=H4K)
+    ap.add_argument("--config", choices=["frames4k", "batch1080"], default="frames4k",
+                    help="frames4k: BASELINE configs[2], --frames 4K frames per rank per step (weak scaling); "
+                         "batch1080: configs[3], 512 frames 1920x1080 sharded over the ranks (strong scaling)")
+    ap.add_argument("--frames", type=int, default=32, help="frames4k: distinct frames per rank per step")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--host-memory", choices=["pageable", "pinned"], default="pageable",
+                    help="where the timed region's frames live (the other kind and the device-resident rate are extra legs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the roofline leg (the filter kernel alone): the command profiled for "
                          "profiles/*_kernel_stats_roofline_leg.csv, where rocprofv3's average must agree with kernel_ms")
     ap.add_argument("--flood-mode", type=int, default=None)
     ap.add_argument("--streams", type=int, default=16, help="frames in flight per GPU (one context + HIP stream + host thread each)")
+    ap.add_argument("--staging-threads", type=int, default=16, help="host threads that stage pageable frames (num_threads of the batch call)")
     args = ap.parse_args()
 
     import torch
@@ -138,88 +201,172 @@ def main():
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
     n_gpus = world if world > 1 else 1
 
-    w, h, B = args.width, args.height, args.frames
-    min_length = float(max(w, h)) / 100.0  # autorectify.cpp:134
-    frames = make_frames(B, w, h, seed0=1 + 100 * rank)
-    d_frames = torch.empty((B, h, w), dtype=torch.float32, device=dev)
-    for i, f in enumerate(frames):
-        d_frames[i].copy_(torch.from_numpy(f))
-    torch.cuda.synchronize()
-
-    S = max(1, min(args.streams, B))
     ctx = L.Context(local_rank)
     ctx.set_seed(0)
+    S = max(1, args.streams)
     ctx.set_batch_streams(S)
     if args.flood_mode is not None:
         ctx.set_flood_mode(args.flood_mode)
-    ctxs = [ctx]
-    cap = 8192
-    out = np.zeros((B, cap), L.LINE_DTYPE)
-    n_lines = np.zeros(B, np.int32)
-    tforms = np.zeros((B, 6, 3), np.float32)
     cfg = L.RectificationConfig()
-    filt_ms = []
-    stage_acc = np.zeros(L.T_COUNT)
-    base = d_frames.data_ptr()
-
-    def step(record):
-        # one C call per step: S frames in flight inside the library (host thread + HIP stream + workspace each);
-        # it returns the segments and the rectification transform of every frame
-        _, n, tf = ctx.find_line_segment_groups_batch_device(base, h * w, B, w, h, min_length, capacity=cap, cfg=cfg, out=out)
-        n_lines[:] = n
-        for b in range(B):
-            tforms[b] = tf[b].as_array()
-        if record:
-            t = ctx.stage_times()  # lane 0's last frame of this step
-            filt_ms.append(float(t[L.T_FILTER_KERNEL]))
-            stage_acc[:] += t
-        if world > 1:  # the path's one exchange step: gather the per-frame results over RCCL
-            D.gather_results([out[b][: n_lines[b]] for b in range(B)], tforms, B * world, device=cdev)
-
-    if args.roofline_only:
-        args.steps = args.warmup = 0
-        args.no_cpu_baseline = True
-    for _ in range(args.warmup):
-        step(False)
 
     def fence():
         if world > 1:
             dist.barrier()
-        for c in ctxs:
-            c.synchronize()
+        ctx.synchronize()
         torch.cuda.synchronize()
 
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    fence()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    def timed(fn, steps):
+        """barrier + sync, `steps` calls, barrier + sync; MAX over ranks"""
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    class Workload:
+        """B frames of one size in pageable host memory, page-locked host memory and (4K only) HBM."""
+
+        def __init__(self, w, h, B, seed0, bases, cap, want_device):
+            self.w, self.h, self.B, self.cap = w, h, B, cap
+            self.min_length = float(max(w, h)) / 100.0  # autorectify.cpp:134
+            self.pageable = make_frames(B, w, h, seed0, bases) if B else np.empty((0, h, w), np.float32)
+            self.pinned = None
+            self.d = None
+            self.want_device = want_device
+            self.out = np.zeros((max(B, 1), cap), L.LINE_DTYPE)
+            self.n_lines = np.zeros(max(B, 1), np.int32)
+            self.tforms = np.zeros((max(B, 1), 6, 3), np.float32)
+
+        def ensure_pinned(self):
+            if self.pinned is None and self.B:
+                self.pinned = ctx.host_alloc((self.B, self.h, self.w))
+                self.pinned[:] = self.pageable
+
+        def ensure_device(self):
+            if self.d is None and self.B:
+                self.d = torch.empty((self.B, self.h, self.w), dtype=torch.float32, device=dev)
+                self.d.copy_(torch.from_numpy(self.pageable))
+                torch.cuda.synchronize()
+
+        def step(self, kind, n_total=None):
+            """one pass over the B frames; returns nothing, results land in self.out / n_lines / tforms"""
+            if self.B:
+                if kind == "device":
+                    _, n, tf = ctx.find_line_segment_groups_batch_device(self.d.data_ptr(), self.h * self.w, self.B, self.w, self.h, self.min_length, capacity=self.cap, cfg=cfg, out=self.out)
+                else:
+                    src = self.pageable if kind == "pageable" else self.pinned
+                    _, n, tf = ctx.find_line_segment_groups_batch_host(src, self.min_length, num_threads=args.staging_threads, capacity=self.cap, cfg=cfg, out=self.out)
+                self.n_lines[: self.B] = n
+                for b in range(self.B):
+                    self.tforms[b] = tf[b].as_array()
+            if world > 1:  # the path's one exchange step: gather the per-frame results over RCCL
+                D.gather_results([self.out[b][: self.n_lines[b]] for b in range(self.B)], self.tforms[: self.B], n_total if n_total is not None else self.B * world, device=cdev)
+
+    def make_batch1080():
+        b, e = D.shard_range(512, rank, world)
+        wl = Workload(1920, 1080, e - b, 1000 + b, 8, 2048, False)
+        return wl, 512
+
+    if args.config == "batch1080":
+        wl, n_total = make_batch1080()
+        scaling = "strong"
+        total_frames = 512
+    else:
+        w = args.width or W4K
+        h = args.height or H4K
+        wl = Workload(w, h, args.frames, 1 + 100 * rank, 2, 8192, True)
+        n_total = None
+        scaling = "weak"
+        total_frames = args.frames * n_gpus
+    kind = args.host_memory
+    if kind == "pinned":
+        wl.ensure_pinned()
+
+    if args.roofline_only:
+        args.steps = args.warmup = 0
+        args.no_cpu_baseline = args.no_extra_legs = True
+    for _ in range(args.warmup):
+        wl.step(kind, n_total)
+    filt_ms = []
+    stage_acc = np.zeros(L.T_COUNT)
+
+    def timed_step():
+        wl.step(kind, n_total)
+        t = ctx.stage_times()  # lane 0's last frame of this step
+        filt_ms.append(float(t[L.T_FILTER_KERNEL]))
+        stage_acc[:] += t
+
+    el = timed(timed_step, args.steps)
+    segs = float(np.mean(wl.n_lines[: max(wl.B, 1)]))
+
+    # ---- extra legs (outside the timed region; each bracketed like it) ------------------------------------------
+    extra = {}
+    if not args.no_extra_legs:
+        legs = [k for k in ("pageable", "pinned", "device") if k != kind and (k != "device" or wl.want_device)]
+        for k in legs:
+            if k == "pinned":
+                wl.ensure_pinned()
+            if k == "device":
+                wl.ensure_device()
+            wl.step(k, n_total)
+            steps = 3
+            e = timed(lambda: wl.step(k, n_total), steps)
+            extra[k] = round(total_frames * wl.w * wl.h * steps / e / 1e6, 3)
+        if args.config == "frames4k":
+            wl.d = None  # release the resident copy before the next workload
+            if wl.pinned is not None:
+                ctx.host_free(wl.pinned)
+                wl.pinned = None
+            torch.cuda.empty_cache()
+            w2, nt2 = make_batch1080()
+            w2.step("pageable", nt2)
+            e = timed(lambda: w2.step("pageable", nt2), 2)
+            extra["config4_batch1080"] = {
+                "workload": "512 frames 1920x1080 (seeds 1000+i), sharded over %d rank(s), pageable host pointers, one gather of the results" % n_gpus,
+                "ms_per_pass": round(e / 2 * 1e3, 3),
+                "frames_per_s": round(512 * 2 / e, 2),
+                "Mpix_per_s": round(512 * 2 * 1920 * 1080 / e / 1e6, 3),
+                "scaling": "strong",
+                "segments_per_frame": float(np.mean(w2.n_lines[: max(w2.B, 1)])),
+            }
 
     # roofline leg (after the timed region): the filter kernel alone, one launch at a time on one stream, over
-    # the same resident frames, timed with the HIP events the library records around the launch
+    # distinct resident frames (more than the 256 MiB Infinity Cache holds), timed with the HIP events the library
+    # records around the launch
     iso = []
+    rw, rh = (W4K, H4K) if args.config == "batch1080" else (wl.w, wl.h)
     if rank == 0:
-        c0 = ctxs[0]
+        nroof = 32
+        wl.d = None
+        torch.cuda.empty_cache()
+        d_roof = torch.empty((nroof, rh, rw), dtype=torch.float32, device=dev)
+        src = wl.pageable if (wl.w, wl.h) == (rw, rh) and wl.B >= 1 else make_frames(2, rw, rh, 1, 2)
+        for i in range(nroof):
+            d_roof[i].copy_(torch.from_numpy(src[i % len(src)]))
+        torch.cuda.synchronize()
         for lap in range(3):
-            for b in range(B):
-                c0.stage_filter_device(base + b * h * w * 4, w, h)
-                c0.synchronize()
+            for b in range(nroof):
+                ctx.stage_filter_device(d_roof.data_ptr() + b * rh * rw * 4, rw, rh)
+                ctx.synchronize()
                 if lap > 0:
-                    iso.append(c0.stage_times_partial())
+                    iso.append(ctx.stage_times_partial())
 
     if rank == 0:
-        total_px = float(n_gpus) * B * w * h * args.steps
+        w, h = wl.w, wl.h
+        total_px = float(total_frames) * w * h * args.steps
         value = total_px / el / 1e6 if args.steps > 0 else None
         kdur_ms = float(np.mean(iso)) if iso else float("nan")
-        achieved = ALGO_BYTES_PER_PX * w * h / (kdur_ms * 1e-3) / 1e9
+        achieved = ALGO_BYTES_PER_PX * rw * rh / (kdur_ms * 1e-3) / 1e9
+        traffic = pmc_traffic(rw, rh)
         nfr = max(1, len(filt_ms))
         res = {
-            "metric": "Mpix/s end-to-end (detect+VP) on 4K frames",
+            "metric": "Mpix/s end-to-end (detect+VP) on 4K frames" if args.config == "frames4k" else "Mpix/s end-to-end (detect+VP), batch of 512 1920x1080 frames",
             "value": round(value, 3) if value is not None else None,
             "unit": "Mpix/s",
             "n_gpus": n_gpus,
@@ -227,18 +374,28 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(el / max(1, args.steps) * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%dx%d frames, find_line_segment_groups + compute_rectification_transform, default constants, refine=false, min_length=max(W,H)/100" % (w, h),
-                "frames_per_gpu_per_step": B,
+                "workload": "%dx%d frames in %s HOST memory -> find_line_segment_groups + compute_rectification_transform per frame "
+                            "(lr_find_line_segment_groups_batch_host): H2D of every frame and D2H of its results are inside the timed "
+                            "region; default constants, refine=false, min_length=max(W,H)/100" % (w, h, kind),
+                "frames_per_step_all_gpus": total_frames,
                 "frames_in_flight_per_gpu": S,
+                "staging_threads": args.staging_threads,
                 "ransac_iterations": 10000,
-                "segments_per_frame": float(np.mean(n_lines)),
-                "parallelism": "frames sharded over %d GPU(s), RCCL all_gather of results" % n_gpus,
+                "segments_per_frame": segs,
+                "parallelism": "frames sharded over %d GPU(s), no data-path collective, RCCL all_gather of the results" % n_gpus,
             },
+            "other_rates_Mpix_per_s": {
+                "note": "same workload, 3 steps each, outside the timed region: frames in the other kind of host memory, and frames already resident in HBM (no H2D: NOT the metric)",
+                "host_pageable": extra.get("pageable"),
+                "host_pinned": extra.get("pinned"),
+                "device_resident": extra.get("device"),
+            },
+            "config4_batch1080": extra.get("config4_batch1080"),
             "roofline": {
                 "bound": "hbm",
                 "kernel": "filter_lanes_kernel (row-streaming fused 5x5 derivative + magnitude + bin + dilated mask + NMS candidates)",
@@ -246,23 +403,29 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": pmc_traffic(w, h),
-                "traffic_source": "profiles/r01_f_pmc_filter_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2.000 calibrated on a 2 GiB read of the same 4 B/lane shape)",
+                "traffic": traffic,
+                "traffic_source": PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2.000 calibrated on a 2 GiB read of the same 4 B/lane shape)",
+                "achieved_moved_bytes": round(traffic / (kdur_ms * 1e-3) / 1e9, 2) if traffic else None,
+                "frac_moved_bytes": round(traffic / (kdur_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                 "kernel_ms": round(kdur_ms, 5),
                 "kernel_ms_in_pipeline": round(float(np.mean(filt_ms)), 5) if filt_ms else None,
-                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PX * w * h,
+                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PX * rw * rh,
+                "frame": "%dx%d" % (rw, rh),
             },
             "stage_ms_per_frame": {
                 k: round(float(stage_acc[i]) / nfr, 4)
                 for k, i in [("filter", L.T_FILTER), ("seeds", L.T_SEEDS), ("flood", L.T_FLOOD), ("fit", L.T_FIT), ("ransac", L.T_RANSAC), ("total_device", L.T_TOTAL)]
             },
         }
-        if not args.no_cpu_baseline and n_gpus == 1:
-            res["cpu_baseline"] = cpu_baseline(frames[:2], w, h, min_length)
+        if not args.no_extra_legs:
+            res["ransac_hypotheses_per_s"] = ransac_rates(ctx)
+        if not args.no_cpu_baseline and n_gpus == 1 and wl.B:
+            res["cpu_baseline"] = cpu_baseline(wl.pageable[:2], w, h, wl.min_length)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

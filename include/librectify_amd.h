@@ -71,6 +71,25 @@ int lr_find_line_segment_groups_batch_device(lr_context* ctx, const float* d_ima
                                              int num_threads, LineSegment* out, int capacity, int* n_lines,
                                              const RectificationConfig* cfg, ImageTransform* transforms);
 
+/* Batch of `batch` HOST-resident frames of one size, frame b at frames + b*image_stride (elements), rows `stride`
+ * elements apart (any sign, as image.cpp:11-19).  This is the reference's own kind of input, many frames at once:
+ * each lane stages and uploads its next frame on a copy stream of its own while the kernels of its current frame run.
+ * Pageable memory goes through a pinned staging buffer (copied in row bands by the lane's share of `num_threads`
+ * host threads, the reference's knob); page-locked memory (lr_host_alloc, hipHostMalloc, hipHostRegister) is
+ * DMA-copied where it lies.  Outputs as for the device batch. */
+int lr_find_line_segment_groups_batch_host(lr_context* ctx, const float* frames, size_t image_stride, int batch,
+                                           int width, int height, int stride, float min_length, int refine,
+                                           int num_threads, LineSegment* out, int capacity, int* n_lines,
+                                           const RectificationConfig* cfg, ImageTransform* transforms);
+/* Same with one pointer per frame. */
+int lr_find_line_segment_groups_batch_host_ptrs(lr_context* ctx, const float* const* frames, int batch, int width,
+                                                int height, int stride, float min_length, int refine, int num_threads,
+                                                LineSegment* out, int capacity, int* n_lines,
+                                                const RectificationConfig* cfg, ImageTransform* transforms);
+/* Page-locked host memory for frames (hipHostMalloc / hipHostFree): uploads from it skip the staging copy. */
+int lr_host_alloc(lr_context* ctx, size_t bytes, void** out);
+int lr_host_free(lr_context* ctx, void* p);
+
 /* Minimal device-memory helpers (hipMalloc / hipFree / synchronous hipMemcpy H2D on the context's device). */
 int lr_device_malloc(lr_context* ctx, size_t bytes, void** out);
 int lr_device_free(lr_context* ctx, void* p);
@@ -86,7 +105,9 @@ int lr_stage_filter(lr_context* ctx, const float* d_image, int width, int height
 int lr_stage_filter_host(lr_context* ctx, const float* buffer, int width, int height, int stride);
 /* Stage 2: global max, seed threshold, ordered seed list (line_detector.cpp:209-220, filter.cpp:168-194). */
 int lr_stage_seeds(lr_context* ctx, int* n_seeds);
-/* Stage 3: ordered flood (filter.cpp:101-153, line_detector.cpp:92-122). */
+/* Stage 3: ordered flood (filter.cpp:101-153, line_detector.cpp:92-122).  The parallel flood (mode >= 1) CONSUMES the
+ * filter output: it clears the direction mask of every pixel it labels, so LR_BUF_DMASK can no longer be downloaded
+ * and a second flood of the same frame needs lr_stage_filter + lr_stage_seeds again (both fail with a message). */
 int lr_stage_flood(lr_context* ctx, int* n_components);
 /* Stage 4: weighted-PCA line fit per component (geometry.cpp:20-61); output in seed order. */
 int lr_stage_fit(lr_context* ctx, LineSegment* out, int capacity, int* n_lines);

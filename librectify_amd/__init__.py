@@ -68,6 +68,7 @@ EXPORTS = [
     "lr_find_line_segment_groups_host", "lr_find_line_segment_groups_batch_device", "lr_stage_filter",
     "lr_stage_filter_host", "lr_stage_seeds", "lr_stage_flood", "lr_stage_fit", "lr_download", "lr_stage_times",
     "lr_stage_counters", "lr_filter_kernel_ms", "lr_ransac_best", "lr_estimate_line_pencils",
+    "lr_find_line_segment_groups_batch_host", "lr_find_line_segment_groups_batch_host_ptrs", "lr_host_alloc", "lr_host_free",
     "lr_set_batch_streams", "lr_device_malloc", "lr_device_free", "lr_memcpy_h2d", "lr_cht_vanishing_point", "lr_refine_lines", "lr_set_estimator", "lr_ht_weights", "lr_prosac_solve", "lr_estimate_line_pencils_prosac",
 ]
 
@@ -114,6 +115,10 @@ def lib():
         L.lr_find_line_segment_groups_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.lr_find_line_segment_groups_host.argtypes = L.lr_find_line_segment_groups_device.argtypes
         L.lr_find_line_segment_groups_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lr_find_line_segment_groups_batch_host.argtypes = L.lr_find_line_segment_groups_batch_device.argtypes
+        L.lr_find_line_segment_groups_batch_host_ptrs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lr_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.lr_host_free.argtypes = [C.c_void_p, C.c_void_p]
         L.lr_stage_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.lr_stage_filter_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.lr_stage_seeds.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
@@ -298,6 +303,45 @@ class Context:
         self.shape = (h, w)
         _check(lib().lr_find_line_segment_groups_batch_device(self._h, C.c_void_p(dptr), image_stride, batch, w, h, w, min_length, int(refine), -1, _ptr(out), capacity, _ptr(n), C.byref(cfg), C.byref(tf)))
         return out, n, tf
+
+    def find_line_segment_groups_batch_host(self, frames, min_length, refine=False, num_threads=-1, capacity=4096, cfg=None, out=None):
+        """frames: float32 array [B, H, W] (rows contiguous; any row/frame strides) or a list of 2-D float32 arrays
+        of one shape, in HOST memory (pageable, or page-locked as host_alloc returns it)."""
+        if isinstance(frames, np.ndarray) and frames.ndim == 3:
+            assert frames.dtype == np.float32 and frames.strides[2] == 4
+            batch, h, w = frames.shape
+            stride = frames.strides[1] // 4
+            ptrs = (C.c_void_p * batch)(*[frames.ctypes.data + b * frames.strides[0] for b in range(batch)])
+        else:
+            frames = [np.asarray(f, np.float32) for f in frames]
+            batch = len(frames)
+            h, w = frames[0].shape
+            stride = frames[0].strides[0] // 4
+            assert all(f.shape == (h, w) and f.strides == frames[0].strides and f.strides[1] == 4 for f in frames)
+            ptrs = (C.c_void_p * batch)(*[f.ctypes.data for f in frames])
+        if out is None:
+            out = np.zeros((batch, capacity), LINE_DTYPE)
+        n = np.zeros(batch, np.int32)
+        tf = (ImageTransform * batch)()
+        cfg = cfg or RectificationConfig()
+        self.shape = (h, w)
+        _check(lib().lr_find_line_segment_groups_batch_host_ptrs(self._h, ptrs, batch, w, h, stride, min_length, int(refine), num_threads, _ptr(out), capacity, _ptr(n), C.byref(cfg), C.byref(tf)))
+        return out, n, tf
+
+    def host_alloc(self, shape, dtype=np.float32):
+        """Page-locked host array (free with host_free(array)): frames in it are uploaded without a staging copy."""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        _check(lib().lr_host_alloc(self._h, nbytes, C.byref(p)))
+        buf = (C.c_ubyte * nbytes).from_address(p.value)
+        a = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[a.ctypes.data] = p.value
+        return a
+
+    def host_free(self, array):
+        p = self._pinned.pop(array.ctypes.data)
+        _check(lib().lr_host_free(self._h, C.c_void_p(p)))
 
     # ---- RANSAC ----
     def ransac_best(self, lines_norm, indices, tol, n_iter, seed, rnd=0):

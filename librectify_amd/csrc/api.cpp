@@ -29,16 +29,11 @@ lr_context* thread_context() {
     return ctx.get();
 }
 
-int upload_host_image(lr_context* c, const float* buffer, int width, int height, int stride) {
-    // image_from_buffer (reference image.cpp:11-19): a negative stride addresses the same rows from the other end
-    if (stride < 0) {
-        buffer = buffer + (std::ptrdiff_t)(height - 1) * stride;
-        stride = -stride;
-    }
-    if (ctx_ensure_image_capacity(c, width, height)) return 1;
-    LR_HIP(hipSetDevice(c->device));
-    LR_HIP(hipMemcpy2DAsync(c->d_img, (size_t)width * sizeof(float), buffer, (size_t)stride * sizeof(float),
-                            (size_t)width * sizeof(float), (size_t)height, hipMemcpyHostToDevice, c->stream));
+// image_from_buffer (reference image.cpp:11-19): the frame goes to device slot 0 on the context's copy stream
+// (pinned staging for pageable sources, see ctx_upload_frame) and the compute stream waits for it.
+int upload_host_image(lr_context* c, const float* buffer, int width, int height, int stride, int num_threads) {
+    if (ctx_upload_frame(c, 0, buffer, width, height, stride, num_threads)) return 1;
+    LR_HIP(hipStreamWaitEvent(c->stream, c->ev_up[0], 0));
     return 0;
 }
 
@@ -57,7 +52,8 @@ extern "C" {
 
 LineSegment* find_line_segment_groups(float* buffer, int width, int height, int stride, float min_length, bool refine,
                                       int num_threads, int* n_lines) {
-    (void)num_threads;  // the reference's OpenMP knob; the per-pixel stages run on the GPU regardless
+    // num_threads is the reference's OpenMP knob (threading.h:24-27).  The per-pixel stages run on the GPU
+    // regardless; here it sets how many host threads stage a pageable frame for its upload (< 0: serial).
     if (n_lines) *n_lines = 0;
     set_error("");
     // The reference signals "nothing found" by NULL (interface.cpp:50-54,65-69) and has no error
@@ -70,8 +66,12 @@ LineSegment* find_line_segment_groups(float* buffer, int width, int height, int 
     lr_context* c = thread_context();
     if (!c) return fail();
     std::vector<LineSegment> res;
-    if (upload_host_image(c, buffer, width, height, stride)) return fail();
-    if (ctx_find_groups_device(c, c->d_img, width, height, width, min_length, refine, res)) return fail();
+    if (width < 5 || height < 5 || buffer == nullptr) {
+        set_error("image smaller than the 5x5 filter");
+        return fail();
+    }
+    if (upload_host_image(c, buffer, width, height, stride, num_threads)) return fail();
+    if (ctx_find_groups_device(c, c->d_img_slot[0], width, height, width, min_length, refine, res)) return fail();
     if (res.empty()) return nullptr;
     LineSegment* out = new (std::nothrow) LineSegment[res.size()];
     if (!out) return nullptr;
@@ -140,10 +140,13 @@ int lr_find_line_segment_groups_device(lr_context* ctx, const float* d_image, in
 int lr_find_line_segment_groups_host(lr_context* ctx, const float* buffer, int width, int height, int stride,
                                      float min_length, int refine, int num_threads, LineSegment* out, int capacity,
                                      int* n_lines) {
-    (void)num_threads;
-    if (upload_host_image(ctx, buffer, width, height, stride)) return 1;
+    if (width < 5 || height < 5 || buffer == nullptr) {
+        set_error("image smaller than the 5x5 filter");
+        return 1;
+    }
+    if (upload_host_image(ctx, buffer, width, height, stride, num_threads)) return 1;
     std::vector<LineSegment> res;
-    if (ctx_find_groups_device(ctx, ctx->d_img, width, height, width, min_length, refine != 0, res)) return 1;
+    if (ctx_find_groups_device(ctx, ctx->d_img_slot[0], width, height, width, min_length, refine != 0, res)) return 1;
     return copy_out(res, out, capacity, n_lines);
 }
 
@@ -154,6 +157,35 @@ int lr_find_line_segment_groups_batch_device(lr_context* ctx, const float* d_ima
     (void)num_threads;
     return ctx_find_groups_batch_device(ctx, d_images, image_stride, batch, width, height, stride, min_length,
                                         refine != 0, out, capacity, n_lines, cfg, transforms);
+}
+
+int lr_find_line_segment_groups_batch_host(lr_context* ctx, const float* frames, size_t image_stride, int batch,
+                                           int width, int height, int stride, float min_length, int refine,
+                                           int num_threads, LineSegment* out, int capacity, int* n_lines,
+                                           const RectificationConfig* cfg, ImageTransform* transforms) {
+    std::vector<const float*> ptrs((size_t)std::max(batch, 0));
+    for (int b = 0; b < batch; ++b) ptrs[b] = frames + (size_t)b * image_stride;
+    return ctx_find_groups_batch_host(ctx, ptrs.data(), batch, width, height, stride, min_length, refine != 0,
+                                      num_threads, out, capacity, n_lines, cfg, transforms);
+}
+
+int lr_find_line_segment_groups_batch_host_ptrs(lr_context* ctx, const float* const* frames, int batch, int width,
+                                                int height, int stride, float min_length, int refine, int num_threads,
+                                                LineSegment* out, int capacity, int* n_lines,
+                                                const RectificationConfig* cfg, ImageTransform* transforms) {
+    return ctx_find_groups_batch_host(ctx, frames, batch, width, height, stride, min_length, refine != 0, num_threads,
+                                      out, capacity, n_lines, cfg, transforms);
+}
+
+int lr_host_alloc(lr_context* ctx, size_t bytes, void** out) {
+    LR_HIP(hipSetDevice(ctx->device));
+    LR_HIP(hipHostMalloc(out, bytes));
+    return 0;
+}
+int lr_host_free(lr_context* ctx, void* p) {
+    LR_HIP(hipSetDevice(ctx->device));
+    LR_HIP(hipHostFree(p));
+    return 0;
 }
 
 // minimal device-memory helpers so that C callers (and the tests) need no other runtime binding
@@ -179,8 +211,12 @@ int lr_stage_filter(lr_context* ctx, const float* d_image, int width, int height
     return ctx_stage_filter(ctx, d_image, width, height, stride);
 }
 int lr_stage_filter_host(lr_context* ctx, const float* buffer, int width, int height, int stride) {
-    if (upload_host_image(ctx, buffer, width, height, stride)) return 1;
-    return ctx_stage_filter(ctx, ctx->d_img, width, height, width);
+    if (width < 5 || height < 5 || buffer == nullptr) {
+        set_error("image smaller than the 5x5 filter");
+        return 1;
+    }
+    if (upload_host_image(ctx, buffer, width, height, stride, -1)) return 1;
+    return ctx_stage_filter(ctx, ctx->d_img_slot[0], width, height, width);
 }
 int lr_stage_seeds(lr_context* ctx, int* n_seeds) {
     if (ctx_stage_seeds(ctx)) return 1;
@@ -214,6 +250,10 @@ int lr_download(lr_context* ctx, int buffer_id, void* dst, size_t bytes) {
         case LR_BUF_MAXMAG: src = ctx->maxmag; have = 4; break;
         case LR_BUF_SEED_SIZE: src = ctx->seed_size; have = (size_t)ctx->n_seeds * 4; break;
         default: set_error("lr_download: unknown buffer id"); return 1;
+    }
+    if (buffer_id == LR_BUF_DMASK && ctx->dmask_consumed) {
+        set_error("lr_download: LR_BUF_DMASK was consumed by lr_stage_flood (labelled pixels are cleared); download it after lr_stage_filter");
+        return 1;
     }
     if (bytes > have) {
         set_error("lr_download: request larger than the buffer");

@@ -149,7 +149,7 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
                    BinTrig trig, uint32_t* label, int32_t* seed_size, int32_t* queue, uint32_t* h_ctrl, int* rounds_out,
                    uint32_t* tiers_out /* [4]: seeds moved to the second tier, slabs used, seeds left to the ordered tail,
                                           hold-back engaged */,
-                   hipStream_t s);
+                   hipStream_t s, void (*before_wait)(void*) = nullptr, void* before_wait_arg = nullptr);
 
 // kernels_fit.hip
 size_t fit_temp_bytes(size_t max_pixels, uint32_t max_segments);

@@ -1,5 +1,6 @@
 // lr_context: one device, one stream, one reusable workspace (see include/librectify_amd.h).
 #pragma once
+#include <functional>
 #include <vector>
 
 #include "common.h"
@@ -14,8 +15,21 @@ struct lr_context {
     int cap_tiles = 0;
     int w = 0, h = 0;
 
+    // Host-buffer entry points (the reference's only kind, image.cpp:11-19): frames go through one of two device
+    // slots on a copy stream of their own, so the upload of a lane's next frame overlaps the kernels of its current
+    // one.  Pageable sources are first copied (in row bands, by `upload_threads` host threads) into a pinned staging
+    // buffer per slot; sources that are already page-locked (lr_host_alloc, hipHostMalloc, hipHostRegister) are
+    // DMA-copied where they lie.
+    hipStream_t copy_stream = nullptr;
+    float* d_img_slot[2] = {nullptr, nullptr};
+    size_t cap_slot[2] = {0, 0};
+    float* h_stage[2] = {nullptr, nullptr};
+    size_t cap_stage[2] = {0, 0};
+    hipEvent_t ev_up[2] = {};
+    std::function<void()> prefetch;  // one-shot: run at the frame's first long wait (see ctx_run_prefetch)
+    int prefetch_rc = 0;
+    std::string prefetch_err;
     // stage 1
-    float* d_img = nullptr;  // staging for the host-buffer entry points
     float* dx = nullptr;
     float* dy = nullptr;
     uint8_t* dmask = nullptr;
@@ -95,6 +109,7 @@ struct lr_context {
     hipEvent_t ev[16] = {};
     float stage_ms[LR_T_COUNT] = {};
     bool stage_valid[4] = {false, false, false, false};
+    bool dmask_consumed = false;  // the parallel flood clears the mask of labelled pixels: LR_BUF_DMASK is then stale
 };
 
 namespace lramd {
@@ -128,4 +143,13 @@ int ctx_find_groups_device(lr_context* c, const float* d_image, int w, int h, in
 int ctx_find_groups_batch_device(lr_context* c, const float* d_images, size_t image_stride, int batch, int w, int h,
                                  int stride, float min_length, bool refine, LineSegment* out, int capacity, int* n_lines,
                                  const RectificationConfig* cfg, ImageTransform* transforms);
+// host-resident frames (any stride sign, pageable or page-locked): staged uploads overlap the kernels
+int ctx_find_groups_batch_host(lr_context* c, const float* const* frames, int batch, int w, int h, int stride,
+                               float min_length, bool refine, int num_threads, LineSegment* out, int capacity,
+                               int* n_lines, const RectificationConfig* cfg, ImageTransform* transforms);
+// Enqueues the upload of a host frame into device slot `slot` on the copy stream and records ev_up[slot];
+// the caller makes its compute stream wait on that event.  num_threads: the reference's knob (threading.h:24-27),
+// here the number of host threads that stage a pageable frame (< 0: serial, as there).
+int ctx_upload_frame(lr_context* c, int slot, const float* buffer, int w, int h, int stride, int num_threads);
+void ctx_run_prefetch(lr_context* c);
 }  // namespace lramd

@@ -75,7 +75,7 @@ int ctx_ensure_image_capacity(lr_context* c, int w, int h) {
     LR_HIP(hipStreamSynchronize(c->stream));
     const size_t cp = std::max(npix, c->cap_pix);
     const int ct = std::max(ntiles, c->cap_tiles);
-    if (dev_alloc(c->d_img, cp) || dev_alloc(c->dx, cp) || dev_alloc(c->dy, cp) || dev_alloc(c->dmask, cp + 16) ||
+    if (dev_alloc(c->dx, cp) || dev_alloc(c->dy, cp) || dev_alloc(c->dmask, cp + 16) ||
         dev_alloc(c->cand, (size_t)ct * std::max(fg.cand_cap, (int)kCandPerTile)) || dev_alloc(c->cand_count, ct) || dev_alloc(c->tile_max, ct) ||
         dev_alloc(c->tile_pass, ct) || dev_alloc(c->tile_off, ct) || dev_alloc(c->keys_a, cp) ||
         dev_alloc(c->keys_b, cp) || dev_alloc(c->seed_idx, cp) || dev_alloc(c->seed_bin, cp) ||
@@ -139,6 +139,113 @@ int ctx_ensure_ransac_capacity(lr_context* c, size_t n_lines, size_t n_iter) {
     return 0;
 }
 
+// ---- host frames -> device slots -------------------------------------------------------------
+
+namespace {
+
+bool is_page_locked(const void* p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // an ordinary malloc'ed pointer: not an error of ours
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+int staging_threads(int num_threads) {
+    // reference threading.h:24-27: t < 0 is the serial mode, otherwise min(t, available) threads (t = 0 is
+    // ill-defined there: one thread here).  Eight threads saturate the copy into the staging buffer.
+    if (num_threads <= 1) return 1;
+    const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+    return std::min(std::min(num_threads, hw), 8);
+}
+
+}  // namespace
+
+int ctx_upload_frame(lr_context* c, int slot, const float* buffer, int w, int h, int stride, int num_threads) {
+    LR_HIP(hipSetDevice(c->device));
+    if (w < 1 || h < 1 || buffer == nullptr) {
+        set_error("upload: bad frame");
+        return 1;
+    }
+    // image_from_buffer (reference image.cpp:11-19): a negative stride addresses the same rows from the other end
+    if (stride < 0) {
+        buffer = buffer + (std::ptrdiff_t)(h - 1) * stride;
+        stride = -stride;
+    }
+    if (stride < w) {
+        set_error("upload: |stride| smaller than the width");
+        return 1;
+    }
+    const size_t npix = (size_t)w * h;
+    if (c->cap_slot[slot] < npix) {
+        LR_HIP(hipStreamSynchronize(c->stream));
+        LR_HIP(hipStreamSynchronize(c->copy_stream));
+        if (dev_alloc(c->d_img_slot[slot], npix)) return 1;
+        c->cap_slot[slot] = npix;
+    }
+    float* dst = c->d_img_slot[slot];
+    const size_t row_bytes = (size_t)w * sizeof(float);
+    if (is_page_locked(buffer)) {
+        LR_HIP(hipMemcpy2DAsync(dst, row_bytes, buffer, (size_t)stride * sizeof(float), row_bytes, (size_t)h,
+                                hipMemcpyHostToDevice, c->copy_stream));
+    } else {
+        if (c->cap_stage[slot] < npix) {
+            LR_HIP(hipStreamSynchronize(c->copy_stream));
+            if (c->h_stage[slot]) (void)hipHostFree(c->h_stage[slot]);
+            c->h_stage[slot] = nullptr;
+            c->cap_stage[slot] = 0;
+            LR_HIP(hipHostMalloc((void**)&c->h_stage[slot], npix * sizeof(float)));
+            c->cap_stage[slot] = npix;
+        }
+        // the DMA that last read this staging buffer has long finished (its frame has been processed), but make sure
+        LR_HIP(hipEventSynchronize(c->ev_up[slot]));
+        float* stage = c->h_stage[slot];
+        const int rows_per_band = (int)std::max<size_t>(1, ((size_t)4 << 20) / row_bytes);
+        const int n_bands = (h + rows_per_band - 1) / rows_per_band;
+        const int T = std::min(staging_threads(num_threads), n_bands);
+        std::vector<int> rc(T, 0);
+        // band k: rows into the pinned buffer, then its DMA is enqueued at once: the copy of the next band overlaps it
+        auto run = [&](int t) {
+            if (t > 0 && hipSetDevice(c->device) != hipSuccess) {
+                rc[t] = 1;
+                return;
+            }
+            for (int k = t; k < n_bands; k += T) {
+                const int r0 = k * rows_per_band, r1 = std::min(h, r0 + rows_per_band);
+                if (stride == w) {
+                    std::memcpy(stage + (size_t)r0 * w, buffer + (size_t)r0 * stride, (size_t)(r1 - r0) * row_bytes);
+                } else {
+                    for (int r = r0; r < r1; ++r) std::memcpy(stage + (size_t)r * w, buffer + (size_t)r * stride, row_bytes);
+                }
+                if (hipMemcpyAsync(dst + (size_t)r0 * w, stage + (size_t)r0 * w, (size_t)(r1 - r0) * row_bytes,
+                                   hipMemcpyHostToDevice, c->copy_stream) != hipSuccess)
+                    rc[t] = 1;
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t) th.emplace_back(run, t);
+        run(0);
+        for (auto& x : th) x.join();
+        for (int t = 0; t < T; ++t)
+            if (rc[t]) {
+                set_error("upload: staging copy failed");
+                return 1;
+            }
+    }
+    LR_HIP(hipEventRecord(c->ev_up[slot], c->copy_stream));
+    return 0;
+}
+
+// The pipeline calls this where it is about to block for the first time with most of a frame's kernels enqueued:
+// a batch lane then stages and uploads its next frame while the GPU works on the current one.
+void ctx_run_prefetch(lr_context* c) {
+    if (!c->prefetch) return;
+    std::function<void()> f;
+    f.swap(c->prefetch);
+    f();
+}
+
 int ctx_create(int device, lr_context** out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -157,7 +264,14 @@ int ctx_create(int device, lr_context** out) {
         set_error("hipStreamCreate failed");
         return 1;
     }
+    if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        set_error("hipStreamCreate failed");
+        return 1;
+    }
     for (auto& e : c->ev) (void)hipEventCreate(&e);
+    for (auto& e : c->ev_up) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
     (void)hipMalloc((void**)&c->maxmag, sizeof(float));
     (void)hipMalloc((void**)&c->d_counts, 64 * sizeof(uint32_t));
     (void)hipMalloc((void**)&c->d_best_score, sizeof(float));
@@ -179,7 +293,7 @@ void ctx_destroy(lr_context* c) {
     c->workers.clear();
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    void* ptrs[] = {c->d_img, c->dx, c->dy, c->dmask, c->cand, c->cand_count, c->tile_max, c->tile_pass, c->tile_off,
+    void* ptrs[] = {c->d_img_slot[0], c->d_img_slot[1], c->dx, c->dy, c->dmask, c->cand, c->cand_count, c->tile_max, c->tile_pass, c->tile_off,
                     c->maxmag, c->keys_a, c->keys_b, c->d_counts, c->seed_idx, c->seed_bin, c->seed_thr, c->seed_size,
                     c->label, c->queue, c->comp_rank, c->comp_seed, c->comp_off, c->cursor, c->px_a, c->px_b,
                     c->scratch_w, c->d_lines, c->temp, c->d_model, c->d_scores, c->d_best_score, c->d_best_iter,
@@ -188,6 +302,12 @@ void ctx_destroy(lr_context* c) {
                     c->d_samples, c->d_hcounts};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    (void)hipStreamSynchronize(c->copy_stream);
+    for (float* p : c->h_stage)
+        if (p) (void)hipHostFree(p);
+    for (auto& e : c->ev_up)
+        if (e) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(c->copy_stream);
     if (c->h_model) (void)hipHostFree(c->h_model);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
     if (c->h_best) (void)hipHostFree(c->h_best);
@@ -213,6 +333,7 @@ int ctx_stage_filter(lr_context* c, const float* d_image, int w, int h, int stri
     c->w = w;
     c->h = h;
     c->n_seeds = c->n_comp = c->n_px = 0;
+    c->dmask_consumed = false;
     for (bool& v : c->stage_valid) v = false;
     LR_HIP(hipEventRecord(c->ev[0], c->stream));
     if (launch_filter(d_image, w, h, stride, c->fconsts, c->dx, c->dy, c->dmask, c->cand, c->cand_count, c->tile_max,
@@ -246,7 +367,8 @@ int ctx_stage_seeds(lr_context* c) {
 
 int ctx_stage_flood(lr_context* c) {
     if (!c->stage_valid[1]) {
-        set_error("lr_stage_flood: run lr_stage_seeds first");
+        set_error(c->dmask_consumed ? "lr_stage_flood: the previous flood consumed the filter output; run lr_stage_filter and lr_stage_seeds again"
+                                    : "lr_stage_flood: run lr_stage_seeds first");
         return 1;
     }
     const size_t npix = (size_t)c->w * c->h;
@@ -273,10 +395,14 @@ int ctx_stage_flood(lr_context* c) {
         if (c->flood_staged) fbuf.win_first_shift = 3;
         if (flood_parallel(fbuf, c->dx, c->dy, c->dmask, c->w, c->h, c->seed_idx, c->seed_bin, c->seed_thr,
                            c->n_seeds, c->trig, c->label, c->seed_size, c->queue, c->h_counts + 16, &c->flood_rounds,
-                           c->flood_tiers, c->stream))
+                           c->flood_tiers, c->stream, [](void* p) { ctx_run_prefetch(static_cast<lr_context*>(p)); }, c))
             return 1;
         c->flood_big_hint = c->flood_tiers[0] > 0 || c->flood_tiers[1] > 0;
         c->flood_hold_hint = c->flood_tiers[3] != 0;
+        // the commit pass has cleared the direction mask of every labelled pixel (kernels_flood.hip): the filter
+        // output is consumed, a second flood needs lr_stage_filter + lr_stage_seeds again
+        c->stage_valid[0] = c->stage_valid[1] = false;
+        c->dmask_consumed = true;
     }
     LR_HIP(hipEventRecord(c->ev[3], c->stream));
     c->stage_valid[2] = true;
@@ -318,6 +444,7 @@ int ctx_stage_fit(lr_context* c, std::vector<LineSegment>& out) {
                               c->stream));
     }
     LR_HIP(hipEventRecord(c->ev[4], c->stream));
+    ctx_run_prefetch(c);  // (if the flood had no wait of its own)
     LR_HIP(hipStreamSynchronize(c->stream));
     c->stage_valid[3] = true;
     float ms = 0.f;
@@ -775,8 +902,19 @@ int ctx_refine(lr_context* c, std::vector<LineSegment>& lines) {
 }
 
 // find_line_segment_groups (interface.cpp:35-80) on a device-resident image.
+static int find_groups_device_impl(lr_context* c, const float* d_image, int w, int h, int stride, float min_length,
+                                   bool refine, std::vector<LineSegment>& out);
+
 int ctx_find_groups_device(lr_context* c, const float* d_image, int w, int h, int stride, float min_length, bool refine,
                            std::vector<LineSegment>& out) {
+    const int rc = find_groups_device_impl(c, d_image, w, h, stride, min_length, refine, out);
+    if (rc) c->prefetch = nullptr;
+    ctx_run_prefetch(c);  // a frame that ended before its first long wait (nothing found)
+    return rc;
+}
+
+static int find_groups_device_impl(lr_context* c, const float* d_image, int w, int h, int stride, float min_length,
+                                   bool refine, std::vector<LineSegment>& out) {
     out.clear();
     std::vector<LineSegment> raw;
     if (ctx_detect(c, d_image, w, h, stride, raw)) return 1;
@@ -805,10 +943,14 @@ int ctx_find_groups_device(lr_context* c, const float* d_image, int w, int h, in
 }
 
 // Batch of independent frames: the stages of one frame are latency-bound (flood rounds,
-// host round trips), so several frames are kept in flight, one host thread + context + HIP stream each.
-int ctx_find_groups_batch_device(lr_context* c, const float* d_images, size_t image_stride, int batch, int w, int h,
-                                 int stride, float min_length, bool refine, LineSegment* out, int capacity, int* n_lines,
-                                 const RectificationConfig* cfg, ImageTransform* transforms) {
+// host round trips), so several frames are kept in flight, one host thread + context + HIP stream each ("lanes").
+// Host-resident frames (h_frames != nullptr) go through each lane's two device slots: the upload of the lane's next
+// frame is issued while the kernels of its current frame run (ctx_run_prefetch), on the lane's copy stream.
+static int find_groups_batch(lr_context* c, const float* d_images, size_t image_stride, const float* const* h_frames,
+                             int batch, int w, int h, int stride, float min_length, bool refine, int num_threads,
+                             LineSegment* out, int capacity, int* n_lines, const RectificationConfig* cfg,
+                             ImageTransform* transforms) {
+    if (batch <= 0) return 0;
     const int S = std::max(1, std::min(c->batch_streams, batch));
     while ((int)c->workers.size() < S - 1) {
         lr_context* wc = nullptr;
@@ -826,16 +968,48 @@ int ctx_find_groups_batch_device(lr_context* c, const float* d_images, size_t im
         l->estimator = c->estimator;
         l->prosac_T_N = c->prosac_T_N;
     }
+    // the lanes share the host's cores: a lane stages its frames with its share of the caller's thread budget
+    const int lane_threads = num_threads > 1 ? std::max(1, num_threads / S) : 1;
     std::vector<int> rc(S, 0);
     std::vector<std::string> err(S);
     auto work = [&](int si) {
         lr_context* l = lanes[si];
-        for (int b = si; b < batch; b += S) {
+        auto fail = [&]() {
+            rc[si] = 1;
+            err[si] = get_error();
+            l->prefetch = nullptr;
+        };
+        if (h_frames && ctx_upload_frame(l, 0, h_frames[si], w, h, stride, lane_threads)) return fail();
+        int j = 0;
+        for (int b = si; b < batch; b += S, ++j) {
+            const float* img = nullptr;
+            int img_stride = stride;
+            if (h_frames) {
+                const int cur = j & 1;
+                if (hipStreamWaitEvent(l->stream, l->ev_up[cur], 0) != hipSuccess) {
+                    set_error("hipStreamWaitEvent failed");
+                    return fail();
+                }
+                img = l->d_img_slot[cur];
+                img_stride = w;
+                l->prefetch_rc = 0;
+                const int nb = b + S;
+                if (nb < batch)
+                    l->prefetch = [l, cur, nb, h_frames, w, h, stride, lane_threads]() {
+                        // slot cur^1 was last read by this lane's previous frame, which is finished
+                        if (ctx_upload_frame(l, cur ^ 1, h_frames[nb], w, h, stride, lane_threads)) {
+                            l->prefetch_rc = 1;
+                            l->prefetch_err = get_error();
+                        }
+                    };
+            } else {
+                img = d_images + (size_t)b * image_stride;
+            }
             std::vector<LineSegment> res;
-            if (ctx_find_groups_device(l, d_images + (size_t)b * image_stride, w, h, stride, min_length, refine, res)) {
-                rc[si] = 1;
-                err[si] = get_error();
-                return;
+            if (ctx_find_groups_device(l, img, w, h, img_stride, min_length, refine, res)) return fail();
+            if (l->prefetch_rc) {
+                set_error(l->prefetch_err);
+                return fail();
             }
             const int n = (int)res.size();
             if (n_lines) n_lines[b] = n;
@@ -859,6 +1033,20 @@ int ctx_find_groups_batch_device(lr_context* c, const float* d_images, size_t im
             return 1;
         }
     return 0;
+}
+
+int ctx_find_groups_batch_device(lr_context* c, const float* d_images, size_t image_stride, int batch, int w, int h,
+                                 int stride, float min_length, bool refine, LineSegment* out, int capacity, int* n_lines,
+                                 const RectificationConfig* cfg, ImageTransform* transforms) {
+    return find_groups_batch(c, d_images, image_stride, nullptr, batch, w, h, stride, min_length, refine, -1, out,
+                             capacity, n_lines, cfg, transforms);
+}
+
+int ctx_find_groups_batch_host(lr_context* c, const float* const* frames, int batch, int w, int h, int stride,
+                               float min_length, bool refine, int num_threads, LineSegment* out, int capacity,
+                               int* n_lines, const RectificationConfig* cfg, ImageTransform* transforms) {
+    return find_groups_batch(c, nullptr, 0, frames, batch, w, h, stride, min_length, refine, num_threads, out, capacity,
+                             n_lines, cfg, transforms);
 }
 
 }  // namespace lramd

@@ -12,6 +12,7 @@
 //      (dmask[q] >> bin) & 1  &&  |fmaf(dx[q], sin_bin, dy[q]*cos_bin)| > thr
 // on the fly (dmask = 0 on the 1-px border, which also stands in for flood_init_mask).
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1166,7 +1167,7 @@ static void flood_debug_round(const FloodBuffers& B, uint32_t n_seeds, const uin
 int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, const uint8_t* dmask, int w, int h,
                    const int32_t* seed_idx, const int32_t* seed_bin, const float* seed_thr, uint32_t n_seeds,
                    BinTrig trig, uint32_t* label, int32_t* seed_size, int32_t* queue, uint32_t* h_ctrl, int* rounds_out,
-                   uint32_t* tiers_out, hipStream_t s) {
+                   uint32_t* tiers_out, hipStream_t s, void (*before_wait)(void*), void* before_wait_arg) {
     *rounds_out = 0;
     if (n_seeds == 0) return 0;
     const size_t npix = (size_t)w * h;
@@ -1215,13 +1216,20 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
     bool use_big = B.second_tier && B.second_tier_from_start;
     const uint32_t big_cap = B.big_cap_override ? B.big_cap_override : kBigCap;
     A.big_cap = use_big ? big_cap : 0u;
-    static const bool big_ok = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(flood_explore_big_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigLdsBytes) == hipSuccess;
-    }();
-    if (!big_ok) {
-        set_error("flood: cannot reserve the second-tier LDS");
-        return 1;
+    // the opt-in for 72 KB of dynamic LDS is a per-device attribute of the kernel: once per device of this process
+    {
+        static std::atomic<uint64_t> done_mask{0};
+        int dev = 0;
+        LR_HIP(hipGetDevice(&dev));
+        const uint64_t bit = 1ull << (dev & 63);
+        if (!(done_mask.load(std::memory_order_acquire) & bit)) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(flood_explore_big_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigLdsBytes) != hipSuccess) {
+                set_error("flood: cannot reserve the second-tier LDS");
+                return 1;
+            }
+            done_mask.fetch_or(bit, std::memory_order_release);
+        }
     }
     uint32_t* lists[2] = {B.act_a, B.act_b};
     hipLaunchKernelGGL(flood_init_seeds_kernel, dim3((n_seeds + 255) / 256), dim3(256), 0, s, n_seeds, lists[0], B.state,
@@ -1250,6 +1258,7 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
                                act_next);
         }
         LR_HIP(hipMemcpyAsync(h_ctrl, B.ctrl, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        if (before_wait) before_wait(before_wait_arg);  // the bulk of the frame's kernels is enqueued: host work goes here
         LR_HIP(hipStreamSynchronize(s));
         if (debug)
             std::fprintf(stderr, "flood after %d rounds enqueued: %u done, active %u, remain %u, stall %u\n", enqueued,

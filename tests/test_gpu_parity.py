@@ -303,6 +303,72 @@ def test_batch_entry_point_matches_single_calls(L, ctx):
         np.testing.assert_array_equal(tf[i].as_array(), Tr)
 
 
+def test_host_batch_entry_point_pageable_pinned_and_strided(L, ctx):
+    """lr_find_line_segment_groups_batch_host (the reference's kind of input, many frames at once): pageable frames
+    through the pinned staging ring, page-locked frames DMA-copied where they lie, row strides > width, a negative
+    stride, more frames than lanes (so every lane prefetches) and fewer; all equal to the single-frame call."""
+    import ctypes as C
+
+    from librectify_amd import synth
+
+    w, h = 333, 190
+    frames = np.stack([synth.frame(w, h, 70 + i, bars=18) for i in range(9)])
+    ctx.set_seed(0)
+    single = [ctx.find_line_segment_groups(f, 3.3) for f in frames]
+    tf_single = [L.compute_rectification_transform(s, w, h).as_array() for s in single]
+    assert sum(len(s) for s in single) > 100
+
+    def check(out, n, tf, order=range(9)):
+        for k, i in enumerate(order):
+            _assert_lines_equal(out[k][: n[k]], single[i])
+            np.testing.assert_array_equal(tf[k].as_array(), tf_single[i])
+
+    for lanes in (1, 2, 4, 16):
+        ctx.set_batch_streams(lanes)
+        check(*ctx.find_line_segment_groups_batch_host(frames, 3.3, capacity=1024))
+    ctx.set_batch_streams(3)
+    check(*ctx.find_line_segment_groups_batch_host([f.copy() for f in frames], 3.3, capacity=1024, num_threads=8))
+    padded = np.zeros((9, h, w + 11), np.float32)
+    padded[:, :, :w] = frames
+    check(*ctx.find_line_segment_groups_batch_host(padded[:, :, :w], 3.3, capacity=1024))  # stride > width
+    pinned = ctx.host_alloc((9, h, w))
+    pinned[:] = frames
+    check(*ctx.find_line_segment_groups_batch_host(pinned, 3.3, capacity=1024))
+    check(*ctx.find_line_segment_groups_batch_host(pinned[::2], 3.3, capacity=1024), order=range(0, 9, 2))
+    # negative stride through the C entry point: frame pointers address the LAST row (image.cpp:14-18)
+    out = np.zeros((9, 1024), L.LINE_DTYPE)
+    n = np.zeros(9, np.int32)
+    rc = L.lib().lr_find_line_segment_groups_batch_host(ctx._h, C.c_void_p(pinned.ctypes.data + (h - 1) * w * 4), h * w, 9, w, h, -w,
+                                                        3.3, 0, -1, out.ctypes.data_as(C.c_void_p), 1024, n.ctypes.data_as(C.c_void_p), None, None)
+    assert rc == 0
+    for i in range(9):
+        _assert_lines_equal(out[i][: n[i]], single[i])
+    ctx.host_free(pinned)
+    with pytest.raises(Exception):
+        ctx.find_line_segment_groups_batch_host(np.zeros((3, 4, 40), np.float32), 2.0)  # below the 5x5 filter: loud
+
+
+def test_second_flood_on_a_consumed_filter_output_is_refused(L, ctx):
+    """The parallel flood clears the direction mask of the pixels it labels: flooding the same filter output again
+    (e.g. after lr_set_flood_mode) must fail loudly instead of returning labels of a mutated mask."""
+    img = FRAMES["320x240"]
+    ref = O.find_line_segments(img)
+    ctx.set_flood_mode(1)
+    ctx.stage_filter_host(img)
+    ctx.stage_seeds()
+    ctx.stage_flood()
+    np.testing.assert_array_equal(ctx.download(L.BUF_LABEL), ref["label"])
+    with pytest.raises(Exception, match="consumed"):
+        ctx.stage_flood()
+    with pytest.raises(Exception, match="consumed"):
+        ctx.download(L.BUF_DMASK)
+    _assert_lines_equal(ctx.stage_fit(), ref["lines"])  # the flood's own products are intact
+    ctx.stage_filter_host(img)  # and the staged API works again from the filter on
+    ctx.stage_seeds()
+    ctx.stage_flood()
+    np.testing.assert_array_equal(ctx.download(L.BUF_LABEL), ref["label"])
+
+
 def test_refine_flag_matches_oracle(L, ctx):
     img = FRAMES["320x240"]
     ml = 3.2

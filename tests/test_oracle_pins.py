@@ -104,3 +104,22 @@ def test_sampler_distribution_matches_knuth():
     for hist in (hk, hc):
         chi2 = ((hist[iu] - exp) ** 2 / exp).sum()
         assert chi2 < 120, chi2  # 65 dof; p ~ 1e-5 at 120
+
+
+def test_oracle_threaded_equals_serial():
+    """The oracle's OpenMP regions (placed where the reference has them) write indexed outputs: its results do not
+    depend on the thread count, so the large GPU parity tests may run it threaded."""
+    from librectify_amd import synth
+
+    img = synth.frame(640, 480, 5)
+    a = O.find_line_segments(img, num_threads=-1)
+    b = O.find_line_segments(img, num_threads=O.max_threads())
+    assert a["lines"].tobytes() == b["lines"].tobytes()
+    np.testing.assert_array_equal(a["label"], b["label"])
+    fa, _ = O.find_line_segment_groups(img, 6.4, seed=0, num_threads=-1)
+    fb, _ = O.find_line_segment_groups(img, 6.4, seed=0, num_threads=O.max_threads())
+    assert fa.tobytes() == fb.tobytes()
+    for refine in (True,):
+        ra, _ = O.find_line_segment_groups(img, 6.4, refine=refine, seed=0, num_threads=-1)
+        rb, _ = O.find_line_segment_groups(img, 6.4, refine=refine, seed=0, num_threads=O.max_threads())
+        assert ra.tobytes() == rb.tobytes()
