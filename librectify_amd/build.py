@@ -16,6 +16,7 @@ SOURCES = [
     "kernels_flood.hip",
     "kernels_fit.hip",
     "kernels_ransac.hip",
+    "kernels_groups.hip",
     "context.hip",
     "vp_host.cpp",
     "api.cpp",

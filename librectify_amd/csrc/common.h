@@ -97,16 +97,18 @@ inline int tiles_y(int h) { return (h + kTileH - 1) / kTileH; }
 size_t seeds_temp_bytes(int n_tiles, size_t max_seeds);
 int launch_seed_select(const uint64_t* cand, const uint32_t* cand_count, const uint32_t* tile_max, int n_tiles,
                        int cand_cap, float seed_keep_ratio, float* maxmag, uint32_t* tile_pass, uint32_t* tile_off, uint64_t* keys,
-                       uint32_t* n_seeds, void* temp, size_t temp_bytes, hipStream_t s);
+                       uint32_t key_cap, uint32_t* n_seeds, void* temp, size_t temp_bytes, hipStream_t s);
 int launch_seed_sort(uint64_t* keys_in, uint64_t* keys_out, uint32_t n, void* temp, size_t temp_bytes, hipStream_t s);
-int launch_seed_setup(const uint64_t* keys_sorted, uint32_t n, const float* dx, const float* dy, BinTrig trig,
-                      float trace_tolerance, int32_t* seed_idx, int32_t* seed_bin, float* seed_thr, hipStream_t s);
+// the seed count stays on the device (*n_seeds, clamped to cap); the launch covers `cap` seeds
+int launch_seed_setup(const uint64_t* keys_sorted, const uint32_t* n_seeds, uint32_t cap, const float* dx, const float* dy,
+                      BinTrig trig, float trace_tolerance, int32_t* seed_idx, int32_t* seed_bin, float* seed_thr,
+                      hipStream_t s);
 
 // kernels_flood.hip
 int launch_label_init(uint32_t* label, size_t n, hipStream_t s);
 int launch_flood_ordered(const float* dx, const float* dy, const uint8_t* dmask, int w, int h, const int32_t* seed_idx,
-                         const int32_t* seed_bin, const float* seed_thr, uint32_t n_seeds, BinTrig trig,
-                         uint32_t* label, int32_t* seed_size, int32_t* queue, hipStream_t s);
+                         const int32_t* seed_bin, const float* seed_thr, const uint32_t* d_n_seeds, uint32_t seed_cap,
+                         BinTrig trig, uint32_t* label, int32_t* seed_size, int32_t* queue, hipStream_t s);
 
 // parallel-round flood (mode 1): per-seed round state, active lists and overflow slabs
 struct FloodBuffers {
@@ -117,7 +119,7 @@ struct FloodBuffers {
     uint8_t* tier = nullptr;        // per seed: 1 = its walk outgrew the first storage tier in an earlier round
     uint32_t* act_a = nullptr;
     uint32_t* act_b = nullptr;
-    uint32_t* ctrl = nullptr;       // 16 words
+    uint32_t* ctrl = nullptr;       // kFloodCtrlWords words
     uint32_t* big_list = nullptr;   // 8192 seeds: this round's hand-over to the second storage tier
     void* slab_ring = nullptr;  // n_slabs x slab_ring_cap 16-byte records
     void* slab_hash = nullptr;  // n_slabs x slab_hash_cap 16-byte records
@@ -142,27 +144,54 @@ struct FloodBuffers {
     bool hold_from_start = false;
     uint32_t big_cap_override = 0;  // test hook: seeds per round the second tier takes (0 = the default, 8192)
 };
-// Runs all rounds (enqueued in batches; one stream synchronisation per batch, normally one per flood).
-// h_ctrl: >= 16 words of pinned host memory.
-int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, const uint8_t* dmask, int w, int h,
-                   const int32_t* seed_idx, const int32_t* seed_bin, const float* seed_thr, uint32_t n_seeds,
-                   BinTrig trig, uint32_t* label, int32_t* seed_size, int32_t* queue, uint32_t* h_ctrl, int* rounds_out,
-                   uint32_t* tiers_out /* [4]: seeds moved to the second tier, slabs used, seeds left to the ordered tail,
-                                          hold-back engaged */,
-                   hipStream_t s, void (*before_wait)(void*) = nullptr, void* before_wait_arg = nullptr);
+// What a frame hands to the flood.  The seed count stays on the device (*d_n_seeds, clamped to seed_cap, the
+// capacity the seed sort ran with): launches are sized by seed_cap.
+struct FloodFrame {
+    const float* dx;
+    const float* dy;
+    const uint8_t* dmask;
+    int w, h;
+    const int32_t* seed_idx;
+    const int32_t* seed_bin;
+    const float* seed_thr;
+    const uint32_t* d_n_seeds;
+    uint32_t seed_cap;
+    BinTrig trig;
+    uint32_t* label;
+    int32_t* seed_size;
+    int32_t* queue;
+};
+struct FloodProgress {
+    int enqueued = 0;  // rounds enqueued so far
+    bool use_big = false;
+    int win_growth = 2;
+};
+constexpr int kFloodCtrlWords = 32;
+// Enqueues the initialisation and a first batch of rounds, then an asynchronous copy of the control block into
+// h_ctrl (kFloodCtrlWords words of pinned host memory).  Never synchronises (except in LIBRECTIFY_FLOOD_DEBUG mode).
+int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, uint32_t* h_ctrl, hipStream_t s);
+// After the stream has been synchronised: completes the flood if the first batch did not (more rounds, ordered tail;
+// synchronises).  *extra = the label image changed after flood_enqueue's rounds, so later stages must run again.
+int flood_finish(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, uint32_t* h_ctrl, int* rounds_out,
+                 uint32_t* tiers_out /* [4]: seeds moved to the second tier, slabs used, seeds left to the ordered tail,
+                                        hold-back engaged */,
+                 bool* extra, hipStream_t s);
 
-// kernels_fit.hip
+// kernels_fit.hip (all counts stay on the device: launches cover seed_cap / comp_cap)
 size_t fit_temp_bytes(size_t max_pixels, uint32_t max_segments);
-int launch_component_offsets(const int32_t* seed_size, uint32_t n_seeds, int min_size, uint32_t* comp_rank,
-                             uint32_t* comp_seed, uint32_t* comp_off, uint32_t* totals /*[0]=n_comp,[1]=n_px*/,
-                             void* temp, size_t temp_bytes, hipStream_t s);
+int launch_component_offsets(const int32_t* seed_size, const uint32_t* d_n_seeds, uint32_t seed_cap, int min_size,
+                             uint32_t* comp_rank, uint32_t* comp_seed, uint32_t* comp_off,
+                             uint32_t* totals /*[0]=n_comp,[1]=n_px*/, uint32_t* large_list, uint32_t* n_large, void* temp,
+                             size_t temp_bytes, hipStream_t s);
 int launch_component_scatter(const uint32_t* label, size_t npix, const uint32_t* comp_rank, const uint32_t* comp_off,
                              uint32_t* cursor, uint32_t* px, hipStream_t s);
-int launch_component_sort(uint32_t* px_in, uint32_t* px_out, uint32_t n_px, uint32_t n_comp, const uint32_t* comp_off,
-                          int idx_bits, void* temp, size_t temp_bytes, hipStream_t s);
-int launch_fit(const uint32_t* px_sorted, const uint32_t* comp_off, const uint32_t* comp_seed, uint32_t n_comp,
-               const int32_t* seed_bin, const float* dx, const float* dy, int w, BinTrig trig, float* scratch_w,
-               LineSegment* out, hipStream_t s);
+// scratch: >= 2 x (pixels of the frame) words, used by lists of more than 4096 pixels only
+int launch_component_sort(const uint32_t* px_in, uint32_t* px_out, const uint32_t* comp_off, const uint32_t* d_n_comp,
+                          uint32_t comp_cap, const uint32_t* large_list, const uint32_t* n_large, uint32_t* scratch,
+                          hipStream_t s);
+int launch_fit(const uint32_t* px_sorted, const uint32_t* comp_off, const uint32_t* comp_seed, const uint32_t* d_n_comp,
+               uint32_t comp_cap, const int32_t* seed_bin, const float* dx, const float* dy, int w, BinTrig trig,
+               float* scratch_w, LineSegment* out, hipStream_t s);
 
 // kernels_ransac.hip
 struct PencilSoA {  // device pointers, n entries each (lines of the current round, compacted)
@@ -177,6 +206,38 @@ struct PencilSoA {  // device pointers, n entries each (lines of the current rou
 };
 int launch_ransac_score(PencilSoA m, uint32_t n, float tol, float degeneracy_tol, uint32_t n_iter, uint64_t seed,
                         uint32_t round, float* scores, hipStream_t s);
+int launch_ransac_score_dev(PencilSoA m, const uint32_t* gctl, int max_models, float tol, float degeneracy_tol,
+                            uint32_t n_iter, uint64_t seed, float* scores, hipStream_t s);
+
+// kernels_groups.hip: filter_lines and the vanishing-point peeling on the device
+struct PencilTable {  // PencilSoA plus the index of each entry in the frame's list of filtered lines
+    float* ax;
+    float* ay;
+    float* dx;
+    float* dy;
+    float* len;
+    float* hx;
+    float* hy;
+    float* hz;
+    uint32_t* orig;
+    PencilSoA soa() const { return PencilSoA{ax, ay, dx, dy, len, hx, hy, hz}; }
+};
+enum {  // words of the peeling control block
+    kGcLines = 0,      // filtered lines of the frame (the model's size)
+    kGcRemaining = 1,  // lines neither grouped nor garbage yet
+    kGcRound = 2,      // peeling rounds done
+    kGcActive = 3,     // lines in the compacted table of the coming round (== kGcRemaining)
+    kGcBestIter0 = 4,  // [4..7]: winning iteration of each round (diagnostics)
+    kGcWords = 8,
+};
+int launch_filter_lines(const LineSegment* raw, const uint32_t* d_n_raw, uint32_t raw_cap, float min_length,
+                        LineSegment* out, uint32_t* gctl, float* gnorm, hipStream_t s);
+int launch_lines_bbox(LineSegment* lines, uint32_t n, uint32_t* gctl, float* gnorm, hipStream_t s);
+int launch_pencil_model(const LineSegment* lines, const uint32_t* gctl, const float* gnorm, PencilTable all,
+                        PencilTable round0, uint32_t line_cap, hipStream_t s);
+int launch_peel(PencilTable cur, PencilTable nxt, PencilTable all, const float* scores, uint32_t n_iter, uint64_t seed,
+                float tol, float garbage_tol, int max_models, uint32_t* gctl, uint32_t* inl, LineSegment* lines,
+                float* models, hipStream_t s);
 int launch_ransac_argmax(const float* scores, uint32_t n_iter, float* best_score, int32_t* best_iter, hipStream_t s);
 int launch_cht_accumulate(PencilSoA m, uint32_t n, int d, unsigned long long* acc, hipStream_t s);
 // refine: seg = n records of 7 floats {x1,y1,x2,y2,dx,dy,len}; edges = pairs of uint32 (i<j); *n_edges may exceed cap

@@ -63,6 +63,27 @@ struct lr_context {
     LineSegment* d_lines = nullptr;
     void* temp = nullptr;
     size_t temp_bytes = 0;
+    uint32_t* comp_large = nullptr;  // components of more than 64 pixels (sorted by a workgroup each)
+    uint32_t seed_cap = 0;           // capacity the seed sort runs with (the seed count is not known when it is enqueued)
+    lramd::FloodProgress flood_prog;
+    // filter_lines + peeling on the device (kernels_groups.hip)
+    size_t cap_glines = 0, cap_flines = 0;
+    float* d_tables = nullptr;      // 3 pencil tables (all lines, two ping-pong round tables) x 8 arrays x cap_glines
+    uint32_t* d_orig = nullptr;     // 3 x cap_glines
+    uint32_t* d_inl = nullptr;      // cap_glines
+    LineSegment* d_flines = nullptr;  // filtered (then grouped) lines
+    uint32_t* d_gctl = nullptr;     // peeling control block (kGc*)
+    float* d_gnorm = nullptr;       // bounding-box centre and scale
+    float* d_models = nullptr;      // refit model of each round
+    uint8_t* h_res = nullptr;       // pinned: header (counts, control block, models) + the first res_lines_cap lines
+    size_t res_lines_cap = 0;
+    // grow-on-demand workspaces of the opt-in paths
+    float* d_refine_table = nullptr;
+    size_t cap_refine_table = 0;
+    void* d_refine_edges = nullptr;
+    size_t cap_refine_edges = 0;
+    unsigned long long* d_cht_acc = nullptr;
+    size_t cap_cht = 0;
     // RANSAC
     size_t cap_lines = 0;
     float* d_model = nullptr;  // 8 arrays of cap_lines
@@ -113,6 +134,7 @@ struct lr_context {
 };
 
 namespace lramd {
+constexpr size_t kResHeaderBytes = 256;
 int ctx_create(int device, lr_context** out);
 void ctx_destroy(lr_context* c);
 const std::string& get_error();

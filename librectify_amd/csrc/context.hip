@@ -82,7 +82,8 @@ int ctx_ensure_image_capacity(lr_context* c, int w, int h) {
         dev_alloc(c->seed_thr, cp) || dev_alloc(c->seed_size, cp) || dev_alloc(c->label, cp) ||
         dev_alloc(c->queue, cp) || dev_alloc(c->comp_rank, cp) || dev_alloc(c->comp_seed, cp) ||
         dev_alloc(c->comp_off, cp + 1) || dev_alloc(c->cursor, cp) || dev_alloc(c->px_a, cp) ||
-        dev_alloc(c->px_b, cp) || dev_alloc(c->scratch_w, cp) || dev_alloc(c->d_lines, cp / 6 + 16))
+        dev_alloc(c->px_b, cp) || dev_alloc(c->scratch_w, cp) || dev_alloc(c->d_lines, cp / 6 + 16) ||
+        dev_alloc(c->comp_large, cp / 64 + 16))
         return 1;
     const size_t tb = std::max(seeds_temp_bytes(ct, cp), fit_temp_bytes(cp, (uint32_t)std::min<size_t>(cp / 6 + 16, 0xFFFFFFFFu)));
     if (c->temp) (void)hipFree(c->temp);
@@ -100,7 +101,7 @@ static int ensure_flood_buffers(lr_context* c) {
     LR_HIP(hipStreamSynchronize(c->stream));
     const size_t cs = c->cap_pix;
     if (dev_alloc(f.blocked, cs) || dev_alloc(f.count, cs) || dev_alloc(f.flags, cs) || dev_alloc(f.state, cs) || dev_alloc(f.tier, cs) ||
-        dev_alloc(f.act_a, cs) || dev_alloc(f.act_b, cs) || dev_alloc(f.ctrl, 16) || dev_alloc(f.big_list, 8192))
+        dev_alloc(f.act_a, cs) || dev_alloc(f.act_b, cs) || dev_alloc(f.ctrl, kFloodCtrlWords) || dev_alloc(f.big_list, 8192))
         return 1;
     f.n_slabs = 128;  // 128 x 2.25 MB = 288 MB; only walks over ~1500 tiles (both LDS tiers outgrown) get here
     if (const char* e = std::getenv("LIBRECTIFY_FLOOD_SLABS")) f.n_slabs = (uint32_t)std::max(1, std::atoi(e));
@@ -115,7 +116,7 @@ static int ensure_flood_buffers(lr_context* c) {
         f.slab_hash = hsh;
     }
     LR_HIP(hipMemsetAsync(f.slab_hash, 0, (size_t)f.n_slabs * f.slab_hash_cap * 32, c->stream));
-    LR_HIP(hipMemsetAsync(f.ctrl, 0, 16 * sizeof(uint32_t), c->stream));
+    LR_HIP(hipMemsetAsync(f.ctrl, 0, kFloodCtrlWords * sizeof(uint32_t), c->stream));
     c->fb_cap_seeds = cs;
     return 0;
 }
@@ -274,6 +275,11 @@ int ctx_create(int device, lr_context** out) {
     for (auto& e : c->ev_up) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
     (void)hipMalloc((void**)&c->maxmag, sizeof(float));
     (void)hipMalloc((void**)&c->d_counts, 64 * sizeof(uint32_t));
+    (void)hipMalloc((void**)&c->d_gctl, kGcWords * sizeof(uint32_t));
+    (void)hipMalloc((void**)&c->d_gnorm, 4 * sizeof(float));
+    (void)hipMalloc((void**)&c->d_models, 16 * sizeof(float));
+    (void)hipMemset(c->d_models, 0, 16 * sizeof(float));
+    (void)hipMemset(c->d_counts, 0, 64 * sizeof(uint32_t));
     (void)hipMalloc((void**)&c->d_best_score, sizeof(float));
     (void)hipMalloc((void**)&c->d_best_iter, sizeof(int32_t));
     (void)hipHostMalloc((void**)&c->h_counts, 64 * sizeof(uint32_t));
@@ -299,7 +305,8 @@ void ctx_destroy(lr_context* c) {
                     c->scratch_w, c->d_lines, c->temp, c->d_model, c->d_scores, c->d_best_score, c->d_best_iter,
                     c->fb.blocked, c->fb.count, c->fb.flags, c->fb.state, c->fb.tier, c->fb.act_a, c->fb.act_b,
                     c->fb.ctrl, c->fb.big_list, c->fb.slab_ring, c->fb.slab_hash, c->d_pairs, c->d_peak, c->d_weights,
-                    c->d_samples, c->d_hcounts};
+                    c->d_samples, c->d_hcounts, c->comp_large, c->d_tables, c->d_orig, c->d_inl, c->d_flines, c->d_gctl,
+                    c->d_gnorm, c->d_models, c->d_refine_table, c->d_refine_edges, c->d_cht_acc};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     (void)hipStreamSynchronize(c->copy_stream);
@@ -308,6 +315,7 @@ void ctx_destroy(lr_context* c) {
     for (auto& e : c->ev_up)
         if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->copy_stream);
+    if (c->h_res) (void)hipHostFree(c->h_res);
     if (c->h_model) (void)hipHostFree(c->h_model);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
     if (c->h_best) (void)hipHostFree(c->h_best);
@@ -322,14 +330,98 @@ void ctx_destroy(lr_context* c) {
 }
 
 // ---- stages ------------------------------------------------------------------------------
+//
+// Every stage is an "enqueue" function that launches its kernels on the context stream and never waits: seed,
+// component, pixel and line counts stay in device memory (d_counts, d_gctl) and the kernels read them there;
+// launches cover capacities (seed_cap, line_cap) chosen before the counts exist.  The frame driver (run_frame) enqueues
+// all stages back to back and synchronises once; the staged API (lr_stage_*) wraps one enqueue function each and waits
+// for it, because its callers want the counts.
 
-int ctx_stage_filter(lr_context* c, const float* d_image, int w, int h, int stride) {
+namespace {
+
+// d_counts words
+enum { kCntSeeds = 0, kCntComp = 1, kCntPx = 2, kCntLarge = 4 };
+
+uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
+
+// capacity of the seed sort for a frame of this size when nothing better is known: one seed per 32 pixels (the
+// synthetic 4K frame has one per 204, the reference's doc image one per 85)
+uint32_t initial_seed_cap(size_t npix) {
+    return (uint32_t)std::min<size_t>(npix, std::max<size_t>(round_up((uint32_t)(npix / 32), 1024), 4096));
+}
+
+uint32_t line_cap_for(const lr_context* c) {
+    return (uint32_t)std::min<size_t>(c->seed_cap, c->cap_pix / 6 + 16);
+}
+
+int ensure_group_capacity(lr_context* c, size_t n_lines, size_t n_iter) {
+    if (n_lines > c->cap_glines) {
+        LR_HIP(hipStreamSynchronize(c->stream));
+        const size_t cl = std::max<size_t>(n_lines, 4096);
+        if (dev_alloc(c->d_tables, 3 * 8 * cl) || dev_alloc(c->d_orig, 3 * cl) || dev_alloc(c->d_inl, cl)) return 1;
+        c->cap_glines = cl;
+    }
+    if (n_lines > c->cap_flines) {
+        LR_HIP(hipStreamSynchronize(c->stream));
+        if (dev_alloc(c->d_flines, n_lines + 16)) return 1;
+        c->cap_flines = n_lines + 16;
+    }
+    if (n_iter > c->cap_iter) {
+        LR_HIP(hipStreamSynchronize(c->stream));
+        const size_t ci = std::max<size_t>(n_iter, 16384);
+        if (dev_alloc(c->d_scores, ci)) return 1;
+        c->cap_iter = ci;
+    }
+    return 0;
+}
+
+PencilTable table_of(lr_context* c, int which) {
+    const size_t cl = c->cap_glines;
+    float* b = c->d_tables + (size_t)which * 8 * cl;
+    return PencilTable{b, b + cl, b + 2 * cl, b + 3 * cl, b + 4 * cl, b + 5 * cl, b + 6 * cl, b + 7 * cl,
+                       c->d_orig + (size_t)which * cl};
+}
+
+int ensure_result_block(lr_context* c, size_t lines) {
+    if (lines <= c->res_lines_cap && c->h_res) return 0;
+    LR_HIP(hipStreamSynchronize(c->stream));
+    if (c->h_res) (void)hipHostFree(c->h_res);
+    c->h_res = nullptr;
+    LR_HIP(hipHostMalloc((void**)&c->h_res, kResHeaderBytes + lines * sizeof(LineSegment)));
+    c->res_lines_cap = lines;
+    return 0;
+}
+
+FloodBuffers flood_buffers_for(lr_context* c) {
+    FloodBuffers fbuf = c->fb;
+    // test hooks: 2 and 3 exercise the slab and exhausted-storage paths (no second LDS tier, no / two slabs),
+    // 4 the slab path with the full pool, 5 a stall during the hold-back
+    if (c->flood_mode >= 2 && c->flood_mode <= 4) fbuf.second_tier = false;
+    fbuf.second_tier_from_start = c->flood_big_hint;
+    fbuf.hold_from_start = c->flood_hold_hint;
+    if (c->flood_mode == 2) fbuf.n_slabs = 0;
+    if (c->flood_mode == 3) fbuf.n_slabs = 2;
+    if (c->flood_mode == 5) {  // second tier with room for one seed per round and no slab: the rounds stall while
+        fbuf.n_slabs = 0;      // the weakest seeds are held back, and must still hand over to the ordered tail
+        fbuf.big_cap_override = 1;
+    }
+    if (c->flood_staged) fbuf.win_first_shift = 3;
+    return fbuf;
+}
+
+FloodFrame flood_frame_for(lr_context* c) {
+    return FloodFrame{c->dx, c->dy, c->dmask, c->w, c->h, c->seed_idx, c->seed_bin, c->seed_thr,
+                      c->d_counts + kCntSeeds, c->seed_cap, c->trig, c->label, c->seed_size, c->queue};
+}
+
+int enqueue_filter(lr_context* c, const float* d_image, int w, int h, int stride) {
     LR_HIP(hipSetDevice(c->device));
     if (w < 5 || h < 5) {
         set_error("image smaller than the 5x5 filter");
         return 1;
     }
     if (ctx_ensure_image_capacity(c, w, h)) return 1;
+    if (c->w != w || c->h != h || c->seed_cap == 0) c->seed_cap = initial_seed_cap((size_t)w * h);
     c->w = w;
     c->h = h;
     c->n_seeds = c->n_comp = c->n_px = 0;
@@ -340,113 +432,109 @@ int ctx_stage_filter(lr_context* c, const float* d_image, int w, int h, int stri
                       c->stream))
         return 1;
     LR_HIP(hipEventRecord(c->ev[1], c->stream));
-    c->stage_valid[0] = true;
     return 0;
 }
 
-int ctx_stage_seeds(lr_context* c) {
-    if (!c->stage_valid[0]) {
-        set_error("lr_stage_seeds: run lr_stage_filter first");
-        return 1;
-    }
+int enqueue_seeds(lr_context* c) {
     const FilterGeom fg = filter_geometry(c->w, c->h);
-    if (launch_seed_select(c->cand, c->cand_count, c->tile_max, fg.n_tiles, fg.cand_cap, c->seed_keep_ratio, c->maxmag, c->tile_pass,
-                           c->tile_off, c->keys_a, c->d_counts, c->temp, c->temp_bytes, c->stream))
+    if (launch_seed_select(c->cand, c->cand_count, c->tile_max, fg.n_tiles, fg.cand_cap, c->seed_keep_ratio, c->maxmag,
+                           c->tile_pass, c->tile_off, c->keys_a, c->seed_cap, c->d_counts + kCntSeeds, c->temp,
+                           c->temp_bytes, c->stream))
         return 1;
-    LR_HIP(hipMemcpyAsync(c->h_counts, c->d_counts, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    LR_HIP(hipStreamSynchronize(c->stream));
-    c->n_seeds = c->h_counts[0];
-    if (launch_seed_sort(c->keys_a, c->keys_b, c->n_seeds, c->temp, c->temp_bytes, c->stream)) return 1;
-    if (launch_seed_setup(c->keys_b, c->n_seeds, c->dx, c->dy, c->trig, kTraceTolerance, c->seed_idx, c->seed_bin,
-                          c->seed_thr, c->stream))
+    if (launch_seed_sort(c->keys_a, c->keys_b, c->seed_cap, c->temp, c->temp_bytes, c->stream)) return 1;
+    if (launch_seed_setup(c->keys_b, c->d_counts + kCntSeeds, c->seed_cap, c->dx, c->dy, c->trig, kTraceTolerance,
+                          c->seed_idx, c->seed_bin, c->seed_thr, c->stream))
         return 1;
     LR_HIP(hipEventRecord(c->ev[2], c->stream));
-    c->stage_valid[1] = true;
     return 0;
 }
 
-int ctx_stage_flood(lr_context* c) {
-    if (!c->stage_valid[1]) {
-        set_error(c->dmask_consumed ? "lr_stage_flood: the previous flood consumed the filter output; run lr_stage_filter and lr_stage_seeds again"
-                                    : "lr_stage_flood: run lr_stage_seeds first");
-        return 1;
-    }
+// the flood's rounds, blindly (parallel modes) or the single-wave ordered kernel (mode 0)
+int enqueue_flood(lr_context* c) {
     const size_t npix = (size_t)c->w * c->h;
     if (launch_label_init(c->label, npix, c->stream)) return 1;
     c->flood_rounds = 1;
     if (c->flood_mode == 0) {
         if (launch_flood_ordered(c->dx, c->dy, c->dmask, c->w, c->h, c->seed_idx, c->seed_bin, c->seed_thr,
-                                 c->n_seeds, c->trig, c->label, c->seed_size, c->queue, c->stream))
+                                 c->d_counts + kCntSeeds, c->seed_cap, c->trig, c->label, c->seed_size, c->queue, c->stream))
             return 1;
     } else {
         if (ensure_flood_buffers(c)) return 1;
-        FloodBuffers fbuf = c->fb;
-        // test hooks: 2 and 3 exercise the slab and exhausted-storage paths (no second LDS tier, no / two slabs),
-        // 4 the slab path with the full pool, 5 a stall during the hold-back
-        if (c->flood_mode >= 2 && c->flood_mode <= 4) fbuf.second_tier = false;
-        fbuf.second_tier_from_start = c->flood_big_hint;
-        fbuf.hold_from_start = c->flood_hold_hint;
-        if (c->flood_mode == 2) fbuf.n_slabs = 0;
-        if (c->flood_mode == 3) fbuf.n_slabs = 2;
-        if (c->flood_mode == 5) {  // second tier with room for one seed per round and no slab: the rounds stall while
-            fbuf.n_slabs = 0;      // the weakest seeds are held back, and must still hand over to the ordered tail
-            fbuf.big_cap_override = 1;
-        }
-        if (c->flood_staged) fbuf.win_first_shift = 3;
-        if (flood_parallel(fbuf, c->dx, c->dy, c->dmask, c->w, c->h, c->seed_idx, c->seed_bin, c->seed_thr,
-                           c->n_seeds, c->trig, c->label, c->seed_size, c->queue, c->h_counts + 16, &c->flood_rounds,
-                           c->flood_tiers, c->stream, [](void* p) { ctx_run_prefetch(static_cast<lr_context*>(p)); }, c))
-            return 1;
-        c->flood_big_hint = c->flood_tiers[0] > 0 || c->flood_tiers[1] > 0;
-        c->flood_hold_hint = c->flood_tiers[3] != 0;
-        // the commit pass has cleared the direction mask of every labelled pixel (kernels_flood.hip): the filter
+        if (flood_enqueue(flood_buffers_for(c), flood_frame_for(c), &c->flood_prog, c->h_counts + 16, c->stream)) return 1;
+        // the commit pass clears the direction mask of every labelled pixel (kernels_flood.hip): the filter
         // output is consumed, a second flood needs lr_stage_filter + lr_stage_seeds again
         c->stage_valid[0] = c->stage_valid[1] = false;
         c->dmask_consumed = true;
     }
     LR_HIP(hipEventRecord(c->ev[3], c->stream));
-    c->stage_valid[2] = true;
     return 0;
 }
 
-int ctx_stage_fit(lr_context* c, std::vector<LineSegment>& out) {
-    if (!c->stage_valid[2]) {
-        set_error("lr_stage_fit: run lr_stage_flood first");
+// After a synchronisation: did the blind rounds finish the flood?  If not, finish it now (synchronises).
+int finish_flood(lr_context* c, bool* extra) {
+    *extra = false;
+    if (c->flood_mode == 0) return 0;
+    if (flood_finish(flood_buffers_for(c), flood_frame_for(c), &c->flood_prog, c->h_counts + 16, &c->flood_rounds,
+                     c->flood_tiers, extra, c->stream))
         return 1;
-    }
-    out.clear();
+    c->flood_big_hint = c->flood_tiers[0] > 0 || c->flood_tiers[1] > 0;
+    c->flood_hold_hint = c->flood_tiers[3] != 0;
+    return 0;
+}
+
+int enqueue_fit(lr_context* c) {
     const size_t npix = (size_t)c->w * c->h;
-    c->n_comp = c->n_px = 0;
-    if (c->n_seeds > 0) {
-        if (launch_component_offsets(c->seed_size, c->n_seeds, kComponentMinSize, c->comp_rank, c->comp_seed,
-                                     c->comp_off, c->d_counts + 1, c->temp, c->temp_bytes, c->stream))
-            return 1;
-        LR_HIP(hipMemcpyAsync(c->h_counts + 1, c->d_counts + 1, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        LR_HIP(hipStreamSynchronize(c->stream));
-        c->n_comp = c->h_counts[1];
-        c->n_px = c->h_counts[2];
-    }
-    if (c->n_comp > 0) {
-        if ((size_t)c->n_comp > c->cap_pix / 6 + 16) {
-            set_error("component count exceeds workspace");
-            return 1;
-        }
-        LR_HIP(hipMemsetAsync(c->cursor, 0, (size_t)c->n_comp * sizeof(uint32_t), c->stream));
-        if (launch_component_scatter(c->label, npix, c->comp_rank, c->comp_off, c->cursor, c->px_a, c->stream)) return 1;
-        if (launch_component_sort(c->px_a, c->px_b, c->n_px, c->n_comp, c->comp_off, idx_bits_for(npix), c->temp,
-                                  c->temp_bytes, c->stream))
-            return 1;
-        if (launch_fit(c->px_b, c->comp_off, c->comp_seed, c->n_comp, c->seed_bin, c->dx, c->dy, c->w, c->trig,
-                       c->scratch_w, c->d_lines, c->stream))
-            return 1;
-        out.resize(c->n_comp);
-        LR_HIP(hipMemcpyAsync(out.data(), c->d_lines, (size_t)c->n_comp * sizeof(LineSegment), hipMemcpyDeviceToHost,
-                              c->stream));
-    }
+    const uint32_t comp_cap = line_cap_for(c);
+    if (launch_component_offsets(c->seed_size, c->d_counts + kCntSeeds, c->seed_cap, kComponentMinSize, c->comp_rank,
+                                 c->comp_seed, c->comp_off, c->d_counts + kCntComp, c->comp_large, c->d_counts + kCntLarge,
+                                 c->temp, c->temp_bytes, c->stream))
+        return 1;
+    LR_HIP(hipMemsetAsync(c->cursor, 0, (size_t)comp_cap * sizeof(uint32_t), c->stream));
+    if (launch_component_scatter(c->label, npix, c->comp_rank, c->comp_off, c->cursor, c->px_a, c->stream)) return 1;
+    // (the sorted seed keys are dead once the seeds are set up: their buffer is the large lists' sorting scratch)
+    if (launch_component_sort(c->px_a, c->px_b, c->comp_off, c->d_counts + kCntComp, comp_cap, c->comp_large,
+                              c->d_counts + kCntLarge, reinterpret_cast<uint32_t*>(c->keys_b), c->stream))
+        return 1;
+    if (launch_fit(c->px_b, c->comp_off, c->comp_seed, c->d_counts + kCntComp, comp_cap, c->seed_bin, c->dx, c->dy, c->w,
+                   c->trig, c->scratch_w, c->d_lines, c->stream))
+        return 1;
     LR_HIP(hipEventRecord(c->ev[4], c->stream));
-    ctx_run_prefetch(c);  // (if the flood had no wait of its own)
-    LR_HIP(hipStreamSynchronize(c->stream));
-    c->stage_valid[3] = true;
+    return 0;
+}
+
+// estimate_line_pencils (line_pencil.cpp:148-177) on the lines in d_flines, whose count, bounding box and control
+// words a filter_lines / lines_bbox launch has left in d_gctl / d_gnorm.
+int enqueue_groups(lr_context* c, uint32_t line_cap, int max_models, float inlier_deg, float garbage_deg, int n_iter,
+                   uint64_t seed) {
+    const float tol = cos_threshold(inlier_deg), garbage_tol = cos_threshold(garbage_deg);
+    const PencilTable all = table_of(c, 0);
+    PencilTable tab[2] = {table_of(c, 1), table_of(c, 2)};
+    if (launch_pencil_model(c->d_flines, c->d_gctl, c->d_gnorm, all, tab[0], line_cap, c->stream)) return 1;
+    const float degeneracy_tol = 0.05f;  // line_pencil.h:25
+    for (int k = 0; k < max_models; ++k) {
+        if (n_iter > 0 &&
+            launch_ransac_score_dev(tab[k & 1].soa(), c->d_gctl, max_models, tol, degeneracy_tol, (uint32_t)n_iter, seed,
+                                    c->d_scores, c->stream))
+            return 1;
+        if (launch_peel(tab[k & 1], tab[(k + 1) & 1], all, c->d_scores, (uint32_t)std::max(n_iter, 0), seed, tol, garbage_tol,
+                        max_models, c->d_gctl, c->d_inl, c->d_flines, c->d_models, c->stream))
+            return 1;
+    }
+    return 0;
+}
+
+// header (counts, peeling control block, refit models) and the first res_lines_cap grouped lines -> pinned host block
+int enqueue_result_copy(lr_context* c) {
+    uint8_t* h = c->h_res;
+    LR_HIP(hipMemcpyAsync(h, c->d_counts, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    LR_HIP(hipMemcpyAsync(h + 32, c->d_gctl, kGcWords * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    LR_HIP(hipMemcpyAsync(h + 64, c->d_models, 12 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    const size_t nl = std::min<size_t>(c->res_lines_cap, c->cap_flines);
+    LR_HIP(hipMemcpyAsync(h + kResHeaderBytes, c->d_flines, nl * sizeof(LineSegment), hipMemcpyDeviceToHost, c->stream));
+    return 0;
+}
+
+void record_stage_times(lr_context* c, bool with_groups) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
     c->stage_ms[LR_T_FILTER] = ms;
@@ -457,6 +545,87 @@ int ctx_stage_fit(lr_context* c, std::vector<LineSegment>& out) {
     c->stage_ms[LR_T_FLOOD] = ms;
     (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]);
     c->stage_ms[LR_T_FIT] = ms;
+    if (with_groups) {
+        (void)hipEventElapsedTime(&ms, c->ev[5], c->ev[6]);
+        c->stage_ms[LR_T_RANSAC] = ms;
+        (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[6]);
+        c->stage_ms[LR_T_TOTAL] = ms;
+    }
+}
+
+// the seed sort's capacity follows the frames: grown at once when a frame overflows it (that frame is repeated),
+// shrunk slowly when frames use a small part of it
+void adapt_seed_cap(lr_context* c, uint32_t n_seeds) {
+    const size_t npix = (size_t)c->w * c->h;
+    if (n_seeds > c->seed_cap) {
+        c->seed_cap = (uint32_t)std::min<size_t>(npix, round_up(n_seeds + n_seeds / 2, 1024));
+    } else if (c->seed_cap > 4096 && n_seeds < c->seed_cap / 8) {
+        c->seed_cap = std::max<uint32_t>(4096, round_up(c->seed_cap / 2, 1024));
+    }
+}
+
+}  // namespace
+
+int ctx_stage_filter(lr_context* c, const float* d_image, int w, int h, int stride) {
+    if (enqueue_filter(c, d_image, w, h, stride)) return 1;
+    c->stage_valid[0] = true;
+    return 0;
+}
+
+int ctx_stage_seeds(lr_context* c) {
+    if (!c->stage_valid[0]) {
+        set_error("lr_stage_seeds: run lr_stage_filter first");
+        return 1;
+    }
+    for (int attempt = 0;; ++attempt) {
+        if (enqueue_seeds(c)) return 1;
+        LR_HIP(hipMemcpyAsync(c->h_counts, c->d_counts, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        LR_HIP(hipStreamSynchronize(c->stream));
+        c->n_seeds = c->h_counts[0];
+        if (c->n_seeds <= c->seed_cap) break;
+        if (attempt > 0) {
+            set_error("seed count exceeds the sort capacity twice");
+            return 1;
+        }
+        adapt_seed_cap(c, c->n_seeds);  // more seeds than the sort was sized for: again with room
+    }
+    c->stage_valid[1] = true;
+    return 0;
+}
+
+int ctx_stage_flood(lr_context* c) {
+    if (!c->stage_valid[1]) {
+        set_error(c->dmask_consumed ? "lr_stage_flood: the previous flood consumed the filter output; run lr_stage_filter and lr_stage_seeds again"
+                                    : "lr_stage_flood: run lr_stage_seeds first");
+        return 1;
+    }
+    if (enqueue_flood(c)) return 1;
+    LR_HIP(hipStreamSynchronize(c->stream));
+    bool extra;
+    if (finish_flood(c, &extra)) return 1;
+    c->stage_valid[2] = true;
+    return 0;
+}
+
+int ctx_stage_fit(lr_context* c, std::vector<LineSegment>& out) {
+    if (!c->stage_valid[2]) {
+        set_error("lr_stage_fit: run lr_stage_flood first");
+        return 1;
+    }
+    out.clear();
+    if (enqueue_fit(c)) return 1;
+    LR_HIP(hipMemcpyAsync(c->h_counts, c->d_counts, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    LR_HIP(hipStreamSynchronize(c->stream));
+    c->n_comp = c->h_counts[kCntComp];
+    c->n_px = c->h_counts[kCntPx];
+    if (c->n_comp > 0) {
+        out.resize(c->n_comp);
+        LR_HIP(hipMemcpyAsync(out.data(), c->d_lines, (size_t)c->n_comp * sizeof(LineSegment), hipMemcpyDeviceToHost,
+                              c->stream));
+        LR_HIP(hipStreamSynchronize(c->stream));
+    }
+    c->stage_valid[3] = true;
+    record_stage_times(c, false);
     return 0;
 }
 
@@ -512,49 +681,18 @@ int ctx_ransac_best(lr_context* c, const PencilModel& model, const std::vector<i
     return 0;
 }
 
-// estimate_multiple_structures (estimator.h:99-145) around the GPU scorer.
+// estimate_line_pencils (line_pencil.cpp:148-177) for lines the host holds: upload, peel on the device, download.
 int ctx_estimate_line_pencils(lr_context* c, std::vector<LineSegment>& lines, int max_models, float inlier_deg,
                               float garbage_deg, int n_iter, uint64_t seed) {
     if (lines.empty()) return 0;
-    const Normalisation nrm = bbox_normalisation(lines);
-    const PencilModel model(normalise(lines, nrm));
-    const float tol = cos_threshold(inlier_deg);
-    const float garbage_tol = cos_threshold(garbage_deg);
-    const int N = model.size();
-    std::vector<int> inlier_flag(N, -1), garbage_flag(N, 0);
-    int remaining = N;
-    int k = 0;
-    while (remaining >= 2 && k < max_models) {
-        std::vector<int> obs;
-        obs.reserve(remaining);
-        for (int i = 0; i < N; ++i)
-            if (inlier_flag[i] < 0 && garbage_flag[i] == 0) obs.push_back(i);
-        Vec3 best_h;
-        float best_score;
-        int best_iter;
-        if (ctx_ransac_best(c, model, obs, tol, n_iter, seed, (uint32_t)k, &best_h, &best_score, &best_iter)) return 1;
-        std::vector<int> inl;  // estimator.h:74-76: refit on the inliers of the best hypothesis
-        for (int i : obs)
-            if (model.error(best_h, i) < tol) inl.push_back(i);
-        const Vec3 hfit = model.fit_optimal(inl);
-        int n_in = 0, n_gb = 0;
-        for (int i : obs) {
-            const float e = model.error(hfit, i);
-            if (e < tol) {
-                inlier_flag[i] = k;
-                ++n_in;
-            } else if (e >= tol && e < garbage_tol) {
-                garbage_flag[i] = 1;
-                ++n_gb;
-            }
-        }
-        remaining -= n_in + n_gb;
-        ++k;
-    }
-    for (int i = 0; i < N; ++i) {
-        if (garbage_flag[i] == 1) inlier_flag[i] = -1;
-        lines[i].group_id = inlier_flag[i];
-    }
+    LR_HIP(hipSetDevice(c->device));
+    const size_t n = lines.size();
+    if (ensure_group_capacity(c, n, (size_t)std::max(n_iter, 1))) return 1;
+    LR_HIP(hipMemcpyAsync(c->d_flines, lines.data(), n * sizeof(LineSegment), hipMemcpyHostToDevice, c->stream));
+    if (launch_lines_bbox(c->d_flines, (uint32_t)n, c->d_gctl, c->d_gnorm, c->stream)) return 1;
+    if (enqueue_groups(c, (uint32_t)n, max_models, inlier_deg, garbage_deg, n_iter, seed)) return 1;
+    LR_HIP(hipMemcpyAsync(lines.data(), c->d_flines, n * sizeof(LineSegment), hipMemcpyDeviceToHost, c->stream));
+    LR_HIP(hipStreamSynchronize(c->stream));
     return 0;
 }
 
@@ -836,13 +974,16 @@ int ctx_cht_vanishing_point(lr_context* c, const std::vector<LineSegment>& lines
     for (int i = 0; i < model.size(); ++i) all[i] = i;
     PencilSoA soa;
     if (upload_model(c, model, all, &soa)) return 1;
-    unsigned long long* d_acc = nullptr;
-    LR_HIP(hipMalloc((void**)&d_acc, (size_t)d * d * sizeof(unsigned long long)));
-    if (launch_cht_accumulate(soa, (uint32_t)model.size(), d, d_acc, c->stream)) return 1;
-    std::vector<uint64_t> acc((size_t)d * d);
+    const size_t cells = (size_t)d * d;
+    if (cells > c->cap_cht) {  // accumulator kept in the context (no allocation on the path of a call)
+        LR_HIP(hipStreamSynchronize(c->stream));
+        if (dev_alloc(c->d_cht_acc, cells)) return 1;
+        c->cap_cht = cells;
+    }
+    if (launch_cht_accumulate(soa, (uint32_t)model.size(), d, c->d_cht_acc, c->stream)) return 1;
+    std::vector<uint64_t> acc(cells);
+    LR_HIP(hipMemcpyAsync(acc.data(), c->d_cht_acc, acc.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
     LR_HIP(hipStreamSynchronize(c->stream));
-    LR_HIP(hipMemcpy(acc.data(), d_acc, acc.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    (void)hipFree(d_acc);
     size_t best = 0;
     for (size_t i = 1; i < acc.size(); ++i)
         if (acc[i] > acc[best]) best = i;
@@ -873,52 +1014,132 @@ int ctx_refine(lr_context* c, std::vector<LineSegment>& lines) {
     LR_HIP(hipSetDevice(c->device));
     std::vector<float> table;
     refine_segment_table(lines, table);
-    float* d_table = nullptr;
-    uint2* d_edges = nullptr;
-    size_t cap = 16 * n;
+    // segment table and edge list live in the context and grow on demand (no allocation on the path of a call)
+    if (table.size() > c->cap_refine_table) {
+        LR_HIP(hipStreamSynchronize(c->stream));
+        if (dev_alloc(c->d_refine_table, table.size())) return 1;
+        c->cap_refine_table = table.size();
+    }
+    size_t cap = std::max<size_t>(16 * n, c->cap_refine_edges);
     std::vector<std::pair<uint32_t, uint32_t>> edges;
-    LR_HIP(hipMalloc((void**)&d_table, table.size() * sizeof(float)));
-    LR_HIP(hipMemcpyAsync(d_table, table.data(), table.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    static_assert(sizeof(std::pair<uint32_t, uint32_t>) == sizeof(uint2), "edge layout");
+    LR_HIP(hipMemcpyAsync(c->d_refine_table, table.data(), table.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     for (;;) {
-        LR_HIP(hipMalloc((void**)&d_edges, cap * sizeof(uint2)));
+        if (cap > c->cap_refine_edges) {
+            LR_HIP(hipStreamSynchronize(c->stream));
+            uint2* e = static_cast<uint2*>(c->d_refine_edges);
+            if (dev_alloc(e, cap)) return 1;
+            c->d_refine_edges = e;
+            c->cap_refine_edges = cap;
+        }
         LR_HIP(hipMemsetAsync(c->d_counts + 8, 0, sizeof(uint32_t), c->stream));
-        if (launch_refine_pairs(d_table, (uint32_t)n, d_edges, c->d_counts + 8, (uint32_t)std::min<size_t>(cap, 0xFFFFFFFFu), c->stream)) return 1;
+        if (launch_refine_pairs(c->d_refine_table, (uint32_t)n, c->d_refine_edges, c->d_counts + 8,
+                                (uint32_t)std::min<size_t>(c->cap_refine_edges, 0xFFFFFFFFu), c->stream))
+            return 1;
         LR_HIP(hipMemcpyAsync(c->h_counts + 8, c->d_counts + 8, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         LR_HIP(hipStreamSynchronize(c->stream));
         const size_t ne = c->h_counts[8];
-        if (ne <= cap) {
+        if (ne <= c->cap_refine_edges) {
             edges.resize(ne);
-            static_assert(sizeof(std::pair<uint32_t, uint32_t>) == sizeof(uint2), "edge layout");
-            LR_HIP(hipMemcpy(edges.data(), d_edges, ne * sizeof(uint2), hipMemcpyDeviceToHost));
-            (void)hipFree(d_edges);
+            if (ne) {
+                LR_HIP(hipMemcpyAsync(edges.data(), c->d_refine_edges, ne * sizeof(uint2), hipMemcpyDeviceToHost, c->stream));
+                LR_HIP(hipStreamSynchronize(c->stream));
+            }
             break;
         }
-        (void)hipFree(d_edges);
         cap = ne;  // the kernel counted every edge: exactly enough next time
     }
-    (void)hipFree(d_table);
     lines = refine_lines_from_edges(lines, edges);
     return 0;
 }
 
 // find_line_segment_groups (interface.cpp:35-80) on a device-resident image.
-static int find_groups_device_impl(lr_context* c, const float* d_image, int w, int h, int stride, float min_length,
-                                   bool refine, std::vector<LineSegment>& out);
-
-int ctx_find_groups_device(lr_context* c, const float* d_image, int w, int h, int stride, float min_length, bool refine,
-                           std::vector<LineSegment>& out) {
-    const int rc = find_groups_device_impl(c, d_image, w, h, stride, min_length, refine, out);
-    if (rc) c->prefetch = nullptr;
-    ctx_run_prefetch(c);  // a frame that ended before its first long wait (nothing found)
-    return rc;
-}
-
-static int find_groups_device_impl(lr_context* c, const float* d_image, int w, int h, int stride, float min_length,
-                                   bool refine, std::vector<LineSegment>& out) {
+//
+// Default path (RANSAC, refine off): every stage of the frame -- filter, seeds, flood rounds, line fit, filter_lines,
+// the four peeling rounds -- is enqueued without a single host round trip, then the counts and the grouped lines come
+// back in one copy and the host waits ONCE.  Two things can make a frame take a second lap, both rare and both
+// detected from that copy: more seeds than the seed sort was sized for (the frame is repeated with room), and a flood
+// that needs more rounds than were enqueued blindly (the rounds are completed, the stages after the flood repeated).
+// With refine or PROSAC the raw segments go to the host after the fit, as before.
+static int run_frame(lr_context* c, const float* d_image, int w, int h, int stride, float min_length, bool refine,
+                     std::vector<LineSegment>& out) {
     out.clear();
-    std::vector<LineSegment> raw;
-    if (ctx_detect(c, d_image, w, h, stride, raw)) return 1;
-    if (raw.size() < 2) return 0;
+    const bool fused = !refine && c->estimator == 0;
+    const int n_iter = c->ransac_iters;
+    auto groups_after_fit = [&]() -> int {
+        const uint32_t lc = line_cap_for(c);
+        if (ensure_group_capacity(c, lc, (size_t)std::max(n_iter, 1))) return 1;
+        if (ensure_result_block(c, std::max<size_t>(c->res_lines_cap, 4096))) return 1;
+        LR_HIP(hipEventRecord(c->ev[5], c->stream));
+        if (launch_filter_lines(c->d_lines, c->d_counts + kCntComp, lc, min_length, c->d_flines, c->d_gctl, c->d_gnorm,
+                                c->stream))
+            return 1;
+        if (enqueue_groups(c, lc, kMaxModels, kInlierDeg, kGarbageDeg, n_iter, c->ransac_seed)) return 1;
+        LR_HIP(hipEventRecord(c->ev[6], c->stream));
+        return enqueue_result_copy(c);
+    };
+    for (int attempt = 0;; ++attempt) {
+        if (enqueue_filter(c, d_image, w, h, stride)) return 1;
+        if (enqueue_seeds(c)) return 1;
+        if (enqueue_flood(c)) return 1;
+        if (enqueue_fit(c)) return 1;
+        if (fused) {
+            if (groups_after_fit()) return 1;
+        } else {
+            LR_HIP(hipMemcpyAsync(c->h_counts, c->d_counts, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        }
+        ctx_run_prefetch(c);  // everything is enqueued: the lane stages its next frame while the GPU works
+        LR_HIP(hipStreamSynchronize(c->stream));
+        const uint32_t* cnt = fused ? reinterpret_cast<const uint32_t*>(c->h_res) : c->h_counts;
+        c->n_seeds = cnt[kCntSeeds];
+        if (c->n_seeds <= c->seed_cap) break;
+        if (attempt > 0) {
+            set_error("seed count exceeds the sort capacity twice");
+            return 1;
+        }
+        adapt_seed_cap(c, c->n_seeds);
+    }
+    bool extra = false;
+    if (finish_flood(c, &extra)) return 1;
+    if (extra) {  // the label image changed after the fit ran: the stages after the flood again
+        if (enqueue_fit(c)) return 1;
+        if (fused) {
+            if (groups_after_fit()) return 1;
+        } else {
+            LR_HIP(hipMemcpyAsync(c->h_counts, c->d_counts, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        }
+        LR_HIP(hipStreamSynchronize(c->stream));
+    }
+    const uint32_t* cnt = fused ? reinterpret_cast<const uint32_t*>(c->h_res) : c->h_counts;
+    c->n_comp = cnt[kCntComp];
+    c->n_px = cnt[kCntPx];
+    adapt_seed_cap(c, c->n_seeds);
+    c->stage_valid[0] = c->stage_valid[1] = false;
+    c->stage_valid[2] = c->stage_valid[3] = true;
+    if (fused) {
+        const uint32_t* gctl = reinterpret_cast<const uint32_t*>(c->h_res + 32);
+        const size_t n = gctl[kGcLines];
+        out.resize(n);
+        const size_t have = std::min<size_t>(n, c->res_lines_cap);
+        if (have) std::memcpy(out.data(), c->h_res + kResHeaderBytes, have * sizeof(LineSegment));
+        if (n > have) {  // more lines than the result block holds: fetch the rest, and size the block for the next frame
+            LR_HIP(hipMemcpyAsync(out.data() + have, c->d_flines + have, (n - have) * sizeof(LineSegment),
+                                  hipMemcpyDeviceToHost, c->stream));
+            LR_HIP(hipStreamSynchronize(c->stream));
+            if (ensure_result_block(c, round_up((uint32_t)(n + n / 2), 1024))) return 1;
+        }
+        record_stage_times(c, true);
+        return 0;
+    }
+    // ---- refine and / or PROSAC: raw segments to the host
+    std::vector<LineSegment> raw(c->n_comp);
+    if (c->n_comp) {
+        LR_HIP(hipMemcpyAsync(raw.data(), c->d_lines, (size_t)c->n_comp * sizeof(LineSegment), hipMemcpyDeviceToHost,
+                              c->stream));
+        LR_HIP(hipStreamSynchronize(c->stream));
+    }
+    record_stage_times(c, false);
+    if (raw.size() < 2) return 0;  // interface.cpp:50-54
     if (refine && ctx_refine(c, raw)) return 1;
     std::vector<LineSegment> filtered = filter_lines(raw, min_length);
     if (filtered.empty()) return 0;
@@ -927,19 +1148,22 @@ static int find_groups_device_impl(lr_context* c, const float* d_image, int w, i
         if (ctx_estimate_line_pencils_prosac(c, filtered, kMaxModels, kInlierDeg, kGarbageDeg, c->prosac_T_N,
                                              c->ransac_seed))
             return 1;
-    } else if (ctx_estimate_line_pencils(c, filtered, kMaxModels, kInlierDeg, kGarbageDeg, c->ransac_iters,
-                                         c->ransac_seed)) {
+    } else if (ctx_estimate_line_pencils(c, filtered, kMaxModels, kInlierDeg, kGarbageDeg, n_iter, c->ransac_seed)) {
         return 1;
     }
     LR_HIP(hipEventRecord(c->ev[6], c->stream));
     LR_HIP(hipStreamSynchronize(c->stream));
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, c->ev[5], c->ev[6]);
-    c->stage_ms[LR_T_RANSAC] = ms;
-    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[6]);
-    c->stage_ms[LR_T_TOTAL] = ms;
+    record_stage_times(c, true);
     out.swap(filtered);
     return 0;
+}
+
+int ctx_find_groups_device(lr_context* c, const float* d_image, int w, int h, int stride, float min_length, bool refine,
+                           std::vector<LineSegment>& out) {
+    const int rc = run_frame(c, d_image, w, h, stride, min_length, refine, out);
+    if (rc) c->prefetch = nullptr;
+    ctx_run_prefetch(c);  // (a frame that failed before its wait)
+    return rc;
 }
 
 // Batch of independent frames: the stages of one frame are latency-bound (flood rounds,

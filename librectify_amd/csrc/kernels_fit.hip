@@ -2,13 +2,15 @@
 // (reference line_detector.cpp:66-89,111, geometry.cpp:20-61).
 //
 // Components are the floods with more than COMPONENT_MIN_SIZE pixels, in seed order.  Their
-// pixel lists are rebuilt from the label image (scatter by label, then a segmented radix sort
+// pixel lists are rebuilt from the label image (scatter by label, then a sort of every list
 // by pixel index), which puts every component in the canonical row-major order regardless of
 // how the flood discovered it.  One wavefront fits one component with the canonical
 // reduction tree T(): lane-strided sequential partial sums, then an xor butterfly.
+//
+// No size in this stage is known to the host when it enqueues the kernels (seed, component and
+// pixel counts stay on the device until the frame's single synchronisation): launches cover the
+// capacity the seed sort ran with and every kernel reads the real counts from memory.
 #include <cstring>
-
-#include <rocprim/rocprim.hpp>
 
 #include "common.h"
 
@@ -36,9 +38,13 @@ __device__ __forceinline__ void chunk_counts(const int32_t* __restrict__ seed_si
     }
 }
 
-__global__ __launch_bounds__(256) void component_sums_kernel(const int32_t* __restrict__ seed_size, uint32_t n_seeds,
-                                                             int min_size, uint2* __restrict__ chunk_tot) {
+__global__ __launch_bounds__(256) void component_sums_kernel(const int32_t* __restrict__ seed_size,
+                                                             const uint32_t* __restrict__ n_ptr, uint32_t cap,
+                                                             int min_size, uint2* __restrict__ chunk_tot,
+                                                             uint32_t* __restrict__ n_large) {
     __shared__ uint32_t s_c[4], s_p[4];
+    const uint32_t n_seeds = min(*n_ptr, cap);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_large = 0u;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int sz[kOffPer];
     uint32_t c, p;
@@ -57,13 +63,16 @@ __global__ __launch_bounds__(256) void component_sums_kernel(const int32_t* __re
 }
 
 __global__ __launch_bounds__(256) void component_offsets_kernel(const int32_t* __restrict__ seed_size,
-                                                                uint32_t n_seeds, int min_size,
-                                                                const uint2* __restrict__ chunk_tot,
+                                                                const uint32_t* __restrict__ n_ptr, uint32_t cap,
+                                                                int min_size, const uint2* __restrict__ chunk_tot,
                                                                 uint32_t* __restrict__ comp_rank,
                                                                 uint32_t* __restrict__ comp_seed,
                                                                 uint32_t* __restrict__ comp_off,
-                                                                uint32_t* __restrict__ totals) {
+                                                                uint32_t* __restrict__ totals,
+                                                                uint32_t* __restrict__ large_list,
+                                                                uint32_t* __restrict__ n_large) {
     __shared__ uint32_t s_c[4], s_p[4], s_cc[4], s_cp[4];
+    const uint32_t n_seeds = min(*n_ptr, cap);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // totals of the chunks before this one
     uint32_t cc = 0, cp = 0;
@@ -115,6 +124,8 @@ __global__ __launch_bounds__(256) void component_offsets_kernel(const int32_t* _
             if (keep) {
                 comp_seed[rank] = k;
                 comp_off[rank] = off_px;
+                // lists of more than 64 pixels are sorted by a workgroup each (component_sort_large_kernel)
+                if (sz[j] > 64) large_list[atomicAdd(n_large, 1u)] = rank;
                 rank += 1u;
                 off_px += (uint32_t)sz[j];
             }
@@ -198,14 +209,95 @@ __device__ inline void major_axis_2x2(float a_, float b_, float c_, float& d_r, 
 }
 
 // fit_line_parameters (geometry.cpp:20-61) for one component per wavefront.
+// ---- per-component sort of the pixel lists ---------------------------------------------------------------
+// Lists of up to 64 pixels (nearly all of them: the mean flood has some 25 pixels): one wavefront, one pixel per
+// lane, rank = number of smaller keys (keys are distinct), found with 64 scalar broadcasts.
+__global__ __launch_bounds__(256) void component_sort_small_kernel(const uint32_t* __restrict__ px_in,
+                                                                   uint32_t* __restrict__ px_out,
+                                                                   const uint32_t* __restrict__ comp_off,
+                                                                   const uint32_t* __restrict__ n_comp_ptr) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t comp = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (comp >= *n_comp_ptr) return;
+    const uint32_t off = comp_off[comp];
+    const uint32_t n = comp_off[comp + 1] - off;
+    if (n > 64u) return;
+    const uint32_t key = (uint32_t)lane < n ? px_in[off + lane] : 0xFFFFFFFFu;
+    uint32_t rank = 0;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) rank += ((uint32_t)__builtin_amdgcn_readlane((int)key, j) < key) ? 1u : 0u;
+    if ((uint32_t)lane < n) px_out[off + rank] = key;
+}
+
+// Longer lists: one workgroup each, bitonic network on the list padded to a power of two -- in LDS up to 4096 keys,
+// in place in global memory beyond that (rare: a flood of more than 4096 pixels).
+constexpr uint32_t kSortLds = 4096;
+__global__ __launch_bounds__(256) void component_sort_large_kernel(const uint32_t* __restrict__ px_in,
+                                                                   uint32_t* __restrict__ px_out,
+                                                                   const uint32_t* __restrict__ comp_off,
+                                                                   const uint32_t* __restrict__ large_list,
+                                                                   const uint32_t* __restrict__ n_large,
+                                                                   uint32_t* __restrict__ scratch) {
+    __shared__ uint32_t s_key[kSortLds];
+    const uint32_t n_list = *n_large;
+    for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
+        const uint32_t comp = large_list[li];
+        const uint32_t off = comp_off[comp];
+        const uint32_t n = comp_off[comp + 1] - off;
+        uint32_t P = 128;
+        while (P < n) P <<= 1;
+        // two launches share this kernel: many workgroups for the lists that fit the LDS (scratch == nullptr), a
+        // single workgroup with a global scratch buffer for the few that do not
+        if ((P <= kSortLds) != (scratch == nullptr)) continue;
+        if (P <= kSortLds) {
+            for (uint32_t i = threadIdx.x; i < P; i += 256) s_key[i] = i < n ? px_in[off + i] : 0xFFFFFFFFu;
+            __syncthreads();
+            for (uint32_t k = 2; k <= P; k <<= 1)
+                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                    for (uint32_t t = threadIdx.x; t < P / 2; t += 256) {
+                        const uint32_t i = 2 * t - (t & (j - 1));  // index with bit j clear
+                        const uint32_t a = s_key[i], b = s_key[i + j];
+                        const bool up = (i & k) == 0;
+                        if ((a > b) == up) {
+                            s_key[i] = b;
+                            s_key[i + j] = a;
+                        }
+                    }
+                    __syncthreads();
+                }
+            for (uint32_t i = threadIdx.x; i < n; i += 256) px_out[off + i] = s_key[i];
+            __syncthreads();
+        } else {
+            uint32_t* g = scratch;  // >= 2 * (pixels of the frame) words, one list at a time
+            for (uint32_t i = threadIdx.x; i < P; i += 256) g[i] = i < n ? px_in[off + i] : 0xFFFFFFFFu;
+            __syncthreads();
+            for (uint32_t k = 2; k <= P; k <<= 1)
+                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                    for (uint32_t t = threadIdx.x; t < P / 2; t += 256) {
+                        const uint32_t i = 2 * t - (t & (j - 1));
+                        const uint32_t a = g[i], b = g[i + j];
+                        const bool up = (i & k) == 0;
+                        if ((a > b) == up) {
+                            g[i] = b;
+                            g[i + j] = a;
+                        }
+                    }
+                    __syncthreads();
+                }
+            for (uint32_t i = threadIdx.x; i < n; i += 256) px_out[off + i] = g[i];
+            __syncthreads();
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void fit_kernel(const uint32_t* __restrict__ px, const uint32_t* __restrict__ comp_off,
-                                                  const uint32_t* __restrict__ comp_seed, uint32_t n_comp,
+                                                  const uint32_t* __restrict__ comp_seed, const uint32_t* __restrict__ n_comp_ptr,
                                                   const int32_t* __restrict__ seed_bin, const float* __restrict__ dx,
                                                   const float* __restrict__ dy, int w, BinTrig trig,
                                                   float* __restrict__ scratch_w, LineSegment* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const uint32_t comp = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (comp >= n_comp) return;
+    if (comp >= *n_comp_ptr) return;
     const uint32_t off = comp_off[comp];
     const uint32_t n = comp_off[comp + 1] - off;
     const int b = seed_bin[comp_seed[comp]];
@@ -278,21 +370,24 @@ __global__ __launch_bounds__(256) void fit_kernel(const uint32_t* __restrict__ p
 }  // namespace
 
 size_t fit_temp_bytes(size_t max_pixels, uint32_t max_segments) {
-    size_t b = 0;
-    (void)rocprim::segmented_radix_sort_keys(nullptr, b, (uint32_t*)nullptr, (uint32_t*)nullptr, max_pixels,
-                                             max_segments, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 32u);
-    return b + 256;
+    (void)max_segments;
+    // chunk totals of the component scan (8 B per 2048 seeds); seeds <= pixels
+    return (max_pixels / kOffChunk + 2) * sizeof(uint2) + 256;
 }
 
-int launch_component_offsets(const int32_t* seed_size, uint32_t n_seeds, int min_size, uint32_t* comp_rank,
-                             uint32_t* comp_seed, uint32_t* comp_off, uint32_t* totals, void* temp, size_t temp_bytes,
-                             hipStream_t s) {
-    const uint32_t chunks = (n_seeds + kOffChunk - 1) / kOffChunk;
-    if (chunks == 0 || temp_bytes < chunks * sizeof(uint2)) return 1;
+int launch_component_offsets(const int32_t* seed_size, const uint32_t* d_n_seeds, uint32_t seed_cap, int min_size,
+                             uint32_t* comp_rank, uint32_t* comp_seed, uint32_t* comp_off, uint32_t* totals,
+                             uint32_t* large_list, uint32_t* n_large, void* temp, size_t temp_bytes, hipStream_t s) {
+    const uint32_t chunks = (seed_cap + kOffChunk - 1) / kOffChunk;
+    if (chunks == 0 || temp_bytes < chunks * sizeof(uint2)) {
+        set_error("launch_component_offsets: workspace too small");
+        return 1;
+    }
     uint2* chunk_tot = static_cast<uint2*>(temp);
-    hipLaunchKernelGGL(component_sums_kernel, dim3(chunks), dim3(256), 0, s, seed_size, n_seeds, min_size, chunk_tot);
-    hipLaunchKernelGGL(component_offsets_kernel, dim3(chunks), dim3(256), 0, s, seed_size, n_seeds, min_size, chunk_tot,
-                       comp_rank, comp_seed, comp_off, totals);
+    hipLaunchKernelGGL(component_sums_kernel, dim3(chunks), dim3(256), 0, s, seed_size, d_n_seeds, seed_cap, min_size,
+                       chunk_tot, n_large);
+    hipLaunchKernelGGL(component_offsets_kernel, dim3(chunks), dim3(256), 0, s, seed_size, d_n_seeds, seed_cap, min_size,
+                       chunk_tot, comp_rank, comp_seed, comp_off, totals, large_list, n_large);
     LR_HIP(hipGetLastError());
     return 0;
 }
@@ -307,19 +402,26 @@ int launch_component_scatter(const uint32_t* label, size_t npix, const uint32_t*
     return 0;
 }
 
-int launch_component_sort(uint32_t* px_in, uint32_t* px_out, uint32_t n_px, uint32_t n_comp, const uint32_t* comp_off,
-                          int idx_bits, void* temp, size_t temp_bytes, hipStream_t s) {
-    if (n_px == 0 || n_comp == 0) return 0;
-    LR_HIP(rocprim::segmented_radix_sort_keys(temp, temp_bytes, px_in, px_out, (size_t)n_px, n_comp, comp_off,
-                                              comp_off + 1, 0u, (unsigned)idx_bits, s));
+int launch_component_sort(const uint32_t* px_in, uint32_t* px_out, const uint32_t* comp_off, const uint32_t* d_n_comp,
+                          uint32_t comp_cap, const uint32_t* large_list, const uint32_t* n_large, uint32_t* scratch,
+                          hipStream_t s) {
+    if (comp_cap == 0) return 0;
+    hipLaunchKernelGGL(component_sort_small_kernel, dim3((comp_cap + 3) / 4), dim3(256), 0, s, px_in, px_out, comp_off,
+                       d_n_comp);
+    // (lists of more than 4096 pixels: one at a time through the global scratch, by a single workgroup)
+    hipLaunchKernelGGL(component_sort_large_kernel, dim3(1024), dim3(256), 0, s, px_in, px_out, comp_off, large_list, n_large,
+                       (uint32_t*)nullptr);
+    hipLaunchKernelGGL(component_sort_large_kernel, dim3(1), dim3(256), 0, s, px_in, px_out, comp_off, large_list, n_large,
+                       scratch);
+    LR_HIP(hipGetLastError());
     return 0;
 }
 
-int launch_fit(const uint32_t* px_sorted, const uint32_t* comp_off, const uint32_t* comp_seed, uint32_t n_comp,
-               const int32_t* seed_bin, const float* dx, const float* dy, int w, BinTrig trig, float* scratch_w,
-               LineSegment* out, hipStream_t s) {
-    if (n_comp == 0) return 0;
-    hipLaunchKernelGGL(fit_kernel, dim3((n_comp + 3) / 4), dim3(256), 0, s, px_sorted, comp_off, comp_seed, n_comp,
+int launch_fit(const uint32_t* px_sorted, const uint32_t* comp_off, const uint32_t* comp_seed, const uint32_t* d_n_comp,
+               uint32_t comp_cap, const int32_t* seed_bin, const float* dx, const float* dy, int w, BinTrig trig,
+               float* scratch_w, LineSegment* out, hipStream_t s) {
+    if (comp_cap == 0) return 0;
+    hipLaunchKernelGGL(fit_kernel, dim3((comp_cap + 3) / 4), dim3(256), 0, s, px_sorted, comp_off, comp_seed, d_n_comp,
                        seed_bin, dx, dy, w, trig, scratch_w, out);
     LR_HIP(hipGetLastError());
     return 0;

@@ -43,9 +43,11 @@ __global__ __launch_bounds__(64) void flood_ordered_kernel(const float* __restri
                                                            const uint8_t* __restrict__ dmask, int w,
                                                            const int32_t* __restrict__ seed_idx,
                                                            const int32_t* __restrict__ seed_bin,
-                                                           const float* __restrict__ seed_thr, uint32_t n_seeds,
+                                                           const float* __restrict__ seed_thr,
+                                                           const uint32_t* __restrict__ n_ptr, uint32_t cap,
                                                            BinTrig trig, uint32_t* label, int32_t* seed_size,
                                                            int32_t* queue) {
+    const uint32_t n_seeds = min(*n_ptr, cap);
     const int lane = threadIdx.x;
     const int si = lane >> 3, ni = lane & 7;
     // neighbour order of filter.cpp:130-137 (only the set matters)
@@ -105,12 +107,12 @@ int launch_label_init(uint32_t* label, size_t n, hipStream_t s) {
 }
 
 int launch_flood_ordered(const float* dx, const float* dy, const uint8_t* dmask, int w, int h, const int32_t* seed_idx,
-                         const int32_t* seed_bin, const float* seed_thr, uint32_t n_seeds, BinTrig trig,
-                         uint32_t* label, int32_t* seed_size, int32_t* queue, hipStream_t s) {
+                         const int32_t* seed_bin, const float* seed_thr, const uint32_t* d_n_seeds, uint32_t seed_cap,
+                         BinTrig trig, uint32_t* label, int32_t* seed_size, int32_t* queue, hipStream_t s) {
     (void)h;
-    if (n_seeds == 0) return 0;
+    if (seed_cap == 0) return 0;
     hipLaunchKernelGGL(flood_ordered_kernel, dim3(1), dim3(64), 0, s, dx, dy, dmask, w, seed_idx, seed_bin, seed_thr,
-                       n_seeds, trig, label, seed_size, queue);
+                       d_n_seeds, seed_cap, trig, label, seed_size, queue);
     LR_HIP(hipGetLastError());
     return 0;
 }
@@ -170,8 +172,7 @@ struct FloodArgs {
     uint4* slab_ring;   // n_slabs x slab_ring_cap records {tile, -, mask.lo, mask.hi}
     uint4* slab_hash;   // n_slabs x slab_hash_cap x 2 records {generation, tile+1, V.lo, V.hi} {A.lo, A.hi, -, -}
     uint32_t n_slabs, slab_ring_cap, slab_hash_cap;  // caps are powers of two
-    uint32_t n_seeds, win_first, win_shift;          // staged start (see kCtrlWindow)
-    uint32_t win_hold;                               // the window stops here until no seed below it is active
+    uint32_t win_shift;                              // staged start (see kCtrlWindow): growth of the window per round
     uint32_t from_end;                               // explore the active list from its end (see flood_explore_kernel)
     uint32_t big_cap;                                // seeds per round the second tier takes (0: tier switched off)
 };
@@ -200,7 +201,14 @@ enum {
     kCtrlBigTotal = 13,   // ... over the frame (diagnostics: lr_stage_counters)
     kCtrlSlabTotal = 14,  // slabs handed out over the frame
     kCtrlBelow = 15,      // active seeds below the window after this round (the window opens fully when none is left)
+    // The host never learns the seed count before the frame's single synchronisation: everything that depends on it
+    // is worked out by flood_init_seeds_kernel and kept here.
+    kCtrlNSeeds = 16,   // seeds of this frame (clamped to the capacity the seed sort ran with)
+    kCtrlWinHold = 17,  // the window stops here while the weakest seeds are held back
+    kCtrlNext = 18,     // next entry of the active list to hand out (the exploration workgroups pull their seeds)
+    kCtrlWords = 32,
 };
+static_assert(kCtrlWords == kFloodCtrlWords, "control block size");
 
 // Frontier records, table entries and ballots are the same in all 64 lanes.  Saying so (readfirstlane) lets the
 // compiler keep them in SGPRs and run the bit-board logic on the scalar unit instead of the vector ALU.
@@ -863,19 +871,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     __shared__ uint32_t s_pend[2][kPend];
     __shared__ uint8_t s_ord[kHashT];
     const int lane = threadIdx.x & 63;
-    // list length, staged window and list entry are independent loads: one round trip, then the tests
-    const uint32_t ai = uni(blockIdx.x);
     const uint32_t n_act = uni(A.ctrl[kCtrlNAct]), window = uni(A.ctrl[kCtrlWindow]);
-    if (ai >= n_act) return;  // past the list
-    // The list is walked from its end: the first round's list is in seed order, strongest first, and the longest
-    // walks belong to the weak seeds at its end (low thresholds, large footprints).  Started first, they run
-    // alongside the mass of short walks instead of after it.
-    const uint32_t k = uni(act[A.from_end ? n_act - 1u - ai : ai]);
-    if (k >= window) return;  // not yet in the staged window (stays active)
     LdsStore L{s_ring[0], s_ring[1], s_ring[2], s_hash[0], s_hash[1], s_hash[2],
                s_hash[3], s_hash[4], s_hash[5], s_hash[6], s_ord};
     Pending P{s_pend[0], s_pend[1]};
-    explore_seed<LdsStore, true>(A, trig, k, L, P, big_list, lane);
+    // The grid is a fixed number of workgroups (enough to fill the chip), whatever the length of the list, which only
+    // the device knows: every workgroup pulls the next entry until the list is exhausted.
+    for (;;) {
+        uint32_t ai = 0;
+        if (lane == 0) ai = atomicAdd(&A.ctrl[kCtrlNext], 1u);
+        ai = uni(ai);
+        if (ai >= n_act) return;
+        // The list is walked from its end: the first round's list is in seed order, strongest first, and the longest
+        // walks belong to the weak seeds at its end (low thresholds, large footprints).  Started first, they run
+        // alongside the mass of short walks instead of after it.
+        const uint32_t k = uni(act[A.from_end ? n_act - 1u - ai : ai]);
+        if (k >= window) continue;  // not yet in the staged window (stays active)
+        explore_seed<LdsStore, true>(A, trig, k, L, P, big_list, lane);
+    }
 }
 
 // Second storage tier: the same walk from the start with a 1024-record ring and a 2048-tile table (dynamic LDS,
@@ -943,9 +956,10 @@ __global__ __launch_bounds__(256) void flood_commit_pixels_kernel(uint32_t* __re
 
 // End of a round (one thread: the last workgroup of the survivors pass): the next list becomes the current one.  A round without progress (possible only
 // when storage ran out on the lowest active seed) stops the rounds and leaves the rest to the ordered tail.
-__device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t n_seeds, uint32_t win_shift, uint32_t win_hold) {
+__device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift) {
     const uint32_t n_act = ld_agent(&ctrl[kCtrlNAct]);
     if (n_act == 0u) return;
+    const uint32_t n_seeds = ld_agent(&ctrl[kCtrlNSeeds]), win_hold = ld_agent(&ctrl[kCtrlWinHold]);
     const uint32_t n_next = ld_agent(&ctrl[kCtrlNNext]);
     const uint32_t window = ld_agent(&ctrl[kCtrlWindow]);
     const bool moved = ld_agent(&ctrl[kCtrlNCommit]) > 0u || n_next < n_act;
@@ -987,6 +1001,7 @@ __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t n_seeds, uin
     ctrl[kCtrlBarrier] = 0xFFFFFFFFu;
     ctrl[kCtrlSlabs] = 0u;
     ctrl[kCtrlNBig] = 0u;
+    ctrl[kCtrlNext] = 0u;
 }
 
 // After the commit: which seeds go on to the next round?
@@ -1036,19 +1051,30 @@ __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, const
         if (atomicAdd(&A.ctrl[kCtrlDone], 1u) == gridDim.x - 1u) {
             __threadfence();
             A.ctrl[kCtrlDone] = 0u;
-            flood_advance(A.ctrl, A.n_seeds, A.win_shift, A.win_hold);
+            flood_advance(A.ctrl, A.win_shift);
         }
     }
 }
 
-__global__ __launch_bounds__(256) void flood_init_seeds_kernel(uint32_t n_seeds, uint32_t* __restrict__ act,
-                                                               uint8_t* __restrict__ state, uint8_t* __restrict__ tier,
-                                                               uint32_t* __restrict__ blocked, uint32_t* __restrict__ count,
-                                                               uint32_t* __restrict__ flags, int32_t* __restrict__ seed_size,
-                                                               uint32_t* __restrict__ ctrl, uint32_t win_first,
-                                                               uint32_t phase) {
+__global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* __restrict__ n_ptr, uint32_t cap,
+                                                               uint32_t* __restrict__ act, uint8_t* __restrict__ state,
+                                                               uint8_t* __restrict__ tier, uint32_t* __restrict__ blocked,
+                                                               uint32_t* __restrict__ count, uint32_t* __restrict__ flags,
+                                                               int32_t* __restrict__ seed_size, uint32_t* __restrict__ ctrl,
+                                                               int win_first_shift, int hold_pct, uint32_t hold_from_start) {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t n_seeds = min(*n_ptr, cap);
     if (k == 0u) {
+        // staged start and hold-back line (see kCtrlWindow, flood_advance)
+        uint32_t win_first = win_first_shift > 0 ? max(1024u, n_seeds >> win_first_shift) : n_seeds;
+        if (win_first > n_seeds) win_first = n_seeds;
+        uint32_t win_hold = (hold_pct > 0 && hold_pct < 100) ? (uint32_t)((unsigned long long)n_seeds * (uint32_t)hold_pct / 100u) : n_seeds;
+        if (win_hold < 1024u) win_hold = n_seeds;  // not worth another phase
+        const bool hold_now = hold_from_start != 0u && win_hold < n_seeds;
+        if (hold_now && win_first > win_hold) win_first = win_hold;
+        ctrl[kCtrlNSeeds] = n_seeds;
+        ctrl[kCtrlWinHold] = win_hold;
+        ctrl[kCtrlNext] = 0u;
         ctrl[kCtrlWindow] = win_first;
         ctrl[kCtrlDone] = 0u;
         ctrl[kCtrlBelow] = 0u;
@@ -1060,7 +1086,7 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(uint32_t n_seeds,
         ctrl[kCtrlNAct] = n_seeds;
         ctrl[kCtrlNCommit] = 0u;
         ctrl[kCtrlNNext] = 0u;
-        ctrl[kCtrlPhase] = phase;
+        ctrl[kCtrlPhase] = hold_now ? 1u : 0u;
         ctrl[kCtrlRounds] = 0u;
         ctrl[kCtrlStall] = 0u;
         ctrl[kCtrlNRemain] = n_seeds;
@@ -1157,6 +1183,24 @@ static void flood_debug_round(const FloodBuffers& B, uint32_t n_seeds, const uin
             mxk = kk;
         }
     }
+    {  // walk-length histogram (steps) and where in the seed order the long walks sit
+        const uint32_t edges[8] = {8, 16, 32, 48, 64, 128, 192, 0xFFFFFFFFu};
+        uint32_t hist[8] = {0, 0, 0, 0, 0, 0, 0, 0}, long_lo = 0xFFFFFFFFu, nlong_strong = 0;
+        for (uint32_t i = 0; i < n_act; ++i) {
+            const uint32_t kk = actv[i], st_ = flg[kk] >> 8;
+            for (int b = 0; b < 8; ++b)
+                if (st_ <= edges[b]) {
+                    hist[b]++;
+                    break;
+                }
+            if (st_ > 64) {
+                long_lo = std::min(long_lo, kk);
+                if (kk < n_seeds / 10 * 8) nlong_strong++;
+            }
+        }
+        std::fprintf(stderr, "  steps<=8:%u <=16:%u <=32:%u <=48:%u <=64:%u <=128:%u <=192:%u more:%u; lowest seed with >64 steps: %u; such seeds among the strongest 80%%: %u\n",
+                     hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], long_lo, nlong_strong);
+    }
     std::fprintf(stderr,
                  "flood round %u: active %u, %llu px walked in %llu steps, longest walk %u steps (%u px, seed %u), "
                  "blocked %u, committed %u, barrier %u, slabs %u\n",
@@ -1164,24 +1208,20 @@ static void flood_debug_round(const FloodBuffers& B, uint32_t n_seeds, const uin
                  ctrl[kCtrlSlabs]);
 }
 
-int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, const uint8_t* dmask, int w, int h,
-                   const int32_t* seed_idx, const int32_t* seed_bin, const float* seed_thr, uint32_t n_seeds,
-                   BinTrig trig, uint32_t* label, int32_t* seed_size, int32_t* queue, uint32_t* h_ctrl, int* rounds_out,
-                   uint32_t* tiers_out, hipStream_t s, void (*before_wait)(void*), void* before_wait_arg) {
-    *rounds_out = 0;
-    if (n_seeds == 0) return 0;
-    const size_t npix = (size_t)w * h;
+namespace {
+
+FloodArgs flood_args(const FloodBuffers& B, const FloodFrame& F, bool use_big) {
     FloodArgs A;
-    A.dx = dx;
-    A.dy = dy;
-    A.dmask = dmask;
-    A.w = w;
-    A.h = h;
-    A.tiles_x = (w + 7) / 8;
-    A.seed_idx = seed_idx;
-    A.seed_bin = seed_bin;
-    A.seed_thr = seed_thr;
-    A.label = label;
+    A.dx = F.dx;
+    A.dy = F.dy;
+    A.dmask = F.dmask;
+    A.w = F.w;
+    A.h = F.h;
+    A.tiles_x = (F.w + 7) / 8;
+    A.seed_idx = F.seed_idx;
+    A.seed_bin = F.seed_bin;
+    A.seed_thr = F.seed_thr;
+    A.label = F.label;
     A.blocked = B.blocked;
     A.count = B.count;
     A.flags = B.flags;
@@ -1192,7 +1232,71 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
     A.n_slabs = B.n_slabs;
     A.slab_ring_cap = B.slab_ring_cap;
     A.slab_hash_cap = B.slab_hash_cap;
+    static const int order_env = std::getenv("LIBRECTIFY_FLOOD_ORDER") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_ORDER")) : -1;
+    A.from_end = order_env >= 0 ? (uint32_t)order_env : 1u;
+    A.win_shift = 2u;
+    const uint32_t big_cap = B.big_cap_override ? B.big_cap_override : kBigCap;
+    A.big_cap = use_big ? big_cap : 0u;
+    return A;
+}
 
+// workgroups of the exploration kernel: as many as the chip holds at once (LDS: 16-17 per CU), plus a few
+int explore_grid(uint32_t cap) {
+    static const int n = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        return cus * 20;
+    }();
+    return (int)std::min<uint32_t>(std::max(cap, 1u), (uint32_t)n);
+}
+
+const bool g_flood_debug = std::getenv("LIBRECTIFY_FLOOD_DEBUG") != nullptr;
+
+// one round: explore (both LDS tiers), decide, commit, survivors
+void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& A, bool use_big, int index, hipStream_t s) {
+    uint32_t* lists[2] = {B.act_a, B.act_b};
+    uint32_t* act = lists[index & 1];
+    uint32_t* act_next = lists[(index + 1) & 1];
+    const size_t npix = (size_t)F.w * F.h;
+    const int pix_blocks = (int)std::min<size_t>((npix + 255) / 256, 4096);
+    const int seed_blocks = (int)std::min<uint32_t>((F.seed_cap + 255) / 256, 256);
+    hipEvent_t dbg0 = nullptr, dbg1 = nullptr;
+    if (g_flood_debug) {
+        (void)hipEventCreate(&dbg0);
+        (void)hipEventCreate(&dbg1);
+        (void)hipEventRecord(dbg0, s);
+    }
+    hipLaunchKernelGGL(flood_explore_kernel, dim3(explore_grid(F.seed_cap)), dim3(64), 0, s, A, F.trig, act, B.big_list);
+    if (use_big)
+        hipLaunchKernelGGL(flood_explore_big_kernel, dim3(std::min<uint32_t>(F.seed_cap, kBigCap)), dim3(64), kBigLdsBytes, s,
+                           A, F.trig, B.big_list);
+    if (g_flood_debug) (void)hipEventRecord(dbg1, s);
+    hipLaunchKernelGGL(flood_decide_kernel, dim3(seed_blocks), dim3(256), 0, s, A, act, B.state, F.seed_size);
+    if (g_flood_debug) {
+        uint32_t n = 0;
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(&n, F.d_n_seeds, sizeof(n), hipMemcpyDeviceToHost);
+        flood_debug_round(B, std::min(n, F.seed_cap), act, s);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, dbg0, dbg1);
+        std::fprintf(stderr, "  explore kernels of this round: %.1f us\n", ms * 1e3f);
+        (void)hipEventDestroy(dbg0);
+        (void)hipEventDestroy(dbg1);
+    }
+    hipLaunchKernelGGL(flood_commit_pixels_kernel, dim3(pix_blocks), dim3(256), 0, s, F.label, npix, B.state, B.ctrl,
+                       const_cast<uint8_t*>(F.dmask));
+    hipLaunchKernelGGL(flood_survivors_kernel, dim3(seed_blocks), dim3(256), 0, s, A, act, B.state, F.seed_size, act_next);
+}
+
+}  // namespace
+
+// Rounds are enqueued blindly: their kernels read the list length from the control block, and a round enqueued past
+// the end does nothing.  Typical frames finish within the first batch, so the flood needs no host synchronisation of
+// its own: the caller goes on enqueuing the later stages and looks at the control block when the frame is done.
+int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, uint32_t* h_ctrl, hipStream_t s) {
+    P->enqueued = 0;
+    P->use_big = B.second_tier && B.second_tier_from_start;
+    if (F.seed_cap == 0) return 0;
     // staged start (FloodBuffers::win_*); LIBRECTIFY_FLOOD_WINDOW="<first shift>,<growth shift>" overrides
     static const char* win_env = std::getenv("LIBRECTIFY_FLOOD_WINDOW");
     int win_first_shift = B.win_first_shift, win_growth = B.win_growth;
@@ -1201,21 +1305,11 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
         const char* c = std::strchr(win_env, ',');
         if (c) win_growth = std::max(1, std::atoi(c + 1));
     }
-    A.n_seeds = n_seeds;
-    A.win_first = win_first_shift > 0 ? std::max(1024u, n_seeds >> win_first_shift) : n_seeds;
-    if (A.win_first > n_seeds) A.win_first = n_seeds;
-    A.win_shift = (uint32_t)win_growth;
+    P->win_growth = win_growth;
     static const int hold_env = std::getenv("LIBRECTIFY_FLOOD_HOLD") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_HOLD")) : -1;
     const int hold_pct = hold_env >= 0 ? hold_env : B.win_hold_pct;
-    A.win_hold = hold_pct > 0 && hold_pct < 100 ? (uint32_t)((unsigned long long)n_seeds * hold_pct / 100) : n_seeds;
-    if (A.win_hold < 1024u) A.win_hold = n_seeds;  // not worth another phase
-    const bool hold_now = B.hold_from_start && A.win_hold < n_seeds;
-    if (hold_now && A.win_first > A.win_hold) A.win_first = A.win_hold;
-    static const int order_env = std::getenv("LIBRECTIFY_FLOOD_ORDER") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_ORDER")) : -1;
-    A.from_end = order_env >= 0 ? (uint32_t)order_env : 1u;
-    bool use_big = B.second_tier && B.second_tier_from_start;
-    const uint32_t big_cap = B.big_cap_override ? B.big_cap_override : kBigCap;
-    A.big_cap = use_big ? big_cap : 0u;
+    static const bool hold_start_env = std::getenv("LIBRECTIFY_FLOOD_HOLD_START") != nullptr;
+    const bool hold_start = B.hold_from_start || hold_start_env;
     // the opt-in for 72 KB of dynamic LDS is a per-device attribute of the kernel: once per device of this process
     {
         static std::atomic<uint64_t> done_mask{0};
@@ -1231,48 +1325,49 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
             done_mask.fetch_or(bit, std::memory_order_release);
         }
     }
-    uint32_t* lists[2] = {B.act_a, B.act_b};
-    hipLaunchKernelGGL(flood_init_seeds_kernel, dim3((n_seeds + 255) / 256), dim3(256), 0, s, n_seeds, lists[0], B.state,
-                       B.tier, B.blocked, B.count, B.flags, seed_size, B.ctrl, A.win_first, hold_now ? 1u : 0u);
-    const int pix_blocks = (int)std::min<size_t>((npix + 255) / 256, 4096);
-    const int seed_blocks = (int)std::min<uint32_t>((n_seeds + 255) / 256, 256);
-    static const bool debug = std::getenv("LIBRECTIFY_FLOOD_DEBUG") != nullptr;
-    // Rounds are enqueued blindly, a batch at a time: their kernels read the list length from the control block,
-    // and a round enqueued past the end does nothing.  Typical frames finish within the first batch, i.e. with one
-    // host synchronisation for the whole flood.
-    int enqueued = 0;
-    for (;;) {
-        const int batch = debug ? 1 : (enqueued == 0 ? (A.win_first < n_seeds ? 7 : 6) : 3);
-        for (int r = 0; r < batch; ++r, ++enqueued) {
-            uint32_t* act = lists[enqueued & 1];
-            uint32_t* act_next = lists[(enqueued + 1) & 1];
-            hipLaunchKernelGGL(flood_explore_kernel, dim3(n_seeds), dim3(64), 0, s, A, trig, act, B.big_list);
-            if (use_big)
-                hipLaunchKernelGGL(flood_explore_big_kernel, dim3(std::min<uint32_t>(n_seeds, kBigCap)), dim3(64),
-                                   kBigLdsBytes, s, A, trig, B.big_list);
-            hipLaunchKernelGGL(flood_decide_kernel, dim3(seed_blocks), dim3(256), 0, s, A, act, B.state, seed_size);
-            if (debug) flood_debug_round(B, n_seeds, act, s);
-            hipLaunchKernelGGL(flood_commit_pixels_kernel, dim3(pix_blocks), dim3(256), 0, s, label, npix, B.state, B.ctrl,
-                               const_cast<uint8_t*>(dmask));
-            hipLaunchKernelGGL(flood_survivors_kernel, dim3(seed_blocks), dim3(256), 0, s, A, act, B.state, seed_size,
-                               act_next);
-        }
-        LR_HIP(hipMemcpyAsync(h_ctrl, B.ctrl, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        if (before_wait) before_wait(before_wait_arg);  // the bulk of the frame's kernels is enqueued: host work goes here
-        LR_HIP(hipStreamSynchronize(s));
-        if (debug)
-            std::fprintf(stderr, "flood after %d rounds enqueued: %u done, active %u, remain %u, stall %u\n", enqueued,
+    hipLaunchKernelGGL(flood_init_seeds_kernel, dim3((F.seed_cap + 255) / 256), dim3(256), 0, s, F.d_n_seeds, F.seed_cap,
+                       B.act_a, B.state, B.tier, B.blocked, B.count, B.flags, F.seed_size, B.ctrl, win_first_shift, hold_pct,
+                       hold_start ? 1u : 0u);
+    FloodArgs A = flood_args(B, F, P->use_big);
+    A.win_shift = (uint32_t)win_growth;
+    const int batch = g_flood_debug ? 1 : ((win_first_shift > 0 || hold_start) ? 7 : 6);
+    for (int r = 0; r < batch; ++r, ++P->enqueued) enqueue_round(B, F, A, P->use_big, P->enqueued, s);
+    LR_HIP(hipMemcpyAsync(h_ctrl, B.ctrl, kCtrlWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    LR_HIP(hipGetLastError());
+    return 0;
+}
+
+// h_ctrl holds the control block as flood_enqueue's copy delivered it (the stream has been synchronised since).
+// Runs whatever is left: more rounds (three at a time, one synchronisation each), and the ordered tail if the rounds
+// stalled on exhausted storage.  *extra tells the caller that the label image changed after its later stages ran.
+int flood_finish(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, uint32_t* h_ctrl, int* rounds_out,
+                 uint32_t* tiers_out, bool* extra, hipStream_t s) {
+    *extra = false;
+    *rounds_out = 0;
+    if (F.seed_cap == 0) return 0;
+    const uint32_t big_cap = B.big_cap_override ? B.big_cap_override : kBigCap;
+    FloodArgs A = flood_args(B, F, P->use_big);
+    A.win_shift = (uint32_t)P->win_growth;
+    while (h_ctrl[kCtrlNAct] != 0u) {
+        *extra = true;
+        if (g_flood_debug)
+            std::fprintf(stderr, "flood after %d rounds enqueued: %u done, active %u, remain %u, stall %u\n", P->enqueued,
                          h_ctrl[kCtrlRounds], h_ctrl[kCtrlNAct], h_ctrl[kCtrlNRemain], h_ctrl[kCtrlStall]);
-        if (h_ctrl[kCtrlNAct] == 0u) break;
-        if (!use_big && B.second_tier && h_ctrl[kCtrlSlabTotal] > 0u) {  // long walks after all: second tier from now on
-            use_big = true;
+        if (!P->use_big && B.second_tier && h_ctrl[kCtrlSlabTotal] > 0u) {  // long walks after all: second tier from now on
+            P->use_big = true;
             A.big_cap = big_cap;
         }
+        const int batch = g_flood_debug ? 1 : 3;
+        for (int r = 0; r < batch; ++r, ++P->enqueued) enqueue_round(B, F, A, P->use_big, P->enqueued, s);
+        LR_HIP(hipMemcpyAsync(h_ctrl, B.ctrl, kCtrlWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        LR_HIP(hipStreamSynchronize(s));
     }
     int rounds = (int)h_ctrl[kCtrlRounds];
     if (h_ctrl[kCtrlStall] != 0u && h_ctrl[kCtrlNRemain] > 0u) {
         // storage exhausted on the lowest active seed: finish in order (always exact); the list is unordered
+        *extra = true;
         const uint32_t n_rem = h_ctrl[kCtrlNRemain];
+        uint32_t* lists[2] = {B.act_a, B.act_b};
         uint32_t* act = lists[rounds & 1];  // what the last round with work appended to
         {
             std::vector<uint32_t> tmp(n_rem);
@@ -1280,8 +1375,8 @@ int flood_parallel(const FloodBuffers& B, const float* dx, const float* dy, cons
             std::sort(tmp.begin(), tmp.end());
             LR_HIP(hipMemcpy(act, tmp.data(), n_rem * sizeof(uint32_t), hipMemcpyHostToDevice));
         }
-        hipLaunchKernelGGL(flood_ordered_tail_kernel, dim3(1), dim3(64), 0, s, dx, dy, dmask, w, seed_idx, seed_bin,
-                           seed_thr, act, n_rem, trig, label, seed_size, queue);
+        hipLaunchKernelGGL(flood_ordered_tail_kernel, dim3(1), dim3(64), 0, s, F.dx, F.dy, F.dmask, F.w, F.seed_idx,
+                           F.seed_bin, F.seed_thr, act, n_rem, F.trig, F.label, F.seed_size, F.queue);
         ++rounds;
     }
     LR_HIP(hipGetLastError());

@@ -22,41 +22,110 @@ __device__ inline float wave_tree(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void ransac_score_kernel(PencilSoA m, uint32_t n, float tol, float degeneracy_tol,
-                                                           uint32_t n_iter, uint64_t seed, uint32_t round,
-                                                           float* __restrict__ scores) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t hyp = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (hyp >= n_iter) return;
-    uint32_t a, b;
-    sample_pair(seed, round, hyp, n, a, b);
+// ---- inlier test --------------------------------------------------------------------------------------------------
+// The canonical test is   err = 1 - |u . d| < tol   with u = v / |v| from a correctly rounded square root and two
+// correctly rounded divisions (geometry.cpp:214-229): some forty vector instructions per (hypothesis, line), which is
+// what bounds these kernels.  Only the DECISION enters a score, so it is taken from a cheap estimate whenever that
+// is safe: err' = 1 - |v . d| * rsq(|v|^2) differs from err by at most 13 units of 2^-24 (the error analysis is in
+// DESIGN.md §5c), i.e. by less than 8e-7, and if err' is further than kErrBand = 3e-6 from tol the two agree.  Inside
+// the band -- and whenever the estimate is not a number -- the canonical expression decides.  The results are
+// therefore bit-identical to the canonical ones.
+constexpr float kErrBand = 3e-6f;
+
+__device__ __forceinline__ bool inlier_exact(float vx, float vy, float dx, float dy, float tol) {
+    const float nn = vx * vx + vy * vy;
+    const float nrm = sqrtf(nn);
+    const float ux = vx / nrm, uy = vy / nrm;
+    const float inc = fabsf(ux * dx + uy * dy);
+    const float err = -inc + 1.0f;
+    return err < tol;
+}
+
+__device__ __forceinline__ bool inlier_test(float vx, float vy, float dx, float dy, float tol) {
+    const float nn = __builtin_fmaf(vx, vx, vy * vy);
+    const float dot = __builtin_fmaf(vx, dx, vy * dy);
+    const float e = 1.0f - fabsf(dot) * __builtin_amdgcn_rsqf(nn);
+    bool in = e < tol - kErrBand;
+    // not sure: inside the band, not a number, or |v|^2 so small that the reciprocal square root (which flushes
+    // denormals) and the canonical 0 / 0 could part ways
+    const bool sure = (in || e > tol + kErrBand) && nn > 1e-30f;
+    if (__builtin_expect(!sure, 0)) in = inlier_exact(vx, vy, dx, dy, tol);
+    return in;
+}
+
+// A hypothesis as the scoring loop needs it: v = (cx, cy) - sub * anchor  (sub = 0 for an ideal point, whose v is
+// the point itself: geometry.cpp:218-223)
+struct Hyp {
+    float cx, cy, sub;
+    bool valid;
+};
+__device__ __forceinline__ Hyp make_hyp(const PencilSoA& m, uint32_t a, uint32_t b, float degeneracy_tol) {
     const float hax = m.hx[a], hay = m.hy[a], haz = m.hz[a];
     const float hbx = m.hx[b], hby = m.hy[b], hbz = m.hz[b];
     const float ex = hax - hbx, ey = hay - hby, ez = haz - hbz;
     const float dist = sqrtf((ex * ex + ey * ey) + ez * ez);
-    if (!(dist > degeneracy_tol)) {  // sample_check
-        if (lane == 0) scores[hyp] = -1.0f;
-        return;
-    }
-    // fit: h_a x h_b
+    Hyp h;
+    h.valid = dist > degeneracy_tol;  // sample_check (line_pencil.cpp:89-98)
+    // fit: h_a x h_b (line_pencil.cpp:101-108)
     const float px = hay * hbz - haz * hby;
     const float py = haz * hbx - hax * hbz;
     const float pz = hax * hby - hay * hbx;
-    const bool ideal = fabsf(pz) < kEps;  // inclination(): ideal point is used as a direction
-    const float pnx = px / pz, pny = py / pz;
-    float acc = 0.f;
-    for (uint32_t i = lane; i < n; i += 64) {
-        const float vx = ideal ? px : (pnx - m.ax[i]);
-        const float vy = ideal ? py : (pny - m.ay[i]);
-        const float nn = vx * vx + vy * vy;
-        const float nrm = sqrtf(nn);
-        const float ux = vx / nrm, uy = vy / nrm;
-        const float inc = fabsf(ux * m.dx[i] + uy * m.dy[i]);
-        const float err = -inc + 1.0f;
-        acc = acc + ((err < tol) ? m.len[i] : 0.0f);
+    const bool ideal = fabsf(pz) < kEps;
+    h.cx = ideal ? px : px / pz;
+    h.cy = ideal ? py : py / pz;
+    h.sub = ideal ? 0.f : 1.f;
+    return h;
+}
+// v for line i: exactly (cx - ax, cy - ay) or (cx, cy)
+__device__ __forceinline__ void hyp_v(const Hyp& h, float ax, float ay, float& vx, float& vy) {
+    vx = h.sub != 0.f ? h.cx - ax : h.cx;
+    vy = h.sub != 0.f ? h.cy - ay : h.cy;
+}
+
+// One wavefront scores kH hypotheses at a time: each lane loads its lines' (anchor, direction, length) once and tests
+// them against all kH (whose parameters are wave-uniform), so the table is read kH times less often; the score of
+// each hypothesis is the canonical tree T() over the lines (lane-strided partial sums in ascending line order, then
+// the xor butterfly), exactly as when a wavefront owned a single hypothesis.
+// gctl != nullptr: line count and round come from the device (peeling rounds enqueued blindly, kernels_groups.hip);
+// the kernel then leaves at once when the peeling is over.
+template <int kH>
+__global__ __launch_bounds__(256) void ransac_score_kernel(PencilSoA m, uint32_t n_host, float tol, float degeneracy_tol,
+                                                           uint32_t n_iter, uint64_t seed, uint32_t round_host,
+                                                           const uint32_t* __restrict__ gctl, int max_models,
+                                                           float* __restrict__ scores) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t hyp0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kH;
+    if (hyp0 >= n_iter) return;
+    uint32_t n = n_host, round = round_host;
+    if (gctl) {
+        n = gctl[kGcActive];
+        round = gctl[kGcRound];
+        if (gctl[kGcRemaining] < 2u || round >= (uint32_t)max_models) return;
     }
-    const float score = wave_tree(acc);
-    if (lane == 0) scores[hyp] = score;
+    Hyp H[kH];
+#pragma unroll
+    for (int j = 0; j < kH; ++j) {
+        uint32_t a, b;
+        sample_pair(seed, round, min(hyp0 + (uint32_t)j, n_iter - 1u), n, a, b);
+        H[j] = make_hyp(m, a, b, degeneracy_tol);
+    }
+    float acc[kH];
+#pragma unroll
+    for (int j = 0; j < kH; ++j) acc[j] = 0.f;
+    for (uint32_t i = lane; i < n; i += 64) {
+        const float ax = m.ax[i], ay = m.ay[i], dx = m.dx[i], dy = m.dy[i], len = m.len[i];
+#pragma unroll
+        for (int j = 0; j < kH; ++j) {
+            float vx, vy;
+            hyp_v(H[j], ax, ay, vx, vy);
+            acc[j] = acc[j] + (inlier_test(vx, vy, dx, dy, tol) ? len : 0.0f);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kH; ++j) {
+        const float score = wave_tree(acc[j]);
+        if (lane == 0 && hyp0 + (uint32_t)j < n_iter) scores[hyp0 + j] = H[j].valid ? score : -1.0f;
+    }
 }
 
 // First strictly best hypothesis: max score, ties to the lowest iteration; -1 if none scored > 0.
@@ -106,42 +175,40 @@ __global__ __launch_bounds__(1024) void ransac_argmax_kernel(const float* __rest
 
 // Inlier COUNT (prosac.h:208-210) of explicit two-line samples over the quality-sorted line table.
 // One wavefront per hypothesis; the count is an integer, so its reduction order is immaterial.
+template <int kH>
 __global__ __launch_bounds__(256) void prosac_count_kernel(PencilSoA m, uint32_t n, float tol, float degeneracy_tol,
                                                            const uint32_t* __restrict__ sa,
                                                            const uint32_t* __restrict__ sb, uint32_t n_hyp,
                                                            uint32_t* __restrict__ counts) {
     const int lane = threadIdx.x & 63;
-    const uint32_t hyp = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (hyp >= n_hyp) return;
-    const uint32_t a = sa[hyp], b = sb[hyp];
-    const float hax = m.hx[a], hay = m.hy[a], haz = m.hz[a];
-    const float hbx = m.hx[b], hby = m.hy[b], hbz = m.hz[b];
-    const float ex = hax - hbx, ey = hay - hby, ez = haz - hbz;
-    const float dist = sqrtf((ex * ex + ey * ey) + ez * ez);
-    if (!(dist > degeneracy_tol)) {
-        if (lane == 0) counts[hyp] = 0xFFFFFFFFu;  // sample_check failed: the reference skips the iteration
-        return;
+    const uint32_t hyp0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kH;
+    if (hyp0 >= n_hyp) return;
+    Hyp H[kH];
+#pragma unroll
+    for (int j = 0; j < kH; ++j) {
+        const uint32_t h = min(hyp0 + (uint32_t)j, n_hyp - 1u);
+        H[j] = make_hyp(m, sa[h], sb[h], degeneracy_tol);
     }
-    const float px = hay * hbz - haz * hby;
-    const float py = haz * hbx - hax * hbz;
-    const float pz = hax * hby - hay * hbx;
-    const bool ideal = fabsf(pz) < kEps;
-    const float pnx = px / pz, pny = py / pz;
-    uint32_t cnt = 0;
-    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-        const uint32_t i = i0 + lane;
-        bool inl = false;
-        if (i < n) {
-            const float vx = ideal ? px : (pnx - m.ax[i]);
-            const float vy = ideal ? py : (pny - m.ay[i]);
-            const float nrm = sqrtf(vx * vx + vy * vy);
-            const float ux = vx / nrm, uy = vy / nrm;
-            const float err = -fabsf(ux * m.dx[i] + uy * m.dy[i]) + 1.0f;
-            inl = err < tol;
+    uint32_t cnt[kH];
+#pragma unroll
+    for (int j = 0; j < kH; ++j) cnt[j] = 0u;
+    for (uint32_t i = lane; i < n; i += 64) {
+        const float ax = m.ax[i], ay = m.ay[i], dx = m.dx[i], dy = m.dy[i];
+#pragma unroll
+        for (int j = 0; j < kH; ++j) {
+            float vx, vy;
+            hyp_v(H[j], ax, ay, vx, vy);
+            cnt[j] += inlier_test(vx, vy, dx, dy, tol) ? 1u : 0u;
         }
-        cnt += (uint32_t)__popcll(__ballot(inl));
     }
-    if (lane == 0) counts[hyp] = cnt;
+#pragma unroll
+    for (int j = 0; j < kH; ++j) {
+        uint32_t c = cnt[j];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) c += (uint32_t)__shfl_xor((int)c, off);
+        // sample_check failed: the reference skips the iteration
+        if (lane == 0 && hyp0 + (uint32_t)j < n_hyp) counts[hyp0 + j] = H[j].valid ? c : 0xFFFFFFFFu;
+    }
 }
 
 // Hough votes of get_weights on the unit hemisphere: ht x ht accumulator in LDS, 64-bit integer atomics
@@ -368,8 +435,13 @@ int launch_refine_pairs(const void* seg, uint32_t n, void* edges, uint32_t* n_ed
 int launch_prosac_count(PencilSoA m, uint32_t n, float tol, float degeneracy_tol, const uint32_t* sa,
                         const uint32_t* sb, uint32_t n_hyp, uint32_t* counts, hipStream_t s) {
     if (n_hyp == 0) return 0;
-    hipLaunchKernelGGL(prosac_count_kernel, dim3((n_hyp + 3) / 4), dim3(256), 0, s, m, n, tol, degeneracy_tol, sa, sb,
-                       n_hyp, counts);
+    if (n_hyp >= 16384u) {
+        hipLaunchKernelGGL(prosac_count_kernel<8>, dim3((n_hyp + 31) / 32), dim3(256), 0, s, m, n, tol, degeneracy_tol, sa,
+                           sb, n_hyp, counts);
+    } else {
+        hipLaunchKernelGGL(prosac_count_kernel<2>, dim3((n_hyp + 7) / 8), dim3(256), 0, s, m, n, tol, degeneracy_tol, sa, sb,
+                           n_hyp, counts);
+    }
     LR_HIP(hipGetLastError());
     return 0;
 }
@@ -386,14 +458,34 @@ int launch_ht_weights(PencilSoA m, uint32_t n, const int32_t* pa, const int32_t*
     return 0;
 }
 
+// Hypotheses per wavefront: eight when there are enough of them to fill the chip with waves anyway, else four
+static void launch_score(PencilSoA m, uint32_t n, float tol, float degeneracy_tol, uint32_t n_iter, uint64_t seed,
+                         uint32_t round, const uint32_t* gctl, int max_models, float* scores, hipStream_t s) {
+    if (n_iter >= 65536u) {
+        hipLaunchKernelGGL(ransac_score_kernel<8>, dim3((n_iter + 31) / 32), dim3(256), 0, s, m, n, tol, degeneracy_tol,
+                           n_iter, seed, round, gctl, max_models, scores);
+    } else {
+        hipLaunchKernelGGL(ransac_score_kernel<4>, dim3((n_iter + 15) / 16), dim3(256), 0, s, m, n, tol, degeneracy_tol,
+                           n_iter, seed, round, gctl, max_models, scores);
+    }
+}
+
 int launch_ransac_score(PencilSoA m, uint32_t n, float tol, float degeneracy_tol, uint32_t n_iter, uint64_t seed,
                         uint32_t round, float* scores, hipStream_t s) {
     if (n < 2 || n_iter == 0) {
         set_error("launch_ransac_score: need at least 2 lines and 1 iteration");
         return 1;
     }
-    hipLaunchKernelGGL(ransac_score_kernel, dim3((n_iter + 3) / 4), dim3(256), 0, s, m, n, tol, degeneracy_tol, n_iter,
-                       seed, round, scores);
+    launch_score(m, n, tol, degeneracy_tol, n_iter, seed, round, nullptr, 0, scores, s);
+    LR_HIP(hipGetLastError());
+    return 0;
+}
+
+// line count and round from the peeling control block (kernels_groups.hip)
+int launch_ransac_score_dev(PencilSoA m, const uint32_t* gctl, int max_models, float tol, float degeneracy_tol,
+                            uint32_t n_iter, uint64_t seed, float* scores, hipStream_t s) {
+    if (n_iter == 0) return 0;
+    launch_score(m, 0u, tol, degeneracy_tol, n_iter, seed, 0u, gctl, max_models, scores, s);
     LR_HIP(hipGetLastError());
     return 0;
 }

@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256) void seed_write_kernel(const uint64_t* __restr
                                                          int cand_cap, const float* __restrict__ maxmag,
                                                          float keep_ratio, const uint32_t* __restrict__ tile_pass,
                                                          const uint32_t* __restrict__ tile_off,
-                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ n_seeds) {
+                                                         uint64_t* __restrict__ keys, uint32_t cap,
+                                                         uint32_t* __restrict__ n_seeds) {
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (tile >= n_tiles) return;
@@ -69,20 +70,30 @@ __global__ __launch_bounds__(256) void seed_write_kernel(const uint64_t* __restr
         }
         const uint64_t m = __ballot(pass);
         if (pass) {
-            const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
-            keys[base + rank] = ((uint64_t)(~(uint32_t)(k >> 32)) << 32) | (k & 0xFFFFFFFFull);
+            const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            // beyond the sort's capacity: dropped, and the frame is repeated with a larger one (the count says so)
+            if (pos < cap) keys[pos] = ((uint64_t)(~(uint32_t)(k >> 32)) << 32) | (k & 0xFFFFFFFFull);
         }
         base += (uint32_t)__popcll(m);
     }
     if (tile == n_tiles - 1 && lane == 0) *n_seeds = tile_off[tile] + tile_pass[tile];
 }
 
-__global__ __launch_bounds__(256) void seed_setup_kernel(const uint64_t* __restrict__ keys, uint32_t n,
+// The sort runs on a fixed number of keys (`cap`, chosen by the host before it knows the seed count, so that no
+// host round trip sits between the filter and the flood): the slots past the seeds are filled with the largest key.
+__global__ __launch_bounds__(256) void seed_pad_kernel(uint64_t* __restrict__ keys, uint32_t cap,
+                                                       const uint32_t* __restrict__ n_seeds) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < cap && i >= *n_seeds) keys[i] = ~0ull;
+}
+
+__global__ __launch_bounds__(256) void seed_setup_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ n_ptr, uint32_t cap,
                                                          const float* __restrict__ dx, const float* __restrict__ dy,
                                                          BinTrig trig, float trace_tolerance,
                                                          int32_t* __restrict__ seed_idx, int32_t* __restrict__ seed_bin,
                                                          float* __restrict__ seed_thr) {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t n = min(*n_ptr, cap);
     if (k >= n) return;
     const uint32_t lo = (uint32_t)keys[k];
     const uint32_t idx = lo >> 3;
@@ -106,7 +117,7 @@ size_t seeds_temp_bytes(int n_tiles, size_t max_seeds) {
 
 int launch_seed_select(const uint64_t* cand, const uint32_t* cand_count, const uint32_t* tile_max, int n_tiles,
                        int cand_cap, float seed_keep_ratio, float* maxmag, uint32_t* tile_pass, uint32_t* tile_off, uint64_t* keys,
-                       uint32_t* n_seeds, void* temp, size_t temp_bytes, hipStream_t s) {
+                       uint32_t key_cap, uint32_t* n_seeds, void* temp, size_t temp_bytes, hipStream_t s) {
     hipLaunchKernelGGL(reduce_max_kernel, dim3(1), dim3(256), 0, s, tile_max, n_tiles, maxmag);
     const int blocks = (n_tiles + 3) / 4;
     hipLaunchKernelGGL(seed_count_kernel, dim3(blocks), dim3(256), 0, s, cand, cand_count, n_tiles, cand_cap, maxmag,
@@ -114,7 +125,8 @@ int launch_seed_select(const uint64_t* cand, const uint32_t* cand_count, const u
     LR_HIP(rocprim::exclusive_scan(temp, temp_bytes, tile_pass, tile_off, 0u, (size_t)n_tiles,
                                    rocprim::plus<uint32_t>(), s));
     hipLaunchKernelGGL(seed_write_kernel, dim3(blocks), dim3(256), 0, s, cand, cand_count, n_tiles, cand_cap, maxmag,
-                       seed_keep_ratio, tile_pass, tile_off, keys, n_seeds);
+                       seed_keep_ratio, tile_pass, tile_off, keys, key_cap, n_seeds);
+    hipLaunchKernelGGL(seed_pad_kernel, dim3((key_cap + 255) / 256), dim3(256), 0, s, keys, key_cap, n_seeds);
     LR_HIP(hipGetLastError());
     return 0;
 }
@@ -126,10 +138,11 @@ int launch_seed_sort(uint64_t* keys_in, uint64_t* keys_out, uint32_t n, void* te
     return 0;
 }
 
-int launch_seed_setup(const uint64_t* keys_sorted, uint32_t n, const float* dx, const float* dy, BinTrig trig,
-                      float trace_tolerance, int32_t* seed_idx, int32_t* seed_bin, float* seed_thr, hipStream_t s) {
-    if (n == 0) return 0;
-    hipLaunchKernelGGL(seed_setup_kernel, dim3((n + 255) / 256), dim3(256), 0, s, keys_sorted, n, dx, dy, trig,
+int launch_seed_setup(const uint64_t* keys_sorted, const uint32_t* n_seeds, uint32_t cap, const float* dx, const float* dy,
+                      BinTrig trig, float trace_tolerance, int32_t* seed_idx, int32_t* seed_bin, float* seed_thr,
+                      hipStream_t s) {
+    if (cap == 0) return 0;
+    hipLaunchKernelGGL(seed_setup_kernel, dim3((cap + 255) / 256), dim3(256), 0, s, keys_sorted, n_seeds, cap, dx, dy, trig,
                        trace_tolerance, seed_idx, seed_bin, seed_thr);
     LR_HIP(hipGetLastError());
     return 0;

@@ -299,19 +299,18 @@ bool PencilModel::sample_check(int a, int b) const {
 }
 
 Vec3 PencilModel::fit_optimal(const std::vector<int>& idx) const {
-    float cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    auto accumulate = [&](int i) {
-        const float hv[3] = {h[i].x, h[i].y, h[i].z};
-        for (int a = 0; a < 3; ++a) {
-            const float t = hv[a] * length[i];
-            for (int b = 0; b < 3; ++b) cov[a * 3 + b] = cov[a * 3 + b] + t * hv[b];
-        }
-    };
-    if (idx.empty()) {
-        for (int i = 0; i < size(); ++i) accumulate(i);
-    } else {
-        for (int i : idx) accumulate(i);
-    }
+    // cov = sum_i (h_i * len_i) h_i^T over the index set in its order (empty set: every line), each of the nine sums
+    // with the canonical tree T() -- what the device's peeling kernel computes (kernels_groups.hip)
+    const size_t m = idx.empty() ? (size_t)size() : idx.size();
+    float cov[9];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b)
+            cov[a * 3 + b] = tree_sum(m, [&](size_t j) {
+                const int i = idx.empty() ? (int)j : idx[j];
+                const float hv[3] = {h[i].x, h[i].y, h[i].z};
+                const float t = hv[a] * length[i];
+                return t * hv[b];
+            });
     return smallest_eigenvector(cov);
 }
 

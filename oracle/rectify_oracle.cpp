@@ -596,18 +596,18 @@ struct LinePencilModel {
     }
     V3 fit(int a, int b) const { return cross(h[a], h[b]); }  // :101-108
     V3 fit_optimal(const std::vector<int>& idx) const {       // :111-128 (empty set => all lines)
-        float cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        auto add = [&](int i) {
-            float hv[3] = {h[i].x, h[i].y, h[i].z};
-            for (int a = 0; a < 3; ++a) {
-                float t = hv[a] * length[i];
-                for (int b = 0; b < 3; ++b) cov[a * 3 + b] = cov[a * 3 + b] + t * hv[b];
-            }
-        };
-        if (idx.empty())
-            for (int i = 0; i < size(); ++i) add(i);
-        else
-            for (int i : idx) add(i);
+        // cov = h^T diag(length) h over the index set; each of the nine sums is the canonical tree (the reference's
+        // Eigen product leaves the order unspecified)
+        const size_t m = idx.empty() ? size_t(size()) : idx.size();
+        float cov[9];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b)
+                cov[a * 3 + b] = wave_tree_sum(m, [&](size_t j) {
+                    int i = idx.empty() ? int(j) : idx[j];
+                    float hv[3] = {h[i].x, h[i].y, h[i].z};
+                    float t = hv[a] * length[i];
+                    return t * hv[b];
+                });
         return min_eigvec_3x3(cov);
     }
     float error1(V3 hyp, int i) const {  // :131-134
