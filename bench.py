@@ -34,6 +34,10 @@ import time
 
 import numpy as np
 
+# HIP maps its streams onto this many hardware queues (default 4); kernels of streams that share a queue run one after
+# the other.  The batch entry keeps one stream per frame in flight, so give them a queue each (read at HIP start-up).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -169,8 +173,9 @@ def main():
                     help="run only the roofline leg (the filter kernel alone): the command profiled for "
                          "profiles/*_kernel_stats_roofline_leg.csv, where rocprofv3's average must agree with kernel_ms")
     ap.add_argument("--flood-mode", type=int, default=None)
-    ap.add_argument("--streams", type=int, default=16, help="frames in flight per GPU (one context + HIP stream + host thread each)")
-    ap.add_argument("--staging-threads", type=int, default=16, help="host threads that stage pageable frames (num_threads of the batch call)")
+    ap.add_argument("--streams", type=int, default=6, help="frames in flight per GPU (one context + HIP stream + host thread each); "
+                    "more than a handful only dilutes the 256 MB Infinity Cache that the flood's gathers live on")
+    ap.add_argument("--staging-threads", type=int, default=12, help="host threads that stage pageable frames (num_threads of the batch call)")
     args = ap.parse_args()
 
     import torch

@@ -181,14 +181,14 @@ int flood_finish(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, u
 size_t fit_temp_bytes(size_t max_pixels, uint32_t max_segments);
 int launch_component_offsets(const int32_t* seed_size, const uint32_t* d_n_seeds, uint32_t seed_cap, int min_size,
                              uint32_t* comp_rank, uint32_t* comp_seed, uint32_t* comp_off,
-                             uint32_t* totals /*[0]=n_comp,[1]=n_px*/, uint32_t* large_list, uint32_t* n_large, void* temp,
-                             size_t temp_bytes, hipStream_t s);
+                             uint32_t* totals /*[0]=n_comp,[1]=n_px*/, uint32_t* large_list, uint32_t large_cap,
+                             uint32_t* n_large /*[2]*/, void* temp, size_t temp_bytes, hipStream_t s);
 int launch_component_scatter(const uint32_t* label, size_t npix, const uint32_t* comp_rank, const uint32_t* comp_off,
                              uint32_t* cursor, uint32_t* px, hipStream_t s);
 // scratch: >= 2 x (pixels of the frame) words, used by lists of more than 4096 pixels only
 int launch_component_sort(const uint32_t* px_in, uint32_t* px_out, const uint32_t* comp_off, const uint32_t* d_n_comp,
-                          uint32_t comp_cap, const uint32_t* large_list, const uint32_t* n_large, uint32_t* scratch,
-                          hipStream_t s);
+                          uint32_t comp_cap, const uint32_t* large_list, uint32_t large_cap, const uint32_t* n_large,
+                          uint32_t* scratch, hipStream_t s);
 int launch_fit(const uint32_t* px_sorted, const uint32_t* comp_off, const uint32_t* comp_seed, const uint32_t* d_n_comp,
                uint32_t comp_cap, const int32_t* seed_bin, const float* dx, const float* dy, int w, BinTrig trig,
                float* scratch_w, LineSegment* out, hipStream_t s);
@@ -236,8 +236,8 @@ int launch_lines_bbox(LineSegment* lines, uint32_t n, uint32_t* gctl, float* gno
 int launch_pencil_model(const LineSegment* lines, const uint32_t* gctl, const float* gnorm, PencilTable all,
                         PencilTable round0, uint32_t line_cap, hipStream_t s);
 int launch_peel(PencilTable cur, PencilTable nxt, PencilTable all, const float* scores, uint32_t n_iter, uint64_t seed,
-                float tol, float garbage_tol, int max_models, uint32_t* gctl, uint32_t* inl, LineSegment* lines,
-                float* models, hipStream_t s);
+                float tol, float garbage_tol, int max_models, uint32_t* gctl, float* stage4 /* 4 floats per line */,
+                LineSegment* lines, float* models, hipStream_t s);
 int launch_ransac_argmax(const float* scores, uint32_t n_iter, float* best_score, int32_t* best_iter, hipStream_t s);
 int launch_cht_accumulate(PencilSoA m, uint32_t n, int d, unsigned long long* acc, hipStream_t s);
 // refine: seg = n records of 7 floats {x1,y1,x2,y2,dx,dy,len}; edges = pairs of uint32 (i<j); *n_edges may exceed cap

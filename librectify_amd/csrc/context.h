@@ -70,7 +70,7 @@ struct lr_context {
     size_t cap_glines = 0, cap_flines = 0;
     float* d_tables = nullptr;      // 3 pencil tables (all lines, two ping-pong round tables) x 8 arrays x cap_glines
     uint32_t* d_orig = nullptr;     // 3 x cap_glines
-    uint32_t* d_inl = nullptr;      // cap_glines
+    float* d_inl = nullptr;         // 4 x cap_glines: (h, length) of a round's inliers beyond those staged in LDS
     LineSegment* d_flines = nullptr;  // filtered (then grouped) lines
     uint32_t* d_gctl = nullptr;     // peeling control block (kGc*)
     float* d_gnorm = nullptr;       // bounding-box centre and scale

@@ -358,7 +358,7 @@ int ensure_group_capacity(lr_context* c, size_t n_lines, size_t n_iter) {
     if (n_lines > c->cap_glines) {
         LR_HIP(hipStreamSynchronize(c->stream));
         const size_t cl = std::max<size_t>(n_lines, 4096);
-        if (dev_alloc(c->d_tables, 3 * 8 * cl) || dev_alloc(c->d_orig, 3 * cl) || dev_alloc(c->d_inl, cl)) return 1;
+        if (dev_alloc(c->d_tables, 3 * 8 * cl) || dev_alloc(c->d_orig, 3 * cl) || dev_alloc(c->d_inl, 4 * cl)) return 1;
         c->cap_glines = cl;
     }
     if (n_lines > c->cap_flines) {
@@ -486,14 +486,15 @@ int enqueue_fit(lr_context* c) {
     const size_t npix = (size_t)c->w * c->h;
     const uint32_t comp_cap = line_cap_for(c);
     if (launch_component_offsets(c->seed_size, c->d_counts + kCntSeeds, c->seed_cap, kComponentMinSize, c->comp_rank,
-                                 c->comp_seed, c->comp_off, c->d_counts + kCntComp, c->comp_large, c->d_counts + kCntLarge,
-                                 c->temp, c->temp_bytes, c->stream))
+                                 c->comp_seed, c->comp_off, c->d_counts + kCntComp, c->comp_large,
+                                 (uint32_t)(c->cap_pix / 64 + 16), c->d_counts + kCntLarge, c->temp, c->temp_bytes, c->stream))
         return 1;
     LR_HIP(hipMemsetAsync(c->cursor, 0, (size_t)comp_cap * sizeof(uint32_t), c->stream));
     if (launch_component_scatter(c->label, npix, c->comp_rank, c->comp_off, c->cursor, c->px_a, c->stream)) return 1;
     // (the sorted seed keys are dead once the seeds are set up: their buffer is the large lists' sorting scratch)
     if (launch_component_sort(c->px_a, c->px_b, c->comp_off, c->d_counts + kCntComp, comp_cap, c->comp_large,
-                              c->d_counts + kCntLarge, reinterpret_cast<uint32_t*>(c->keys_b), c->stream))
+                              (uint32_t)(c->cap_pix / 64 + 16), c->d_counts + kCntLarge, reinterpret_cast<uint32_t*>(c->keys_b),
+                              c->stream))
         return 1;
     if (launch_fit(c->px_b, c->comp_off, c->comp_seed, c->d_counts + kCntComp, comp_cap, c->seed_bin, c->dx, c->dy, c->w,
                    c->trig, c->scratch_w, c->d_lines, c->stream))
@@ -553,15 +554,15 @@ void record_stage_times(lr_context* c, bool with_groups) {
     }
 }
 
-// the seed sort's capacity follows the frames: grown at once when a frame overflows it (that frame is repeated),
-// shrunk slowly when frames use a small part of it
+// The seed sort's capacity follows the frames: kept between 1.25 and 3 times the last frame's seed count (launches of
+// the flood and the fit are sized by it, and empty workgroups are not free), grown at once when a frame overflows it
+// (that frame is repeated).
 void adapt_seed_cap(lr_context* c, uint32_t n_seeds) {
     const size_t npix = (size_t)c->w * c->h;
-    if (n_seeds > c->seed_cap) {
-        c->seed_cap = (uint32_t)std::min<size_t>(npix, round_up(n_seeds + n_seeds / 2, 1024));
-    } else if (c->seed_cap > 4096 && n_seeds < c->seed_cap / 8) {
-        c->seed_cap = std::max<uint32_t>(4096, round_up(c->seed_cap / 2, 1024));
-    }
+    if (n_seeds > c->seed_cap)
+        c->seed_cap = (uint32_t)std::min<size_t>(npix, std::max<uint32_t>(4096, round_up(n_seeds * 2u, 1024)));
+    else if (n_seeds < c->seed_cap / 3 || n_seeds > c->seed_cap / 5 * 4)
+        c->seed_cap = (uint32_t)std::min<size_t>(npix, std::max<uint32_t>(4096, round_up(n_seeds + n_seeds / 2, 1024)));
 }
 
 }  // namespace

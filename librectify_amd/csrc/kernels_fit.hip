@@ -22,6 +22,7 @@ constexpr uint32_t kNoComp = 0xFFFFFFFFu;
 // Rank and pixel offset of every kept flood, in seed order: a two-level scan.  Workgroup b owns seeds
 // [b * kOffChunk, (b + 1) * kOffChunk), eight consecutive seeds per thread.  First kernel: per-chunk totals.
 // Second kernel: every workgroup adds up the totals of the chunks before it and scans its own chunk.
+constexpr uint32_t kSortLds = 4096;  // longest pixel list sorted in LDS
 constexpr int kOffPer = 8;
 constexpr uint32_t kOffChunk = 256 * kOffPer;
 
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(256) void component_sums_kernel(const int32_t* __re
                                                              uint32_t* __restrict__ n_large) {
     __shared__ uint32_t s_c[4], s_p[4];
     const uint32_t n_seeds = min(*n_ptr, cap);
-    if (blockIdx.x == 0 && threadIdx.x == 0) *n_large = 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) n_large[0] = n_large[1] = 0u;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int sz[kOffPer];
     uint32_t c, p;
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void component_offsets_kernel(const int32_t* _
                                                                 uint32_t* __restrict__ comp_off,
                                                                 uint32_t* __restrict__ totals,
                                                                 uint32_t* __restrict__ large_list,
-                                                                uint32_t* __restrict__ n_large) {
+                                                                uint32_t large_cap, uint32_t* __restrict__ n_large) {
     __shared__ uint32_t s_c[4], s_p[4], s_cc[4], s_cp[4];
     const uint32_t n_seeds = min(*n_ptr, cap);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -124,8 +125,10 @@ __global__ __launch_bounds__(256) void component_offsets_kernel(const int32_t* _
             if (keep) {
                 comp_seed[rank] = k;
                 comp_off[rank] = off_px;
-                // lists of more than 64 pixels are sorted by a workgroup each (component_sort_large_kernel)
-                if (sz[j] > 64) large_list[atomicAdd(n_large, 1u)] = rank;
+                // lists of more than 64 pixels are sorted by a workgroup each (component_sort_large_kernel): in LDS up to
+                // 4096 pixels (list filled from the front), through global memory beyond (filled from the back)
+                if (sz[j] > (int)kSortLds) large_list[large_cap - 1u - atomicAdd(n_large + 1, 1u)] = rank;
+                else if (sz[j] > 64) large_list[atomicAdd(n_large, 1u)] = rank;
                 rank += 1u;
                 off_px += (uint32_t)sz[j];
             }
@@ -231,24 +234,23 @@ __global__ __launch_bounds__(256) void component_sort_small_kernel(const uint32_
 
 // Longer lists: one workgroup each, bitonic network on the list padded to a power of two -- in LDS up to 4096 keys,
 // in place in global memory beyond that (rare: a flood of more than 4096 pixels).
-constexpr uint32_t kSortLds = 4096;
 __global__ __launch_bounds__(256) void component_sort_large_kernel(const uint32_t* __restrict__ px_in,
                                                                    uint32_t* __restrict__ px_out,
                                                                    const uint32_t* __restrict__ comp_off,
                                                                    const uint32_t* __restrict__ large_list,
+                                                                   uint32_t large_cap,
                                                                    const uint32_t* __restrict__ n_large,
                                                                    uint32_t* __restrict__ scratch) {
     __shared__ uint32_t s_key[kSortLds];
-    const uint32_t n_list = *n_large;
+    // two launches share this kernel: many workgroups for the lists that fit the LDS (scratch == nullptr; entries at the
+    // front of large_list), a single workgroup with a global scratch buffer for the few that do not (at its back)
+    const uint32_t n_list = scratch ? n_large[1] : n_large[0];
     for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
-        const uint32_t comp = large_list[li];
+        const uint32_t comp = large_list[scratch ? large_cap - 1u - li : li];
         const uint32_t off = comp_off[comp];
         const uint32_t n = comp_off[comp + 1] - off;
         uint32_t P = 128;
         while (P < n) P <<= 1;
-        // two launches share this kernel: many workgroups for the lists that fit the LDS (scratch == nullptr), a
-        // single workgroup with a global scratch buffer for the few that do not
-        if ((P <= kSortLds) != (scratch == nullptr)) continue;
         if (P <= kSortLds) {
             for (uint32_t i = threadIdx.x; i < P; i += 256) s_key[i] = i < n ? px_in[off + i] : 0xFFFFFFFFu;
             __syncthreads();
@@ -377,7 +379,8 @@ size_t fit_temp_bytes(size_t max_pixels, uint32_t max_segments) {
 
 int launch_component_offsets(const int32_t* seed_size, const uint32_t* d_n_seeds, uint32_t seed_cap, int min_size,
                              uint32_t* comp_rank, uint32_t* comp_seed, uint32_t* comp_off, uint32_t* totals,
-                             uint32_t* large_list, uint32_t* n_large, void* temp, size_t temp_bytes, hipStream_t s) {
+                             uint32_t* large_list, uint32_t large_cap, uint32_t* n_large, void* temp, size_t temp_bytes,
+                             hipStream_t s) {
     const uint32_t chunks = (seed_cap + kOffChunk - 1) / kOffChunk;
     if (chunks == 0 || temp_bytes < chunks * sizeof(uint2)) {
         set_error("launch_component_offsets: workspace too small");
@@ -387,7 +390,7 @@ int launch_component_offsets(const int32_t* seed_size, const uint32_t* d_n_seeds
     hipLaunchKernelGGL(component_sums_kernel, dim3(chunks), dim3(256), 0, s, seed_size, d_n_seeds, seed_cap, min_size,
                        chunk_tot, n_large);
     hipLaunchKernelGGL(component_offsets_kernel, dim3(chunks), dim3(256), 0, s, seed_size, d_n_seeds, seed_cap, min_size,
-                       chunk_tot, comp_rank, comp_seed, comp_off, totals, large_list, n_large);
+                       chunk_tot, comp_rank, comp_seed, comp_off, totals, large_list, large_cap, n_large);
     LR_HIP(hipGetLastError());
     return 0;
 }
@@ -403,16 +406,16 @@ int launch_component_scatter(const uint32_t* label, size_t npix, const uint32_t*
 }
 
 int launch_component_sort(const uint32_t* px_in, uint32_t* px_out, const uint32_t* comp_off, const uint32_t* d_n_comp,
-                          uint32_t comp_cap, const uint32_t* large_list, const uint32_t* n_large, uint32_t* scratch,
-                          hipStream_t s) {
+                          uint32_t comp_cap, const uint32_t* large_list, uint32_t large_cap, const uint32_t* n_large,
+                          uint32_t* scratch, hipStream_t s) {
     if (comp_cap == 0) return 0;
     hipLaunchKernelGGL(component_sort_small_kernel, dim3((comp_cap + 3) / 4), dim3(256), 0, s, px_in, px_out, comp_off,
                        d_n_comp);
     // (lists of more than 4096 pixels: one at a time through the global scratch, by a single workgroup)
-    hipLaunchKernelGGL(component_sort_large_kernel, dim3(1024), dim3(256), 0, s, px_in, px_out, comp_off, large_list, n_large,
-                       (uint32_t*)nullptr);
-    hipLaunchKernelGGL(component_sort_large_kernel, dim3(1), dim3(256), 0, s, px_in, px_out, comp_off, large_list, n_large,
-                       scratch);
+    hipLaunchKernelGGL(component_sort_large_kernel, dim3(1024), dim3(256), 0, s, px_in, px_out, comp_off, large_list,
+                       large_cap, n_large, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(component_sort_large_kernel, dim3(1), dim3(256), 0, s, px_in, px_out, comp_off, large_list, large_cap,
+                       n_large, scratch);
     LR_HIP(hipGetLastError());
     return 0;
 }

@@ -205,7 +205,6 @@ enum {
     // is worked out by flood_init_seeds_kernel and kept here.
     kCtrlNSeeds = 16,   // seeds of this frame (clamped to the capacity the seed sort ran with)
     kCtrlWinHold = 17,  // the window stops here while the weakest seeds are held back
-    kCtrlNext = 18,     // next entry of the active list to hand out (the exploration workgroups pull their seeds)
     kCtrlWords = 32,
 };
 static_assert(kCtrlWords == kFloodCtrlWords, "control block size");
@@ -875,13 +874,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     LdsStore L{s_ring[0], s_ring[1], s_ring[2], s_hash[0], s_hash[1], s_hash[2],
                s_hash[3], s_hash[4], s_hash[5], s_hash[6], s_ord};
     Pending P{s_pend[0], s_pend[1]};
-    // The grid is a fixed number of workgroups (enough to fill the chip), whatever the length of the list, which only
-    // the device knows: every workgroup pulls the next entry until the list is exhausted.
-    for (;;) {
-        uint32_t ai = 0;
-        if (lane == 0) ai = atomicAdd(&A.ctrl[kCtrlNext], 1u);
-        ai = uni(ai);
-        if (ai >= n_act) return;
+    // The host knows neither the seed count nor the length of the round's list when it enqueues the round: the grid is
+    // its guess (the capacity of the seed sort, halved from round to round as the lists shrink), and a workgroup takes
+    // entries b, b + grid, ... so that a low guess costs balance, not correctness.  With a good guess it is one seed per
+    // workgroup and the hardware's dispatcher balances the walks, whose lengths differ by three orders of magnitude.
+    // (Measured and rejected: a chip-sized grid pulling entries through one atomic counter -- 40 000 same-address
+    // atomics serialise in L2, +0.4 ms per frame; the same grid striding over the list -- the slowest workgroup's
+    // eight walks in a row make the first round half again as long; a grid of the full capacity in every round --
+    // an empty workgroup costs the dispatcher 0.4 ns, 0.3 ms per frame that other frames' kernels wait for.)
+    for (uint32_t ai = uni(blockIdx.x); ai < n_act; ai += gridDim.x) {
         // The list is walked from its end: the first round's list is in seed order, strongest first, and the longest
         // walks belong to the weak seeds at its end (low thresholds, large footprints).  Started first, they run
         // alongside the mass of short walks instead of after it.
@@ -1001,7 +1002,6 @@ __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift) {
     ctrl[kCtrlBarrier] = 0xFFFFFFFFu;
     ctrl[kCtrlSlabs] = 0u;
     ctrl[kCtrlNBig] = 0u;
-    ctrl[kCtrlNext] = 0u;
 }
 
 // After the commit: which seeds go on to the next round?
@@ -1074,7 +1074,6 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
         if (hold_now && win_first > win_hold) win_first = win_hold;
         ctrl[kCtrlNSeeds] = n_seeds;
         ctrl[kCtrlWinHold] = win_hold;
-        ctrl[kCtrlNext] = 0u;
         ctrl[kCtrlWindow] = win_first;
         ctrl[kCtrlDone] = 0u;
         ctrl[kCtrlBelow] = 0u;
@@ -1240,16 +1239,6 @@ FloodArgs flood_args(const FloodBuffers& B, const FloodFrame& F, bool use_big) {
     return A;
 }
 
-// workgroups of the exploration kernel: as many as the chip holds at once (LDS: 16-17 per CU), plus a few
-int explore_grid(uint32_t cap) {
-    static const int n = [] {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        return cus * 20;
-    }();
-    return (int)std::min<uint32_t>(std::max(cap, 1u), (uint32_t)n);
-}
-
 const bool g_flood_debug = std::getenv("LIBRECTIFY_FLOOD_DEBUG") != nullptr;
 
 // one round: explore (both LDS tiers), decide, commit, survivors
@@ -1266,7 +1255,10 @@ void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& 
         (void)hipEventCreate(&dbg1);
         (void)hipEventRecord(dbg0, s);
     }
-    hipLaunchKernelGGL(flood_explore_kernel, dim3(explore_grid(F.seed_cap)), dim3(64), 0, s, A, F.trig, act, B.big_list);
+    // grid: see flood_explore_kernel.  A staged start keeps the list long for a round more.
+    const int shift = std::min(std::max(index - (B.win_first_shift > 0 ? 1 : 0), 0), 4);
+    const uint32_t grid = std::max<uint32_t>(std::min<uint32_t>(F.seed_cap, 2048u), F.seed_cap >> shift);
+    hipLaunchKernelGGL(flood_explore_kernel, dim3(grid), dim3(64), 0, s, A, F.trig, act, B.big_list);
     if (use_big)
         hipLaunchKernelGGL(flood_explore_big_kernel, dim3(std::min<uint32_t>(F.seed_cap, kBigCap)), dim3(64), kBigLdsBytes, s,
                            A, F.trig, B.big_list);

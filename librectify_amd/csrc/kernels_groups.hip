@@ -256,21 +256,35 @@ __device__ void smallest_eigenvector_3x3(const float c[9], float out[3]) {
 
 // ---- one peeling round after its hypotheses have been scored (estimator.h:62-76,118-139) -----------------------------
 // cur: the compacted table the scores refer to (kGcActive lines); nxt: where the lines that go on to the next round
-// are written, in order; all: every line of the model; inl: scratch for the inlier positions (>= kGcActive words).
+// are written, in order; all: every line of the model; stage_g: scratch for the inliers' (h, length) beyond the first
+// kStage, which live in LDS (>= 4 * kGcActive floats).
+// The kernel is a chain of short dependent phases, so what counts is the number of memory round trips: a thread keeps
+// its line of the first 1024 in registers from the start, and the inliers are staged in LDS for the refit's sums.
+constexpr uint32_t kStage = 2048;
 __global__ __launch_bounds__(kWG) void peel_kernel(PencilTable cur, PencilTable nxt, PencilTable all,
                                                    const float* __restrict__ scores, uint32_t n_iter, uint64_t seed,
                                                    float tol, float garbage_tol, int max_models,
-                                                   uint32_t* __restrict__ gctl, uint32_t* __restrict__ inl,
+                                                   uint32_t* __restrict__ gctl, float4* __restrict__ stage_g,
                                                    LineSegment* __restrict__ lines, float* __restrict__ models) {
     __shared__ uint32_t s_cnt[kWaves];
     __shared__ float s_bv[kWaves];
     __shared__ int s_bi[kWaves];
     __shared__ float s_h[3];
+    __shared__ float4 s_stage[kStage];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t n = gctl[kGcActive];
     const uint32_t round = gctl[kGcRound];
     // estimator.h:115: while (num_observations >= minimum_set_size && k < max_structures)
     if (gctl[kGcRemaining] < 2u || round >= (uint32_t)max_models) return;
+
+    // this thread's line of the first chunk, in flight while the best hypothesis is looked up
+    float r_ax = 0.f, r_ay = 0.f, r_dx = 0.f, r_dy = 0.f, r_len = 0.f, r_hx = 0.f, r_hy = 0.f, r_hz = 0.f;
+    uint32_t r_orig = 0;
+    if (threadIdx.x < n) {
+        const uint32_t i = threadIdx.x;
+        r_ax = cur.ax[i]; r_ay = cur.ay[i]; r_dx = cur.dx[i]; r_dy = cur.dy[i]; r_len = cur.len[i];
+        r_hx = cur.hx[i]; r_hy = cur.hy[i]; r_hz = cur.hz[i]; r_orig = cur.orig[i];
+    }
 
     // -- first strictly best hypothesis: highest score, lowest iteration among equals; none if no score is positive
     float bv = 0.f;
@@ -320,19 +334,32 @@ __global__ __launch_bounds__(kWG) void peel_kernel(PencilTable cur, PencilTable 
         s_h[0] = hx;
         s_h[1] = hy;
         s_h[2] = hz;
+        gctl[kGcBestIter0 + round] = (uint32_t)bi;
     }
     __syncthreads();
     const float bx_ = s_h[0], by_ = s_h[1], bz_ = s_h[2];
 
-    // -- inliers of the best hypothesis, in order (estimator.h:74-75)
+    // -- inliers of the best hypothesis, in order (estimator.h:74-75): their (h, length) staged for the refit
     uint32_t n_inl = 0;
     for (uint32_t i0 = 0; i0 < n; i0 += kWG) {
         const uint32_t i = i0 + threadIdx.x;
         bool in = false;
-        if (i < n) in = pencil_error(cur.ax[i], cur.ay[i], cur.dx[i], cur.dy[i], bx_, by_, bz_) < tol;
+        float4 hl = make_float4(r_hx, r_hy, r_hz, r_len);
+        if (i < n) {
+            if (i0 == 0) {
+                in = pencil_error(r_ax, r_ay, r_dx, r_dy, bx_, by_, bz_) < tol;
+            } else {
+                in = pencil_error(cur.ax[i], cur.ay[i], cur.dx[i], cur.dy[i], bx_, by_, bz_) < tol;
+                if (in) hl = make_float4(cur.hx[i], cur.hy[i], cur.hz[i], cur.len[i]);
+            }
+        }
         uint32_t tot;
         const uint32_t r = block_rank(in, s_cnt, tot);
-        if (in) inl[n_inl + r] = i;
+        if (in) {
+            const uint32_t o = n_inl + r;
+            if (o < kStage) s_stage[o] = hl;
+            else stage_g[o] = hl;
+        }
         n_inl += tot;
     }
     __syncthreads();
@@ -340,18 +367,18 @@ __global__ __launch_bounds__(kWG) void peel_kernel(PencilTable cur, PencilTable 
     // -- fit_optimal (line_pencil.cpp:111-128): cov = sum_i (h_i * len_i) h_i^T over the inliers, or over EVERY line of
     // the model if there is none (the reference's "empty index set means all"); nine tree sums by the first wavefront
     if (wv == 0) {
-        const PencilTable& T = n_inl ? cur : all;
         const uint32_t m = n_inl ? n_inl : gctl[kGcLines];
         float acc[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) acc[k] = 0.f;
         for (uint32_t j = lane; j < m; j += 64) {
-            const uint32_t i = n_inl ? inl[j] : j;
-            const float hv[3] = {T.hx[i], T.hy[i], T.hz[i]};
-            const float len = T.len[i];
+            float4 hl;
+            if (n_inl) hl = j < kStage ? s_stage[j] : stage_g[j];
+            else hl = make_float4(all.hx[j], all.hy[j], all.hz[j], all.len[j]);
+            const float hv[3] = {hl.x, hl.y, hl.z};
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                const float t = hv[a] * len;
+                const float t = hv[a] * hl.w;
 #pragma unroll
                 for (int b = 0; b < 3; ++b) acc[a * 3 + b] = acc[a * 3 + b] + t * hv[b];
             }
@@ -378,15 +405,14 @@ __global__ __launch_bounds__(kWG) void peel_kernel(PencilTable cur, PencilTable 
     for (uint32_t i0 = 0; i0 < n; i0 += kWG) {
         const uint32_t i = i0 + threadIdx.x;
         bool stay = false, gone = false;
-        float ax = 0, ay = 0, dx = 0, dy = 0;
         if (i < n) {
-            ax = cur.ax[i];
-            ay = cur.ay[i];
-            dx = cur.dx[i];
-            dy = cur.dy[i];
-            const float e = pencil_error(ax, ay, dx, dy, fx, fy, fz);
+            if (i0 != 0) {
+                r_ax = cur.ax[i]; r_ay = cur.ay[i]; r_dx = cur.dx[i]; r_dy = cur.dy[i]; r_len = cur.len[i];
+                r_hx = cur.hx[i]; r_hy = cur.hy[i]; r_hz = cur.hz[i]; r_orig = cur.orig[i];
+            }
+            const float e = pencil_error(r_ax, r_ay, r_dx, r_dy, fx, fy, fz);
             if (e < tol) {
-                lines[cur.orig[i]].group_id = (int)round;
+                lines[r_orig].group_id = (int)round;
                 gone = true;
             } else if (e >= tol && e < garbage_tol) {
                 gone = true;
@@ -398,9 +424,9 @@ __global__ __launch_bounds__(kWG) void peel_kernel(PencilTable cur, PencilTable 
         const uint32_t r = block_rank(stay, s_cnt, tot);
         if (stay) {
             const uint32_t o = n_next + r;
-            nxt.ax[o] = ax; nxt.ay[o] = ay; nxt.dx[o] = dx; nxt.dy[o] = dy;
-            nxt.len[o] = cur.len[i]; nxt.hx[o] = cur.hx[i]; nxt.hy[o] = cur.hy[i]; nxt.hz[o] = cur.hz[i];
-            nxt.orig[o] = cur.orig[i];
+            nxt.ax[o] = r_ax; nxt.ay[o] = r_ay; nxt.dx[o] = r_dx; nxt.dy[o] = r_dy;
+            nxt.len[o] = r_len; nxt.hx[o] = r_hx; nxt.hy[o] = r_hy; nxt.hz[o] = r_hz;
+            nxt.orig[o] = r_orig;
         }
         (void)block_rank(gone, s_cnt, tg);
         n_next += tot;
@@ -410,7 +436,6 @@ __global__ __launch_bounds__(kWG) void peel_kernel(PencilTable cur, PencilTable 
         gctl[kGcActive] = n_next;
         gctl[kGcRemaining] = gctl[kGcRemaining] - n_gone;
         gctl[kGcRound] = round + 1u;
-        gctl[kGcBestIter0 + round] = (uint32_t)bi;
     }
 }
 
@@ -438,10 +463,10 @@ int launch_pencil_model(const LineSegment* lines, const uint32_t* gctl, const fl
 }
 
 int launch_peel(PencilTable cur, PencilTable nxt, PencilTable all, const float* scores, uint32_t n_iter, uint64_t seed,
-                float tol, float garbage_tol, int max_models, uint32_t* gctl, uint32_t* inl, LineSegment* lines,
+                float tol, float garbage_tol, int max_models, uint32_t* gctl, float* stage4, LineSegment* lines,
                 float* models, hipStream_t s) {
     hipLaunchKernelGGL(peel_kernel, dim3(1), dim3(kWG), 0, s, cur, nxt, all, scores, n_iter, seed, tol, garbage_tol,
-                       max_models, gctl, inl, lines, models);
+                       max_models, gctl, reinterpret_cast<float4*>(stage4), lines, models);
     LR_HIP(hipGetLastError());
     return 0;
 }
