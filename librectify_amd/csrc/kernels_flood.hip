@@ -860,11 +860,23 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
 }
 
 // One wavefront per workgroup (walks differ in length by three orders of magnitude, and a workgroup keeps its
-// LDS until its longest wave is done), one seed per wavefront.  The grid covers the frame's seed count; the
-// length of the round's active list is read from the control block, so the host need not know it (workgroups
-// beyond the list leave at once).
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void flood_explore_kernel(
-    FloodArgs A, BinTrig trig, const uint32_t* __restrict__ act, uint32_t* __restrict__ big_list) {
+// LDS until its longest wave is done), one seed per wavefront.
+//
+// The host knows neither the seed count nor the length of the round's list when it enqueues the round: the grid is
+// its guess (the capacity of the seed sort, halved from round to round as the lists shrink), one entry per workgroup,
+// so that the hardware's dispatcher balances the walks.  If the list turns out longer than the guess, the entries
+// past it are taken by the `rest` launch that follows every main launch (a few workgroups striding over them; it
+// leaves at once otherwise).
+// (Measured and rejected: a chip-sized grid pulling entries through one atomic counter -- 40 000 same-address atomics
+// serialise in L2, +0.4 ms per frame; one kernel whose workgroups stride over the list -- the loop around the walk
+// costs 137 spilled registers, and the slowest workgroup's eight walks in a row make the first round half again as
+// long; a grid of the full capacity in every round -- an empty workgroup costs the dispatcher 0.4 ns, 0.3 ms per frame
+// that other frames' kernels wait for; a smaller first storage tier (64-record ring, 128-tile table, 4.9 KB) for more
+// walks in flight, handing longer walks to a second kernel -- the tiers' kernels run one after the other, so every
+// round lasts as long as the longest walk of EACH tier: 1.43 -> 2.0 ms per flood.)
+template <bool kRest>
+__device__ __forceinline__ void explore_body(const FloodArgs& A, const BinTrig& trig, const uint32_t* __restrict__ act,
+                                             uint32_t* __restrict__ big_list, uint32_t first) {
     __shared__ uint32_t s_ring[3][kRingT];
     __shared__ uint32_t s_hash[7][kHashT];
     __shared__ uint32_t s_pend[2][kPend];
@@ -874,22 +886,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
     LdsStore L{s_ring[0], s_ring[1], s_ring[2], s_hash[0], s_hash[1], s_hash[2],
                s_hash[3], s_hash[4], s_hash[5], s_hash[6], s_ord};
     Pending P{s_pend[0], s_pend[1]};
-    // The host knows neither the seed count nor the length of the round's list when it enqueues the round: the grid is
-    // its guess (the capacity of the seed sort, halved from round to round as the lists shrink), and a workgroup takes
-    // entries b, b + grid, ... so that a low guess costs balance, not correctness.  With a good guess it is one seed per
-    // workgroup and the hardware's dispatcher balances the walks, whose lengths differ by three orders of magnitude.
-    // (Measured and rejected: a chip-sized grid pulling entries through one atomic counter -- 40 000 same-address
-    // atomics serialise in L2, +0.4 ms per frame; the same grid striding over the list -- the slowest workgroup's
-    // eight walks in a row make the first round half again as long; a grid of the full capacity in every round --
-    // an empty workgroup costs the dispatcher 0.4 ns, 0.3 ms per frame that other frames' kernels wait for.)
-    for (uint32_t ai = uni(blockIdx.x); ai < n_act; ai += gridDim.x) {
-        // The list is walked from its end: the first round's list is in seed order, strongest first, and the longest
-        // walks belong to the weak seeds at its end (low thresholds, large footprints).  Started first, they run
-        // alongside the mass of short walks instead of after it.
+    // The list is walked from its end: the first round's list is in seed order, strongest first, and the longest
+    // walks belong to the weak seeds at its end (low thresholds, large footprints).  Started first, they run
+    // alongside the mass of short walks instead of after it.
+    if (!kRest) {
+        const uint32_t ai = uni(blockIdx.x);
+        if (ai >= n_act) return;
         const uint32_t k = uni(act[A.from_end ? n_act - 1u - ai : ai]);
-        if (k >= window) continue;  // not yet in the staged window (stays active)
+        if (k >= window) return;  // not yet in the staged window (stays active)
         explore_seed<LdsStore, true>(A, trig, k, L, P, big_list, lane);
+    } else {
+        for (uint32_t ai = first + uni(blockIdx.x); ai < n_act; ai += gridDim.x) {
+            const uint32_t k = uni(act[A.from_end ? n_act - 1u - ai : ai]);
+            if (k >= window) continue;
+            explore_seed<LdsStore, true>(A, trig, k, L, P, big_list, lane);
+        }
     }
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void flood_explore_kernel(
+    FloodArgs A, BinTrig trig, const uint32_t* __restrict__ act, uint32_t* __restrict__ big_list) {
+    explore_body<false>(A, trig, act, big_list, 0u);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void flood_explore_rest_kernel(
+    FloodArgs A, BinTrig trig, const uint32_t* __restrict__ act, uint32_t* __restrict__ big_list, uint32_t first) {
+    explore_body<true>(A, trig, act, big_list, first);
 }
 
 // Second storage tier: the same walk from the start with a 1024-record ring and a 2048-tile table (dynamic LDS,
@@ -1259,6 +1279,8 @@ void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& 
     const int shift = std::min(std::max(index - (B.win_first_shift > 0 ? 1 : 0), 0), 4);
     const uint32_t grid = std::max<uint32_t>(std::min<uint32_t>(F.seed_cap, 2048u), F.seed_cap >> shift);
     hipLaunchKernelGGL(flood_explore_kernel, dim3(grid), dim3(64), 0, s, A, F.trig, act, B.big_list);
+    if (grid < F.seed_cap)  // entries past the guess, if any
+        hipLaunchKernelGGL(flood_explore_rest_kernel, dim3(256), dim3(64), 0, s, A, F.trig, act, B.big_list, grid);
     if (use_big)
         hipLaunchKernelGGL(flood_explore_big_kernel, dim3(std::min<uint32_t>(F.seed_cap, kBigCap)), dim3(64), kBigLdsBytes, s,
                            A, F.trig, B.big_list);
