@@ -25,14 +25,9 @@ constexpr float kLineMinLength = 5.f;
 constexpr int kComponentMinSize = 5;
 constexpr int kBins = 8;
 
-// Filter tile geometry (kernels_filter.hip)
-constexpr int kTileW = 64;
-constexpr int kTileH = 32;
-constexpr int kCandPerTile = kTileW * kTileH;  // worst case: every core pixel is a plateau peak
-
 struct FilterConsts {
-    float kx[25];   // Hx taps, row-major (reference filter.cpp:65-78, dir_x = true)
-    float ky[25];   // Hy taps
+    float d[5];  // 1-D factors of the 5x5 taps (reference filter.cpp:65-78): Hx(i,j) = d[j] g[i], Hy(i,j) = d[i] g[j]
+    float g[5];
     float st[kBins];  // sin(theta_b), theta_b = float(b*pi)/8 (line_detector.cpp:144-145)
     float ct[kBins];  // cos(theta_b)
 };
@@ -90,8 +85,6 @@ struct FilterGeom {
     int cand_cap;  // slots per list
 };
 FilterGeom filter_geometry(int w, int h);
-inline int tiles_x(int w) { return (w + kTileW - 1) / kTileW; }
-inline int tiles_y(int h) { return (h + kTileH - 1) / kTileH; }
 
 // kernels_seeds.hip
 size_t seeds_temp_bytes(int n_tiles, size_t max_seeds);

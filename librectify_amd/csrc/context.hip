@@ -29,23 +29,21 @@ int dev_alloc(T*& p, size_t count) {
     return 0;
 }
 
-// reference filter.cpp:65-78
-void gauss_deriv_taps(int size, float sigma, bool dir_x, float* H) {
+// 1-D factors of the reference's taps (filter.cpp:65-78: H = z / a * exp(-(x^2 + y^2) / 2s^2), a = 2 pi s^4):
+// d(t) = t / a * exp(-t^2 / 2s^2), g(t) = exp(-t^2 / 2s^2), evaluated with the same float operations
+void gauss_deriv_factors(int size, float sigma, float* d, float* g) {
     const int n = 2 * size + 1;
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) {
-            const float x = float(j - size);
-            const float y = float(i - size);
-            const float z = dir_x ? x : y;
-            const float a = float(2 * M_PI * std::pow(sigma, 4.0f));
-            const float e = std::exp(-(std::pow(x, 2.0f) + std::pow(y, 2.0f)) / (2 * std::pow(sigma, 2.0f)));
-            H[i * n + j] = z / a * e;
-        }
+    for (int t = 0; t < n; ++t) {
+        const float x = float(t - size);
+        const float a = float(2 * M_PI * std::pow(sigma, 4.0f));
+        const float e = std::exp(-std::pow(x, 2.0f) / (2 * std::pow(sigma, 2.0f)));
+        d[t] = x / a * e;
+        g[t] = e;
+    }
 }
 
 void init_constants(lr_context* c) {
-    gauss_deriv_taps(kEdgeKernelSize, kEdgeKernelSigma, true, c->fconsts.kx);
-    gauss_deriv_taps(kEdgeKernelSize, kEdgeKernelSigma, false, c->fconsts.ky);
+    gauss_deriv_factors(kEdgeKernelSize, kEdgeKernelSigma, c->fconsts.d, c->fconsts.g);
     for (int b = 0; b < kBins; ++b) {
         const float theta = float(b * M_PI) / kBins;  // line_detector.cpp:144
         c->trig.st[b] = std::sin(theta);
@@ -76,7 +74,7 @@ int ctx_ensure_image_capacity(lr_context* c, int w, int h) {
     const size_t cp = std::max(npix, c->cap_pix);
     const int ct = std::max(ntiles, c->cap_tiles);
     if (dev_alloc(c->dx, cp) || dev_alloc(c->dy, cp) || dev_alloc(c->dmask, cp + 16) ||
-        dev_alloc(c->cand, (size_t)ct * std::max(fg.cand_cap, (int)kCandPerTile)) || dev_alloc(c->cand_count, ct) || dev_alloc(c->tile_max, ct) ||
+        dev_alloc(c->cand, (size_t)ct * fg.cand_cap) || dev_alloc(c->cand_count, ct) || dev_alloc(c->tile_max, ct) ||
         dev_alloc(c->tile_pass, ct) || dev_alloc(c->tile_off, ct) || dev_alloc(c->keys_a, cp) ||
         dev_alloc(c->keys_b, cp) || dev_alloc(c->seed_idx, cp) || dev_alloc(c->seed_bin, cp) ||
         dev_alloc(c->seed_thr, cp) || dev_alloc(c->seed_size, cp) || dev_alloc(c->label, cp) ||

@@ -9,15 +9,14 @@
 //   write dx, dy                    8 B/px   (fp32, reused by flood + line fit)
 //   write dmask                     1 B/px   (bit b: pixel lies in dilate3x3(grad_bin == b))
 //   write peak candidates           sparse   (mag == max5x5 && mag > 0, with value, index, bin)
-//   write per-tile max(mag)         4 B/tile
+//   write per-band max(mag)         4 B/band
 //
-// A 256-thread workgroup owns a 64x32 output tile.  The image tile with a 4-px halo
-// (conv radius 2 + NMS radius 2) is staged in LDS; the 5x5 correlation is evaluated on the
-// tile grown by 2 px (so mag/bin of the NMS/dilate halo are recomputed, not exchanged), each
-// thread producing 1x4 strips from an aligned 5x8 LDS window.  Arithmetic is the canonical
-// form shared with the CPU oracle: acc = fmaf(img, K, acc) in row-major tap order,
-// mag = sqrtf(dx*dx + dy*dy) without contraction, bin = first strict argmax of
-// |fmaf(dx, sin, dy*cos)|.
+// Row streaming, one pixel per lane: a wavefront owns a band of 56 columns (lanes 4..59; four halo lanes on each
+// side: conv radius 2 + NMS radius 2) x 30 rows and walks down it one image row per step.  Horizontal neighbours
+// come from DPP wavefront shifts, vertical ones from registers that roll with the rows; there is no LDS and no
+// barrier.  Arithmetic is the canonical form shared with the CPU oracle: the separable evaluation
+// of the 5x5 Gaussian-derivative correlation (row pass hx, hs; column pass dx, dy; explicit fmaf),
+// mag = sqrtf(dx*dx + dy*dy) without contraction, bin = first strict argmax of |fmaf(dx, sin, dy*cos)|.
 #include <cstdlib>
 #include <cstring>
 
@@ -26,226 +25,16 @@
 namespace lramd {
 namespace {
 
-constexpr int IW = 76;  // image tile: cols x0-6 .. x0+69 (16-B aligned windows), rows y0-4 .. y0+35
-constexpr int IH = 40;
-constexpr int CW = 72;  // conv region: cols x0-4 .. x0+67, rows y0-2 .. y0+33
-constexpr int CH = 36;
-constexpr int CSTRIPS = CW / 4;
-
-// The 5x5 Gaussian-derivative taps as the host computes them (filter.cpp:72-75) satisfy, bit for bit,
-//   Hx[i][j] = -Hx[i][4-j] = Hx[4-i][j],  Hx[i][2] = +0      Hy[i][j] = Hx[j][i]
-// (the sign enters only through z, and exp() sees the same argument), so six magnitudes describe
-// both kernels.  The kernel keeps them in SGPRs; a negated tap is an FMA source modifier, and the
-// zero taps are skipped: fmaf(v, +0, acc) == acc for every finite v because acc is never -0
-// (it starts at +0 and x + (-x) rounds to +0).
+// 1-D factors of the taps (filter.cpp:72-75): Hx(i,j) = d(x_j) g(y_i), Hy(i,j) = d(y_i) g(x_j) with
+// d(t) = t/a exp(-t^2/2s^2), g(t) = exp(-t^2/2s^2); d(-t) = -d(t), d(0) = 0, g(-t) = g(t), g(0) = 1 exactly.
 struct FilterTaps {
-    float k[3][2];    // Hx[i][j] for i = 0..2 (|y| = 2,1,0), j = 0..1 (x = -2,-1)
+    float d1, d2, g1, g2;
     float st[kBins];
     float ct[kBins];
 };
 
-__global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ img, int w, int h, int stride,
-                                                     FilterTaps fc, float* __restrict__ dx_out,
-                                                     float* __restrict__ dy_out, uint8_t* __restrict__ dmask_out,
-                                                     uint64_t* __restrict__ cand, uint32_t* __restrict__ cand_count,
-                                                     uint32_t* __restrict__ tile_max) {
-    __shared__ __attribute__((aligned(16))) float s_img[IH][IW];
-    __shared__ __attribute__((aligned(16))) float s_mag[CH][CW];
-    __shared__ __attribute__((aligned(16))) uint8_t s_bin[CH][CW];       // bin index (for the peak records)
-    __shared__ __attribute__((aligned(16))) uint8_t s_bit[CH][CW + 8];   // 1 << bin, stored one column to the right
-    __shared__ uint32_t s_cnt;
-    __shared__ float s_wmax[4];
-
-    const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * kTileW;
-    const int y0 = blockIdx.y * kTileH;
-    const uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;
-
-    // image tile: 20 aligned float4 groups per row (x0-8 .. x0+71); the LDS copy starts at x0-6 so
-    // that the 5x8 conv windows are 16-B aligned, hence each group lands as two 8-B halves
-    const bool in_vec = ((stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(img) & 15) == 0);
-    for (int i = tid; i < IH * 20; i += 256) {
-        const int r = i / 20, m = i - r * 20;
-        const int y = y0 - 4 + r, x = x0 - 8 + 4 * m;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (y >= 0 && y < h) {
-            const float* row = img + (size_t)y * stride;
-            if (in_vec && x >= 0 && x + 3 < w) {
-                v = *reinterpret_cast<const float4*>(row + x);
-            } else {
-                if (x >= 0 && x < w) v.x = row[x];
-                if (x + 1 >= 0 && x + 1 < w) v.y = row[x + 1];
-                if (x + 2 >= 0 && x + 2 < w) v.z = row[x + 2];
-                if (x + 3 >= 0 && x + 3 < w) v.w = row[x + 3];
-            }
-        }
-        const int c = 4 * m - 2;
-        if (m > 0) *reinterpret_cast<float2*>(&s_img[r][c]) = make_float2(v.x, v.y);
-        if (m < 19) *reinterpret_cast<float2*>(&s_img[r][c + 2]) = make_float2(v.z, v.w);
-    }
-    if (tid == 0) s_cnt = 0;
-    __syncthreads();
-
-    const bool vec_ok = (w & 3) == 0;
-
-    for (int sidx = tid; sidx < CH * CSTRIPS; sidx += 256) {
-        const int sr = sidx / CSTRIPS, sc = sidx - sr * CSTRIPS;
-        float win[5][8];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const float4 a = *reinterpret_cast<const float4*>(&s_img[sr + i][4 * sc]);
-            const float4 b = *reinterpret_cast<const float4*>(&s_img[sr + i][4 * sc + 4]);
-            win[i][0] = a.x; win[i][1] = a.y; win[i][2] = a.z; win[i][3] = a.w;
-            win[i][4] = b.x; win[i][5] = b.y; win[i][6] = b.z; win[i][7] = b.w;
-        }
-        float ddx[4], ddy[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            float ax = 0.f, ay = 0.f;
-#pragma unroll
-            for (int i = 0; i < 5; ++i)
-#pragma unroll
-                for (int j = 0; j < 5; ++j) {  // row-major tap order, as the oracle
-                    const int ii = i < 3 ? i : 4 - i, jj = j < 3 ? j : 4 - j;
-                    if (j != 2) {
-                        const float kx = fc.k[ii][jj];  // |Hx[i][j]|, sign by column
-                        ax = (j < 2) ? fmaf(win[i][j + p], kx, ax) : fmaf(win[i][j + p], -kx, ax);
-                    }
-                    if (i != 2) {
-                        const float ky = fc.k[jj][ii];  // Hy = Hx^T
-                        ay = (i < 2) ? fmaf(win[i][j + p], ky, ay) : fmaf(win[i][j + p], -ky, ay);
-                    }
-                }
-            ddx[p] = ax;
-            ddy[p] = ay;
-        }
-        const int y = y0 - 2 + sr;
-        const int xb = x0 - 4 + 4 * sc;
-        const bool row_ok = (y >= 2) && (y < h - 2);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int x = xb + p;
-            const bool ok = row_ok && (x >= 2) && (x < w - 2);  // conv_2d leaves a zero border (filter.cpp:89-97)
-            const float vx = ok ? ddx[p] : 0.f;
-            const float vy = ok ? ddy[p] : 0.f;
-            ddx[p] = vx;
-            ddy[p] = vy;
-            const float m = sqrtf(vx * vx + vy * vy);
-            int bin = 0;  // grad_bin is left uninitialised by the reference where all planes are 0; canonical 0
-            float gmax = 0.f;
-#pragma unroll
-            for (int b = 0; b < kBins; ++b) {
-                const float g = directional(vx, vy, fc.st[b], fc.ct[b]);
-                if (g > gmax) {
-                    bin = b;
-                    gmax = g;
-                }
-            }
-            s_mag[sr][4 * sc + p] = m;
-            s_bin[sr][4 * sc + p] = (uint8_t)bin;
-            s_bit[sr][4 * sc + p + 1] = (uint8_t)(1u << bin);
-        }
-        // core strips write dx, dy straight from registers
-        if (sr >= 2 && sr < CH - 2 && sc >= 1 && sc <= 16 && y < h && xb < w) {
-            const size_t o = (size_t)y * w + xb;
-            if (vec_ok && xb + 3 < w) {
-                *reinterpret_cast<float4*>(dx_out + o) = make_float4(ddx[0], ddx[1], ddx[2], ddx[3]);
-                *reinterpret_cast<float4*>(dy_out + o) = make_float4(ddy[0], ddy[1], ddy[2], ddy[3]);
-            } else {
-#pragma unroll
-                for (int p = 0; p < 4; ++p)
-                    if (xb + p < w) {
-                        dx_out[o + p] = ddx[p];
-                        dy_out[o + p] = ddy[p];
-                    }
-            }
-        }
-    }
-    __syncthreads();
-
-    float lmax = 0.f;
-    for (int sidx = tid; sidx < kTileH * (kTileW / 4); sidx += 256) {
-        const int cr = sidx / (kTileW / 4), cs = sidx - cr * (kTileW / 4);
-        const int y = y0 + cr, xb = x0 + 4 * cs;
-        if (y >= h || xb >= w) continue;
-        // 5-row column maxima over conv-region cols 4cs+2 .. 4cs+9 (rows cr .. cr+4)
-        float colmax[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float m = s_mag[cr][4 * cs + 2 + j];
-#pragma unroll
-            for (int i = 1; i < 5; ++i) m = fmaxf(m, s_mag[cr + i][4 * cs + 2 + j]);
-            colmax[j] = m;
-        }
-        const bool row_in = (y >= 2) && (y < h - 2);
-        const bool row_border = (y == 0) || (y == h - 1);
-        // dilated-bin mask of the 4 pixels at once: the 3x3 windows span conv cols 4cs+3 .. 4cs+8, i.e. the
-        // two aligned words at s_bit cols 4cs+4 and 4cs+8 of rows cr+1 .. cr+3; byte p of
-        // (W | W>>8 | W>>16) is the OR of bytes p..p+2
-        uint32_t dm4 = 0;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const uint32_t lo = *reinterpret_cast<const uint32_t*>(&s_bit[cr + 1 + i][4 * cs + 4]);
-            const uint32_t hi = *reinterpret_cast<const uint32_t*>(&s_bit[cr + 1 + i][4 * cs + 8]);
-            const uint64_t W = ((uint64_t)hi << 32) | lo;
-            dm4 |= (uint32_t)(W | (W >> 8) | (W >> 16));
-        }
-        uint8_t dm[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int x = xb + p;
-            dm[p] = 0;
-            if (x < w) {
-                const float center = s_mag[cr + 2][4 * cs + 4 + p];
-                lmax = fmaxf(lmax, center);
-                float mx = colmax[p];
-#pragma unroll
-                for (int j = 1; j < 5; ++j) mx = fmaxf(mx, colmax[p + j]);
-                // binary_dilate leaves a 1-px zero border (filter.cpp:52-61)
-                dm[p] = (!row_border && x != 0 && x != w - 1) ? (uint8_t)(dm4 >> (8 * p)) : (uint8_t)0;
-                const bool peak = row_in && (x >= 2) && (x < w - 2) && (center > 0.f) && (center == mx);
-                if (peak) {
-                    const uint32_t slot = atomicAdd(&s_cnt, 1u);
-                    const uint32_t idx = (uint32_t)y * (uint32_t)w + (uint32_t)x;
-                    const uint32_t bin = s_bin[cr + 2][4 * cs + 4 + p];
-                    cand[(size_t)tile * kCandPerTile + slot] =
-                        ((uint64_t)__float_as_uint(center) << 32) | (uint64_t)((idx << 3) | bin);
-                }
-            }
-        }
-        const size_t o = (size_t)y * w + xb;
-        if (vec_ok && xb + 3 < w) {
-            *reinterpret_cast<uint32_t*>(dmask_out + o) =
-                (uint32_t)dm[0] | ((uint32_t)dm[1] << 8) | ((uint32_t)dm[2] << 16) | ((uint32_t)dm[3] << 24);
-        } else {
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-                if (xb + p < w) dmask_out[o + p] = dm[p];
-        }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off));
-    if ((tid & 63) == 0) s_wmax[tid >> 6] = lmax;
-    __syncthreads();
-    if (tid == 0) {
-        const float m = fmaxf(fmaxf(s_wmax[0], s_wmax[1]), fmaxf(s_wmax[2], s_wmax[3]));
-        tile_max[tile] = __float_as_uint(m);
-        cand_count[tile] = s_cnt;
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// Row-streaming variant (default).  One wavefront owns a band of 120 columns x 32 rows and walks
-// it top to bottom, two adjacent pixels per lane (lanes 0-1 and 62-63 are halo).  Everything
-// rolls in registers: the last five image rows (own float2 plus the neighbours' via lane shifts),
-// five rows of magnitudes and of direction bits.  No LDS, no barriers, no per-pixel index math;
-// every global access is a coalesced row segment (512 B loads, 512 B + 512 B + 128 B stores), and
-// the 5x5 correlation is computed once per pixel except for the band halo (1.2x instead of the
-// tile kernel's 1.5x).  Same canonical arithmetic, same outputs as filter_kernel above.
-constexpr int kBandCols = 120;
-constexpr int kBandRows = 30;  // 2160 = 72 x 30: no ragged last band at 4K, 4968 waves = 4.85 per SIMD
-constexpr int kBandSteps = kBandRows + 8;  // image rows y0-4 .. y0+35
+constexpr int kBandRows = 30;  // 2160 = 72 x 30: no ragged last band at 4K
+constexpr int kBandSteps = kBandRows + 8;  // image rows y0-4 .. y0+33
 
 // value of the lower / upper neighbour lane as a DPP wavefront shift (a VALU move, not an LDS crossbar
 // trip like ds_bpermute); the end lanes read 0, and they are halo lanes anyway
@@ -264,205 +53,11 @@ __device__ __forceinline__ uint32_t from_upper(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x130, 0xF, 0xF, true);
 }
 
-struct Roll {
-    float win[5][6];   // image rows t-4..t (slot = row mod 5), cols xc-2 .. xc+3
-    float mag[5][2];   // own magnitudes of the last five conv rows
-    uint32_t bits[5];  // (1 << bin) of the two own pixels, packed b0 | b1 << 8
-    float2 q[5];       // prefetched image rows
-};
-
-__device__ __forceinline__ float2 load_row2(const float* __restrict__ img, int stride, int w, int h, int yr, int xc,
-                                            bool vec2) {
-    float2 v = make_float2(0.f, 0.f);
-    if (yr >= 0 && yr < h) {
-        const float* row = img + (size_t)yr * stride;
-        if (vec2 && xc >= 0 && xc + 1 < w) {
-            v = *reinterpret_cast<const float2*>(row + xc);
-        } else {
-            if (xc >= 0 && xc < w) v.x = row[xc];
-            if (xc + 1 >= 0 && xc + 1 < w) v.y = row[xc + 1];
-        }
-    }
-    return v;
-}
-
-template <int K>
-__device__ __forceinline__ void band_step(Roll& R, const int t, const float* __restrict__ img, const int w, const int h,
-                                          const int stride, const FilterTaps& fc, float* __restrict__ dx_out,
-                                          float* __restrict__ dy_out, uint8_t* __restrict__ dmask_out,
-                                          uint64_t* __restrict__ cand_band, uint32_t& ncand, float& lmax, const int y0,
-                                          const int xc, const int lane, const bool vec2, const bool useful) {
-    // newest image row -> slot K; prefetch the row four steps ahead into the slot it will be read from
-    const float2 cur = R.q[K];
-    R.q[(K + 4) % 5] = load_row2(img, stride, w, h, y0 - 4 + t + 4, xc, vec2);
-    R.win[K][0] = from_lower(cur.x);
-    R.win[K][1] = from_lower(cur.y);
-    R.win[K][2] = cur.x;
-    R.win[K][3] = cur.y;
-    R.win[K][4] = from_upper(cur.x);
-    R.win[K][5] = from_upper(cur.y);
-    if (t < 4) return;  // wave-uniform: the window is not full yet
-
-    // ---- conv row yc = yr - 2 -----------------------------------------------------------------
-    const int yc = y0 - 6 + t;
-    float ddx[2], ddy[2];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        float ax = 0.f, ay = 0.f;
-#pragma unroll
-        for (int i = 0; i < 5; ++i)
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {  // row-major tap order, as the oracle
-                const float v = R.win[(K + 1 + i) % 5][p + j];
-                const int ii = i < 3 ? i : 4 - i, jj = j < 3 ? j : 4 - j;
-                if (j != 2) ax = (j < 2) ? fmaf(v, fc.k[ii][jj], ax) : fmaf(v, -fc.k[ii][jj], ax);
-                if (i != 2) ay = (i < 2) ? fmaf(v, fc.k[jj][ii], ay) : fmaf(v, -fc.k[jj][ii], ay);
-            }
-        ddx[p] = ax;
-        ddy[p] = ay;
-    }
-    const bool row_ok = (yc >= 2) && (yc < h - 2);
-    uint32_t bits = 0;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int x = xc + p;
-        const bool ok = row_ok && (x >= 2) && (x < w - 2);  // conv_2d leaves a zero border (filter.cpp:89-97)
-        const float vx = ok ? ddx[p] : 0.f;
-        const float vy = ok ? ddy[p] : 0.f;
-        ddx[p] = vx;
-        ddy[p] = vy;
-        R.mag[K][p] = sqrtf(vx * vx + vy * vy);
-        int bin = 0;
-        float gmax = 0.f;
-#pragma unroll
-        for (int b = 0; b < kBins; ++b) {
-            const float g = directional(vx, vy, fc.st[b], fc.ct[b]);
-            bin = (g > gmax) ? b : bin;
-            gmax = fmaxf(gmax, g);
-        }
-        bits |= (1u << bin) << (8 * p);
-    }
-    R.bits[K] = bits;
-    if (useful && yc >= y0 && yc < y0 + kBandRows && yc < h && xc < w) {
-        const size_t o = (size_t)yc * w + xc;
-        if (((w & 1) == 0) && xc + 1 < w) {
-            *reinterpret_cast<float2*>(dx_out + o) = make_float2(ddx[0], ddx[1]);
-            *reinterpret_cast<float2*>(dy_out + o) = make_float2(ddy[0], ddy[1]);
-        } else {
-            dx_out[o] = ddx[0];
-            dy_out[o] = ddy[0];
-            if (xc + 1 < w) {
-                dx_out[o + 1] = ddx[1];
-                dy_out[o + 1] = ddy[1];
-            }
-        }
-    }
-    if (t < 8) return;  // wave-uniform
-
-    // ---- NMS + dilated mask for output row yo = yc - 2 -------------------------------------------
-    const int yo = yc - 2;
-    if (yo >= h) return;  // wave-uniform
-    const float cm0 = fmaxf(fmaxf(fmaxf(R.mag[0][0], R.mag[1][0]), fmaxf(R.mag[2][0], R.mag[3][0])), R.mag[4][0]);
-    const float cm1 = fmaxf(fmaxf(fmaxf(R.mag[0][1], R.mag[1][1]), fmaxf(R.mag[2][1], R.mag[3][1])), R.mag[4][1]);
-    const float l0 = from_lower(cm0), l1 = from_lower(cm1);
-    const float r0 = from_upper(cm0), r1 = from_upper(cm1);
-    const float mx0 = fmaxf(fmaxf(fmaxf(l0, l1), fmaxf(cm0, cm1)), r0);
-    const float mx1 = fmaxf(fmaxf(fmaxf(l1, cm0), fmaxf(cm1, r0)), r1);
-    const float c0 = R.mag[(K + 3) % 5][0], c1 = R.mag[(K + 3) % 5][1];
-    const uint32_t cb = R.bits[(K + 3) % 5];
-    const uint32_t v = R.bits[(K + 2) % 5] | cb | R.bits[(K + 4) % 5];
-    const uint32_t lv = from_lower(v), rv = from_upper(v);
-    uint32_t dm0 = ((lv >> 8) | v | (v >> 8)) & 0xFFu;
-    uint32_t dm1 = (v | (v >> 8) | rv) & 0xFFu;
-    const bool row_in = (yo >= 2) && (yo < h - 2);
-    const bool row_border = (yo == 0) || (yo == h - 1);
-    const bool in0 = useful && xc < w, in1 = useful && xc + 1 < w;
-    if (row_border || xc == 0 || xc == w - 1) dm0 = 0;  // binary_dilate leaves a 1-px zero border (filter.cpp:52-61)
-    if (row_border || xc + 1 == w - 1) dm1 = 0;
-    if (in0) {
-        lmax = fmaxf(lmax, c0);
-        const size_t o = (size_t)yo * w + xc;
-        if (((w & 1) == 0) && in1) {
-            *reinterpret_cast<uint16_t*>(dmask_out + o) = (uint16_t)(dm0 | (dm1 << 8));
-        } else {
-            dmask_out[o] = (uint8_t)dm0;
-            if (in1) dmask_out[o + 1] = (uint8_t)dm1;
-        }
-    }
-    if (in1) lmax = fmaxf(lmax, c1);
-    const bool peak0 = in0 && row_in && (xc >= 2) && (xc < w - 2) && (c0 > 0.f) && (c0 == mx0);
-    const bool peak1 = in1 && row_in && (xc + 1 >= 2) && (xc + 1 < w - 2) && (c1 > 0.f) && (c1 == mx1);
-    const uint64_t m0 = __ballot(peak0), m1 = __ballot(peak1);
-    if (m0 | m1) {  // wave-uniform, rare
-        const uint64_t below = (1ull << lane) - 1ull;
-        if (peak0) {
-            const uint32_t idx = (uint32_t)yo * (uint32_t)w + (uint32_t)xc;
-            const uint32_t bin = (uint32_t)__ffs((int)(cb & 0xFFu)) - 1u;
-            cand_band[ncand + (uint32_t)__popcll(m0 & below)] =
-                ((uint64_t)__float_as_uint(c0) << 32) | (uint64_t)((idx << 3) | bin);
-        }
-        ncand += (uint32_t)__popcll(m0);
-        if (peak1) {
-            const uint32_t idx = (uint32_t)yo * (uint32_t)w + (uint32_t)xc + 1u;
-            const uint32_t bin = (uint32_t)__ffs((int)((cb >> 8) & 0xFFu)) - 1u;
-            cand_band[ncand + (uint32_t)__popcll(m1 & below)] =
-                ((uint64_t)__float_as_uint(c1) << 32) | (uint64_t)((idx << 3) | bin);
-        }
-        ncand += (uint32_t)__popcll(m1);
-    }
-}
-
-__global__ __launch_bounds__(256) void filter_rows_kernel(const float* __restrict__ img, int w, int h, int stride,
-                                                          FilterTaps fc, float* __restrict__ dx_out,
-                                                          float* __restrict__ dy_out, uint8_t* __restrict__ dmask_out,
-                                                          uint64_t* __restrict__ cand, uint32_t* __restrict__ cand_count,
-                                                          uint32_t* __restrict__ tile_max, int bands_x, int n_bands) {
-    const int lane = threadIdx.x & 63;
-    const int band = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (band >= n_bands) return;
-    const int by = band / bands_x, bx = band - by * bands_x;
-    const int y0 = by * kBandRows;
-    const int xc = bx * kBandCols - 4 + 2 * lane;
-    const bool vec2 = ((stride & 1) == 0) && ((reinterpret_cast<uintptr_t>(img) & 7) == 0);
-    const bool useful = lane >= 2 && lane <= 61;
-    Roll R;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-#pragma unroll
-        for (int j = 0; j < 6; ++j) R.win[i][j] = 0.f;
-        R.mag[i][0] = R.mag[i][1] = 0.f;
-        R.bits[i] = 0x0101u;
-        R.q[i] = make_float2(0.f, 0.f);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) R.q[i] = load_row2(img, stride, w, h, y0 - 4 + i, xc, vec2);
-    uint64_t* cand_band = cand + (size_t)band * (kBandCols * kBandRows);
-    uint32_t ncand = 0;
-    float lmax = 0.f;
-    for (int t0 = 0; t0 < kBandSteps; t0 += 5) {
-        band_step<0>(R, t0 + 0, img, w, h, stride, fc, dx_out, dy_out, dmask_out, cand_band, ncand, lmax, y0, xc, lane, vec2, useful);
-        band_step<1>(R, t0 + 1, img, w, h, stride, fc, dx_out, dy_out, dmask_out, cand_band, ncand, lmax, y0, xc, lane, vec2, useful);
-        band_step<2>(R, t0 + 2, img, w, h, stride, fc, dx_out, dy_out, dmask_out, cand_band, ncand, lmax, y0, xc, lane, vec2, useful);
-        band_step<3>(R, t0 + 3, img, w, h, stride, fc, dx_out, dy_out, dmask_out, cand_band, ncand, lmax, y0, xc, lane, vec2, useful);
-        band_step<4>(R, t0 + 4, img, w, h, stride, fc, dx_out, dy_out, dmask_out, cand_band, ncand, lmax, y0, xc, lane, vec2, useful);
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, off));
-    if (lane == 0) {
-        tile_max[band] = __float_as_uint(lmax);
-        cand_count[band] = ncand;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Same row-streaming scheme with ONE pixel per lane: a wavefront owns 56 columns (lanes 4..59; four
-// halo lanes on each side) x 32 rows.  Half the serial instruction stream per wavefront and twice
-// the wavefronts of the two-pixel variant: the per-wave VALU stream, not bandwidth, is what bounds
-// this kernel, so more, shorter waves win.
 constexpr int kLaneCols = 56;
 
 struct Roll1 {
-    float win[5][5];   // image rows t-4..t (slot = row mod 5), cols x-2 .. x+2
+    float hx[5];       // row pass of image rows t-4..t (slot = row mod 5): derivative along x ...
+    float hs[5];       // ... and smoothing along x
     float mag[5];
     uint32_t bits[5];  // 1 << bin
     float q[10];       // prefetched image rows (nine steps ahead: loads share the in-order vmcnt with the stores)
@@ -508,25 +103,18 @@ __device__ __forceinline__ void lane_step(Roll1& R, const int t, const float* __
         R.q[(K10 + 9) % 10] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                   r_img, (unsigned)xcl * 4u, (unsigned)yy * (unsigned)stride * 4u, 0));
     }
+    // row pass of the new image row (oracle: conv_gradients)
     const float l1 = from_lower(cur), r1 = from_upper(cur);
-    R.win[K][0] = from_lower(l1);
-    R.win[K][1] = l1;
-    R.win[K][2] = cur;
-    R.win[K][3] = r1;
-    R.win[K][4] = from_upper(r1);
-    if (t < 4) return;  // wave-uniform: the window is not full yet
+    const float l2 = from_lower(l1), r2 = from_upper(r1);
+    R.hx[K] = fmaf(r2 - l2, fc.d2, (r1 - l1) * fc.d1);
+    R.hs[K] = fmaf(r2 + l2, fc.g2, fmaf(r1 + l1, fc.g1, cur));
+    if (t < 4) return;  // wave-uniform: five rows are not there yet
 
-    const int yc = y0 - 6 + t;  // conv row
-    float ax = 0.f, ay = 0.f;
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {  // row-major tap order, as the oracle
-            const float v = R.win[(K + 1 + i) % 5][j];
-            const int ii = i < 3 ? i : 4 - i, jj = j < 3 ? j : 4 - j;
-            if (j != 2) ax = (j < 2) ? fmaf(v, fc.k[ii][jj], ax) : fmaf(v, -fc.k[ii][jj], ax);
-            if (i != 2) ay = (i < 2) ? fmaf(v, fc.k[jj][ii], ay) : fmaf(v, -fc.k[jj][ii], ay);
-        }
+    const int yc = y0 - 6 + t;  // conv row: the middle one of the five
+    // column pass: rows yc-2 .. yc+2 sit in slots K+1 .. K+5 (mod 5)
+    const float ax = fmaf(R.hx[K] + R.hx[(K + 1) % 5], fc.g2,
+                          fmaf(R.hx[(K + 4) % 5] + R.hx[(K + 2) % 5], fc.g1, R.hx[(K + 3) % 5]));
+    const float ay = fmaf(R.hs[K] - R.hs[(K + 1) % 5], fc.d2, (R.hs[(K + 4) % 5] - R.hs[(K + 2) % 5]) * fc.d1);
     const bool ok = INTERIOR || ((yc >= 2) && (yc < h - 2) && (x >= 2) && (x < w - 2));  // conv_2d's zero border (filter.cpp:89-97)
     const float vx = ok ? ax : 0.f;
     const float vy = ok ? ay : 0.f;
@@ -596,8 +184,8 @@ __global__ __launch_bounds__(256) void filter_lanes_kernel(const float* __restri
     Roll1 R;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-#pragma unroll
-        for (int j = 0; j < 5; ++j) R.win[i][j] = 0.f;
+        R.hx[i] = 0.f;
+        R.hs[i] = 0.f;
         R.mag[i] = 0.f;
         R.bits[i] = 1u;
     }
@@ -629,29 +217,10 @@ __global__ __launch_bounds__(256) void filter_lanes_kernel(const float* __restri
 
 }  // namespace
 
-// 0 = 64x32 LDS tiles, 1 = row streaming with 2 px/lane, 2 = row streaming with 1 px/lane (default)
-static int filter_variant() {
-    static const int v = [] {
-        const char* e = std::getenv("LIBRECTIFY_FILTER");
-        if (e && std::strcmp(e, "tile") == 0) return 0;
-        if (e && std::strcmp(e, "rows2") == 0) return 1;
-        return 2;
-    }();
-    return v;
-}
-
 FilterGeom filter_geometry(int w, int h) {
     FilterGeom g;
-    if (filter_variant() == 2) {
-        g.n_tiles = ((w + kLaneCols - 1) / kLaneCols) * ((h + kBandRows - 1) / kBandRows);
-        g.cand_cap = kLaneCols * kBandRows;
-    } else if (filter_variant() == 1) {
-        g.n_tiles = ((w + kBandCols - 1) / kBandCols) * ((h + kBandRows - 1) / kBandRows);
-        g.cand_cap = kBandCols * kBandRows;
-    } else {
-        g.n_tiles = tiles_x(w) * tiles_y(h);
-        g.cand_cap = kCandPerTile;
-    }
+    g.n_tiles = ((w + kLaneCols - 1) / kLaneCols) * ((h + kBandRows - 1) / kBandRows);
+    g.cand_cap = kLaneCols * kBandRows;
     return g;
 }
 
@@ -665,39 +234,25 @@ int launch_filter(const float* img, int w, int h, int stride, const FilterConsts
         set_error("launch_filter: image larger than 2^29 pixels is not supported (seed key packs index in 29 bits)");
         return 1;
     }
+    // the (anti)symmetry the separable form relies on is a property of the host's libm results: verify, never assume
+    if (!(fc.d[2] == 0.f && fc.g[2] == 1.f && fc.d[1] == -fc.d[3] && fc.d[0] == -fc.d[4] && fc.g[1] == fc.g[3] &&
+          fc.g[0] == fc.g[4])) {
+        set_error("launch_filter: derivative factors are not (anti)symmetric on this host");
+        return 1;
+    }
     FilterTaps ft;
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 2; ++j) ft.k[i][j] = fc.kx[i * 5 + j];
-    // the symmetry the kernels rely on is a property of the host's libm results: verify, never assume
-    for (int i = 0; i < 5; ++i)
-        for (int j = 0; j < 5; ++j) {
-            const int ii = i < 3 ? i : 4 - i, jj = j < 3 ? j : 4 - j;
-            const float ex = (j == 2) ? 0.f : (j < 2 ? ft.k[ii][jj] : -ft.k[ii][jj]);
-            const float ey = (i == 2) ? 0.f : (i < 2 ? ft.k[jj][ii] : -ft.k[jj][ii]);
-            if (!(ex == fc.kx[i * 5 + j]) || !(ey == fc.ky[i * 5 + j])) {
-                set_error("launch_filter: derivative taps are not (anti)symmetric on this host");
-                return 1;
-            }
-        }
+    ft.d1 = fc.d[3];
+    ft.d2 = fc.d[4];
+    ft.g1 = fc.g[3];
+    ft.g2 = fc.g[4];
     for (int b = 0; b < kBins; ++b) {
         ft.st[b] = fc.st[b];
         ft.ct[b] = fc.ct[b];
     }
-    if (filter_variant() == 2) {
-        const int bands_x = (w + kLaneCols - 1) / kLaneCols;
-        const int n_bands = bands_x * ((h + kBandRows - 1) / kBandRows);
-        hipLaunchKernelGGL(filter_lanes_kernel, dim3((n_bands + 3) / 4), dim3(256), 0, s, img, w, h, stride, ft, dx, dy,
-                           dmask, cand, cand_count, tile_max, bands_x, n_bands);
-    } else if (filter_variant() == 1) {
-        const int bands_x = (w + kBandCols - 1) / kBandCols;
-        const int n_bands = bands_x * ((h + kBandRows - 1) / kBandRows);
-        hipLaunchKernelGGL(filter_rows_kernel, dim3((n_bands + 3) / 4), dim3(256), 0, s, img, w, h, stride, ft, dx, dy,
-                           dmask, cand, cand_count, tile_max, bands_x, n_bands);
-    } else {
-        dim3 grid(tiles_x(w), tiles_y(h));
-        hipLaunchKernelGGL(filter_kernel, grid, dim3(256), 0, s, img, w, h, stride, ft, dx, dy, dmask, cand, cand_count,
-                           tile_max);
-    }
+    const int bands_x = (w + kLaneCols - 1) / kLaneCols;
+    const int n_bands = bands_x * ((h + kBandRows - 1) / kBandRows);
+    hipLaunchKernelGGL(filter_lanes_kernel, dim3((n_bands + 3) / 4), dim3(256), 0, s, img, w, h, stride, ft, dx, dy, dmask,
+                       cand, cand_count, tile_max, bands_x, n_bands);
     LR_HIP(hipGetLastError());
     return 0;
 }

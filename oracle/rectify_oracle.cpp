@@ -149,7 +149,7 @@ void gauss_deriv_kernel(int size, float sigma, bool dir_x, float* H) {
         }
 }
 
-// filter.cpp:81-98  (correlation, zero border of kernel radius)
+// filter.cpp:81-98  (correlation, zero border of kernel radius): the generic 25-tap form, kept for the tap KAT
 void conv_2d(const float* img, int w, int h, const float* K, int ksz, float* out, const ThreadContext& ctx) {
     int n = 2 * ksz + 1;
     std::fill(out, out + size_t(w) * h, 0.0f);
@@ -163,13 +163,56 @@ void conv_2d(const float* img, int w, int h, const float* K, int ksz, float* out
         }
 }
 
+// The taps of filter.cpp:65-78 are a product: H(i,j) = z/a * exp(-(x^2+y^2)/2s^2) = d(x) * g(y) for Hx (and
+// d(y) * g(x) for Hy) with d(t) = t/a * exp(-t^2/2s^2), g(t) = exp(-t^2/2s^2).  The reference evaluates the 25-tap
+// correlation with an Eigen block product whose summation order (under -ffast-math) is unspecified; the canonical
+// arithmetic of this build is the separable form, which uses the (anti)symmetry of d and g:
+//   row pass     hx = fma(I[x+2]-I[x-2], d2, (I[x+1]-I[x-1])*d1)      hs = fma(I[x+2]+I[x-2], g2, fma(I[x+1]+I[x-1], g1, I[x]))
+//   column pass  dx = fma(hx[y+2]+hx[y-2], g2, fma(hx[y+1]+hx[y-1], g1, hx[y]))
+//                dy = fma(hs[y+2]-hs[y-2], d2, (hs[y+1]-hs[y-1])*d1)
+// (g(0) = exp(0) = 1, d(0) = 0, d(-t) = -d(t), g(-t) = g(t), all exactly in fp32.)  16 operations per pixel instead of
+// 50; pinned by the detector KAT (tests/test_oracle_pins.py::test_pin2_*).
+void gauss_deriv_factors(int size, float sigma, float* d, float* g) {
+    int n = 2 * size + 1;
+    for (int t = 0; t < n; ++t) {
+        float x = float(t - size);
+        float a = float(2 * M_PI * std::pow(sigma, 4.0f));
+        float e = std::exp(-std::pow(x, 2.0f) / (2 * std::pow(sigma, 2.0f)));
+        d[t] = x / a * e;
+        g[t] = e;
+    }
+}
+
+void conv_gradients(const float* img, int w, int h, float* dx, float* dy, const ThreadContext& ctx) {
+    float d[5], g[5];
+    gauss_deriv_factors(EDGE_KERNEL_SIZE, EDGE_KERNEL_SIGMA, d, g);
+    const float d1 = d[3], d2 = d[4], g1 = g[3], g2 = g[4];
+    std::vector<float> hx(size_t(w) * h, 0.0f), hs(size_t(w) * h, 0.0f);
+    std::fill(dx, dx + size_t(w) * h, 0.0f);
+    std::fill(dy, dy + size_t(w) * h, 0.0f);
+#pragma omp parallel for num_threads(ctx.get()) if (ctx.enabled())
+    for (int r = 0; r < h; ++r) {
+        const float* I = img + size_t(r) * w;
+        for (int x = 2; x < w - 2; ++x) {
+            float a1 = I[x + 1] - I[x - 1], a2 = I[x + 2] - I[x - 2];
+            float s1 = I[x + 1] + I[x - 1], s2 = I[x + 2] + I[x - 2];
+            hx[size_t(r) * w + x] = std::fmaf(a2, d2, a1 * d1);
+            hs[size_t(r) * w + x] = std::fmaf(s2, g2, std::fmaf(s1, g1, I[x]));
+        }
+    }
+#pragma omp parallel for num_threads(ctx.get()) if (ctx.enabled())
+    for (int y = 2; y < h - 2; ++y)
+        for (int x = 2; x < w - 2; ++x) {
+            auto HX = [&](int k) { return hx[size_t(y + k) * w + x]; };
+            auto HS = [&](int k) { return hs[size_t(y + k) * w + x]; };
+            dx[size_t(y) * w + x] = std::fmaf(HX(2) + HX(-2), g2, std::fmaf(HX(1) + HX(-1), g1, HX(0)));
+            dy[size_t(y) * w + x] = std::fmaf(HS(2) - HS(-2), d2, (HS(1) - HS(-1)) * d1);
+        }
+}
+
 // line_detector.cpp:41-49
 void image_gradients(const float* img, int w, int h, float* dx, float* dy, float* mag, const ThreadContext& ctx) {
-    float Hx[25], Hy[25];
-    gauss_deriv_kernel(EDGE_KERNEL_SIZE, EDGE_KERNEL_SIGMA, true, Hx);
-    gauss_deriv_kernel(EDGE_KERNEL_SIZE, EDGE_KERNEL_SIGMA, false, Hy);
-    conv_2d(img, w, h, Hx, EDGE_KERNEL_SIZE, dx, ctx);
-    conv_2d(img, w, h, Hy, EDGE_KERNEL_SIZE, dy, ctx);
+    conv_gradients(img, w, h, dx, dy, ctx);
     size_t n = size_t(w) * h;
 #pragma omp parallel for num_threads(ctx.get()) if (ctx.enabled())
     for (long long i = 0; i < (long long)n; ++i) {
