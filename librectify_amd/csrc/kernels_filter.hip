@@ -33,7 +33,10 @@ struct FilterTaps {
     float ct[kBins];
 };
 
-constexpr int kBandRows = 30;  // 2160 = 72 x 30: no ragged last band at 4K
+#ifndef LR_BAND_ROWS
+#define LR_BAND_ROWS 30
+#endif
+constexpr int kBandRows = LR_BAND_ROWS;  // 2160 = 72 x 30: no ragged last band at 4K
 constexpr int kBandSteps = kBandRows + 8;  // image rows y0-4 .. y0+33
 
 // value of the lower / upper neighbour lane as a DPP wavefront shift (a VALU move, not an LDS crossbar
@@ -123,6 +126,7 @@ __device__ __forceinline__ void lane_step(Roll1& R, const int t, const float* __
     float g[kBins];
 #pragma unroll
     for (int b = 0; b < kBins; ++b) g[b] = directional(vx, vy, fc.st[b], fc.ct[b]);
+
     const float gm = fmaxf(fmaxf(fmaxf(g[0], g[1]), fmaxf(g[2], g[3])), fmaxf(fmaxf(g[4], g[5]), fmaxf(g[6], g[7])));
     uint32_t bit = 1u << 7;
 #pragma unroll
@@ -174,7 +178,16 @@ __global__ __launch_bounds__(256) void filter_lanes_kernel(const float* __restri
     const int lane = threadIdx.x & 63;
     // the band index is the same in all 64 lanes: say so, and every row pointer, row test and loop bound below
     // lives in SGPRs (scalar base + 32-bit lane offset addressing) instead of 64-bit VGPR arithmetic
-    const int band = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+#ifndef LR_NO_XCD_ORDER
+    // Workgroups go to the eight XCDs round-robin, and each XCD has its own L2.  Give every XCD one contiguous run of
+    // bands (a horizontal stripe of the image) instead of every eighth group of four: neighbouring bands share the halo
+    // rows and columns they read, and the 128-byte lines of the byte mask they write, and now find them in their L2.
+    const int chunk = (int)gridDim.x / 8;  // the launcher rounds the grid up to a multiple of eight
+    const int wg = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
+#else
+    const int wg = (int)blockIdx.x;
+#endif
+    const int band = __builtin_amdgcn_readfirstlane(wg * 4 + (int)(threadIdx.x >> 6));
     if (band >= n_bands) return;
     const int by = band / bands_x, bx = band - by * bands_x;
     const int y0 = by * kBandRows;
@@ -199,8 +212,10 @@ __global__ __launch_bounds__(256) void filter_lanes_kernel(const float* __restri
     const BufRsrc r_dx = make_rsrc(dx_out, npx * 4u), r_dy = make_rsrc(dy_out, npx * 4u), r_dm = make_rsrc(dmask_out, npx);
 #define LR_STEP(k, I) lane_step<k, I>(R, t0 + k, img, w, h, stride, fc, dx_out, dy_out, dmask_out, cand_band, ncand, lmax, y0, x, xcl, lane, useful, r_img, r_dx, r_dy, r_dm)
     // fully unrolled: across a loop back-edge the compiler can only wait for vmcnt(0), which would expose the
-    // latency of every store in flight once per iteration.  (An INTERIOR = true instantiation for bands away
-    // from the image border was measured: no gain, twice the code; the kernel is bound by VALU issue.)
+    // latency of every store in flight once per iteration.
+    // (An INTERIOR = true instantiation for the bands away from the image border -- no border test, clamp or predicate,
+    // some 55 scalar instructions per row fewer -- was measured twice, with the 25-tap and with the separable filter:
+    // no gain either time, twice the code.)
 #pragma unroll
     for (int t0 = 0; t0 < (kBandSteps + 9) / 10 * 10; t0 += 10) {
         LR_STEP(0, false); LR_STEP(1, false); LR_STEP(2, false); LR_STEP(3, false); LR_STEP(4, false);
@@ -251,7 +266,8 @@ int launch_filter(const float* img, int w, int h, int stride, const FilterConsts
     }
     const int bands_x = (w + kLaneCols - 1) / kLaneCols;
     const int n_bands = bands_x * ((h + kBandRows - 1) / kBandRows);
-    hipLaunchKernelGGL(filter_lanes_kernel, dim3((n_bands + 3) / 4), dim3(256), 0, s, img, w, h, stride, ft, dx, dy, dmask,
+    const int n_wg = ((n_bands + 3) / 4 + 7) / 8 * 8;  // a multiple of eight: see the XCD mapping in the kernel
+    hipLaunchKernelGGL(filter_lanes_kernel, dim3(n_wg), dim3(256), 0, s, img, w, h, stride, ft, dx, dy, dmask,
                        cand, cand_count, tile_max, bands_x, n_bands);
     LR_HIP(hipGetLastError());
     return 0;
