@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <random>
@@ -275,8 +276,8 @@ int ctx_create(int device, lr_context** out) {
     (void)hipMalloc((void**)&c->d_counts, 64 * sizeof(uint32_t));
     (void)hipMalloc((void**)&c->d_gctl, kGcWords * sizeof(uint32_t));
     (void)hipMalloc((void**)&c->d_gnorm, 4 * sizeof(float));
-    (void)hipMalloc((void**)&c->d_models, 16 * sizeof(float));
-    (void)hipMemset(c->d_models, 0, 16 * sizeof(float));
+    (void)hipMalloc((void**)&c->d_models, 64 * sizeof(float));
+    (void)hipMemset(c->d_models, 0, 64 * sizeof(float));
     (void)hipMemset(c->d_counts, 0, 64 * sizeof(uint32_t));
     (void)hipMalloc((void**)&c->d_best_score, sizeof(float));
     (void)hipMalloc((void**)&c->d_best_iter, sizeof(int32_t));
@@ -527,7 +528,7 @@ int enqueue_result_copy(lr_context* c) {
     uint8_t* h = c->h_res;
     LR_HIP(hipMemcpyAsync(h, c->d_counts, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     LR_HIP(hipMemcpyAsync(h + 32, c->d_gctl, kGcWords * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    LR_HIP(hipMemcpyAsync(h + 64, c->d_models, 12 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    LR_HIP(hipMemcpyAsync(h + 64, c->d_models, 40 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     const size_t nl = std::min<size_t>(c->res_lines_cap, c->cap_flines);
     LR_HIP(hipMemcpyAsync(h + kResHeaderBytes, c->d_flines, nl * sizeof(LineSegment), hipMemcpyDeviceToHost, c->stream));
     return 0;
@@ -1128,6 +1129,14 @@ static int run_frame(lr_context* c, const float* d_image, int w, int h, int stri
             if (ensure_result_block(c, round_up((uint32_t)(n + n / 2), 1024))) return 1;
         }
         record_stage_times(c, true);
+#ifdef LR_PEEL_TIMING
+        {
+            const float* tm = reinterpret_cast<const float*>(c->h_res + 64) + 16;
+            for (int r = 0; r < 4; ++r)
+                std::fprintf(stderr, "peel round %d: best %.1f us, inliers %.1f, sums %.1f, jacobi %.1f, verdict %.1f\n", r,
+                             tm[r * 5], tm[r * 5 + 1], tm[r * 5 + 2], tm[r * 5 + 3], tm[r * 5 + 4]);
+        }
+#endif
         return 0;
     }
     // ---- refine and / or PROSAC: raw segments to the host

@@ -220,7 +220,10 @@ __device__ void smallest_eigenvector_3x3(const float c[9], float out[3]) {
         for (int j = 0; j < 3; ++j) A[i][j] = 0.5 * ((double)c[i * 3 + j] + (double)c[j * 3 + i]);
     for (int sweep = 0; sweep < 64; ++sweep) {
         const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
-        if (off == 0.0) break;
+        // converged: the off-diagonal part is below double precision relative to the diagonal (waiting for it to
+        // underflow to exactly zero can take all 64 sweeps and changes nothing in the float result)
+        const double dg = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+        if (off <= 1e-36 * dg) break;
         for (int p = 0; p < 2; ++p)
             for (int q = p + 1; q < 3; ++q) {
                 if (A[p][q] == 0.0) continue;
@@ -277,6 +280,10 @@ __global__ __launch_bounds__(kWG) void peel_kernel(PencilTable cur, PencilTable 
     // estimator.h:115: while (num_observations >= minimum_set_size && k < max_structures)
     if (gctl[kGcRemaining] < 2u || round >= (uint32_t)max_models) return;
 
+#ifdef LR_PEEL_TIMING
+    unsigned long long tm[6];
+    tm[0] = wall_clock64();
+#endif
     // this thread's line of the first chunk, in flight while the best hypothesis is looked up
     float r_ax = 0.f, r_ay = 0.f, r_dx = 0.f, r_dy = 0.f, r_len = 0.f, r_hx = 0.f, r_hy = 0.f, r_hz = 0.f;
     uint32_t r_orig = 0;
@@ -338,6 +345,9 @@ __global__ __launch_bounds__(kWG) void peel_kernel(PencilTable cur, PencilTable 
     }
     __syncthreads();
     const float bx_ = s_h[0], by_ = s_h[1], bz_ = s_h[2];
+#ifdef LR_PEEL_TIMING
+    tm[1] = wall_clock64();
+#endif
 
     // -- inliers of the best hypothesis, in order (estimator.h:74-75): their (h, length) staged for the refit
     uint32_t n_inl = 0;
@@ -364,6 +374,9 @@ __global__ __launch_bounds__(kWG) void peel_kernel(PencilTable cur, PencilTable 
     }
     __syncthreads();
 
+#ifdef LR_PEEL_TIMING
+    tm[2] = wall_clock64();
+#endif
     // -- fit_optimal (line_pencil.cpp:111-128): cov = sum_i (h_i * len_i) h_i^T over the inliers, or over EVERY line of
     // the model if there is none (the reference's "empty index set means all"); nine tree sums by the first wavefront
     if (wv == 0) {
@@ -385,6 +398,9 @@ __global__ __launch_bounds__(kWG) void peel_kernel(PencilTable cur, PencilTable 
         }
 #pragma unroll
         for (int k = 0; k < 9; ++k) acc[k] = wave_tree(acc[k]);
+#ifdef LR_PEEL_TIMING
+        tm[3] = wall_clock64();
+#endif
         if (lane == 0) {
             float hf[3];
             smallest_eigenvector_3x3(acc, hf);
@@ -398,6 +414,9 @@ __global__ __launch_bounds__(kWG) void peel_kernel(PencilTable cur, PencilTable 
     }
     __syncthreads();
     const float fx = s_h[0], fy = s_h[1], fz = s_h[2];
+#ifdef LR_PEEL_TIMING
+    tm[4] = wall_clock64();
+#endif
 
     // -- the round's verdict per line (estimator.h:122-135): inlier -> id of the round; near miss -> garbage (out of the
     // game, final id -1); the others go on, in order, into the next round's table
@@ -432,6 +451,12 @@ __global__ __launch_bounds__(kWG) void peel_kernel(PencilTable cur, PencilTable 
         n_next += tot;
         n_gone += tg;
     }
+#ifdef LR_PEEL_TIMING
+    if (threadIdx.x == 0) {
+        tm[5] = wall_clock64();
+        for (int q = 0; q < 5; ++q) models[16 + round * 5 + q] = (float)(tm[q + 1] - tm[q]) * 0.01f;  // us (100 MHz clock)
+    }
+#endif
     if (threadIdx.x == 0) {
         gctl[kGcActive] = n_next;
         gctl[kGcRemaining] = gctl[kGcRemaining] - n_gone;

@@ -79,7 +79,10 @@ Vec3 smallest_eigenvector(const float c[9]) {
         for (int j = 0; j < 3; ++j) A[i][j] = 0.5 * ((double)c[i * 3 + j] + (double)c[j * 3 + i]);
     for (int sweep = 0; sweep < 64; ++sweep) {
         const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
-        if (off == 0.0) break;
+        // converged: the off-diagonal part is below double precision relative to the diagonal (waiting for it to
+        // underflow to exactly zero can take all 64 sweeps and changes nothing in the float result)
+        const double dg = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+        if (off <= 1e-36 * dg) break;
         for (int p = 0; p < 2; ++p)
             for (int q = p + 1; q < 3; ++q) {
                 if (A[p][q] == 0.0) continue;

@@ -149,20 +149,7 @@ void gauss_deriv_kernel(int size, float sigma, bool dir_x, float* H) {
         }
 }
 
-// filter.cpp:81-98  (correlation, zero border of kernel radius): the generic 25-tap form, kept for the tap KAT
-void conv_2d(const float* img, int w, int h, const float* K, int ksz, float* out, const ThreadContext& ctx) {
-    int n = 2 * ksz + 1;
-    std::fill(out, out + size_t(w) * h, 0.0f);
-#pragma omp parallel for num_threads(ctx.get()) if (ctx.enabled())
-    for (int i = 0; i < h - n + 1; ++i)
-        for (int j = 0; j < w - n + 1; ++j) {
-            float acc = 0.0f;
-            for (int a = 0; a < n; ++a)
-                for (int b = 0; b < n; ++b) acc = std::fmaf(img[size_t(i + a) * w + (j + b)], K[a * n + b], acc);
-            out[size_t(i + ksz) * w + (j + ksz)] = acc;
-        }
-}
-
+// filter.cpp:81-98 (conv_2d: correlation, zero border of kernel radius) -- as conv_gradients below.
 // The taps of filter.cpp:65-78 are a product: H(i,j) = z/a * exp(-(x^2+y^2)/2s^2) = d(x) * g(y) for Hx (and
 // d(y) * g(x) for Hy) with d(t) = t/a * exp(-t^2/2s^2), g(t) = exp(-t^2/2s^2).  The reference evaluates the 25-tap
 // correlation with an Eigen block product whose summation order (under -ffast-math) is unspecified; the canonical
@@ -574,7 +561,10 @@ V3 min_eigvec_3x3(const float cov[9]) {
         for (int j = 0; j < 3; ++j) A[i][j] = 0.5 * (double(cov[i * 3 + j]) + double(cov[j * 3 + i]));
     for (int sweep = 0; sweep < 64; ++sweep) {
         double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
-        if (off == 0.0) break;
+        // converged: the off-diagonal part is below double precision relative to the diagonal (waiting for it to
+        // underflow to exactly zero can take all 64 sweeps and changes nothing in the float result)
+        double dg = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+        if (off <= 1e-36 * dg) break;
         for (int p = 0; p < 2; ++p)
             for (int q = p + 1; q < 3; ++q) {
                 if (A[p][q] == 0.0) continue;
