@@ -1,6 +1,7 @@
 // lr_context: one device, one stream, one reusable workspace (see include/librectify_amd.h).
 #pragma once
 #include <functional>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -26,6 +27,9 @@ struct lr_context {
     float* h_stage[2] = {nullptr, nullptr};
     size_t cap_stage[2] = {0, 0};
     hipEvent_t ev_up[2] = {};
+    lr_context* upload_owner = nullptr;  // batch lanes: the context whose copy stream (and mutex) all uploads go through
+    bool upload_ordered = false;
+    std::mutex upload_mu;
     std::function<void()> prefetch;  // one-shot: run at the frame's first long wait (see ctx_run_prefetch)
     int prefetch_rc = 0;
     std::string prefetch_err;
@@ -129,6 +133,7 @@ struct lr_context {
     bool flood_staged = false;  // set on the lanes of a batch call (throughput over latency)
     hipEvent_t ev[16] = {};
     float stage_ms[LR_T_COUNT] = {};
+    double host_ms[3] = {0, 0, 0};  // last frame: enqueue, next-frame staging + upload, wait (LIBRECTIFY_LANE_DEBUG)
     bool stage_valid[4] = {false, false, false, false};
     bool dmask_consumed = false;  // the parallel flood clears the mask of labelled pixels: LR_BUF_DMASK is then stale
 };

@@ -3,6 +3,9 @@
 #include "context.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -62,6 +65,10 @@ int idx_bits_for(size_t npix) {
 }
 
 }  // namespace
+
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 void set_error(const std::string& msg) { g_error = msg; }
 const std::string& get_error() { return g_error; }
@@ -177,63 +184,78 @@ int ctx_upload_frame(lr_context* c, int slot, const float* buffer, int w, int h,
         set_error("upload: |stride| smaller than the width");
         return 1;
     }
+    // In a batch call all lanes send their frames down ONE copy stream (the caller's), one frame at a time: DMA
+    // transfers of different streams share the link, so six frames started together all arrive late, whereas in a
+    // single queue the first is there after a sixth of the time and its lane can start.
+    lr_context* owner = c->upload_owner ? c->upload_owner : c;
+    hipStream_t up = owner->copy_stream;
+    const bool ordered = owner != c || c->upload_ordered;
     const size_t npix = (size_t)w * h;
     if (c->cap_slot[slot] < npix) {
         LR_HIP(hipStreamSynchronize(c->stream));
-        LR_HIP(hipStreamSynchronize(c->copy_stream));
+        LR_HIP(hipStreamSynchronize(up));
         if (dev_alloc(c->d_img_slot[slot], npix)) return 1;
         c->cap_slot[slot] = npix;
     }
     float* dst = c->d_img_slot[slot];
     const size_t row_bytes = (size_t)w * sizeof(float);
     if (is_page_locked(buffer)) {
+        std::unique_lock<std::mutex> lock(owner->upload_mu, std::defer_lock);
+        if (ordered) lock.lock();
         LR_HIP(hipMemcpy2DAsync(dst, row_bytes, buffer, (size_t)stride * sizeof(float), row_bytes, (size_t)h,
-                                hipMemcpyHostToDevice, c->copy_stream));
-    } else {
-        if (c->cap_stage[slot] < npix) {
-            LR_HIP(hipStreamSynchronize(c->copy_stream));
-            if (c->h_stage[slot]) (void)hipHostFree(c->h_stage[slot]);
-            c->h_stage[slot] = nullptr;
-            c->cap_stage[slot] = 0;
-            LR_HIP(hipHostMalloc((void**)&c->h_stage[slot], npix * sizeof(float)));
-            c->cap_stage[slot] = npix;
-        }
-        // the DMA that last read this staging buffer has long finished (its frame has been processed), but make sure
-        LR_HIP(hipEventSynchronize(c->ev_up[slot]));
-        float* stage = c->h_stage[slot];
-        const int rows_per_band = (int)std::max<size_t>(1, ((size_t)4 << 20) / row_bytes);
-        const int n_bands = (h + rows_per_band - 1) / rows_per_band;
-        const int T = std::min(staging_threads(num_threads), n_bands);
-        std::vector<int> rc(T, 0);
-        // band k: rows into the pinned buffer, then its DMA is enqueued at once: the copy of the next band overlaps it
-        auto run = [&](int t) {
-            if (t > 0 && hipSetDevice(c->device) != hipSuccess) {
-                rc[t] = 1;
-                return;
-            }
-            for (int k = t; k < n_bands; k += T) {
-                const int r0 = k * rows_per_band, r1 = std::min(h, r0 + rows_per_band);
-                if (stride == w) {
-                    std::memcpy(stage + (size_t)r0 * w, buffer + (size_t)r0 * stride, (size_t)(r1 - r0) * row_bytes);
-                } else {
-                    for (int r = r0; r < r1; ++r) std::memcpy(stage + (size_t)r * w, buffer + (size_t)r * stride, row_bytes);
-                }
-                if (hipMemcpyAsync(dst + (size_t)r0 * w, stage + (size_t)r0 * w, (size_t)(r1 - r0) * row_bytes,
-                                   hipMemcpyHostToDevice, c->copy_stream) != hipSuccess)
-                    rc[t] = 1;
-            }
-        };
-        std::vector<std::thread> th;
-        for (int t = 1; t < T; ++t) th.emplace_back(run, t);
-        run(0);
-        for (auto& x : th) x.join();
-        for (int t = 0; t < T; ++t)
-            if (rc[t]) {
-                set_error("upload: staging copy failed");
-                return 1;
-            }
+                                hipMemcpyHostToDevice, up));
+        LR_HIP(hipEventRecord(c->ev_up[slot], up));
+        return 0;
     }
-    LR_HIP(hipEventRecord(c->ev_up[slot], c->copy_stream));
+    if (c->cap_stage[slot] < npix) {
+        LR_HIP(hipStreamSynchronize(up));
+        if (c->h_stage[slot]) (void)hipHostFree(c->h_stage[slot]);
+        c->h_stage[slot] = nullptr;
+        c->cap_stage[slot] = 0;
+        LR_HIP(hipHostMalloc((void**)&c->h_stage[slot], npix * sizeof(float)));
+        c->cap_stage[slot] = npix;
+    }
+    // the DMA that last read this staging buffer has long finished (its frame has been processed), but make sure
+    LR_HIP(hipEventSynchronize(c->ev_up[slot]));
+    float* stage = c->h_stage[slot];
+    const int rows_per_band = (int)std::max<size_t>(1, ((size_t)4 << 20) / row_bytes);
+    const int n_bands = (h + rows_per_band - 1) / rows_per_band;
+    const int T = std::min(staging_threads(num_threads), n_bands);
+    std::vector<int> rc(T, 0);
+    // band k: rows into the pinned buffer; a single call (not ordered) enqueues each band's DMA at once, so that the
+    // copy of the next band overlaps it; a batch lane stages the whole frame first and then takes its turn on the link
+    auto run = [&](int t) {
+        if (t > 0 && hipSetDevice(c->device) != hipSuccess) {
+            rc[t] = 1;
+            return;
+        }
+        for (int k = t; k < n_bands; k += T) {
+            const int r0 = k * rows_per_band, r1 = std::min(h, r0 + rows_per_band);
+            if (stride == w) {
+                std::memcpy(stage + (size_t)r0 * w, buffer + (size_t)r0 * stride, (size_t)(r1 - r0) * row_bytes);
+            } else {
+                for (int r = r0; r < r1; ++r) std::memcpy(stage + (size_t)r * w, buffer + (size_t)r * stride, row_bytes);
+            }
+            if (!ordered && hipMemcpyAsync(dst + (size_t)r0 * w, stage + (size_t)r0 * w, (size_t)(r1 - r0) * row_bytes,
+                                           hipMemcpyHostToDevice, up) != hipSuccess)
+                rc[t] = 1;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(run, t);
+    run(0);
+    for (auto& x : th) x.join();
+    for (int t = 0; t < T; ++t)
+        if (rc[t]) {
+            set_error("upload: staging copy failed");
+            return 1;
+        }
+    std::unique_lock<std::mutex> lock(owner->upload_mu, std::defer_lock);
+    if (ordered) {
+        lock.lock();
+        LR_HIP(hipMemcpyAsync(dst, stage, npix * sizeof(float), hipMemcpyHostToDevice, up));
+    }
+    LR_HIP(hipEventRecord(c->ev_up[slot], up));
     return 0;
 }
 
@@ -1064,6 +1086,7 @@ int ctx_refine(lr_context* c, std::vector<LineSegment>& lines) {
 static int run_frame(lr_context* c, const float* d_image, int w, int h, int stride, float min_length, bool refine,
                      std::vector<LineSegment>& out) {
     out.clear();
+    const double t_begin = now_ms();
     const bool fused = !refine && c->estimator == 0;
     const int n_iter = c->ransac_iters;
     auto groups_after_fit = [&]() -> int {
@@ -1088,8 +1111,13 @@ static int run_frame(lr_context* c, const float* d_image, int w, int h, int stri
         } else {
             LR_HIP(hipMemcpyAsync(c->h_counts, c->d_counts, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         }
+        const double t_enq = now_ms();
         ctx_run_prefetch(c);  // everything is enqueued: the lane stages its next frame while the GPU works
+        const double t_pre = now_ms();
         LR_HIP(hipStreamSynchronize(c->stream));
+        c->host_ms[0] = t_enq - t_begin;      // enqueue of the frame's kernels
+        c->host_ms[1] = t_pre - t_enq;        // staging + upload of the lane's next frame
+        c->host_ms[2] = now_ms() - t_pre;     // wait for the GPU
         const uint32_t* cnt = fused ? reinterpret_cast<const uint32_t*>(c->h_res) : c->h_counts;
         c->n_seeds = cnt[kCntSeeds];
         if (c->n_seeds <= c->seed_cap) break;
@@ -1199,11 +1227,15 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
         l->flood_staged = S > 1;
         l->estimator = c->estimator;
         l->prosac_T_N = c->prosac_T_N;
+        l->upload_owner = (h_frames && l != c) ? c : nullptr;
     }
+    c->upload_ordered = h_frames != nullptr;
+    std::atomic<int> first_turn{0};  // the first frames go up the link in lane order
     // the lanes share the host's cores: a lane stages its frames with its share of the caller's thread budget
     const int lane_threads = num_threads > 1 ? std::max(1, num_threads / S) : 1;
     std::vector<int> rc(S, 0);
     std::vector<std::string> err(S);
+    static const bool lane_debug = std::getenv("LIBRECTIFY_LANE_DEBUG") != nullptr;
     auto work = [&](int si) {
         lr_context* l = lanes[si];
         auto fail = [&]() {
@@ -1211,7 +1243,13 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
             err[si] = get_error();
             l->prefetch = nullptr;
         };
-        if (h_frames && ctx_upload_frame(l, 0, h_frames[si], w, h, stride, lane_threads)) return fail();
+        if (h_frames) {
+            // (staging is not ordered, only the transfers: wait for the turn inside would serialise the staging too)
+            while (first_turn.load(std::memory_order_acquire) < si) std::this_thread::yield();
+            const int urc = ctx_upload_frame(l, 0, h_frames[si], w, h, stride, std::max(lane_threads, num_threads > 1 ? num_threads / 2 : 1));
+            first_turn.store(si + 1, std::memory_order_release);
+            if (urc) return fail();
+        }
         int j = 0;
         for (int b = si; b < batch; b += S, ++j) {
             const float* img = nullptr;
@@ -1238,7 +1276,11 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
                 img = d_images + (size_t)b * image_stride;
             }
             std::vector<LineSegment> res;
+            const double t_f0 = now_ms();
             if (ctx_find_groups_device(l, img, w, h, img_stride, min_length, refine, res)) return fail();
+            if (lane_debug)
+                std::fprintf(stderr, "lane %d frame %d: enqueue %.2f ms, next-frame upload %.2f, wait %.2f, whole call %.2f; device total %.2f\n",
+                             si, b, l->host_ms[0], l->host_ms[1], l->host_ms[2], now_ms() - t_f0, l->stage_ms[LR_T_TOTAL]);
             if (l->prefetch_rc) {
                 set_error(l->prefetch_err);
                 return fail();
@@ -1259,6 +1301,8 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
     work(0);
     for (auto& t : th) t.join();
     c->flood_staged = false;  // the caller's context goes back to the latency-oriented single-frame setting
+    c->upload_ordered = false;
+    for (lr_context* l : lanes) l->upload_owner = nullptr;
     for (int si = 0; si < S; ++si)
         if (rc[si]) {
             set_error(err[si]);
