@@ -47,8 +47,9 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PMC_FILE = os.path.join("profiles", "r02_pmc_filter_traffic.txt")
 
 
-def make_frames(n, w, h, seed0, bases=2, out=None):
-    """n distinct frames: `bases` generated, the rest flips / rolls of them (cheap, same statistics).
+def make_frames(n, w, h, seed0, bases=4, out=None):
+    """n frames in distinct buffers: `bases` generated ones (seeds seed0, seed0 + 1, ...) and their three flips, repeated
+    as often as needed (generating a 4K frame takes seconds; what matters is that every frame is its own buffer).
     Written into `out` ([n, h, w] float32) if given."""
     from librectify_amd import synth
 
@@ -56,18 +57,8 @@ def make_frames(n, w, h, seed0, bases=2, out=None):
     res = out if out is not None else np.empty((n, h, w), np.float32)
     for i in range(n):
         b = base[i % len(base)]
-        k = i // len(base)
-        if k == 0:
-            f = b
-        elif k == 1:
-            f = b[:, ::-1]
-        elif k == 2:
-            f = b[::-1, :]
-        elif k == 3:
-            f = b[::-1, ::-1]
-        else:
-            f = np.roll(b, 97 * k, axis=1)
-        res[i] = f
+        k = (i // len(base)) % 4
+        res[i] = b if k == 0 else (b[:, ::-1] if k == 1 else (b[::-1, :] if k == 2 else b[::-1, ::-1]))
     return res
 
 
@@ -285,7 +276,7 @@ def main():
     else:
         w = args.width or W4K
         h = args.height or H4K
-        wl = Workload(w, h, args.frames, 1 + 100 * rank, 2, 8192, True)
+        wl = Workload(w, h, args.frames, 1 + 100 * rank, 4, 8192, True)
         n_total = None
         scaling = "weak"
         total_frames = args.frames * n_gpus

@@ -135,6 +135,7 @@ struct FloodBuffers {
     // Likewise the hold-back: if the context's previous frame engaged it, this frame starts with it (a round of very
     // long walks saved); otherwise it engages after the first full round that shows such walks.
     bool hold_from_start = false;
+    int blind_rounds = 10;  // rounds flood_enqueue enqueues without looking at the control block
     uint32_t big_cap_override = 0;  // test hook: seeds per round the second tier takes (0 = the default, 8192)
 };
 // What a frame hands to the flood.  The seed count stays on the device (*d_n_seeds, clamped to seed_cap, the

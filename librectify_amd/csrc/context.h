@@ -124,6 +124,7 @@ struct lr_context {
     // state of the last run
     uint32_t n_seeds = 0, n_comp = 0, n_px = 0;
     int flood_rounds = 0;
+    int flood_rounds_hint = 10;  // rounds the next flood enqueues blindly
     uint64_t ransac_seed = 0;
     int ransac_iters = lramd::kRansacMaxIter;
     int flood_mode = 1;

@@ -427,6 +427,7 @@ FloodBuffers flood_buffers_for(lr_context* c) {
         fbuf.big_cap_override = 1;
     }
     if (c->flood_staged) fbuf.win_first_shift = 3;
+    fbuf.blind_rounds = c->flood_rounds_hint;
     return fbuf;
 }
 
@@ -500,6 +501,8 @@ int finish_flood(lr_context* c, bool* extra) {
         return 1;
     c->flood_big_hint = c->flood_tiers[0] > 0 || c->flood_tiers[1] > 0;
     c->flood_hold_hint = c->flood_tiers[3] != 0;
+    // blind rounds of the next frame: what this one needed plus two, decaying slowly
+    c->flood_rounds_hint = std::max(c->flood_rounds + 2, c->flood_rounds_hint - 1);
     return 0;
 }
 
@@ -1231,6 +1234,7 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
     }
     c->upload_ordered = h_frames != nullptr;
     std::atomic<int> first_turn{0};  // the first frames go up the link in lane order
+    std::atomic<int> next_frame{S};
     // the lanes share the host's cores: a lane stages its frames with its share of the caller's thread budget
     const int lane_threads = num_threads > 1 ? std::max(1, num_threads / S) : 1;
     std::vector<int> rc(S, 0);
@@ -1251,7 +1255,10 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
             if (urc) return fail();
         }
         int j = 0;
-        for (int b = si; b < batch; b += S, ++j) {
+        // frames are handed out dynamically (a lane reserves its next frame when it starts on the current one, so that
+        // it can upload it meanwhile): frames differ in cost, and with a fixed assignment the batch ends on one lane
+        for (int b = si, nb = -1; b < batch; b = nb, ++j) {
+            nb = next_frame.fetch_add(1, std::memory_order_relaxed);
             const float* img = nullptr;
             int img_stride = stride;
             if (h_frames) {
@@ -1263,7 +1270,6 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
                 img = l->d_img_slot[cur];
                 img_stride = w;
                 l->prefetch_rc = 0;
-                const int nb = b + S;
                 if (nb < batch)
                     l->prefetch = [l, cur, nb, h_frames, w, h, stride, lane_threads]() {
                         // slot cur^1 was last read by this lane's previous frame, which is finished

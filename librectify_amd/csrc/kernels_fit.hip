@@ -232,61 +232,80 @@ __global__ __launch_bounds__(256) void component_sort_small_kernel(const uint32_
     if ((uint32_t)lane < n) px_out[off + rank] = key;
 }
 
-// Longer lists: one workgroup each, bitonic network on the list padded to a power of two -- in LDS up to 4096 keys,
-// in place in global memory beyond that (rare: a flood of more than 4096 pixels).
+// Longer lists: one workgroup each, bitonic network on the list padded to a power of two.  Three classes, told apart
+// when the offsets are computed (component_offsets_kernel): up to 4096 pixels in 16 KB of LDS by 256 threads (many
+// workgroups; entries at the front of large_list); up to 16384 pixels in 64 KB of LDS by 1024 threads; beyond that in
+// place in global memory by a single workgroup (a flood of more than 16384 pixels: rare, and slow here -- every pass
+// is a round trip to L2).  The last two share the entries at the back of large_list.
+template <int kThreads, class Keys>
+__device__ __forceinline__ void bitonic_sort(Keys& key, uint32_t P) {
+    for (uint32_t k = 2; k <= P; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < P / 2; t += kThreads) {
+                const uint32_t i = 2 * t - (t & (j - 1));  // index with bit j clear
+                const uint32_t a = key[i], b = key[i + j];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) {
+                    key[i] = b;
+                    key[i + j] = a;
+                }
+            }
+            __syncthreads();
+        }
+}
+
 __global__ __launch_bounds__(256) void component_sort_large_kernel(const uint32_t* __restrict__ px_in,
                                                                    uint32_t* __restrict__ px_out,
                                                                    const uint32_t* __restrict__ comp_off,
                                                                    const uint32_t* __restrict__ large_list,
-                                                                   uint32_t large_cap,
-                                                                   const uint32_t* __restrict__ n_large,
-                                                                   uint32_t* __restrict__ scratch) {
+                                                                   const uint32_t* __restrict__ n_large) {
     __shared__ uint32_t s_key[kSortLds];
-    // two launches share this kernel: many workgroups for the lists that fit the LDS (scratch == nullptr; entries at the
-    // front of large_list), a single workgroup with a global scratch buffer for the few that do not (at its back)
-    const uint32_t n_list = scratch ? n_large[1] : n_large[0];
+    const uint32_t n_list = n_large[0];
     for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
-        const uint32_t comp = large_list[scratch ? large_cap - 1u - li : li];
+        const uint32_t comp = large_list[li];
         const uint32_t off = comp_off[comp];
         const uint32_t n = comp_off[comp + 1] - off;
         uint32_t P = 128;
         while (P < n) P <<= 1;
-        if (P <= kSortLds) {
-            for (uint32_t i = threadIdx.x; i < P; i += 256) s_key[i] = i < n ? px_in[off + i] : 0xFFFFFFFFu;
+        for (uint32_t i = threadIdx.x; i < P; i += 256) s_key[i] = i < n ? px_in[off + i] : 0xFFFFFFFFu;
+        __syncthreads();
+        bitonic_sort<256>(s_key, P);
+        for (uint32_t i = threadIdx.x; i < n; i += 256) px_out[off + i] = s_key[i];
+        __syncthreads();
+    }
+}
+
+constexpr uint32_t kSortLdsBig = 16384;  // 64 KB
+// kGlobal = false: lists of 4097..16384 pixels, in LDS; true: longer ones, in `scratch` (>= 2 x the frame's pixels;
+// launched with ONE workgroup, which takes them one after the other)
+template <bool kGlobal>
+__global__ __launch_bounds__(1024) void component_sort_big_kernel(const uint32_t* __restrict__ px_in,
+                                                                  uint32_t* __restrict__ px_out,
+                                                                  const uint32_t* __restrict__ comp_off,
+                                                                  const uint32_t* __restrict__ large_list,
+                                                                  uint32_t large_cap,
+                                                                  const uint32_t* __restrict__ n_large,
+                                                                  uint32_t* __restrict__ scratch) {
+    __shared__ uint32_t s_key[kGlobal ? 1 : kSortLdsBig];
+    const uint32_t n_list = n_large[1];
+    for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
+        const uint32_t comp = large_list[large_cap - 1u - li];
+        const uint32_t off = comp_off[comp];
+        const uint32_t n = comp_off[comp + 1] - off;
+        if ((n > kSortLdsBig) != kGlobal) continue;  // the other launch's
+        uint32_t P = 8192;
+        while (P < n) P <<= 1;
+        if (!kGlobal) {
+            for (uint32_t i = threadIdx.x; i < P; i += 1024) s_key[i] = i < n ? px_in[off + i] : 0xFFFFFFFFu;
             __syncthreads();
-            for (uint32_t k = 2; k <= P; k <<= 1)
-                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                    for (uint32_t t = threadIdx.x; t < P / 2; t += 256) {
-                        const uint32_t i = 2 * t - (t & (j - 1));  // index with bit j clear
-                        const uint32_t a = s_key[i], b = s_key[i + j];
-                        const bool up = (i & k) == 0;
-                        if ((a > b) == up) {
-                            s_key[i] = b;
-                            s_key[i + j] = a;
-                        }
-                    }
-                    __syncthreads();
-                }
-            for (uint32_t i = threadIdx.x; i < n; i += 256) px_out[off + i] = s_key[i];
+            bitonic_sort<1024>(s_key, P);
+            for (uint32_t i = threadIdx.x; i < n; i += 1024) px_out[off + i] = s_key[i];
             __syncthreads();
         } else {
-            uint32_t* g = scratch;  // >= 2 * (pixels of the frame) words, one list at a time
-            for (uint32_t i = threadIdx.x; i < P; i += 256) g[i] = i < n ? px_in[off + i] : 0xFFFFFFFFu;
+            for (uint32_t i = threadIdx.x; i < P; i += 1024) scratch[i] = i < n ? px_in[off + i] : 0xFFFFFFFFu;
             __syncthreads();
-            for (uint32_t k = 2; k <= P; k <<= 1)
-                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                    for (uint32_t t = threadIdx.x; t < P / 2; t += 256) {
-                        const uint32_t i = 2 * t - (t & (j - 1));
-                        const uint32_t a = g[i], b = g[i + j];
-                        const bool up = (i & k) == 0;
-                        if ((a > b) == up) {
-                            g[i] = b;
-                            g[i + j] = a;
-                        }
-                    }
-                    __syncthreads();
-                }
-            for (uint32_t i = threadIdx.x; i < n; i += 256) px_out[off + i] = g[i];
+            bitonic_sort<1024>(scratch, P);
+            for (uint32_t i = threadIdx.x; i < n; i += 1024) px_out[off + i] = scratch[i];
             __syncthreads();
         }
     }
@@ -411,11 +430,11 @@ int launch_component_sort(const uint32_t* px_in, uint32_t* px_out, const uint32_
     if (comp_cap == 0) return 0;
     hipLaunchKernelGGL(component_sort_small_kernel, dim3((comp_cap + 3) / 4), dim3(256), 0, s, px_in, px_out, comp_off,
                        d_n_comp);
-    // (lists of more than 4096 pixels: one at a time through the global scratch, by a single workgroup)
-    hipLaunchKernelGGL(component_sort_large_kernel, dim3(1024), dim3(256), 0, s, px_in, px_out, comp_off, large_list,
-                       large_cap, n_large, (uint32_t*)nullptr);
-    hipLaunchKernelGGL(component_sort_large_kernel, dim3(1), dim3(256), 0, s, px_in, px_out, comp_off, large_list, large_cap,
-                       n_large, scratch);
+    hipLaunchKernelGGL(component_sort_large_kernel, dim3(1024), dim3(256), 0, s, px_in, px_out, comp_off, large_list, n_large);
+    hipLaunchKernelGGL(component_sort_big_kernel<false>, dim3(32), dim3(1024), 0, s, px_in, px_out, comp_off, large_list,
+                       large_cap, n_large, scratch);
+    hipLaunchKernelGGL(component_sort_big_kernel<true>, dim3(1), dim3(1024), 0, s, px_in, px_out, comp_off, large_list,
+                       large_cap, n_large, scratch);
     LR_HIP(hipGetLastError());
     return 0;
 }

@@ -1276,11 +1276,12 @@ void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& 
         (void)hipEventRecord(dbg0, s);
     }
     // grid: see flood_explore_kernel.  A staged start keeps the list long for a round more.
-    const int shift = std::min(std::max(index - (B.win_first_shift > 0 ? 1 : 0), 0), 4);
+    // (not below a quarter: while the weakest fifth of the seeds is held back, the list stays that long)
+    const int shift = std::min(std::max(index - (B.win_first_shift > 0 ? 1 : 0), 0), 2);
     const uint32_t grid = std::max<uint32_t>(std::min<uint32_t>(F.seed_cap, 2048u), F.seed_cap >> shift);
     hipLaunchKernelGGL(flood_explore_kernel, dim3(grid), dim3(64), 0, s, A, F.trig, act, B.big_list);
     if (grid < F.seed_cap)  // entries past the guess, if any
-        hipLaunchKernelGGL(flood_explore_rest_kernel, dim3(256), dim3(64), 0, s, A, F.trig, act, B.big_list, grid);
+        hipLaunchKernelGGL(flood_explore_rest_kernel, dim3(1024), dim3(64), 0, s, A, F.trig, act, B.big_list, grid);
     if (use_big)
         hipLaunchKernelGGL(flood_explore_big_kernel, dim3(std::min<uint32_t>(F.seed_cap, kBigCap)), dim3(64), kBigLdsBytes, s,
                            A, F.trig, B.big_list);
@@ -1344,7 +1345,9 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
                        hold_start ? 1u : 0u);
     FloodArgs A = flood_args(B, F, P->use_big);
     A.win_shift = (uint32_t)win_growth;
-    const int batch = g_flood_debug ? 1 : ((win_first_shift > 0 || hold_start) ? 7 : 6);
+    // rounds enqueued blindly: two more than the context's previous frame needed (a round past the end costs five
+    // empty launches, a round too few costs the frame a second lap through the fit and the grouping)
+    const int batch = g_flood_debug ? 1 : std::min(std::max(B.blind_rounds, 6), 16);
     for (int r = 0; r < batch; ++r, ++P->enqueued) enqueue_round(B, F, A, P->use_big, P->enqueued, s);
     LR_HIP(hipMemcpyAsync(h_ctrl, B.ctrl, kCtrlWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     LR_HIP(hipGetLastError());

@@ -485,6 +485,33 @@ def test_every_storage_tier_of_the_flood_is_exact_on_long_edges(L, ctx):
     assert used[5]["second_tier_seeds"] > 0 and used[5]["slabs"] == 0 and used[5]["ordered_tail_seeds"] > 0
 
 
+def test_component_sort_classes_up_to_a_flood_of_20000_pixels(L, ctx):
+    """The per-component pixel sort has four size classes (<= 64 px in a wavefront, <= 4096 and <= 16384 in LDS, beyond
+    that in global memory).  A 3200x200 frame with a soft horizontal step (a 6-px wide, 3200-px long flood) and bars of
+    graded length exercises all of them; label image and segment records against the oracle."""
+    from librectify_amd import synth
+
+    rng = np.random.RandomState(77)
+    W, H = 3200, 200
+    img = np.full((H, W), 0.3, np.float64)
+    img[100:, :] += 0.4                       # one step across the whole width ...
+    img = synth._gauss_blur(img, 4.0)         # ... made soft: its flood is ~6 px thick
+    for k, (x0, ln) in enumerate([(50, 40), (200, 300), (700, 900), (1700, 1400)]):  # sharper bars of graded length
+        img[20 + 3 * k: 26 + 3 * k, x0: x0 + ln] += 0.25
+    img[60:66, 100:3000] += 0.25
+    img = synth._gauss_blur(img, 1.0) + rng.normal(0, 0.002, size=img.shape)
+    img = img.astype(np.float32)
+    ref = O.find_line_segments(img)
+    sizes = np.bincount(ref["label"][ref["label"] >= 0])
+    assert sizes.max() > 16384 and ((sizes > 4096) & (sizes <= 16384)).any() and ((sizes > 64) & (sizes <= 4096)).any()
+    ctx.set_flood_mode(1)
+    ctx.stage_filter_host(img)
+    assert ctx.stage_seeds() == ref["n_seeds"]
+    ctx.stage_flood()
+    np.testing.assert_array_equal(ctx.download(L.BUF_LABEL), ref["label"])
+    _assert_lines_equal(ctx.stage_fit(), ref["lines"])
+
+
 def test_natural_image_at_4k_matches_the_oracle(L, ctx):
     """The reference's doc image upsampled to 3840x2160 (cubic spline): 53 760 seeds, walks of over a thousand tiles,
     second storage tier and the hold-back of the weakest seeds all in play; full path against the oracle."""

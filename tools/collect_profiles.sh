@@ -1,0 +1,17 @@
+#!/bin/bash
+# On the GPU box: the measurements that go into profiles/ for a round.  usage: tools/collect_profiles.sh r02
+R=${1:-r02}
+O=gpurun_out/profiles_$R
+export TMPDIR=/tmp
+mkdir -p $O
+python3 bench.py --steps 20 --warmup 5 > $O/${R}_bench.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/p1 -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-legs > $O/${R}_bench_under_rocprof.json 2> /dev/null
+find $O/p1 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/${R}_kernel_stats.csv; rm -rf $O/p1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/p2 -- python3 bench.py --roofline-only > $O/${R}_bench_roofline_leg.json 2> /dev/null
+find $O/p2 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/${R}_kernel_stats_roofline_leg.csv; rm -rf $O/p2
+W=8192 H=8192 NFRAMES=3 LAPS=4 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p3 -- python3 tools/bench_filter.py > $O/${R}_filter_8k.txt 2> /dev/null
+find $O/p3 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/${R}_kernel_stats_filter_8k.csv; rm -rf $O/p3
+bash tools/pmc_traffic.sh > $O/${R}_pmc_filter_traffic.txt 2>&1
+bash tools/pmc_explore.sh > $O/${R}_pmc_flood_explore.txt 2>&1
+rm -rf gpurun_out/pmc_* gpurun_out/cal_f gpurun_out/flt_* /tmp/pmcx_*
+ls -la $O
