@@ -167,9 +167,10 @@ int lr_cht_vanishing_point(lr_context* ctx, const LineSegment* lines, int n, int
 int lr_refine_lines(lr_context* ctx, const LineSegment* in, int n, LineSegment* out, int* n_out);
 
 /* ---- PROSAC / Hough weights (opt-in) --------------------------------------------------- */
-/* The reference compiles prosac.h but never instantiates it (ChangeLog.md: "pure RANSAC is used"), so RANSAC
- * is the default here too.  kind: 0 = RANSAC, 1 = PROSAC with T_N iterations (<= 0: the reference's
- * niter_RANSAC(0.9, 0.5, 2) = 9, prosac.h:116). */
+/* The reference compiles prosac.h and DirectEstimator (estimator.h:82-96) but never instantiates them (ChangeLog.md:
+ * "pure RANSAC is used"), so RANSAC is the default here too.  kind: 0 = RANSAC, 1 = PROSAC with T_N iterations
+ * (<= 0: the reference's niter_RANSAC(0.9, 0.5, 2) = 9, prosac.h:116), 2 = DirectEstimator (refit on the lines whose
+ * Hough weight exceeds 0.95; prosac_T_N is ignored). */
 void lr_set_estimator(lr_context* ctx, int kind, int prosac_T_N);
 /* LinePencilModel::get_weights (line_pencil.cpp:47-86): 65x65 hemisphere accumulator (LDS, 64-bit integer
  * atomics), peak direction, inclination^4 per line listed in `indices`. */
@@ -179,6 +180,10 @@ int lr_prosac_solve(lr_context* ctx, const LineSegment* lines_norm, int n, const
                     int T_N, uint64_t seed, uint32_t round, float* h3, int32_t* trace4);
 int lr_estimate_line_pencils_prosac(lr_context* ctx, LineSegment* lines, int n, int max_models, float inlier_deg,
                                     float garbage_deg, int T_N, uint64_t seed);
+/* DirectEstimator::solve (estimator.h:82-96) and estimate_multiple_structures around it. */
+int lr_direct_solve(lr_context* ctx, const LineSegment* lines_norm, int n, const int32_t* indices, int n_idx, float* h3);
+int lr_estimate_line_pencils_direct(lr_context* ctx, LineSegment* lines, int n, int max_models, float inlier_deg,
+                                    float garbage_deg);
 
 #ifdef __cplusplus
 }

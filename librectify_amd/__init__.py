@@ -69,7 +69,7 @@ EXPORTS = [
     "lr_stage_filter_host", "lr_stage_seeds", "lr_stage_flood", "lr_stage_fit", "lr_download", "lr_stage_times",
     "lr_stage_counters", "lr_filter_kernel_ms", "lr_ransac_best", "lr_estimate_line_pencils",
     "lr_find_line_segment_groups_batch_host", "lr_find_line_segment_groups_batch_host_ptrs", "lr_host_alloc", "lr_host_free",
-    "lr_set_batch_streams", "lr_device_malloc", "lr_device_free", "lr_memcpy_h2d", "lr_cht_vanishing_point", "lr_refine_lines", "lr_set_estimator", "lr_ht_weights", "lr_prosac_solve", "lr_estimate_line_pencils_prosac",
+    "lr_set_batch_streams", "lr_device_malloc", "lr_device_free", "lr_memcpy_h2d", "lr_cht_vanishing_point", "lr_refine_lines", "lr_set_estimator", "lr_ht_weights", "lr_prosac_solve", "lr_estimate_line_pencils_prosac", "lr_direct_solve", "lr_estimate_line_pencils_direct",
 ]
 
 _lib = None
@@ -142,6 +142,8 @@ def lib():
         L.lr_ht_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.lr_prosac_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
         L.lr_estimate_line_pencils_prosac.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_uint64]
+        L.lr_direct_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.lr_estimate_line_pencils_direct.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
         _lib = L
     return _lib
 
@@ -388,6 +390,18 @@ class Context:
     def estimate_line_pencils_prosac(self, lines, max_models=4, inlier_deg=2.0, garbage_deg=4.0, T_N=-1, seed=0):
         lines = np.ascontiguousarray(lines, LINE_DTYPE).copy()
         _check(lib().lr_estimate_line_pencils_prosac(self._h, _ptr(lines), len(lines), max_models, inlier_deg, garbage_deg, T_N, C.c_uint64(seed)))
+        return lines
+
+    def direct_solve(self, lines_norm, indices):
+        lines_norm = np.ascontiguousarray(lines_norm, LINE_DTYPE)
+        indices = np.ascontiguousarray(indices, np.int32)
+        h = np.zeros(3, np.float32)
+        _check(lib().lr_direct_solve(self._h, _ptr(lines_norm), len(lines_norm), _ptr(indices), len(indices), _ptr(h)))
+        return h
+
+    def estimate_line_pencils_direct(self, lines, max_models=4, inlier_deg=2.0, garbage_deg=4.0):
+        lines = np.ascontiguousarray(lines, LINE_DTYPE).copy()
+        _check(lib().lr_estimate_line_pencils_direct(self._h, _ptr(lines), len(lines), max_models, inlier_deg, garbage_deg))
         return lines
 
     def estimate_line_pencils(self, lines, max_models=4, inlier_deg=2.0, garbage_deg=4.0, n_iter=10000, seed=0):

@@ -356,6 +356,24 @@ int lr_prosac_solve(lr_context* ctx, const LineSegment* lines_norm, int n, const
     return 0;
 }
 
+int lr_direct_solve(lr_context* ctx, const LineSegment* lines_norm, int n, const int32_t* indices, int n_idx, float* h3) {
+    const PencilModel model(std::vector<LineSegment>(lines_norm, lines_norm + n));
+    Vec3 h;
+    if (ctx_direct_solve(ctx, model, std::vector<int>(indices, indices + n_idx), &h)) return 1;
+    h3[0] = h.x;
+    h3[1] = h.y;
+    h3[2] = h.z;
+    return 0;
+}
+
+int lr_estimate_line_pencils_direct(lr_context* ctx, LineSegment* lines, int n, int max_models, float inlier_deg,
+                                    float garbage_deg) {
+    std::vector<LineSegment> v(lines, lines + n);
+    if (ctx_estimate_line_pencils_direct(ctx, v, max_models, inlier_deg, garbage_deg)) return 1;
+    std::memcpy(lines, v.data(), sizeof(LineSegment) * (size_t)n);
+    return 0;
+}
+
 int lr_estimate_line_pencils_prosac(lr_context* ctx, LineSegment* lines, int n, int max_models, float inlier_deg,
                                     float garbage_deg, int T_N, uint64_t seed) {
     std::vector<LineSegment> v(lines, lines + n);

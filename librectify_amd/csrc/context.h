@@ -110,7 +110,7 @@ struct lr_context {
     size_t cap_chunk = 0, cap_wlines = 0;
     std::vector<lr_context*> workers;  // extra contexts (own stream + workspace) for frames in flight in batch calls
     int batch_streams = 4;
-    int estimator = 0;            // 0 = RANSAC (reference default), 1 = PROSAC
+    int estimator = 0;            // 0 = RANSAC (reference default), 1 = PROSAC, 2 = DirectEstimator
     int prosac_T_N = -1;
     // pinned host scalars
     uint32_t* h_counts = nullptr;  // 8 words
@@ -163,6 +163,9 @@ int ctx_estimate_line_pencils_prosac(lr_context* c, std::vector<LineSegment>& li
                                      float garbage_deg, int T_N, uint64_t seed);
 int ctx_estimate_line_pencils(lr_context* c, std::vector<LineSegment>& lines, int max_models, float inlier_deg,
                               float garbage_deg, int n_iter, uint64_t seed);
+int ctx_direct_solve(lr_context* c, const PencilModel& model, const std::vector<int>& indices, Vec3* h);
+int ctx_estimate_line_pencils_direct(lr_context* c, std::vector<LineSegment>& lines, int max_models, float inlier_deg,
+                                     float garbage_deg);
 int ctx_cht_vanishing_point(lr_context* c, const std::vector<LineSegment>& lines, int d, Vec3* vp,
                             std::vector<uint64_t>* acc_out);
 int ctx_refine(lr_context* c, std::vector<LineSegment>& lines);

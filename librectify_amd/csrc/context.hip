@@ -989,6 +989,51 @@ int ctx_estimate_line_pencils_prosac(lr_context* c, std::vector<LineSegment>& li
     return 0;
 }
 
+// DirectEstimator (estimator.h:82-96; compiled by the reference, never instantiated): the lines whose Hough weight
+// (GPU: ctx_ht_weights) exceeds 0.95 decide the refit; an empty set means every line (line_pencil.cpp:114-117).
+int ctx_direct_solve(lr_context* c, const PencilModel& model, const std::vector<int>& indices, Vec3* h) {
+    std::vector<float> weights;
+    if (ctx_ht_weights(c, model, indices, weights)) return 1;
+    std::vector<int> inl;
+    for (size_t j = 0; j < indices.size(); ++j)
+        if (weights[j] > 0.95f) inl.push_back(indices[j]);
+    *h = model.fit_optimal(inl);
+    return 0;
+}
+
+int ctx_estimate_line_pencils_direct(lr_context* c, std::vector<LineSegment>& lines, int max_models, float inlier_deg,
+                                     float garbage_deg) {
+    if (lines.empty()) return 0;
+    const Normalisation nrm = bbox_normalisation(lines);
+    const PencilModel model(normalise(lines, nrm));
+    const float tol = cos_threshold(inlier_deg), garbage_tol = cos_threshold(garbage_deg);
+    const int N = model.size();
+    std::vector<int> inlier_flag(N, -1), garbage_flag(N, 0);
+    int remaining = N, k = 0;
+    while (remaining >= 2 && k < max_models) {
+        std::vector<int> obs;
+        for (int i = 0; i < N; ++i)
+            if (inlier_flag[i] < 0 && garbage_flag[i] == 0) obs.push_back(i);
+        Vec3 h;
+        if (ctx_direct_solve(c, model, obs, &h)) return 1;
+        int n_in = 0, n_gb = 0;
+        for (int i : obs) {
+            const float e = model.error(h, i);
+            if (e < tol) {
+                inlier_flag[i] = k;
+                ++n_in;
+            } else if (e >= tol && e < garbage_tol) {
+                garbage_flag[i] = 1;
+                ++n_gb;
+            }
+        }
+        remaining -= n_in + n_gb;
+        ++k;
+    }
+    for (int i = 0; i < N; ++i) lines[i].group_id = garbage_flag[i] == 1 ? -1 : inlier_flag[i];
+    return 0;
+}
+
 // Diamond-space accumulator (opt-in; cht.h:13-24): de-normalised vanishing point of the strongest pencil.
 int ctx_cht_vanishing_point(lr_context* c, const std::vector<LineSegment>& lines, int d, Vec3* vp,
                             std::vector<uint64_t>* acc_out) {
@@ -1187,6 +1232,8 @@ static int run_frame(lr_context* c, const float* d_image, int w, int h, int stri
         if (ctx_estimate_line_pencils_prosac(c, filtered, kMaxModels, kInlierDeg, kGarbageDeg, c->prosac_T_N,
                                              c->ransac_seed))
             return 1;
+    } else if (c->estimator == 2) {
+        if (ctx_estimate_line_pencils_direct(c, filtered, kMaxModels, kInlierDeg, kGarbageDeg)) return 1;
     } else if (ctx_estimate_line_pencils(c, filtered, kMaxModels, kInlierDeg, kGarbageDeg, n_iter, c->ransac_seed)) {
         return 1;
     }

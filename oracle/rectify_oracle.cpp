@@ -1029,6 +1029,48 @@ V3 cht_peak(const std::vector<uint64_t>& acc, int d) {
 }
 
 // estimate_multiple_structures (estimator.h:99-145) driven by PROSAC instead of RANSAC
+// estimator.h:82-96 — DirectEstimator (compiled header, never instantiated: parity unpinned): the lines whose Hough
+// weight exceeds 0.95 (an empty set means all lines, line_pencil.cpp:114-117) decide the refit alone.
+V3 direct_solve(const LinePencilModel& model, const std::vector<int>& indices) {
+    std::vector<float> weights = get_weights_fixed(model, indices);
+    std::vector<int> inl;
+    for (size_t j = 0; j < indices.size(); ++j)
+        if (weights[j] > 0.95f) inl.push_back(indices[j]);
+    return model.fit_optimal(inl);
+}
+
+void estimate_line_pencils_direct(std::vector<LineSegment>& lines, int max_models, float inlier_deg, float garbage_deg) {
+    BBox bb = bounding_box(lines);
+    V2 p = bbox_center(bb);
+    V2 sz = bbox_size(bb);
+    float scale = std::max(sz.x, sz.y);
+    LinePencilModel model(normalize_lines(lines, p, scale));
+    float tol = cos_threshold(inlier_deg), garbage_tol = cos_threshold(garbage_deg);
+    int N = model.size();
+    std::vector<int> inlier_flag(N, -1), garbage_flag(N, 0);
+    int num_observations = N, k = 0;
+    while (num_observations >= 2 && k < max_models) {  // estimator.h:99-145 around the direct solver
+        std::vector<int> obs;
+        for (int i = 0; i < N; ++i)
+            if (inlier_flag[i] < 0 && garbage_flag[i] == 0) obs.push_back(i);
+        V3 h = direct_solve(model, obs);
+        int n_in = 0, n_gb = 0;
+        for (int i : obs) {
+            float e = model.error1(h, i);
+            if (e < tol) {
+                inlier_flag[i] = k;
+                ++n_in;
+            } else if (e >= tol && e < garbage_tol) {
+                garbage_flag[i] = 1;
+                ++n_gb;
+            }
+        }
+        num_observations -= n_in + n_gb;
+        ++k;
+    }
+    for (int i = 0; i < N; ++i) lines[i].group_id = garbage_flag[i] == 1 ? -1 : inlier_flag[i];
+}
+
 void estimate_line_pencils_prosac(std::vector<LineSegment>& lines, int max_models, float inlier_deg, float garbage_deg,
                                   const ProsacParams& P, uint64_t seed, std::vector<ProsacTrace>* traces = nullptr) {
     BBox bb = bounding_box(lines);
@@ -1679,6 +1721,21 @@ void orc_prosac_solve(const LineSegment* lines_norm, int n, const int32_t* indic
         trace4[2] = tr.best_iter;
         trace4[3] = tr.I_N_best;
     }
+}
+
+void orc_direct_solve(const LineSegment* lines_norm, int n, const int32_t* indices, int n_idx, float* h3) {
+    LinePencilModel model(std::vector<LineSegment>(lines_norm, lines_norm + n));
+    V3 h = direct_solve(model, std::vector<int>(indices, indices + n_idx));
+    h3[0] = h.x;
+    h3[1] = h.y;
+    h3[2] = h.z;
+}
+
+int orc_estimate_line_pencils_direct(LineSegment* lines, int n, int max_models, float inlier_deg, float garbage_deg) {
+    std::vector<LineSegment> v(lines, lines + n);
+    estimate_line_pencils_direct(v, max_models, inlier_deg, garbage_deg);
+    std::copy(v.begin(), v.end(), lines);
+    return 0;
 }
 
 int orc_estimate_line_pencils_prosac(LineSegment* lines, int n, int max_models, float inlier_deg, float garbage_deg,

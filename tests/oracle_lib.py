@@ -256,6 +256,20 @@ def estimate_line_pencils_prosac(lines, max_models=4, inlier_deg=2.0, garbage_de
     return lines
 
 
+def direct_solve(lines_norm, indices):
+    lines_norm = as_lines(lines_norm)
+    indices = np.ascontiguousarray(indices, np.int32)
+    h = np.zeros(3, np.float32)
+    lib().orc_direct_solve(_p(lines_norm), C.c_int(len(lines_norm)), _p(indices), C.c_int(len(indices)), _p(h))
+    return h
+
+
+def estimate_line_pencils_direct(lines, max_models=4, inlier_deg=2.0, garbage_deg=4.0):
+    lines = as_lines(lines).copy()
+    lib().orc_estimate_line_pencils_direct(_p(lines), C.c_int(len(lines)), C.c_int(max_models), C.c_float(inlier_deg), C.c_float(garbage_deg))
+    return lines
+
+
 def cht_vanishing_point(lines, d=128):
     lines = as_lines(lines)
     vp = np.zeros(3, np.float32)

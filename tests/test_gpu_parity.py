@@ -211,6 +211,26 @@ def test_hough_weights_and_prosac_match_oracle(L, ctx):
     np.testing.assert_array_equal(a["group_id"], b["group_id"])
 
 
+def test_direct_estimator_matches_oracle(L, ctx):
+    """DirectEstimator (estimator.h:82-96; never instantiated by the reference, so self-golden): solve on a subset, the
+    peeling around it, and the whole path with lr_set_estimator(2)."""
+    from librectify_amd import synth
+
+    for n, seed in [(120, 3), (1500, 5)]:
+        segs = synth.random_segments(n, seed)
+        norm, _, _ = O.normalize_lines(segs)
+        idx = np.arange(n, dtype=np.int32)[::2]
+        np.testing.assert_array_equal(ctx.direct_solve(norm, idx), O.direct_solve(norm, idx))
+        np.testing.assert_array_equal(ctx.estimate_line_pencils_direct(segs)["group_id"], O.estimate_line_pencils_direct(segs)["group_id"])
+    img = FRAMES["640x480"]
+    raw = O.find_line_segments(img, want_label=False)["lines"]
+    ref = O.estimate_line_pencils_direct(O.filter_lines(raw, 6.4))
+    ctx.set_estimator(2)
+    got = ctx.find_line_segment_groups(img, 6.4)
+    ctx.set_estimator(0)
+    _assert_lines_equal(got, ref)
+
+
 def test_reference_error_convention_and_strides(L, ctx):
     flat = np.full((64, 80), 0.25, np.float32)
     assert len(L.find_line_segment_groups(flat, 5.0)) == 0  # NULL, *n_lines = 0 (interface.cpp:50-54)
