@@ -96,6 +96,13 @@ int lr_device_free(lr_context* ctx, void* p);
 int lr_memcpy_h2d(lr_context* ctx, void* dst, const void* src, size_t bytes);
 /* Frames kept in flight by the batch call (one host thread + HIP stream + workspace each; default 4). */
 void lr_set_batch_streams(lr_context* ctx, int n);
+/* Test hooks for the two situations in which a frame takes a second lap (lr_stage_counters [7] tells): the capacity
+ * the NEXT frame's seed sort starts with (normally 1.5 x the previous frame's seed count; a frame with more seeds is
+ * repeated with room), and the number of flood rounds the next frame enqueues before it looks at the flood's control
+ * block (normally the previous frame's rounds + 2; a flood that needs more is completed after the frame's wait, and
+ * the stages after it run again). */
+void lr_set_seed_capacity(lr_context* ctx, uint32_t cap);
+void lr_set_flood_blind_rounds(lr_context* ctx, int rounds);
 
 /* ---- stage API (tests, bench) --------------------------------------------------------- */
 /* Stage 1: fused 5x5 derivative filter + magnitude + direction bin + dilated-bin mask +
@@ -143,7 +150,7 @@ int lr_stage_times(lr_context* ctx, float* ms, int count);
 int lr_filter_kernel_ms(lr_context* ctx, float* ms);
 /* Extra counters of the last call: [0] seeds, [1] components, [2] flood rounds, [3] labelled pixels, and how the
  * flood's walks were stored: [4] seeds that moved to the second LDS tier, [5] global slabs used, [6] seeds finished by
- * the ordered single-wave tail (storage exhausted). */
+ * the ordered single-wave tail (storage exhausted); [7] laps of the frame through the pipeline (1 normally). */
 int lr_stage_counters(lr_context* ctx, int64_t* out, int count);
 
 /* ---- RANSAC --------------------------------------------------------------------------- */

@@ -69,7 +69,7 @@ EXPORTS = [
     "lr_stage_filter_host", "lr_stage_seeds", "lr_stage_flood", "lr_stage_fit", "lr_download", "lr_stage_times",
     "lr_stage_counters", "lr_filter_kernel_ms", "lr_ransac_best", "lr_estimate_line_pencils",
     "lr_find_line_segment_groups_batch_host", "lr_find_line_segment_groups_batch_host_ptrs", "lr_host_alloc", "lr_host_free",
-    "lr_set_batch_streams", "lr_device_malloc", "lr_device_free", "lr_memcpy_h2d", "lr_cht_vanishing_point", "lr_refine_lines", "lr_set_estimator", "lr_ht_weights", "lr_prosac_solve", "lr_estimate_line_pencils_prosac", "lr_direct_solve", "lr_estimate_line_pencils_direct",
+    "lr_set_seed_capacity", "lr_set_flood_blind_rounds", "lr_set_batch_streams", "lr_device_malloc", "lr_device_free", "lr_memcpy_h2d", "lr_cht_vanishing_point", "lr_refine_lines", "lr_set_estimator", "lr_ht_weights", "lr_prosac_solve", "lr_estimate_line_pencils_prosac", "lr_direct_solve", "lr_estimate_line_pencils_direct",
 ]
 
 _lib = None
@@ -135,6 +135,10 @@ def lib():
         L.lr_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
         L.lr_set_batch_streams.argtypes = [C.c_void_p, C.c_int]
         L.lr_set_batch_streams.restype = None
+        L.lr_set_seed_capacity.argtypes = [C.c_void_p, C.c_uint32]
+        L.lr_set_seed_capacity.restype = None
+        L.lr_set_flood_blind_rounds.argtypes = [C.c_void_p, C.c_int]
+        L.lr_set_flood_blind_rounds.restype = None
         L.lr_cht_vanishing_point.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Point), C.c_void_p]
         L.lr_refine_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
         L.lr_set_estimator.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -254,10 +258,10 @@ class Context:
         return ms.value
 
     def stage_counters(self):
-        c = np.zeros(7, np.int64)
-        _check(lib().lr_stage_counters(self._h, _ptr(c), 7))
+        c = np.zeros(8, np.int64)
+        _check(lib().lr_stage_counters(self._h, _ptr(c), 8))
         return dict(seeds=int(c[0]), components=int(c[1]), flood_rounds=int(c[2]), labelled_px=int(c[3]),
-                    second_tier_seeds=int(c[4]), slabs=int(c[5]), ordered_tail_seeds=int(c[6]))
+                    second_tier_seeds=int(c[4]), slabs=int(c[5]), ordered_tail_seeds=int(c[6]), frame_laps=int(c[7]))
 
     # ---- full path ----
     def find_line_segment_groups(self, img, min_length, refine=False, num_threads=-1, capacity=None):
@@ -292,6 +296,12 @@ class Context:
 
     def device_free(self, ptr):
         _check(lib().lr_device_free(self._h, C.c_void_p(ptr)))
+
+    def set_seed_capacity(self, cap):
+        lib().lr_set_seed_capacity(self._h, int(cap))
+
+    def set_flood_blind_rounds(self, rounds):
+        lib().lr_set_flood_blind_rounds(self._h, int(rounds))
 
     def set_batch_streams(self, n):
         lib().lr_set_batch_streams(self._h, int(n))

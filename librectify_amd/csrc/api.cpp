@@ -206,6 +206,8 @@ int lr_memcpy_h2d(lr_context* ctx, void* dst, const void* src, size_t bytes) {
 }
 
 void lr_set_batch_streams(lr_context* ctx, int n) { ctx->batch_streams = n < 1 ? 1 : n; }
+void lr_set_seed_capacity(lr_context* ctx, uint32_t cap) { ctx->seed_cap_once = cap; }
+void lr_set_flood_blind_rounds(lr_context* ctx, int rounds) { ctx->flood_rounds_hint = rounds; }
 
 int lr_stage_filter(lr_context* ctx, const float* d_image, int width, int height, int stride) {
     return ctx_stage_filter(ctx, d_image, width, height, stride);
@@ -277,10 +279,10 @@ int lr_stage_times(lr_context* ctx, float* ms, int count) {
 }
 
 int lr_stage_counters(lr_context* ctx, int64_t* out, int count) {
-    const int64_t v[7] = {(int64_t)ctx->n_seeds,        (int64_t)ctx->n_comp,         (int64_t)ctx->flood_rounds,
+    const int64_t v[8] = {(int64_t)ctx->n_seeds,        (int64_t)ctx->n_comp,         (int64_t)ctx->flood_rounds,
                           (int64_t)ctx->n_px,           (int64_t)ctx->flood_tiers[0], (int64_t)ctx->flood_tiers[1],
-                          (int64_t)ctx->flood_tiers[2]};
-    for (int i = 0; i < count && i < 7; ++i) out[i] = v[i];
+                          (int64_t)ctx->flood_tiers[2], (int64_t)ctx->frame_laps};
+    for (int i = 0; i < count && i < 8; ++i) out[i] = v[i];
     return 0;
 }
 

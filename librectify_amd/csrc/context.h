@@ -69,6 +69,8 @@ struct lr_context {
     size_t temp_bytes = 0;
     uint32_t* comp_large = nullptr;  // components of more than 64 pixels (sorted by a workgroup each)
     uint32_t seed_cap = 0;           // capacity the seed sort runs with (the seed count is not known when it is enqueued)
+    uint32_t seed_cap_once = 0;      // test hook: capacity of the next frame's seed sort
+    int frame_laps = 0;              // laps the last frame took (1; 2 if the seed sort overflowed or the flood needed more rounds)
     lramd::FloodProgress flood_prog;
     // filter_lines + peeling on the device (kernels_groups.hip)
     size_t cap_glines = 0, cap_flines = 0;

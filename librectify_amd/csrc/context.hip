@@ -444,6 +444,10 @@ int enqueue_filter(lr_context* c, const float* d_image, int w, int h, int stride
     }
     if (ctx_ensure_image_capacity(c, w, h)) return 1;
     if (c->w != w || c->h != h || c->seed_cap == 0) c->seed_cap = initial_seed_cap((size_t)w * h);
+    if (c->seed_cap_once) {  // test hook (lr_set_seed_capacity): this frame starts with the given capacity
+        c->seed_cap = (uint32_t)std::min<size_t>((size_t)w * h, c->seed_cap_once);
+        c->seed_cap_once = 0;
+    }
     c->w = w;
     c->h = h;
     c->n_seeds = c->n_comp = c->n_px = 0;
@@ -502,7 +506,7 @@ int finish_flood(lr_context* c, bool* extra) {
     c->flood_big_hint = c->flood_tiers[0] > 0 || c->flood_tiers[1] > 0;
     c->flood_hold_hint = c->flood_tiers[3] != 0;
     // blind rounds of the next frame: what this one needed plus two, decaying slowly
-    c->flood_rounds_hint = std::max(c->flood_rounds + 2, c->flood_rounds_hint - 1);
+    c->flood_rounds_hint = std::max(std::max(c->flood_rounds + 2, 6), c->flood_rounds_hint - 1);
     return 0;
 }
 
@@ -1149,7 +1153,9 @@ static int run_frame(lr_context* c, const float* d_image, int w, int h, int stri
         LR_HIP(hipEventRecord(c->ev[6], c->stream));
         return enqueue_result_copy(c);
     };
+    c->frame_laps = 0;
     for (int attempt = 0;; ++attempt) {
+        c->frame_laps += 1;
         if (enqueue_filter(c, d_image, w, h, stride)) return 1;
         if (enqueue_seeds(c)) return 1;
         if (enqueue_flood(c)) return 1;
@@ -1178,6 +1184,7 @@ static int run_frame(lr_context* c, const float* d_image, int w, int h, int stri
     bool extra = false;
     if (finish_flood(c, &extra)) return 1;
     if (extra) {  // the label image changed after the fit ran: the stages after the flood again
+        c->frame_laps += 1;
         if (enqueue_fit(c)) return 1;
         if (fused) {
             if (groups_after_fit()) return 1;

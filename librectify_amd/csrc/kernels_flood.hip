@@ -1347,7 +1347,7 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
     A.win_shift = (uint32_t)win_growth;
     // rounds enqueued blindly: two more than the context's previous frame needed (a round past the end costs five
     // empty launches, a round too few costs the frame a second lap through the fit and the grouping)
-    const int batch = g_flood_debug ? 1 : std::min(std::max(B.blind_rounds, 6), 16);
+    const int batch = g_flood_debug ? 1 : std::min(std::max(B.blind_rounds, 1), 16);
     for (int r = 0; r < batch; ++r, ++P->enqueued) enqueue_round(B, F, A, P->use_big, P->enqueued, s);
     LR_HIP(hipMemcpyAsync(h_ctrl, B.ctrl, kCtrlWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     LR_HIP(hipGetLastError());

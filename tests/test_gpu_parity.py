@@ -211,6 +211,35 @@ def test_hough_weights_and_prosac_match_oracle(L, ctx):
     np.testing.assert_array_equal(a["group_id"], b["group_id"])
 
 
+def test_second_laps_of_the_one_wait_pipeline_are_exact(L, ctx):
+    """A frame is one chain of kernels with one host wait; two things make it take a second lap, both detected after
+    that wait: more seeds than the seed sort was sized for, and a flood that needs more rounds than were enqueued
+    blindly.  Both forced here (and both at once), full path against the oracle; then the next frame runs in one lap."""
+    img = FRAMES["640x480"]
+    ref, _ = O.find_line_segment_groups(img, 6.4, seed=0)
+    ctx.set_seed(0)
+    ctx.set_flood_mode(1)
+    _assert_lines_equal(ctx.find_line_segment_groups(img, 6.4), ref)
+    n_seeds = ctx.stage_counters()["seeds"]
+    rounds = ctx.stage_counters()["flood_rounds"]
+    assert n_seeds > 4096 // 4 and rounds >= 3
+    for cap, blind in [(n_seeds // 3, None), (None, 1), (n_seeds // 2, 1)]:
+        if cap:
+            ctx.set_seed_capacity(cap)
+        if blind:
+            ctx.set_flood_blind_rounds(blind)
+        _assert_lines_equal(ctx.find_line_segment_groups(img, 6.4), ref)
+        assert ctx.stage_counters()["frame_laps"] >= 2, (cap, blind, ctx.stage_counters())
+        _assert_lines_equal(ctx.find_line_segment_groups(img, 6.4), ref)
+        assert ctx.stage_counters()["frame_laps"] == 1
+    # the staged API takes the same route when the capacity is too small
+    ctx.set_seed_capacity(n_seeds // 3)
+    ctx.stage_filter_host(img)
+    assert ctx.stage_seeds() == n_seeds
+    ctx.stage_flood()
+    np.testing.assert_array_equal(ctx.download(L.BUF_LABEL), O.find_line_segments(img)["label"])
+
+
 def test_direct_estimator_matches_oracle(L, ctx):
     """DirectEstimator (estimator.h:82-96; never instantiated by the reference, so self-golden): solve on a subset, the
     peeling around it, and the whole path with lr_set_estimator(2)."""

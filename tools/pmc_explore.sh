@@ -11,7 +11,7 @@ import csv,glob,collections
 f=glob.glob("/tmp/pmcx_$i/*/*counter_collection.csv")[0]
 acc=collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-    if "flood_explore" in r["Kernel_Name"]: acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if "flood_explore_kernel" in r["Kernel_Name"]: acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,v in acc.items(): print("%-22s" % k, " ".join("%13.0f" % x for x in v[-6:]))
 PY
 done
