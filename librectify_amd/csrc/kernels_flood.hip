@@ -874,6 +874,15 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
 // that other frames' kernels wait for; a smaller first storage tier (64-record ring, 128-tile table, 4.9 KB) for more
 // walks in flight, handing longer walks to a second kernel -- the tiers' kernels run one after the other, so every
 // round lasts as long as the longest walk of EACH tier: 1.43 -> 2.0 ms per flood.)
+//
+// Nine walks in ten belong to seeds that do not commit in their round (round one of the 4K test frame: 532 000 of
+// 563 000 tile steps; LIBRECTIFY_FLOOD_DEBUG prints the split), and a blocked seed walks again every round.  "Parking"
+// them was built and measured: a finished walk leaves its footprint as a (tile, mask) list, a blocked seed only
+// re-stamps that list in later rounds (no dependent chain), and one that comes out unblocked on the list -- a superset
+// of its present footprint -- commits by a walk of its own after the commit pass.  Exact (all tests passed), but the
+// stale supersets block far more than footprints do, and seeds blocked by each other's stale stamps resolve one per
+// round: 39-55 rounds instead of 6-9; with lists dropped as soon as one of their pixels is committed elsewhere, 9-15
+// rounds and 2.3-3.4 ms instead of 1.5-2.6.  Not in the tree.
 template <bool kRest>
 __device__ __forceinline__ void explore_body(const FloodArgs& A, const BinTrig& trig, const uint32_t* __restrict__ act,
                                              uint32_t* __restrict__ big_list, uint32_t first) {
@@ -1201,6 +1210,24 @@ static void flood_debug_round(const FloodBuffers& B, uint32_t n_seeds, const uin
             mxs = st_;
             mxk = kk;
         }
+    }
+    {  // how much of the walking belongs to seeds that commit in this round
+        std::vector<uint8_t> stt(n_seeds);
+        (void)hipMemcpy(stt.data(), B.state, n_seeds, hipMemcpyDeviceToHost);
+        unsigned long long steps_commit = 0, steps_other = 0;
+        uint32_t longest_commit = 0, longest_other = 0;
+        for (uint32_t i = 0; i < n_act; ++i) {
+            const uint32_t kk = actv[i], st_ = flg[kk] >> 8;
+            if (stt[kk] == 1) {
+                steps_commit += st_;
+                longest_commit = std::max(longest_commit, st_);
+            } else {
+                steps_other += st_;
+                longest_other = std::max(longest_other, st_);
+            }
+        }
+        std::fprintf(stderr, "  committing seeds: %llu steps, longest %u; blocked or dying seeds: %llu steps, longest %u\n",
+                     steps_commit, longest_commit, steps_other, longest_other);
     }
     {  // walk-length histogram (steps) and where in the seed order the long walks sit
         const uint32_t edges[8] = {8, 16, 32, 48, 64, 128, 192, 0xFFFFFFFFu};

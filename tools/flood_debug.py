@@ -8,6 +8,8 @@ from librectify_amd import synth
 which = sys.argv[1] if len(sys.argv) > 1 else "bench"
 if which == "bench":
     img = synth.frame(3840, 2160, 1)
+elif which.startswith("seed"):
+    img = synth.frame(3840, 2160, int(which[4:]))
 elif which == "1080":
     img = synth.frame(1920, 1080, 1000)
 elif which == "doc":
