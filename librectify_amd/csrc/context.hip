@@ -851,12 +851,17 @@ int ctx_ht_weights(lr_context* c, const PencilModel& model, const std::vector<in
 // then cut at that iteration and the rest regenerated, so the outcome equals the sequential run.
 int ctx_prosac_solve(lr_context* c, const PencilModel& model, const std::vector<int>& indices, float tol, int T_N_in,
                      uint64_t seed, uint32_t round, Vec3* h_out, ProsacTrace* trace) {
+    static const bool pdebug = std::getenv("LIBRECTIFY_PROSAC_DEBUG") != nullptr;
+    double t_w = now_ms(), t_events = 0, t_gen = 0, t_gpu = 0;
+    int n_events = 0, n_chunks = 0;
     std::vector<float> weights;
     if (ctx_ht_weights(c, model, indices, weights)) return 1;
+    const double t_w1 = now_ms();
     const int N = (int)indices.size();
     std::vector<int> order(N);
     for (int i = 0; i < N; ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return weights[a] > weights[b]; });  // utils.h:36-44
+    const double t_s1 = now_ms();
     std::vector<int> idx(N);
     for (int i = 0; i < N; ++i) idx[i] = indices[order[i]];
     const int m = 2;
@@ -880,25 +885,33 @@ int ctx_prosac_solve(lr_context* c, const PencilModel& model, const std::vector<
     std::vector<uint8_t> best_inl(N, 0), isInlier(N);
     PencilSoA soa;
     if (N >= 2 && upload_model(c, model, idx, &soa)) return 1;
-    size_t chunk = 256;
+    // sample of iteration s.t from the growth state (prosac.h:170-190)
+    auto sample_of = [&](const Growth& s, uint32_t& sa, uint32_t& sb) {
+        if (s.t > s.T_n_prime) {
+            sample_pair(seed, round, (uint32_t)s.t, (uint32_t)s.n, sa, sb);
+        } else {
+            sa = sample_one(seed, round, (uint32_t)s.t, (uint32_t)(s.n - 1));
+            sb = (uint32_t)(s.n - 1);  // prosac.h:186 writes n (one past U_n); n-1 is meant
+        }
+    };
+    size_t chunk = 1024;
     while (N >= 2 && ((I_N_best < I_N_min) || g.t <= k_n_star) && g.t < T_N) {
         // speculative chunk under "no new best": growth and loop condition then depend on nothing else
         if (ensure_prosac_buffers(c, (size_t)N, 1, chunk)) return 1;
+        const double tg0 = now_ms();
+        ++n_chunks;
         Growth s = g;
         size_t cnt = 0;
         while (cnt < chunk && ((I_N_best < I_N_min) || s.t <= k_n_star) && s.t < T_N) {
             s.advance(n_star, m);
             uint32_t sa, sb;
-            if (s.t > s.T_n_prime) {
-                sample_pair(seed, round, (uint32_t)s.t, (uint32_t)s.n, sa, sb);
-            } else {
-                sa = sample_one(seed, round, (uint32_t)s.t, (uint32_t)(s.n - 1));
-                sb = (uint32_t)(s.n - 1);  // prosac.h:186 writes n (one past U_n); n-1 is meant
-            }
+            sample_of(s, sa, sb);
             c->h_samples[cnt] = sa;
             c->h_samples[chunk + cnt] = sb;
             ++cnt;
         }
+        const double tg1 = now_ms();
+        t_gen += tg1 - tg0;
         LR_HIP(hipMemcpyAsync(c->d_samples, c->h_samples, cnt * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         LR_HIP(hipMemcpyAsync(c->d_samples + chunk, c->h_samples + chunk, cnt * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         if (launch_prosac_count(soa, (uint32_t)N, tol, model.degeneracy_tol, c->d_samples, c->d_samples + chunk,
@@ -906,9 +919,19 @@ int ctx_prosac_solve(lr_context* c, const PencilModel& model, const std::vector<
             return 1;
         LR_HIP(hipMemcpyAsync(c->h_hcounts, c->d_hcounts, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         LR_HIP(hipStreamSynchronize(c->stream));
-        bool event = false;
+        const double tg2 = now_ms();
+        t_gpu += tg2 - tg1;
+        // The chunk was generated under the state at its start.  A new best hypothesis changes n_star and k_n_star;
+        // what follows it in the chunk is still the sequential algorithm's as long as the loop would go on and would
+        // draw the same sample: checked iteration by iteration, and the chunk is cut where that stops being true.
         for (size_t j = 0; j < cnt; ++j) {
-            g.advance(n_star, m);
+            if (!(((I_N_best < I_N_min) || g.t <= k_n_star) && g.t < T_N)) break;
+            Growth gn = g;
+            gn.advance(n_star, m);
+            uint32_t ea, eb;
+            sample_of(gn, ea, eb);
+            if (ea != c->h_samples[j] || eb != c->h_samples[chunk + j]) break;
+            g = gn;
             const uint32_t I = c->h_hcounts[j];
             if (I == 0xFFFFFFFFu) continue;  // degenerate sample
             if ((int)I > I_N_best) {
@@ -941,12 +964,15 @@ int ctx_prosac_solve(lr_context* c, const PencilModel& model, const std::vector<
                     I_n_star = I_n_best;
                     k_n_star = niter_ransac(1. - eta, 1. - I_n_star / (double)n_star, m, T_N);
                 }
-                event = true;  // the rest of the chunk was generated under the old n_star / k_n_star
-                break;
+                ++n_events;
             }
         }
-        chunk = event ? std::max<size_t>(256, chunk / 2) : std::min<size_t>(chunk * 4, 1u << 16);
+        t_events += now_ms() - tg2;
+        chunk = std::min<size_t>(chunk * 4, 1u << 16);
     }
+    if (pdebug)
+        std::fprintf(stderr, "prosac round %u: N %d, weights %.2f ms, sort %.2f, chunks %d (generate %.2f, gpu+sync %.2f, scan+events %.2f; %d events), total %.2f ms\n",
+                     round, N, t_w1 - t_w, t_s1 - t_w1, n_chunks, t_gen, t_gpu, t_events, n_events, now_ms() - t_w);
     if (trace) {
         trace->iterations = g.t;
         trace->n_star = n_star;
