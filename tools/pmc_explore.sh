@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/pmc_explore.sh   (run on the GPU box via gpurun) -- instruction mix of the flood exploration kernel,
-# per dispatch (six rounds per frame, three frames in tools/run4k.py)
+# per dispatch (the first seven rounds of the last of the three frames of tools/run4k.py)
 export TMPDIR=/tmp
 i=0
 for c in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM"; do
@@ -12,6 +12,8 @@ f=glob.glob("/tmp/pmcx_$i/*/*counter_collection.csv")[0]
 acc=collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     if "flood_explore_kernel" in r["Kernel_Name"]: acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k,v in acc.items(): print("%-22s" % k, " ".join("%13.0f" % x for x in v[-6:]))
+for k,v in acc.items():
+    per = len(v) // 3  # three frames in tools/run4k.py: the last frame's rounds (the ones past the end of the flood are empty launches)
+    print("%-22s" % k, " ".join("%13.0f" % x for x in v[-per:][:7]))
 PY
 done
