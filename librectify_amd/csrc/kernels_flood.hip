@@ -942,42 +942,29 @@ __global__ __launch_bounds__(64) void flood_explore_big_kernel(FloodArgs A, BinT
     explore_seed<LdsStoreBig, false>(A, trig, k, L, P, big_list, lane);
 }
 
-// state: 0 = active, 1 = committed in this round, 2 = finished earlier / dead
-__global__ __launch_bounds__(256) void flood_decide_kernel(FloodArgs A, const uint32_t* __restrict__ act,
-                                                           uint8_t* __restrict__ state, int32_t* __restrict__ seed_size) {
-    const uint32_t n_act = A.ctrl[kCtrlNAct];
-    const uint32_t barrier = A.ctrl[kCtrlBarrier];
-    for (uint32_t ai = blockIdx.x * 256 + threadIdx.x; ai < n_act; ai += gridDim.x * 256) {
-        const uint32_t k = act[ai];
-        const uint32_t fl = A.flags[k];
-        if (fl & kFlagSelfFail) {
-            state[k] = 2;
-            seed_size[k] = 0;
-            continue;
-        }
-        const bool walked = A.count[k] > 0u;
-        if (walked && A.blocked[k] == 0u && !(fl & kFlagIncomplete) && k < barrier) {
-            state[k] = 1;
-            seed_size[k] = (int32_t)A.count[k];
-            atomicAdd(&A.ctrl[kCtrlNCommit], 1u);
-        }
-    }
+// Does seed k commit in this round?  Its walk finished (count > 0, not incomplete), no lower active seed reaches its
+// footprint (not blocked), and it lies below the lowest seed whose walk ran out of storage (barrier).  Everything this
+// reads is final once the round's exploration kernels are done, so the commit pass and the survivors pass each
+// evaluate it where they need it (a separate "decide" launch per round used to).
+__device__ __forceinline__ bool seed_commits(const FloodArgs& A, uint32_t k, uint32_t barrier) {
+    const uint32_t fl = A.flags[k];
+    return A.count[k] > 0u && A.blocked[k] == 0u && !(fl & (kFlagIncomplete | kFlagSelfFail)) && k < barrier;
 }
 
 // Stamps of committed seeds become labels, all other stamps are erased.  A committed pixel also loses its direction
 // mask: the walks then reject it on the mask alone and never load the label image (a quarter of their gathers).
-__global__ __launch_bounds__(256) void flood_commit_pixels_kernel(uint32_t* __restrict__ label, size_t npix,
-                                                                  const uint8_t* __restrict__ state,
-                                                                  const uint32_t* __restrict__ ctrl,
+__global__ __launch_bounds__(256) void flood_commit_pixels_kernel(FloodArgs A, uint32_t* __restrict__ label, size_t npix,
                                                                   uint8_t* __restrict__ dmask) {
+    const uint32_t* __restrict__ ctrl = A.ctrl;
     if (ctrl[kCtrlNAct] == 0u) return;  // a round enqueued past the end
+    const uint32_t barrier = ctrl[kCtrlBarrier];
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t step = (size_t)gridDim.x * 256;
     for (; i < npix; i += step) {
         const uint32_t v = label[i];
         if (v >= kMarkBit && v != kLabelFree) {
             const uint32_t k = v & ~kMarkBit;
-            const bool committed = state[k] == 1;
+            const bool committed = seed_commits(A, k, barrier);
             label[i] = committed ? k : kLabelFree;
             if (committed) dmask[i] = 0;
         }
@@ -1041,13 +1028,19 @@ __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, const
     const uint32_t n_act = A.ctrl[kCtrlNAct];
     const uint32_t n_pad = (n_act + 255u) & ~255u;  // whole wavefronts take part in the ballots
     const uint32_t window = A.ctrl[kCtrlWindow];
+    const uint32_t barrier = A.ctrl[kCtrlBarrier];
     for (uint32_t ai = blockIdx.x * 256 + threadIdx.x; ai < n_pad; ai += gridDim.x * 256) {
-        bool a = false;
+        bool a = false, done = false;
         uint32_t k = 0;
         if (ai < n_act) {
             k = act[ai];
-            if (state[k] == 1) {
+            if (A.flags[k] & kFlagSelfFail) {  // flood() accepted nothing, not even the seed
                 state[k] = 2;
+                seed_size[k] = 0;
+            } else if (seed_commits(A, k, barrier)) {  // the commit pass has turned its stamps into labels
+                state[k] = 2;
+                seed_size[k] = (int32_t)A.count[k];
+                done = true;
             } else if (state[k] == 0) {
                 if (A.label[A.seed_idx[k]] < kMarkBit) {  // its pixel now belongs to a committed flood: skipped forever
                     state[k] = 2;
@@ -1060,6 +1053,8 @@ __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, const
                 }
             }
         }
+        const uint64_t md = __ballot(done);
+        if (md != 0ull && (threadIdx.x & 63) == __ffsll((long long)md) - 1) atomicAdd(&A.ctrl[kCtrlNCommit], (uint32_t)__popcll(md));
         // next round's active list: one atomic per wavefront; the order of the list does not matter
         const uint64_t m = __ballot(a);
         if (m) {
@@ -1212,22 +1207,21 @@ static void flood_debug_round(const FloodBuffers& B, uint32_t n_seeds, const uin
         }
     }
     {  // how much of the walking belongs to seeds that commit in this round
-        std::vector<uint8_t> stt(n_seeds);
-        (void)hipMemcpy(stt.data(), B.state, n_seeds, hipMemcpyDeviceToHost);
         unsigned long long steps_commit = 0, steps_other = 0;
-        uint32_t longest_commit = 0, longest_other = 0;
+        uint32_t longest_commit = 0, longest_other = 0, n_commit = 0;
         for (uint32_t i = 0; i < n_act; ++i) {
             const uint32_t kk = actv[i], st_ = flg[kk] >> 8;
-            if (stt[kk] == 1) {
+            if (cnt[kk] > 0 && blk[kk] == 0 && !(flg[kk] & (kFlagIncomplete | kFlagSelfFail)) && kk < ctrl[kCtrlBarrier]) {
                 steps_commit += st_;
+                n_commit += 1;
                 longest_commit = std::max(longest_commit, st_);
             } else {
                 steps_other += st_;
                 longest_other = std::max(longest_other, st_);
             }
         }
-        std::fprintf(stderr, "  committing seeds: %llu steps, longest %u; blocked or dying seeds: %llu steps, longest %u\n",
-                     steps_commit, longest_commit, steps_other, longest_other);
+        std::fprintf(stderr, "  %u committing seeds: %llu steps, longest %u; blocked or dying seeds: %llu steps, longest %u\n",
+                     n_commit, steps_commit, longest_commit, steps_other, longest_other);
     }
     {  // walk-length histogram (steps) and where in the seed order the long walks sit
         const uint32_t edges[8] = {8, 16, 32, 48, 64, 128, 192, 0xFFFFFFFFu};
@@ -1249,8 +1243,8 @@ static void flood_debug_round(const FloodBuffers& B, uint32_t n_seeds, const uin
     }
     std::fprintf(stderr,
                  "flood round %u: active %u, %llu px walked in %llu steps, longest walk %u steps (%u px, seed %u), "
-                 "blocked %u, committed %u, barrier %u, slabs %u\n",
-                 ctrl[kCtrlRounds] + 1, n_act, tpx, tsteps, mxs, cnt[mxk], mxk, nb, ctrl[kCtrlNCommit], ctrl[kCtrlBarrier],
+                 "blocked %u, barrier %u, slabs %u\n",
+                 ctrl[kCtrlRounds] + 1, n_act, tpx, tsteps, mxs, cnt[mxk], mxk, nb, ctrl[kCtrlBarrier],
                  ctrl[kCtrlSlabs]);
 }
 
@@ -1313,7 +1307,6 @@ void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& 
         hipLaunchKernelGGL(flood_explore_big_kernel, dim3(std::min<uint32_t>(F.seed_cap, kBigCap)), dim3(64), kBigLdsBytes, s,
                            A, F.trig, B.big_list);
     if (g_flood_debug) (void)hipEventRecord(dbg1, s);
-    hipLaunchKernelGGL(flood_decide_kernel, dim3(seed_blocks), dim3(256), 0, s, A, act, B.state, F.seed_size);
     if (g_flood_debug) {
         uint32_t n = 0;
         (void)hipStreamSynchronize(s);
@@ -1325,7 +1318,7 @@ void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& 
         (void)hipEventDestroy(dbg0);
         (void)hipEventDestroy(dbg1);
     }
-    hipLaunchKernelGGL(flood_commit_pixels_kernel, dim3(pix_blocks), dim3(256), 0, s, F.label, npix, B.state, B.ctrl,
+    hipLaunchKernelGGL(flood_commit_pixels_kernel, dim3(pix_blocks), dim3(256), 0, s, A, F.label, npix,
                        const_cast<uint8_t*>(F.dmask));
     hipLaunchKernelGGL(flood_survivors_kernel, dim3(seed_blocks), dim3(256), 0, s, A, act, B.state, F.seed_size, act_next);
 }
