@@ -153,7 +153,8 @@ def main():
     ap.add_argument("--config", choices=["frames4k", "batch1080"], default="frames4k",
                     help="frames4k: BASELINE configs[2], --frames 4K frames per rank per step (weak scaling); "
                          "batch1080: configs[3], 512 frames 1920x1080 sharded over the ranks (strong scaling)")
-    ap.add_argument("--frames", type=int, default=32, help="frames4k: distinct frames per rank per step")
+    ap.add_argument("--frames", type=int, default=64, help="frames4k: frames (distinct buffers) per rank per step, i.e. per batch call: the call's "
+                    "fill and drain (first uploads, last frames on fewer lanes) are inside the timed region")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--host-memory", choices=["pageable", "pinned"], default="pageable",

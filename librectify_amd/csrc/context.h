@@ -1,5 +1,6 @@
 // lr_context: one device, one stream, one reusable workspace (see include/librectify_amd.h).
 #pragma once
+#include <atomic>
 #include <functional>
 #include <mutex>
 #include <vector>
@@ -183,6 +184,8 @@ int ctx_find_groups_batch_host(lr_context* c, const float* const* frames, int ba
 // Enqueues the upload of a host frame into device slot `slot` on the copy stream and records ev_up[slot];
 // the caller makes its compute stream wait on that event.  num_threads: the reference's knob (threading.h:24-27),
 // here the number of host threads that stage a pageable frame (< 0: serial, as there).
-int ctx_upload_frame(lr_context* c, int slot, const float* buffer, int w, int h, int stride, int num_threads);
+// turn / my_turn (optional): the transfer is enqueued only when *turn has reached my_turn, and *turn is advanced after
+int ctx_upload_frame(lr_context* c, int slot, const float* buffer, int w, int h, int stride, int num_threads,
+                     std::atomic<int>* turn = nullptr, int my_turn = 0);
 void ctx_run_prefetch(lr_context* c);
 }  // namespace lramd

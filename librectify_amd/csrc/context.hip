@@ -169,7 +169,8 @@ int staging_threads(int num_threads) {
 
 }  // namespace
 
-int ctx_upload_frame(lr_context* c, int slot, const float* buffer, int w, int h, int stride, int num_threads) {
+int ctx_upload_frame(lr_context* c, int slot, const float* buffer, int w, int h, int stride, int num_threads,
+                     std::atomic<int>* turn, int my_turn) {
     LR_HIP(hipSetDevice(c->device));
     if (w < 1 || h < 1 || buffer == nullptr) {
         set_error("upload: bad frame");
@@ -199,7 +200,22 @@ int ctx_upload_frame(lr_context* c, int slot, const float* buffer, int w, int h,
     }
     float* dst = c->d_img_slot[slot];
     const size_t row_bytes = (size_t)w * sizeof(float);
+    // a batch's first frames take the link in lane order (staging is not ordered, only the transfers)
+    auto wait_turn = [&]() {
+        if (turn)
+            while (turn->load(std::memory_order_acquire) < my_turn) std::this_thread::yield();
+    };
+    struct TurnDone {
+        std::atomic<int>* t;
+        int v;
+        ~TurnDone() {  // on every way out, and never out of order (a lane that failed early still waits for its turn)
+            if (!t) return;
+            while (t->load(std::memory_order_acquire) < v - 1) std::this_thread::yield();
+            t->store(v, std::memory_order_release);
+        }
+    } turn_done{turn, my_turn + 1};
     if (is_page_locked(buffer)) {
+        wait_turn();
         std::unique_lock<std::mutex> lock(owner->upload_mu, std::defer_lock);
         if (ordered) lock.lock();
         LR_HIP(hipMemcpy2DAsync(dst, row_bytes, buffer, (size_t)stride * sizeof(float), row_bytes, (size_t)h,
@@ -250,6 +266,7 @@ int ctx_upload_frame(lr_context* c, int slot, const float* buffer, int w, int h,
             set_error("upload: staging copy failed");
             return 1;
         }
+    wait_turn();
     std::unique_lock<std::mutex> lock(owner->upload_mu, std::defer_lock);
     if (ordered) {
         lock.lock();
@@ -1327,13 +1344,7 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
             err[si] = get_error();
             l->prefetch = nullptr;
         };
-        if (h_frames) {
-            // (staging is not ordered, only the transfers: wait for the turn inside would serialise the staging too)
-            while (first_turn.load(std::memory_order_acquire) < si) std::this_thread::yield();
-            const int urc = ctx_upload_frame(l, 0, h_frames[si], w, h, stride, std::max(lane_threads, num_threads > 1 ? num_threads / 2 : 1));
-            first_turn.store(si + 1, std::memory_order_release);
-            if (urc) return fail();
-        }
+        if (h_frames && ctx_upload_frame(l, 0, h_frames[si], w, h, stride, lane_threads, &first_turn, si)) return fail();
         int j = 0;
         // frames are handed out dynamically (a lane reserves its next frame when it starts on the current one, so that
         // it can upload it meanwhile): frames differ in cost, and with a fixed assignment the batch ends on one lane
