@@ -397,6 +397,42 @@ def test_host_batch_entry_point_pageable_pinned_and_strided(L, ctx):
         ctx.find_line_segment_groups_batch_host(np.zeros((3, 4, 40), np.float32), 2.0)  # below the 5x5 filter: loud
 
 
+def test_batch_lanes_with_refine_and_with_prosac_and_concurrent_callers(L, ctx):
+    """The paths that leave the one-wait pipeline after the line fit (refine = true; the opt-in PROSAC estimator) inside
+    batch lanes with prefetching uploads, and the reference's re-entrancy: four host threads calling the drop-in
+    find_line_segment_groups at once (a context per thread) -- all against the oracle."""
+    import threading
+
+    from librectify_amd import synth
+
+    w, h = 400, 300
+    frames = np.stack([synth.frame(w, h, 90 + i, bars=22) for i in range(8)])
+    ctx.set_seed(0)
+    ctx.set_batch_streams(3)
+    refs = [O.find_line_segment_groups(f, 4.0, refine=True, seed=0)[0] for f in frames]
+    out, n, _ = ctx.find_line_segment_groups_batch_host(frames, 4.0, refine=True, capacity=1024)
+    for i in range(len(frames)):
+        _assert_lines_equal(out[i][: n[i]], refs[i])
+    ctx.set_estimator(1, 500)
+    out, n, _ = ctx.find_line_segment_groups_batch_host(frames, 4.0, capacity=1024)
+    ctx.set_estimator(0)
+    for i, f in enumerate(frames):
+        raw = O.find_line_segments(f, want_label=False)["lines"]
+        _assert_lines_equal(out[i][: n[i]], O.estimate_line_pencils_prosac(O.filter_lines(raw, 4.0), T_N=500, seed=0))
+    plain = [O.find_line_segment_groups(f, 4.0, seed=0)[0] for f in frames]
+    got = [None] * len(frames)
+
+    def call(i):
+        got[i] = L.find_line_segment_groups(frames[i], 4.0)  # thread-local context, LIBRECTIFY_SEED default 0
+
+    for rep in range(2):
+        ts = [threading.Thread(target=call, args=(i,)) for i in range(rep * 4, rep * 4 + 4)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+    for i in range(len(frames)):
+        _assert_lines_equal(got[i], plain[i])
+
+
 def test_second_flood_on_a_consumed_filter_output_is_refused(L, ctx):
     """The parallel flood clears the direction mask of the pixels it labels: flooding the same filter output again
     (e.g. after lr_set_flood_mode) must fail loudly instead of returning labels of a mutated mask."""
