@@ -149,7 +149,10 @@ constexpr uint32_t kMarkBit = 0x80000000u;
 // Per-wave LDS storage of a walk, two tiers: every seed starts with a 128-record frontier ring and a 256-tile table
 // (9.5 KB: 16 walks per CU); the few walks that outgrow it (edges over ~1500 px) start again in a workgroup with a
 // 1024-record ring and a 2048-tile table (72 KB: 2 per CU) before the global slabs are the last resort.
-constexpr int kRingT = 128, kHashT = 256;
+#ifndef LR_RING_T
+#define LR_RING_T 128
+#endif
+constexpr int kRingT = LR_RING_T, kHashT = 256;
 constexpr int kRingBig = 1024, kHashBig = 2048;
 constexpr uint32_t kBigCap = 8192;  // seeds per round that can move to the second tier (FloodBuffers::big_list)
 constexpr uint32_t kFlagIncomplete = 1u, kFlagSelfFail = 2u;
@@ -1282,7 +1285,7 @@ FloodArgs flood_args(const FloodBuffers& B, const FloodFrame& F, bool use_big) {
 
 const bool g_flood_debug = std::getenv("LIBRECTIFY_FLOOD_DEBUG") != nullptr;
 
-// one round: explore (both LDS tiers), decide, commit, survivors
+// one round: explore (main launch, the entries past its grid, second LDS tier), commit pass, survivors pass
 void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& A, bool use_big, int index, hipStream_t s) {
     uint32_t* lists[2] = {B.act_a, B.act_b};
     uint32_t* act = lists[index & 1];
