@@ -240,6 +240,23 @@ def test_second_laps_of_the_one_wait_pipeline_are_exact(L, ctx):
     np.testing.assert_array_equal(ctx.download(L.BUF_LABEL), O.find_line_segments(img)["label"])
 
 
+def test_grouping_of_the_reference_golden_lines_on_the_gpu(L, ctx):
+    """Pin 4 through the C ABI: the device peeling (kernels_groups.hip) on the reference's own 848 golden lines gives
+    the oracle's group ids bit for bit, i.e. the reference's three pencils (tests/test_oracle_pins.py::test_pin4_*)."""
+    rows = np.loadtxt(os.path.join(G, "doc_warp_lines.csv"), delimiter=",")
+    lines = O.lines_from_rows(rows)
+    gold = lines["group_id"].copy()
+    blank = lines.copy()
+    blank["group_id"] = -1
+    for seed in (0, 7):
+        ref, _ = O.estimate_line_pencils(blank, seed=seed)
+        got = ctx.estimate_line_pencils(blank, seed=seed)
+        np.testing.assert_array_equal(got["group_id"], ref["group_id"])
+        for g in (0, 1, 2):
+            idx = np.nonzero(gold == g)[0]
+            assert (got["group_id"][idx] == g).sum() >= 0.94 * len(idx)
+
+
 def test_direct_estimator_matches_oracle(L, ctx):
     """DirectEstimator (estimator.h:82-96; never instantiated by the reference, so self-golden): solve on a subset, the
     peeling around it, and the whole path with lr_set_estimator(2)."""

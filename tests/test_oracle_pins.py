@@ -58,6 +58,40 @@ def test_pin2_detector_structural_kat():
     assert hits >= 700, hits
 
 
+def _grouping_agreement(gold_ids, new_ids):
+    """per golden group: (label most of its lines got, how many got it, size)"""
+    import collections
+
+    out = {}
+    for g in (0, 1, 2):
+        idx = np.nonzero(gold_ids == g)[0]
+        lab, cnt = collections.Counter(new_ids[idx].tolist()).most_common(1)[0]
+        out[g] = (lab, cnt, len(idx))
+    return out
+
+
+def test_pin4_grouping_structural_kat():
+    """The 848 golden rows carry the group ids the reference's RANSAC peeling gave them (380 / 192 / 80 / 5 lines,
+    191 ungrouped).  Grouping the same lines again (estimate_line_pencils, line_pencil.cpp:148-177; the reference seeds
+    from random_device, so only the structure can be pinned) must find the same three pencils in the same order:
+    >= 94 % of each golden group under one label (363 of 380, 182 of 192, 80 of 80), label k for group k, and vanishing points within 1 % of the golden
+    groups' (group 2 coincides exactly: 80 of 80 lines).  Any RANSAC seed."""
+    rows = _golden_lines()
+    lines = O.lines_from_rows(rows)
+    gold = lines["group_id"].copy()
+    _, gold_vps = O.fit_vanishing_points(lines)
+    for seed in (0, 1, 7):
+        blank = lines.copy()
+        blank["group_id"] = -1
+        got, _ = O.estimate_line_pencils(blank, seed=seed)
+        agree = _grouping_agreement(gold, got["group_id"])
+        for g, (lab, cnt, size) in agree.items():
+            assert lab == g and cnt >= 0.94 * size, (seed, agree)
+        _, vps = O.fit_vanishing_points(got)
+        for g in (0, 1, 2):
+            np.testing.assert_allclose(vps[g][:2], gold_vps[g][:2], rtol=0.01, atol=2.0)
+
+
 def test_pin3_analytic_kats():
     """src/test.cpp:19-39 inputs; answers derived in SURVEY.md §4."""
     rows = np.array(
