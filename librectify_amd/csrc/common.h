@@ -238,6 +238,7 @@ int launch_cht_accumulate(PencilSoA m, uint32_t n, int d, unsigned long long* ac
 int launch_refine_pairs(const void* seg, uint32_t n, void* edges, uint32_t* n_edges, uint32_t cap, hipStream_t s);
 int launch_prosac_count(PencilSoA m, uint32_t n, float tol, float degeneracy_tol, const uint32_t* sa,
                         const uint32_t* sb, uint32_t n_hyp, uint32_t* counts, hipStream_t s);
+int launch_prosac_flags(PencilSoA m, uint32_t n, float px, float py, float pz, float tol, uint8_t* flags, hipStream_t s);
 int launch_ht_weights(PencilSoA m, uint32_t n, const int32_t* pa, const int32_t* pb, int n_pairs, int ht, float* peak,
                       float* weights, hipStream_t s);
 

@@ -955,9 +955,17 @@ int ctx_prosac_solve(lr_context* c, const PencilModel& model, const std::vector<
                 const int ia = idx[c->h_samples[j]], ib = idx[c->h_samples[chunk + j]];
                 const Vec3 p_t = model.fit(ia, ib);
                 int I_N = 0;
-                for (int i = 0; i < N; ++i) {
-                    isInlier[i] = model.error(p_t, idx[i]) < tol;
-                    I_N += isInlier[i];
+                if (N >= 4096) {  // the inliers of the new best, line by line: on the GPU for large tables
+                    if (launch_prosac_flags(soa, (uint32_t)N, p_t.x, p_t.y, p_t.z, tol, reinterpret_cast<uint8_t*>(c->d_weights), c->stream))  // (the weights buffer is free by now)
+                        return 1;
+                    LR_HIP(hipMemcpyAsync(isInlier.data(), c->d_weights, (size_t)N, hipMemcpyDeviceToHost, c->stream));
+                    LR_HIP(hipStreamSynchronize(c->stream));
+                    for (int i = 0; i < N; ++i) I_N += isInlier[i];
+                } else {
+                    for (int i = 0; i < N; ++i) {
+                        isInlier[i] = model.error(p_t, idx[i]) < tol;
+                        I_N += isInlier[i];
+                    }
                 }
                 I_N_best = I_N;
                 p_best = p_t;

@@ -211,6 +211,23 @@ __global__ __launch_bounds__(256) void prosac_count_kernel(PencilSoA m, uint32_t
     }
 }
 
+// Inlier flags of ONE hypothesis over the whole table (prosac.h:212-222: when a sample is a new best, its inliers are
+// needed line by line for the maximality test): canonical test, one line per thread.
+__global__ __launch_bounds__(256) void prosac_flags_kernel(PencilSoA m, uint32_t n, float px, float py, float pz, float tol,
+                                                           uint8_t* __restrict__ flags) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float vx, vy;
+    if (fabsf(pz) < kEps) {
+        vx = px;
+        vy = py;
+    } else {
+        vx = px / pz - m.ax[i];
+        vy = py / pz - m.ay[i];
+    }
+    flags[i] = inlier_exact(vx, vy, m.dx[i], m.dy[i], tol) ? 1 : 0;
+}
+
 // Hough votes of get_weights on the unit hemisphere: ht x ht accumulator in LDS, 64-bit integer atomics
 // (votes in 2^-20 fixed point, so the result does not depend on arrival order), then the first maximum
 // in column-major order.  Single workgroup: 20 000 votes are nothing.
@@ -442,6 +459,13 @@ int launch_prosac_count(PencilSoA m, uint32_t n, float tol, float degeneracy_tol
         hipLaunchKernelGGL(prosac_count_kernel<2>, dim3((n_hyp + 7) / 8), dim3(256), 0, s, m, n, tol, degeneracy_tol, sa, sb,
                            n_hyp, counts);
     }
+    LR_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_prosac_flags(PencilSoA m, uint32_t n, float px, float py, float pz, float tol, uint8_t* flags, hipStream_t s) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(prosac_flags_kernel, dim3((n + 255) / 256), dim3(256), 0, s, m, n, px, py, pz, tol, flags);
     LR_HIP(hipGetLastError());
     return 0;
 }
