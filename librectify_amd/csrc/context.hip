@@ -1332,7 +1332,7 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
         l->ransac_seed = c->ransac_seed;
         l->ransac_iters = c->ransac_iters;
         l->flood_mode = c->flood_mode;
-        l->flood_staged = S > 1;
+        l->flood_staged = false;  // (staged start of the rounds on batch lanes: +6 % in round 1, -3 % now: see DESIGN.md §7)
         l->estimator = c->estimator;
         l->prosac_T_N = c->prosac_T_N;
         l->upload_owner = (h_frames && l != c) ? c : nullptr;
