@@ -102,6 +102,9 @@ void lr_set_batch_streams(lr_context* ctx, int n);
  * block (normally the previous frame's rounds + 2; a flood that needs more is completed after the frame's wait, and
  * the stages after it run again). */
 void lr_set_seed_capacity(lr_context* ctx, uint32_t cap);
+/* Test / experiment hook: start the flood's rounds on the strongest eighth of the seeds and widen the window round by
+ * round (same result; it was the batch lanes' setting in round 1). */
+void lr_set_flood_staged(lr_context* ctx, int on);
 void lr_set_flood_blind_rounds(lr_context* ctx, int rounds);
 
 /* ---- stage API (tests, bench) --------------------------------------------------------- */

@@ -69,7 +69,7 @@ EXPORTS = [
     "lr_stage_filter_host", "lr_stage_seeds", "lr_stage_flood", "lr_stage_fit", "lr_download", "lr_stage_times",
     "lr_stage_counters", "lr_filter_kernel_ms", "lr_ransac_best", "lr_estimate_line_pencils",
     "lr_find_line_segment_groups_batch_host", "lr_find_line_segment_groups_batch_host_ptrs", "lr_host_alloc", "lr_host_free",
-    "lr_set_seed_capacity", "lr_set_flood_blind_rounds", "lr_set_batch_streams", "lr_device_malloc", "lr_device_free", "lr_memcpy_h2d", "lr_cht_vanishing_point", "lr_refine_lines", "lr_set_estimator", "lr_ht_weights", "lr_prosac_solve", "lr_estimate_line_pencils_prosac", "lr_direct_solve", "lr_estimate_line_pencils_direct",
+    "lr_set_seed_capacity", "lr_set_flood_blind_rounds", "lr_set_flood_staged", "lr_set_batch_streams", "lr_device_malloc", "lr_device_free", "lr_memcpy_h2d", "lr_cht_vanishing_point", "lr_refine_lines", "lr_set_estimator", "lr_ht_weights", "lr_prosac_solve", "lr_estimate_line_pencils_prosac", "lr_direct_solve", "lr_estimate_line_pencils_direct",
 ]
 
 _lib = None
@@ -137,6 +137,8 @@ def lib():
         L.lr_set_batch_streams.restype = None
         L.lr_set_seed_capacity.argtypes = [C.c_void_p, C.c_uint32]
         L.lr_set_seed_capacity.restype = None
+        L.lr_set_flood_staged.argtypes = [C.c_void_p, C.c_int]
+        L.lr_set_flood_staged.restype = None
         L.lr_set_flood_blind_rounds.argtypes = [C.c_void_p, C.c_int]
         L.lr_set_flood_blind_rounds.restype = None
         L.lr_cht_vanishing_point.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Point), C.c_void_p]
@@ -299,6 +301,9 @@ class Context:
 
     def set_seed_capacity(self, cap):
         lib().lr_set_seed_capacity(self._h, int(cap))
+
+    def set_flood_staged(self, on):
+        lib().lr_set_flood_staged(self._h, int(bool(on)))
 
     def set_flood_blind_rounds(self, rounds):
         lib().lr_set_flood_blind_rounds(self._h, int(rounds))

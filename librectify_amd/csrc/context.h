@@ -134,7 +134,7 @@ struct lr_context {
     bool flood_big_hint = true;  // did the last frame's walks outgrow the first storage tier? (none yet: assume so)
     bool flood_hold_hint = false;  // did the last frame hold its weakest seeds back?
     uint32_t flood_tiers[4] = {0, 0, 0, 0};  // last flood: seeds in the second tier, slabs used, seeds of the ordered tail
-    bool flood_staged = false;  // set on the lanes of a batch call (throughput over latency)
+    bool flood_staged = false;  // lr_set_flood_staged: the rounds start on the strongest eighth of the seeds (test / experiment hook)
     hipEvent_t ev[16] = {};
     float stage_ms[LR_T_COUNT] = {};
     double host_ms[3] = {0, 0, 0};  // last frame: enqueue, next-frame staging + upload, wait (LIBRECTIFY_LANE_DEBUG)

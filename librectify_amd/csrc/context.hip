@@ -1332,7 +1332,7 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
         l->ransac_seed = c->ransac_seed;
         l->ransac_iters = c->ransac_iters;
         l->flood_mode = c->flood_mode;
-        l->flood_staged = false;  // (staged start of the rounds on batch lanes: +6 % in round 1, -3 % now: see DESIGN.md §7)
+        l->flood_staged = c->flood_staged;  // (off unless lr_set_flood_staged: +6 % in round 1, -3 % now)
         l->estimator = c->estimator;
         l->prosac_T_N = c->prosac_T_N;
         l->upload_owner = (h_frames && l != c) ? c : nullptr;
@@ -1405,7 +1405,6 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
     for (int si = 1; si < S; ++si) th.emplace_back(work, si);
     work(0);
     for (auto& t : th) t.join();
-    c->flood_staged = false;  // the caller's context goes back to the latency-oriented single-frame setting
     c->upload_ordered = false;
     for (lr_context* l : lanes) l->upload_owner = nullptr;
     for (int si = 0; si < S; ++si)

@@ -527,9 +527,9 @@ def test_parallel_flood_equals_ordered_flood_at_full_size(L, ctx):
 
 
 def test_staged_rounds_of_a_batch_equal_the_single_frame_call_at_full_size(L, ctx):
-    """3840x2160 through the batch entry point (its lanes start the flood rounds on the strongest eighth of the
-    seeds and widen the window round by round) against the single-frame call (all seeds from round one), which the
-    test above ties to the ordered flood: same segments, same groups, same transform."""
+    """3840x2160 through the batch entry point with the staged start of the flood rounds switched on (the rounds begin
+    on the strongest eighth of the seeds and widen the window round by round) against the single-frame call (all
+    seeds from round one), which the test above ties to the ordered flood: same segments, same groups."""
     from librectify_amd import synth
 
     w, h = 3840, 2160
@@ -538,7 +538,9 @@ def test_staged_rounds_of_a_batch_equal_the_single_frame_call_at_full_size(L, ct
     single = [ctx.find_line_segment_groups(f, max(w, h) / 100.0) for f in frames]
     d = ctx.device_upload(np.stack(frames))
     ctx.set_batch_streams(2)
+    ctx.set_flood_staged(True)
     out, n, tf = ctx.find_line_segment_groups_batch_device(d, w * h, len(frames), w, h, max(w, h) / 100.0, capacity=4096)
+    ctx.set_flood_staged(False)
     ctx.device_free(d)
     for i in range(len(frames)):
         assert n[i] == len(single[i]) and n[i] > 500
