@@ -647,6 +647,22 @@ __device__ __forceinline__ TileFetch fetch_tile(const FloodArgs& A, const Store&
 // does not depend on when the stamps land within a round, so the LDS store only remembers the walked pixels (V)
 // and stamps them all at the end (stamp_footprint), with many atomics in flight at once.  The slab store
 // stamps as it goes.
+#ifdef LR_WALK_TIMING
+// Diagnostic build (LR_EXTRA_FLAGS=-DLR_WALK_TIMING, printed by LIBRECTIFY_FLOOD_DEBUG): where a step of a long walk
+// spends its time.  Sums over walks of more than 100 steps: [0] walks, [1] steps, then s_memtime ticks (about one per
+// cycle; every reading costs some 150 itself) [2] waiting for the tile's pixels, [3] closure, [4] table update,
+// [5] push, [6] pop, lookup and issue of the next loads; [7] steps that found their tile in the table.
+__device__ unsigned long long g_walk_timing[8];
+#define LR_TICK(i)                                        \
+    {                                                     \
+        const uint64_t t_ = __builtin_amdgcn_s_memtime(); \
+        tacc[i] += t_ - tlast;                            \
+        tlast = t_;                                       \
+    }
+#else
+#define LR_TICK(i)
+#endif
+
 template <class Store>
 __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, float cs, Store& S, Pending& P,
                     WalkState& st, int lane) {
@@ -668,9 +684,16 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
     G.roff = (uint32_t)(ry * A.w + rx);
     asm volatile("" : "+v"(G.off), "+v"(G.roff));
     TileFetch cur = fetch_tile(A, S, st.head, lr, lc, rx, ry, ring_lane, fw, G);
+#ifdef LR_WALK_TIMING
+    uint64_t tacc[5] = {0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+    uint32_t nknown = 0;
+#endif
     for (;;) {
         st.head += 1;
         st.steps += 1;
+#ifdef LR_WALK_TIMING
+        nknown += cur.known ? 1u : 0u;
+#endif
         const uint32_t tile = cur.tile;
         uint64_t Am = cur.Am, Rg = cur.Rg;
         if (!cur.known) {
@@ -681,6 +704,7 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
                               directional(cur.rdx, cur.rdy, sn, cs) > thr;
             Rg = __ballot(racc);
         }
+        LR_TICK(0)
         uint64_t R = cur.entry & Am;
         uint64_t New = 0ull;
         if (R != 0ull) {
@@ -695,6 +719,7 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
             }
             New = R & ~cur.V;
         }
+        LR_TICK(1)
         if (New != 0ull || !cur.known) {
             S.update(cur.slot, tile, cur.V | New, Am, Rg);
             if (!cur.known) {
@@ -703,6 +728,7 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
             }
         }
         st.cnt += (uint32_t)__popcll(New);
+        LR_TICK(2)
         fw.valid = false;
         const bool was_empty = st.head == st.tail;  // then the first record appended now is the next one popped
         if (New != 0ull) {
@@ -723,10 +749,20 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
             if (H != 0ull) push8(S, P, st, tile, H, lane, pc, fw);
         }
         fw.valid = fw.valid && was_empty;
+        LR_TICK(3)
+#ifdef LR_WALK_TIMING
+        if (st.head == st.tail && st.steps > 100 && lane == 0) {
+            atomicAdd(&g_walk_timing[0], 1ull);
+            atomicAdd(&g_walk_timing[1], (unsigned long long)st.steps);
+            for (int i = 0; i < 5; ++i) atomicAdd(&g_walk_timing[2 + i], (unsigned long long)tacc[i]);
+            atomicAdd(&g_walk_timing[7], (unsigned long long)nknown);
+        }
+#endif
         if (st.head == st.tail) return 0;
         if ((st.tail - st.head) + 8u > S.ring_cap() || st.ntiles + 2u > S.hash_limit()) return 1;
         if (st.steps > kMaxSteps) return 1;  // never reached by a terminating walk; treated like exhausted storage
         cur = fetch_tile(A, S, st.head, lr, lc, rx, ry, ring_lane, fw, G);
+        LR_TICK(4)
     }
 }
 
@@ -886,6 +922,19 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
 // stale supersets block far more than footprints do, and seeds blocked by each other's stale stamps resolve one per
 // round: 39-55 rounds instead of 6-9; with lists dropped as soon as one of their pixels is committed elsewhere, 9-15
 // rounds and 2.3-3.4 ms instead of 1.5-2.6.  Not in the tree.
+//
+// What a step costs (LR_WALK_TIMING above; rocprofv3 counters in profiles/r02_pmc_flood_explore.txt): about 340
+// instructions (168 VALU, 167 SALU, 16 LDS, 6 loads) and some 3000 cycles when the wave has its SIMD to itself, of which
+// the wait for the tile's pixels is 250-400; closure 320, table update 50, push 850, pop + lookup + issue 850.  So a round
+// is (longest walk) x (latency of the bookkeeping chain), not memory, and the bench frame's rounds show it: 373, 296,
+// 231, 207, 139 us for longest walks of 174, 173, 155, 142, 97 steps.  Measured on that basis and NOT in the tree:
+//  - tile-major planes ((dx, dy) interleaved, 8x8 tiles contiguous: 27 cache lines per step instead of 60).
+//    tools/ubench/tile_gather.hip had promised 323 -> 143 us for round 1's gathers; the rounds came out at 373, 296,
+//    231, 207, 139 us again, the batch throughput within noise (7.56-7.58 Gpix/s both, same box, alternating), and the
+//    filter kernel went from 39.0 to 43.0 us (eight 64-byte pieces per store instead of one 512-byte run).
+//  - requesting the pixels of the record behind the head one step early (right after this step's own have arrived, so
+//    that the compiler's s_waitcnt vmcnt(0) does not wait for them too): 385, 304, 238, 207, 142 us.  The same with
+//    throw-away loads that only warm the cache: 446, 370, 270, 240, 160 us.
 template <bool kRest>
 __device__ __forceinline__ void explore_body(const FloodArgs& A, const BinTrig& trig, const uint32_t* __restrict__ act,
                                              uint32_t* __restrict__ big_list, uint32_t first) {
@@ -1197,6 +1246,18 @@ static void flood_debug_round(const FloodBuffers& B, uint32_t n_seeds, const uin
     (void)hipMemcpy(actv.data(), act, n_act * sizeof(uint32_t), hipMemcpyDeviceToHost);
     (void)hipMemcpy(cnt.data(), B.count, n_seeds * sizeof(uint32_t), hipMemcpyDeviceToHost);
     (void)hipMemcpy(blk.data(), B.blocked, n_seeds * sizeof(uint32_t), hipMemcpyDeviceToHost);
+#ifdef LR_WALK_TIMING
+    {
+        unsigned long long t[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_walk_timing), sizeof(t));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_walk_timing), z, sizeof(z));
+        if (t[1] > 0)
+            std::fprintf(stderr, "  walks of more than 100 steps: %llu, %llu steps (%llu of them on a known tile); s_memtime ticks per step: "
+                         "wait for pixels %.1f, closure %.1f, table %.1f, push %.1f, pop + issue %.1f\n",
+                         t[0], t[1], t[7], (double)t[2] / t[1], (double)t[3] / t[1], (double)t[4] / t[1], (double)t[5] / t[1],
+                         (double)t[6] / t[1]);
+    }
+#endif
     unsigned long long tsteps = 0, tpx = 0;
     uint32_t mxs = 0, mxk = 0, nb = 0;
     for (uint32_t i = 0; i < n_act; ++i) {

@@ -4,6 +4,10 @@
 //   tile-major plane: 256 contiguous bytes (2 lines)
 // plus the walk's real pattern (tile + the 36 ring pixels around it, three planes).  Many independent wavefronts,
 // DEP dependent fetches each (the walk's chain tile -> neighbour tile).
+// RESULT (MI355X): 40 000 wavefronts x 14 fetches: three row-major planes 323 us, row-major float2 + byte 212 us,
+// tile-major float2 + byte 143 us; a single chain costs 650-750 ns per fetch whatever the layout.  The flood itself did
+// NOT get faster with the tile-major layout (kernels_flood.hip, "What a step costs"): its steps are bound by their own
+// bookkeeping, not by these gathers, and the filter's stores got slower.  Kept as the record of that measurement.
 // Build: hipcc -O3 --offload-arch=gfx950 -o tile_gather tile_gather.hip
 #include <hip/hip_runtime.h>
 
