@@ -113,6 +113,7 @@ struct FloodBuffers {
     uint32_t* act_a = nullptr;
     uint32_t* act_b = nullptr;
     uint32_t* ctrl = nullptr;       // kFloodCtrlWords words
+    uint8_t* dirty = nullptr;       // one mark per 256 pixels of the label image: stamped in the current round
     uint32_t* big_list = nullptr;   // 8192 seeds: this round's hand-over to the second storage tier
     void* slab_ring = nullptr;  // n_slabs x slab_ring_cap 16-byte records
     void* slab_hash = nullptr;  // n_slabs x slab_hash_cap 16-byte records

@@ -172,6 +172,7 @@ struct FloodArgs {
     uint32_t* flags;    // per seed
     uint8_t* tier;      // per seed, kept across rounds: 1 = go to the second storage tier at once
     uint32_t* ctrl;     // kCtrl* words
+    uint8_t* dirty;     // per 256 consecutive pixels of the label image: stamped in this round (see the commit pass)
     uint4* slab_ring;   // n_slabs x slab_ring_cap records {tile, -, mask.lo, mask.hi}
     uint4* slab_hash;   // n_slabs x slab_hash_cap x 2 records {generation, tile+1, V.lo, V.hi} {A.lo, A.hi, -, -}
     uint32_t n_slabs, slab_ring_cap, slab_hash_cap;  // caps are powers of two
@@ -735,7 +736,10 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
             if constexpr (!Store::kDeferStamps) {
                 uint32_t old = kLabelFree;
                 const bool issue = (New >> lane) & 1ull;
-                if (issue) old = atomicMin(&A.label[cur.q], mine);
+                if (issue) {
+                    old = atomicMin(&A.label[cur.q], mine);
+                    A.dirty[cur.q >> 8] = 1;
+                }
                 bool foreign = false;
                 if (old > mine) {  // free, or stamped by a higher seed that is hereby blocked
                     if (old != kLabelFree) A.blocked[old & ~kMarkBit] = 1u;
@@ -788,6 +792,7 @@ __device__ __forceinline__ void stamp_footprint(const FloodArgs& A, uint32_t k, 
                 if ((V >> lane) & 1ull) {
                     const size_t q = (size_t)((tile >> 16) * 8 + lr) * A.w + ((tile & 0xFFFFu) * 8 + lc);
                     old[j] = atomicMin(&A.label[q], mine);
+                    A.dirty[q >> 8] = 1;
                 }
             }
         }
@@ -1005,20 +1010,36 @@ __device__ __forceinline__ bool seed_commits(const FloodArgs& A, uint32_t k, uin
 
 // Stamps of committed seeds become labels, all other stamps are erased.  A committed pixel also loses its direction
 // mask: the walks then reject it on the mask alone and never load the label image (a quarter of their gathers).
+// Only the parts of the label image that were stamped in this round are read: every stamp marks its run of 256
+// consecutive pixels in A.dirty, a wavefront takes one run (four pixels per lane) and clears the mark.  After the first
+// two rounds few runs are marked, and the pass costs a launch instead of a sweep over 4 bytes per pixel.
 __global__ __launch_bounds__(256) void flood_commit_pixels_kernel(FloodArgs A, uint32_t* __restrict__ label, size_t npix,
                                                                   uint8_t* __restrict__ dmask) {
     const uint32_t* __restrict__ ctrl = A.ctrl;
     if (ctrl[kCtrlNAct] == 0u) return;  // a round enqueued past the end
     const uint32_t barrier = ctrl[kCtrlBarrier];
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t step = (size_t)gridDim.x * 256;
-    for (; i < npix; i += step) {
-        const uint32_t v = label[i];
-        if (v >= kMarkBit && v != kLabelFree) {
-            const uint32_t k = v & ~kMarkBit;
-            const bool committed = seed_commits(A, k, barrier);
-            label[i] = committed ? k : kLabelFree;
-            if (committed) dmask[i] = 0;
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_runs = (uint32_t)((npix + 255) >> 8);
+    for (uint32_t run = blockIdx.x * 4u + (threadIdx.x >> 6); run < n_runs; run += gridDim.x * 4u) {
+        if (uni((uint32_t)A.dirty[run]) == 0u) continue;
+        if (lane == 0) A.dirty[run] = 0;
+        const size_t i0 = ((size_t)run << 8) + (size_t)lane * 4;
+        uint32_t v[4] = {kLabelFree, kLabelFree, kLabelFree, kLabelFree};
+        if (i0 + 3 < npix) {
+            const uint4 q = *reinterpret_cast<const uint4*>(label + i0);
+            v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
+        } else {
+            for (int j = 0; j < 4; ++j)
+                if (i0 + j < npix) v[j] = label[i0 + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (v[j] >= kMarkBit && v[j] != kLabelFree) {
+                const uint32_t k = v[j] & ~kMarkBit;
+                const bool committed = seed_commits(A, k, barrier);
+                label[i0 + j] = committed ? k : kLabelFree;
+                if (committed) dmask[i0 + j] = 0;
+            }
         }
     }
 }
@@ -1078,9 +1099,14 @@ __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, const
                                                               int32_t* __restrict__ seed_size,
                                                               uint32_t* __restrict__ act_next) {
     const uint32_t n_act = A.ctrl[kCtrlNAct];
-    const uint32_t n_pad = (n_act + 255u) & ~255u;  // whole wavefronts take part in the ballots
+    const uint32_t n_pad = (n_act + 255u) & ~255u;  // whole workgroups take part in the ballots and barriers
     const uint32_t window = A.ctrl[kCtrlWindow];
     const uint32_t barrier = A.ctrl[kCtrlBarrier];
+    // Counters of the control block are added to once per workgroup: an atomic per wavefront was 640 atomics on one
+    // address in the first round, which the L2 executes one after the other (28 us for 40 000 seeds; 10 us now).
+    __shared__ uint32_t s_cnt[4][3];  // per wavefront: survivors, committed, survivors below the window
+    __shared__ uint32_t s_base;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (uint32_t ai = blockIdx.x * 256 + threadIdx.x; ai < n_pad; ai += gridDim.x * 256) {
         bool a = false, done = false;
         uint32_t k = 0;
@@ -1105,19 +1131,29 @@ __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, const
                 }
             }
         }
-        const uint64_t md = __ballot(done);
-        if (md != 0ull && (threadIdx.x & 63) == __ffsll((long long)md) - 1) atomicAdd(&A.ctrl[kCtrlNCommit], (uint32_t)__popcll(md));
-        // next round's active list: one atomic per wavefront; the order of the list does not matter
-        const uint64_t m = __ballot(a);
-        if (m) {
-            const int lane = threadIdx.x & 63;
-            uint32_t base = 0;
-            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&A.ctrl[kCtrlNNext], (uint32_t)__popcll(m));
-            base = (uint32_t)__shfl((int)base, __ffsll((long long)m) - 1);
-            if (a) act_next[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = k;
-            const uint64_t mb = __ballot(a && k < window);
-            if (mb != 0ull && lane == __ffsll((long long)m) - 1) atomicAdd(&A.ctrl[kCtrlBelow], (uint32_t)__popcll(mb));
+        // next round's active list: the order of the list does not matter
+        const uint64_t m = __ballot(a), md = __ballot(done), mb = __ballot(a && k < window);
+        if (lane == 0) {
+            s_cnt[wave][0] = (uint32_t)__popcll(m);
+            s_cnt[wave][1] = (uint32_t)__popcll(md);
+            s_cnt[wave][2] = (uint32_t)__popcll(mb);
         }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t na = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0];
+            const uint32_t nd = s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1];
+            const uint32_t nb = s_cnt[0][2] + s_cnt[1][2] + s_cnt[2][2] + s_cnt[3][2];
+            s_base = na ? atomicAdd(&A.ctrl[kCtrlNNext], na) : 0u;
+            if (nd) atomicAdd(&A.ctrl[kCtrlNCommit], nd);
+            if (nb) atomicAdd(&A.ctrl[kCtrlBelow], nb);
+        }
+        __syncthreads();
+        if (a) {
+            uint32_t base = s_base;
+            for (int w2 = 0; w2 < wave; ++w2) base += s_cnt[w2][0];
+            act_next[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = k;
+        }
+        __syncthreads();  // s_cnt and s_base are rewritten by the next pass of the loop
     }
     // the workgroup that finishes last closes the round (every other one has read the control block and added its
     // counts by then)
@@ -1137,6 +1173,7 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
                                                                uint8_t* __restrict__ tier, uint32_t* __restrict__ blocked,
                                                                uint32_t* __restrict__ count, uint32_t* __restrict__ flags,
                                                                int32_t* __restrict__ seed_size, uint32_t* __restrict__ ctrl,
+                                                               uint8_t* __restrict__ dirty, uint32_t n_runs,
                                                                int win_first_shift, int hold_pct, uint32_t hold_from_start) {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     const uint32_t n_seeds = min(*n_ptr, cap);
@@ -1166,6 +1203,7 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
         ctrl[kCtrlStall] = 0u;
         ctrl[kCtrlNRemain] = n_seeds;
     }
+    for (uint32_t r = k; r < n_runs; r += gridDim.x * 256) dirty[r] = 0;  // (all clear after a flood that ran to its end)
     if (k >= n_seeds) return;
     act[k] = k;
     state[k] = 0;
@@ -1331,6 +1369,7 @@ FloodArgs flood_args(const FloodBuffers& B, const FloodFrame& F, bool use_big) {
     A.flags = B.flags;
     A.tier = B.tier;
     A.ctrl = B.ctrl;
+    A.dirty = B.dirty;
     A.slab_ring = (uint4*)B.slab_ring;
     A.slab_hash = (uint4*)B.slab_hash;
     A.n_slabs = B.n_slabs;
@@ -1425,7 +1464,8 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
         }
     }
     hipLaunchKernelGGL(flood_init_seeds_kernel, dim3((F.seed_cap + 255) / 256), dim3(256), 0, s, F.d_n_seeds, F.seed_cap,
-                       B.act_a, B.state, B.tier, B.blocked, B.count, B.flags, F.seed_size, B.ctrl, win_first_shift, hold_pct,
+                       B.act_a, B.state, B.tier, B.blocked, B.count, B.flags, F.seed_size, B.ctrl, B.dirty,
+                       (uint32_t)(((size_t)F.w * F.h + 255) >> 8), win_first_shift, hold_pct,
                        hold_start ? 1u : 0u);
     FloodArgs A = flood_args(B, F, P->use_big);
     A.win_shift = (uint32_t)win_growth;
