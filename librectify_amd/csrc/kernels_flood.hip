@@ -152,7 +152,12 @@ constexpr uint32_t kMarkBit = 0x80000000u;
 #ifndef LR_RING_T
 #define LR_RING_T 128
 #endif
-constexpr int kRingT = LR_RING_T, kHashT = 256;
+// (first-tier table: 256 tiles.  With 128 -- 5.8 KB of LDS per walk instead of 9.5, 20 walks per CU instead of 17 -- too
+// many walks outgrow the tier: 6.6-6.7 Gpix/s instead of 7.5-7.6 on the bench, single frames 4.4 ms instead of 3.2.)
+#ifndef LR_HASH_T
+#define LR_HASH_T 256
+#endif
+constexpr int kRingT = LR_RING_T, kHashT = LR_HASH_T;
 constexpr int kRingBig = 1024, kHashBig = 2048;
 constexpr uint32_t kBigCap = 8192;  // seeds per round that can move to the second tier (FloodBuffers::big_list)
 constexpr uint32_t kFlagIncomplete = 1u, kFlagSelfFail = 2u;
@@ -1273,7 +1278,7 @@ __global__ __launch_bounds__(64) void flood_ordered_tail_kernel(const float* __r
 // ---- host side of the rounds ------------------------------------------------------------------
 
 // LIBRECTIFY_FLOOD_DEBUG: what the round's exploration did (synchronises; rounds are then enqueued one at a time)
-static void flood_debug_round(const FloodBuffers& B, uint32_t n_seeds, const uint32_t* act, hipStream_t s) {
+static void flood_debug_round(const FloodBuffers& B, const FloodFrame& F, uint32_t n_seeds, const uint32_t* act, hipStream_t s) {
     uint32_t ctrl[16];
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(ctrl, B.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost);
@@ -1324,6 +1329,38 @@ static void flood_debug_round(const FloodBuffers& B, uint32_t n_seeds, const uin
         }
         std::fprintf(stderr, "  %u committing seeds: %llu steps, longest %u; blocked or dying seeds: %llu steps, longest %u\n",
                      n_commit, steps_commit, longest_commit, steps_other, longest_other);
+    }
+    {  // seeds that end with this round because a committing seed takes their pixel: what their walks cost
+        const size_t npix = (size_t)F.w * F.h;
+        std::vector<uint32_t> lab(npix);
+        std::vector<int32_t> sidx(n_seeds);
+        (void)hipMemcpy(lab.data(), F.label, npix * sizeof(uint32_t), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(sidx.data(), F.seed_idx, n_seeds * sizeof(int32_t), hipMemcpyDeviceToHost);
+        auto commits = [&](uint32_t kk) {
+            return cnt[kk] > 0 && blk[kk] == 0 && !(flg[kk] & (kFlagIncomplete | kFlagSelfFail)) && kk < ctrl[kCtrlBarrier];
+        };
+        unsigned long long steps_dying = 0, steps_dying_own = 0;
+        uint32_t n_dying = 0, n_own = 0, longest = 0;
+        for (uint32_t i = 0; i < n_act; ++i) {
+            const uint32_t kk = actv[i], st_ = flg[kk] >> 8;
+            if (commits(kk)) continue;
+            const uint32_t v = lab[(size_t)sidx[kk]];
+            if (v >= kMarkBit && v != kLabelFree) {
+                const uint32_t j = v & ~kMarkBit;
+                if (j != kk && commits(j)) {
+                    steps_dying += st_;
+                    n_dying += 1;
+                    longest = std::max(longest, st_);
+                }
+                if (j != kk) {  // a lower seed reaches the seed pixel, whether or not it commits
+                    steps_dying_own += st_;
+                    n_own += 1;
+                }
+            }
+        }
+        std::fprintf(stderr, "  %u seeds die with this round (a committing seed takes their pixel): %llu steps, longest %u; "
+                     "%u seeds have their own pixel stamped by a lower seed: %llu steps\n",
+                     n_dying, steps_dying, longest, n_own, steps_dying_own);
     }
     {  // walk-length histogram (steps) and where in the seed order the long walks sit
         const uint32_t edges[8] = {8, 16, 32, 48, 64, 128, 192, 0xFFFFFFFFu};
@@ -1414,7 +1451,7 @@ void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& 
         uint32_t n = 0;
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(&n, F.d_n_seeds, sizeof(n), hipMemcpyDeviceToHost);
-        flood_debug_round(B, std::min(n, F.seed_cap), act, s);
+        flood_debug_round(B, F, std::min(n, F.seed_cap), act, s);
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, dbg0, dbg1);
         std::fprintf(stderr, "  explore kernels of this round: %.1f us\n", ms * 1e3f);
