@@ -28,9 +28,13 @@ struct lr_context {
     float* h_stage[2] = {nullptr, nullptr};
     size_t cap_stage[2] = {0, 0};
     hipEvent_t ev_up[2] = {};
-    lr_context* upload_owner = nullptr;  // batch lanes: the context whose copy stream (and mutex) all uploads go through
-    bool upload_ordered = false;
-    std::mutex upload_mu;
+    // Batch calls on host frames: a ring of device frames (and, for pageable frames, of page-locked staging buffers)
+    // that ONE uploader fills in frame order on the copy stream, as far ahead of the lanes as the ring allows
+    // (find_groups_batch).
+    std::vector<float*> ring_img;
+    std::vector<float*> ring_stage;
+    std::vector<hipEvent_t> ring_ev;
+    size_t ring_cap_pix = 0, ring_stage_cap_pix = 0;
     std::function<void()> prefetch;  // one-shot: run at the frame's first long wait (see ctx_run_prefetch)
     int prefetch_rc = 0;
     std::string prefetch_err;
@@ -184,8 +188,6 @@ int ctx_find_groups_batch_host(lr_context* c, const float* const* frames, int ba
 // Enqueues the upload of a host frame into device slot `slot` on the copy stream and records ev_up[slot];
 // the caller makes its compute stream wait on that event.  num_threads: the reference's knob (threading.h:24-27),
 // here the number of host threads that stage a pageable frame (< 0: serial, as there).
-// turn / my_turn (optional): the transfer is enqueued only when *turn has reached my_turn, and *turn is advanced after
-int ctx_upload_frame(lr_context* c, int slot, const float* buffer, int w, int h, int stride, int num_threads,
-                     std::atomic<int>* turn = nullptr, int my_turn = 0);
+int ctx_upload_frame(lr_context* c, int slot, const float* buffer, int w, int h, int stride, int num_threads);
 void ctx_run_prefetch(lr_context* c);
 }  // namespace lramd

@@ -169,77 +169,30 @@ int staging_threads(int num_threads) {
 
 }  // namespace
 
-int ctx_upload_frame(lr_context* c, int slot, const float* buffer, int w, int h, int stride, int num_threads,
-                     std::atomic<int>* turn, int my_turn) {
-    LR_HIP(hipSetDevice(c->device));
-    if (w < 1 || h < 1 || buffer == nullptr) {
-        set_error("upload: bad frame");
-        return 1;
-    }
-    // image_from_buffer (reference image.cpp:11-19): a negative stride addresses the same rows from the other end
+// Rows of a host frame (|stride| >= w; a negative stride addresses the same rows from the other end, reference
+// image.cpp:11-19) into a device buffer of w x h floats, on stream `up`.  Page-locked memory goes as it lies; pageable
+// memory goes through the page-locked buffer `stage` in 4 MB bands, copied by up to `num_threads` threads, each band's
+// transfer enqueued as soon as it is staged.  Nothing here waits for the transfers.
+static int upload_rows(lr_context* c, float* dst, float* stage, const float* buffer, int w, int h, int stride, int num_threads,
+                       hipStream_t up) {
     if (stride < 0) {
         buffer = buffer + (std::ptrdiff_t)(h - 1) * stride;
         stride = -stride;
     }
-    if (stride < w) {
-        set_error("upload: |stride| smaller than the width");
-        return 1;
-    }
-    // In a batch call all lanes send their frames down ONE copy stream (the caller's), one frame at a time: DMA
-    // transfers of different streams share the link, so six frames started together all arrive late, whereas in a
-    // single queue the first is there after a sixth of the time and its lane can start.
-    lr_context* owner = c->upload_owner ? c->upload_owner : c;
-    hipStream_t up = owner->copy_stream;
-    const bool ordered = owner != c || c->upload_ordered;
     const size_t npix = (size_t)w * h;
-    if (c->cap_slot[slot] < npix) {
-        LR_HIP(hipStreamSynchronize(c->stream));
-        LR_HIP(hipStreamSynchronize(up));
-        if (dev_alloc(c->d_img_slot[slot], npix)) return 1;
-        c->cap_slot[slot] = npix;
-    }
-    float* dst = c->d_img_slot[slot];
     const size_t row_bytes = (size_t)w * sizeof(float);
-    // a batch's first frames take the link in lane order (staging is not ordered, only the transfers)
-    auto wait_turn = [&]() {
-        if (turn)
-            while (turn->load(std::memory_order_acquire) < my_turn) std::this_thread::yield();
-    };
-    struct TurnDone {
-        std::atomic<int>* t;
-        int v;
-        ~TurnDone() {  // on every way out, and never out of order (a lane that failed early still waits for its turn)
-            if (!t) return;
-            while (t->load(std::memory_order_acquire) < v - 1) std::this_thread::yield();
-            t->store(v, std::memory_order_release);
-        }
-    } turn_done{turn, my_turn + 1};
-    if (is_page_locked(buffer)) {
-        wait_turn();
-        std::unique_lock<std::mutex> lock(owner->upload_mu, std::defer_lock);
-        if (ordered) lock.lock();
-        LR_HIP(hipMemcpy2DAsync(dst, row_bytes, buffer, (size_t)stride * sizeof(float), row_bytes, (size_t)h,
-                                hipMemcpyHostToDevice, up));
-        LR_HIP(hipEventRecord(c->ev_up[slot], up));
+    if (stage == nullptr) {
+        if (stride == w)  // one linear transfer: a pitched copy of the same bytes goes row by row
+            LR_HIP(hipMemcpyAsync(dst, buffer, npix * sizeof(float), hipMemcpyHostToDevice, up));
+        else
+            LR_HIP(hipMemcpy2DAsync(dst, row_bytes, buffer, (size_t)stride * sizeof(float), row_bytes, (size_t)h,
+                                    hipMemcpyHostToDevice, up));
         return 0;
     }
-    if (c->cap_stage[slot] < npix) {
-        LR_HIP(hipStreamSynchronize(up));
-        if (c->h_stage[slot]) (void)hipHostFree(c->h_stage[slot]);
-        c->h_stage[slot] = nullptr;
-        c->cap_stage[slot] = 0;
-        LR_HIP(hipHostMalloc((void**)&c->h_stage[slot], npix * sizeof(float)));
-        c->cap_stage[slot] = npix;
-    }
-    // the DMA that last read this staging buffer has long finished (its frame has been processed), but make sure
-    LR_HIP(hipEventSynchronize(c->ev_up[slot]));
-    float* stage = c->h_stage[slot];
     const int rows_per_band = (int)std::max<size_t>(1, ((size_t)4 << 20) / row_bytes);
     const int n_bands = (h + rows_per_band - 1) / rows_per_band;
     const int T = std::min(staging_threads(num_threads), n_bands);
     std::vector<int> rc(T, 0);
-    // band k: rows into the pinned buffer; a single call (not ordered) enqueues each band's DMA at once, so that the
-    // copy of the next band overlaps it; a batch lane stages the whole frame first and then takes its turn on the link
     auto run = [&](int t) {
         if (t > 0 && hipSetDevice(c->device) != hipSuccess) {
             rc[t] = 1;
@@ -252,8 +205,8 @@ int ctx_upload_frame(lr_context* c, int slot, const float* buffer, int w, int h,
             } else {
                 for (int r = r0; r < r1; ++r) std::memcpy(stage + (size_t)r * w, buffer + (size_t)r * stride, row_bytes);
             }
-            if (!ordered && hipMemcpyAsync(dst + (size_t)r0 * w, stage + (size_t)r0 * w, (size_t)(r1 - r0) * row_bytes,
-                                           hipMemcpyHostToDevice, up) != hipSuccess)
+            if (hipMemcpyAsync(dst + (size_t)r0 * w, stage + (size_t)r0 * w, (size_t)(r1 - r0) * row_bytes,
+                               hipMemcpyHostToDevice, up) != hipSuccess)
                 rc[t] = 1;
         }
     };
@@ -263,15 +216,46 @@ int ctx_upload_frame(lr_context* c, int slot, const float* buffer, int w, int h,
     for (auto& x : th) x.join();
     for (int t = 0; t < T; ++t)
         if (rc[t]) {
+            (void)hipGetLastError();
             set_error("upload: staging copy failed");
             return 1;
         }
-    wait_turn();
-    std::unique_lock<std::mutex> lock(owner->upload_mu, std::defer_lock);
-    if (ordered) {
-        lock.lock();
-        LR_HIP(hipMemcpyAsync(dst, stage, npix * sizeof(float), hipMemcpyHostToDevice, up));
+    return 0;
+}
+
+int ctx_upload_frame(lr_context* c, int slot, const float* buffer, int w, int h, int stride, int num_threads) {
+    LR_HIP(hipSetDevice(c->device));
+    if (w < 1 || h < 1 || buffer == nullptr) {
+        set_error("upload: bad frame");
+        return 1;
     }
+    if ((stride < 0 ? -stride : stride) < w) {
+        set_error("upload: |stride| smaller than the width");
+        return 1;
+    }
+    hipStream_t up = c->copy_stream;
+    const size_t npix = (size_t)w * h;
+    if (c->cap_slot[slot] < npix) {
+        LR_HIP(hipStreamSynchronize(c->stream));
+        LR_HIP(hipStreamSynchronize(up));
+        if (dev_alloc(c->d_img_slot[slot], npix)) return 1;
+        c->cap_slot[slot] = npix;
+    }
+    float* stage = nullptr;
+    if (!is_page_locked(buffer)) {
+        if (c->cap_stage[slot] < npix) {
+            LR_HIP(hipStreamSynchronize(up));
+            if (c->h_stage[slot]) (void)hipHostFree(c->h_stage[slot]);
+            c->h_stage[slot] = nullptr;
+            c->cap_stage[slot] = 0;
+            LR_HIP(hipHostMalloc((void**)&c->h_stage[slot], npix * sizeof(float)));
+            c->cap_stage[slot] = npix;
+        }
+        // the DMA that last read this staging buffer has long finished (its frame has been processed), but make sure
+        LR_HIP(hipEventSynchronize(c->ev_up[slot]));
+        stage = c->h_stage[slot];
+    }
+    if (upload_rows(c, c->d_img_slot[slot], stage, buffer, w, h, stride, num_threads, up)) return 1;
     LR_HIP(hipEventRecord(c->ev_up[slot], up));
     return 0;
 }
@@ -310,7 +294,10 @@ int ctx_create(int device, lr_context** out) {
         return 1;
     }
     for (auto& e : c->ev) (void)hipEventCreate(&e);
-    for (auto& e : c->ev_up) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    {
+        static const bool lane_debug = std::getenv("LIBRECTIFY_LANE_DEBUG") != nullptr;  // (its timeline times the uploads)
+        for (auto& e : c->ev_up) (void)hipEventCreateWithFlags(&e, lane_debug ? hipEventDefault : hipEventDisableTiming);
+    }
     (void)hipMalloc((void**)&c->maxmag, sizeof(float));
     (void)hipMalloc((void**)&c->d_counts, 64 * sizeof(uint32_t));
     (void)hipMalloc((void**)&c->d_gctl, kGcWords * sizeof(uint32_t));
@@ -351,6 +338,12 @@ void ctx_destroy(lr_context* c) {
     for (float* p : c->h_stage)
         if (p) (void)hipHostFree(p);
     for (auto& e : c->ev_up)
+        if (e) (void)hipEventDestroy(e);
+    for (float* p : c->ring_img)
+        if (p) (void)hipFree(p);
+    for (float* p : c->ring_stage)
+        if (p) (void)hipHostFree(p);
+    for (auto& e : c->ring_ev)
         if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->copy_stream);
     if (c->h_res) (void)hipHostFree(c->h_res);
@@ -1311,9 +1304,46 @@ int ctx_find_groups_device(lr_context* c, const float* d_image, int w, int h, in
 }
 
 // Batch of independent frames: the stages of one frame are latency-bound (flood rounds,
-// host round trips), so several frames are kept in flight, one host thread + context + HIP stream each ("lanes").
-// Host-resident frames (h_frames != nullptr) go through each lane's two device slots: the upload of the lane's next
-// frame is issued while the kernels of its current frame run (ctx_run_prefetch), on the lane's copy stream.
+// host round trips), so several frames are kept in flight, one host thread + context + HIP stream each ("lanes");
+// frames are handed out dynamically (they differ in cost, and with a fixed assignment the batch ends on one lane).
+//
+// Host-resident frames (h_frames != nullptr) are uploaded by ONE uploader thread, in frame order, on the caller's
+// copy stream, into a pool of lanes + 6 device frames: frame i goes to whichever slot is free (frames finish out of
+// order: a heavy frame runs as long as three light ones, and slot i mod R would make the link wait for it), so the link
+// works up to six frames ahead of the lanes instead of starting a lane's next transfer only when the lane starts a
+// frame.  (With one slot ahead per lane -- the first design -- a quarter to a third of the frames of a 4K
+// batch still waited for their own upload, although the link was busy only two thirds of the time: 7.5 Gpix/s where
+// the same batch without the transfers ran at 9.0; LIBRECTIFY_LANE_DEBUG prints each frame's lead.)  A lane makes its
+// stream wait for the frame's transfer and never touches host memory itself.
+static int ensure_upload_ring(lr_context* c, int R, size_t npix, bool staging) {
+    if ((int)c->ring_img.size() < R || c->ring_cap_pix < npix) {
+        LR_HIP(hipStreamSynchronize(c->copy_stream));
+        for (float* p : c->ring_img)
+            if (p) (void)hipFree(p);
+        c->ring_img.assign((size_t)std::max<int>(R, (int)c->ring_img.size()), nullptr);
+        c->ring_cap_pix = 0;
+        const size_t cap = std::max(npix, c->ring_cap_pix);
+        for (float*& p : c->ring_img) LR_HIP(hipMalloc((void**)&p, cap * sizeof(float)));
+        c->ring_cap_pix = cap;
+    }
+    static const bool lane_debug = std::getenv("LIBRECTIFY_LANE_DEBUG") != nullptr;  // (its timeline times the uploads)
+    while ((int)c->ring_ev.size() < (int)c->ring_img.size()) {
+        hipEvent_t e = nullptr;
+        LR_HIP(hipEventCreateWithFlags(&e, lane_debug ? hipEventDefault : hipEventDisableTiming));
+        c->ring_ev.push_back(e);
+    }
+    if (staging && ((int)c->ring_stage.size() < (int)c->ring_img.size() || c->ring_stage_cap_pix < npix)) {
+        LR_HIP(hipStreamSynchronize(c->copy_stream));
+        for (float* p : c->ring_stage)
+            if (p) (void)hipHostFree(p);
+        c->ring_stage.assign(c->ring_img.size(), nullptr);
+        c->ring_stage_cap_pix = 0;
+        for (float*& p : c->ring_stage) LR_HIP(hipHostMalloc((void**)&p, npix * sizeof(float)));
+        c->ring_stage_cap_pix = npix;
+    }
+    return 0;
+}
+
 static int find_groups_batch(lr_context* c, const float* d_images, size_t image_stride, const float* const* h_frames,
                              int batch, int w, int h, int stride, float min_length, bool refine, int num_threads,
                              LineSegment* out, int capacity, int* n_lines, const RectificationConfig* cfg,
@@ -1335,61 +1365,115 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
         l->flood_staged = c->flood_staged;  // (off unless lr_set_flood_staged: +6 % in round 1, -3 % now)
         l->estimator = c->estimator;
         l->prosac_T_N = c->prosac_T_N;
-        l->upload_owner = (h_frames && l != c) ? c : nullptr;
+        l->prefetch = nullptr;
     }
-    c->upload_ordered = h_frames != nullptr;
-    std::atomic<int> first_turn{0};  // the first frames go up the link in lane order
-    std::atomic<int> next_frame{S};
-    // the lanes share the host's cores: a lane stages its frames with its share of the caller's thread budget
-    const int lane_threads = num_threads > 1 ? std::max(1, num_threads / S) : 1;
+    // ---- the upload ring
+    const size_t npix = (size_t)w * h;
+    int R = 0;
+    bool any_pageable = false;
+    if (h_frames) {
+        if (w < 1 || h < 1) {
+            set_error("upload: bad frame");
+            return 1;
+        }
+        if ((stride < 0 ? -stride : stride) < w) {
+            set_error("upload: |stride| smaller than the width");
+            return 1;
+        }
+        for (int i = 0; i < batch; ++i) {
+            if (h_frames[i] == nullptr) {
+                set_error("upload: bad frame");
+                return 1;
+            }
+        }
+        for (int i = 0; i < batch && !any_pageable; ++i) any_pageable = !is_page_locked(h_frames[i]);
+        // slots beyond one per lane: what the link may be ahead.  Six absorb the moments when several lanes finish
+        // together (pageable 4K frames: 7.8 Gpix/s with three, 8.0 with six or ten); at most 2 GiB of frames, though.
+        static const int extra_env = std::getenv("LIBRECTIFY_RING_EXTRA") ? std::max(1, std::atoi(std::getenv("LIBRECTIFY_RING_EXTRA"))) : 0;
+        const int by_bytes = (int)std::min<size_t>(64, ((size_t)2 << 30) / (npix * sizeof(float)));
+        R = extra_env ? S + extra_env : std::max(S + 1, std::min(S + 6, by_bytes));
+        R = std::min(batch, R);
+        if (ensure_upload_ring(c, R, npix, any_pageable)) return 1;
+    }
+    std::vector<std::atomic<int>> enq(h_frames ? (size_t)batch : 0);  // frame's slot + 1 once its transfer is enqueued
+    std::vector<std::atomic<int>> slot_busy((size_t)R);
+    for (auto& a : enq) a.store(0, std::memory_order_relaxed);
+    for (auto& a : slot_busy) a.store(0, std::memory_order_relaxed);
+    static const bool lane_debug = std::getenv("LIBRECTIFY_LANE_DEBUG") != nullptr;
+    std::atomic<int> abort_all{0};
+    std::string up_err;
+    auto nap = [](int& spins) {  // a wait that is usually short: yield first, then sleep
+        if (++spins < 64) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(30));
+    };
+    auto uploader = [&]() {
+        if (hipSetDevice(c->device) != hipSuccess) {
+            up_err = "hipSetDevice failed";
+            abort_all.store(1);
+            return;
+        }
+        for (int i = 0; i < batch; ++i) {
+            int slot = -1, spins = 0;
+            // a slot whose frame is done (its transfer and its staging buffer are then free as well)
+            while (slot < 0 && !abort_all.load(std::memory_order_relaxed)) {
+                for (int k = 0; k < R && slot < 0; ++k)
+                    if (!slot_busy[(size_t)k].load(std::memory_order_acquire)) slot = k;
+                if (slot < 0) nap(spins);
+            }
+            if (abort_all.load(std::memory_order_relaxed)) return;
+            slot_busy[(size_t)slot].store(1, std::memory_order_relaxed);
+            float* stage = is_page_locked(h_frames[i]) ? nullptr : c->ring_stage[(size_t)slot];
+            const double t_u0 = now_ms();
+            if (upload_rows(c, c->ring_img[(size_t)slot], stage, h_frames[i], w, h, stride, num_threads, c->copy_stream) ||
+                hipEventRecord(c->ring_ev[(size_t)slot], c->copy_stream) != hipSuccess) {
+                up_err = get_error().empty() ? "upload failed" : get_error();
+                abort_all.store(1);
+                return;
+            }
+            enq[(size_t)i].store(slot + 1, std::memory_order_release);
+            if (lane_debug) std::fprintf(stderr, "uploader frame %d: slot %d, waited %d naps for it, staged and enqueued in %.2f ms\n", i, slot, spins, now_ms() - t_u0);
+        }
+    };
+    std::atomic<int> next_frame{0};
     std::vector<int> rc(S, 0);
     std::vector<std::string> err(S);
-    static const bool lane_debug = std::getenv("LIBRECTIFY_LANE_DEBUG") != nullptr;
     auto work = [&](int si) {
         lr_context* l = lanes[si];
         auto fail = [&]() {
             rc[si] = 1;
             err[si] = get_error();
-            l->prefetch = nullptr;
+            abort_all.store(1);
         };
-        if (h_frames && ctx_upload_frame(l, 0, h_frames[si], w, h, stride, lane_threads, &first_turn, si)) return fail();
-        int j = 0;
-        // frames are handed out dynamically (a lane reserves its next frame when it starts on the current one, so that
-        // it can upload it meanwhile): frames differ in cost, and with a fixed assignment the batch ends on one lane
-        for (int b = si, nb = -1; b < batch; b = nb, ++j) {
-            nb = next_frame.fetch_add(1, std::memory_order_relaxed);
+        if (si > 0 && hipSetDevice(c->device) != hipSuccess) {
+            set_error("hipSetDevice failed");
+            return fail();
+        }
+        for (int b = next_frame.fetch_add(1, std::memory_order_relaxed); b < batch; b = next_frame.fetch_add(1, std::memory_order_relaxed)) {
             const float* img = nullptr;
-            int img_stride = stride;
+            int img_stride = stride, slot = -1;
             if (h_frames) {
-                const int cur = j & 1;
-                if (hipStreamWaitEvent(l->stream, l->ev_up[cur], 0) != hipSuccess) {
+                int spins = 0;
+                while ((slot = enq[(size_t)b].load(std::memory_order_acquire) - 1) < 0 && !abort_all.load(std::memory_order_relaxed)) nap(spins);
+                if (slot < 0) return;  // (whoever stopped the batch has the message)
+                if (hipStreamWaitEvent(l->stream, c->ring_ev[(size_t)slot], 0) != hipSuccess) {
                     set_error("hipStreamWaitEvent failed");
                     return fail();
                 }
-                img = l->d_img_slot[cur];
+                img = c->ring_img[(size_t)slot];
                 img_stride = w;
-                l->prefetch_rc = 0;
-                if (nb < batch)
-                    l->prefetch = [l, cur, nb, h_frames, w, h, stride, lane_threads]() {
-                        // slot cur^1 was last read by this lane's previous frame, which is finished
-                        if (ctx_upload_frame(l, cur ^ 1, h_frames[nb], w, h, stride, lane_threads)) {
-                            l->prefetch_rc = 1;
-                            l->prefetch_err = get_error();
-                        }
-                    };
             } else {
                 img = d_images + (size_t)b * image_stride;
             }
             std::vector<LineSegment> res;
             const double t_f0 = now_ms();
             if (ctx_find_groups_device(l, img, w, h, img_stride, min_length, refine, res)) return fail();
-            if (lane_debug)
-                std::fprintf(stderr, "lane %d frame %d: enqueue %.2f ms, next-frame upload %.2f, wait %.2f, whole call %.2f; device total %.2f\n",
-                             si, b, l->host_ms[0], l->host_ms[1], l->host_ms[2], now_ms() - t_f0, l->stage_ms[LR_T_TOTAL]);
-            if (l->prefetch_rc) {
-                set_error(l->prefetch_err);
-                return fail();
+            if (lane_debug) {
+                float lead = 0.f;  // how long the frame's upload had been finished when its first kernel started
+                if (h_frames && hipEventElapsedTime(&lead, c->ring_ev[(size_t)slot], l->ev[0]) != hipSuccess) (void)hipGetLastError();
+                std::fprintf(stderr, "lane %d frame %d: enqueue %.2f ms, wait %.2f, whole call %.2f; device total %.2f; upload done %.2f ms before the first kernel\n",
+                             si, b, l->host_ms[0], l->host_ms[2], now_ms() - t_f0, l->stage_ms[LR_T_TOTAL], lead);
             }
+            if (h_frames) slot_busy[(size_t)slot].store(0, std::memory_order_release);
             const int n = (int)res.size();
             if (n_lines) n_lines[b] = n;
             if (out && capacity > 0)
@@ -1402,16 +1486,20 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
         }
     };
     std::vector<std::thread> th;
+    if (h_frames) th.emplace_back(uploader);
     for (int si = 1; si < S; ++si) th.emplace_back(work, si);
     work(0);
     for (auto& t : th) t.join();
-    c->upload_ordered = false;
-    for (lr_context* l : lanes) l->upload_owner = nullptr;
+    if (h_frames) (void)hipStreamSynchronize(c->copy_stream);  // (after an error: nothing may still read the caller's frames)
     for (int si = 0; si < S; ++si)
         if (rc[si]) {
             set_error(err[si]);
             return 1;
         }
+    if (abort_all.load()) {
+        set_error(up_err.empty() ? "batch: upload failed" : up_err);
+        return 1;
+    }
     return 0;
 }
 
