@@ -35,9 +35,6 @@ struct lr_context {
     std::vector<float*> ring_stage;
     std::vector<hipEvent_t> ring_ev;
     size_t ring_cap_pix = 0, ring_stage_cap_pix = 0;
-    std::function<void()> prefetch;  // one-shot: run at the frame's first long wait (see ctx_run_prefetch)
-    int prefetch_rc = 0;
-    std::string prefetch_err;
     // stage 1
     float* dx = nullptr;
     float* dy = nullptr;
@@ -189,5 +186,4 @@ int ctx_find_groups_batch_host(lr_context* c, const float* const* frames, int ba
 // the caller makes its compute stream wait on that event.  num_threads: the reference's knob (threading.h:24-27),
 // here the number of host threads that stage a pageable frame (< 0: serial, as there).
 int ctx_upload_frame(lr_context* c, int slot, const float* buffer, int w, int h, int stride, int num_threads);
-void ctx_run_prefetch(lr_context* c);
 }  // namespace lramd

@@ -260,15 +260,6 @@ int ctx_upload_frame(lr_context* c, int slot, const float* buffer, int w, int h,
     return 0;
 }
 
-// The pipeline calls this where it is about to block for the first time with most of a frame's kernels enqueued:
-// a batch lane then stages and uploads its next frame while the GPU works on the current one.
-void ctx_run_prefetch(lr_context* c) {
-    if (!c->prefetch) return;
-    std::function<void()> f;
-    f.swap(c->prefetch);
-    f();
-}
-
 int ctx_create(int device, lr_context** out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -1210,7 +1201,6 @@ static int run_frame(lr_context* c, const float* d_image, int w, int h, int stri
             LR_HIP(hipMemcpyAsync(c->h_counts, c->d_counts, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         }
         const double t_enq = now_ms();
-        ctx_run_prefetch(c);  // everything is enqueued: the lane stages its next frame while the GPU works
         const double t_pre = now_ms();
         LR_HIP(hipStreamSynchronize(c->stream));
         c->host_ms[0] = t_enq - t_begin;      // enqueue of the frame's kernels
@@ -1298,8 +1288,6 @@ static int run_frame(lr_context* c, const float* d_image, int w, int h, int stri
 int ctx_find_groups_device(lr_context* c, const float* d_image, int w, int h, int stride, float min_length, bool refine,
                            std::vector<LineSegment>& out) {
     const int rc = run_frame(c, d_image, w, h, stride, min_length, refine, out);
-    if (rc) c->prefetch = nullptr;
-    ctx_run_prefetch(c);  // (a frame that failed before its wait)
     return rc;
 }
 
@@ -1365,7 +1353,6 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
         l->flood_staged = c->flood_staged;  // (off unless lr_set_flood_staged: +6 % in round 1, -3 % now)
         l->estimator = c->estimator;
         l->prosac_T_N = c->prosac_T_N;
-        l->prefetch = nullptr;
     }
     // ---- the upload ring
     const size_t npix = (size_t)w * h;

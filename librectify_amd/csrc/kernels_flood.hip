@@ -248,10 +248,6 @@ struct LdsStoreT {
     uint32_t* hk;   // table: tile + 1 (0 = empty)
     uint32_t* hv0;  // V
     uint32_t* hv1;
-    uint32_t* ha0;  // A
-    uint32_t* ha1;
-    uint32_t* hr0;  // acceptable pixels of the 36-pixel ring around the tile (lane order, see ring_xy)
-    uint32_t* hr1;
     OrdT* ord;      // table slots in order of insertion (what stamp_footprint walks)
     __device__ void note_new(uint32_t i, uint32_t slot) { ord[i] = (OrdT)slot; }
     __device__ uint32_t ring_cap() const { return kRing; }
@@ -268,7 +264,7 @@ struct LdsStoreT {
         rhi[j] = (uint32_t)(m >> 32);
     }
     // returns true if the tile is known; slot = where it is or where it would go
-    __device__ bool lookup(uint32_t tile, uint32_t& slot, uint64_t& V, uint64_t& Am, uint64_t& Rg) const {
+    __device__ bool lookup(uint32_t tile, uint32_t& slot, uint64_t& V) const {
         const uint32_t key = tile + 1u;
         uint32_t hs = (key * 2654435761u) >> kHashShift;
         for (int probe = 0; probe < kHash; ++probe) {
@@ -276,8 +272,6 @@ struct LdsStoreT {
             if (cur == key) {
                 slot = hs;
                 V = uni64(hv0[hs], hv1[hs]);
-                Am = uni64(ha0[hs], ha1[hs]);
-                Rg = uni64(hr0[hs], hr1[hs]);
                 return true;
             }
             if (cur == 0u) break;
@@ -285,23 +279,13 @@ struct LdsStoreT {
         }
         slot = hs;
         V = 0ull;
-        Am = 0ull;
-        Rg = 0ull;
         return false;
     }
-    __device__ void values(uint32_t slot, uint64_t& V, uint64_t& Am, uint64_t& Rg) const {
-        V = uni64(hv0[slot], hv1[slot]);
-        Am = uni64(ha0[slot], ha1[slot]);
-        Rg = uni64(hr0[slot], hr1[slot]);
-    }
-    __device__ void update(uint32_t slot, uint32_t tile, uint64_t V, uint64_t Am, uint64_t Rg) {
+    __device__ void value(uint32_t slot, uint64_t& V) const { V = uni64(hv0[slot], hv1[slot]); }
+    __device__ void update(uint32_t slot, uint32_t tile, uint64_t V) {
         hk[slot] = tile + 1u;
         hv0[slot] = (uint32_t)V;
         hv1[slot] = (uint32_t)(V >> 32);
-        ha0[slot] = (uint32_t)Am;
-        ha1[slot] = (uint32_t)(Am >> 32);
-        hr0[slot] = (uint32_t)Rg;
-        hr1[slot] = (uint32_t)(Rg >> 32);
     }
 };
 
@@ -341,36 +325,29 @@ struct SlabStore {
         st(&ring[i & (rcap - 1)], make_uint4(tile, 0u, (uint32_t)m, (uint32_t)(m >> 32)));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
-    __device__ bool lookup(uint32_t tile, uint32_t& slot, uint64_t& V, uint64_t& Am, uint64_t& Rg) const {
+    // (records keep their stride of two 16-byte words; the second one is unused since the table holds V only)
+    __device__ bool lookup(uint32_t tile, uint32_t& slot, uint64_t& V) const {
         const uint32_t key = tile + 1u;
         uint32_t hs = (key * 2654435761u) & (hcap - 1);
         for (uint32_t probe = 0; probe < hcap; ++probe) {
             const uint4 v = ld(&hash[2 * hs]);
             if (uni(v.x) != gen) break;  // another generation's record reads as empty
             if (uni(v.y) == key) {
-                const uint4 a = ld(&hash[2 * hs + 1]);
                 slot = hs;
                 V = uni64(v.z, v.w);
-                Am = uni64(a.x, a.y);
-                Rg = uni64(a.z, a.w);
                 return true;
             }
             hs = (hs + 1) & (hcap - 1);
         }
         slot = hs;
         V = 0ull;
-        Am = 0ull;
-        Rg = 0ull;
         return false;
     }
-    __device__ void values(uint32_t slot, uint64_t& V, uint64_t& Am, uint64_t& Rg) const {
-        const uint4 v = ld(&hash[2 * slot]), a = ld(&hash[2 * slot + 1]);
+    __device__ void value(uint32_t slot, uint64_t& V) const {
+        const uint4 v = ld(&hash[2 * slot]);
         V = uni64(v.z, v.w);
-        Am = uni64(a.x, a.y);
-        Rg = uni64(a.z, a.w);
     }
-    __device__ void update(uint32_t slot, uint32_t tile, uint64_t V, uint64_t Am, uint64_t Rg) {
-        st(&hash[2 * slot + 1], make_uint4((uint32_t)Am, (uint32_t)(Am >> 32), (uint32_t)Rg, (uint32_t)(Rg >> 32)));
+    __device__ void update(uint32_t slot, uint32_t tile, uint64_t V) {
         st(&hash[2 * slot], make_uint4(gen, tile + 1u, (uint32_t)V, (uint32_t)(V >> 32)));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
@@ -526,8 +503,8 @@ __device__ __forceinline__ void push8(SlabStore& S, Pending& P, WalkState& st, u
     const uint64_t up = H & 0xFFull, dn = (H >> 8) & 0xFFull, lf = (H >> 16) & 0xFFull, rt = (H >> 24) & 0xFFull;
     auto send = [&](uint32_t nt, uint64_t E) {  // same filter as the LDS form: skip entries the neighbour has walked
         uint32_t slot;
-        uint64_t V, Am, Rg;
-        if (S.lookup(nt, slot, V, Am, Rg)) E &= ~V;
+        uint64_t V;
+        if (S.lookup(nt, slot, V)) E &= ~V;
         if (E != 0ull) P.push(S, st, nt, E);
     };
     if (up) send(tile - 0x10000u, up << 56);          // (x,-1) -> pixel (x,7) of the tile above
@@ -578,7 +555,7 @@ __device__ __forceinline__ uint64_t tile_neighbours(int lane) {
 // the surrounding ring are loaded.
 struct TileFetch {
     uint32_t tile, slot;
-    uint64_t entry, V, Am, Rg;
+    uint64_t entry, V;
     size_t q;
     float dx, dy, rdx, rdy;
     uint32_t dm, rdm;
@@ -609,13 +586,8 @@ __device__ __forceinline__ TileFetch fetch_tile(const FloodArgs& A, const Store&
     if (fw.valid) {
         f.tile = fw.tile;
         f.entry = fw.entry;
-        f.slot = fw.slot;
-        f.known = fw.known;
-        f.V = f.Am = f.Rg = 0ull;
-        if (f.known) S.values(f.slot, f.V, f.Am, f.Rg);
     } else {
         S.get(i, f.tile, f.entry);
-        f.known = S.lookup(f.tile, f.slot, f.V, f.Am, f.Rg);
     }
     // Addresses: the tile's first pixel is a wave-uniform index (scalar unit), the lane's place in the tile and in
     // the ring around it are per-lane constants of the walk (G.off, G.roff): one 32-bit add per pixel, and the loads
@@ -625,21 +597,27 @@ __device__ __forceinline__ TileFetch fetch_tile(const FloodArgs& A, const Store&
     f.inside = (ty * 8 + lr) < A.h && (tx * 8 + lc) < A.w;
     const uint32_t q = f.inside ? base + G.off : 0u;
     f.q = q;
-    f.dm = f.rdm = 0u;
-    f.dx = f.dy = f.rdx = f.rdy = 0.f;
-    f.rinside = false;
-    if (!f.known) {  // wave-uniform
-        // (no label load: the commit pass clears the direction mask of every pixel it commits, so "not claimed by
-        // an earlier flood" is part of the mask test)
-        f.dm = ld8(A.dmask, q);
-        f.dx = ldf(A.dx, q);
-        f.dy = ldf(A.dy, q);
-        const int rr = ty * 8 + ry, rc = tx * 8 + rx;
-        f.rinside = ring_lane && rr >= 0 && rr < A.h && rc >= 0 && rc < A.w;
-        const uint32_t rq = f.rinside ? base + G.roff : 0u;
-        f.rdm = ld8(A.dmask, rq);
-        f.rdx = ldf(A.dx, rq);
-        f.rdy = ldf(A.dy, rq);
+    // The pixels are requested whether or not the wave has been in this tile before (one step in fourteen is a
+    // revisit): the table then holds the walked pixels only -- 12 bytes a tile instead of 28, which is what lets more
+    // walks share a CU -- and the loads are on their way before the table is looked at.
+    // (no label load: the commit pass clears the direction mask of every pixel it commits, so "not claimed by an
+    // earlier flood" is part of the mask test)
+    f.dm = ld8(A.dmask, q);
+    f.dx = ldf(A.dx, q);
+    f.dy = ldf(A.dy, q);
+    const int rr = ty * 8 + ry, rc = tx * 8 + rx;
+    f.rinside = ring_lane && rr >= 0 && rr < A.h && rc >= 0 && rc < A.w;
+    const uint32_t rq = f.rinside ? base + G.roff : 0u;
+    f.rdm = ld8(A.dmask, rq);
+    f.rdx = ldf(A.dx, rq);
+    f.rdy = ldf(A.dy, rq);
+    if (fw.valid) {
+        f.slot = fw.slot;
+        f.known = fw.known;
+        f.V = 0ull;
+        if (f.known) S.value(f.slot, f.V);
+    } else {
+        f.known = S.lookup(f.tile, f.slot, f.V);
     }
     return f;
 }
@@ -701,15 +679,10 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
         nknown += cur.known ? 1u : 0u;
 #endif
         const uint32_t tile = cur.tile;
-        uint64_t Am = cur.Am, Rg = cur.Rg;
-        if (!cur.known) {
-            const bool acc = cur.inside && ((cur.dm >> b) & 1) &&
-                             directional(cur.dx, cur.dy, sn, cs) > thr;
-            Am = __ballot(acc);
-            const bool racc = cur.rinside && ((cur.rdm >> b) & 1) &&
-                              directional(cur.rdx, cur.rdy, sn, cs) > thr;
-            Rg = __ballot(racc);
-        }
+        const bool acc = cur.inside && ((cur.dm >> b) & 1) && directional(cur.dx, cur.dy, sn, cs) > thr;
+        const uint64_t Am = __ballot(acc);  // acceptable pixels of the tile
+        const bool racc = cur.rinside && ((cur.rdm >> b) & 1) && directional(cur.rdx, cur.rdy, sn, cs) > thr;
+        const uint64_t Rg = __ballot(racc);  // ... of the 36-pixel ring around it (lane order, see ring_xy)
         LR_TICK(0)
         uint64_t R = cur.entry & Am;
         uint64_t New = 0ull;
@@ -727,7 +700,7 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
         }
         LR_TICK(1)
         if (New != 0ull || !cur.known) {
-            S.update(cur.slot, tile, cur.V | New, Am, Rg);
+            S.update(cur.slot, tile, cur.V | New);
             if (!cur.known) {
                 S.note_new(st.ntiles, cur.slot);
                 st.ntiles += 1;
@@ -888,10 +861,9 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
                 const uint32_t key = L.hk[i];
                 if (key) {
                     uint32_t slot;
-                    uint64_t v0, a0, r0;
-                    (void)G.lookup(key - 1u, slot, v0, a0, r0);
-                    G.update(slot, key - 1u, ((uint64_t)L.hv1[i] << 32) | L.hv0[i], ((uint64_t)L.ha1[i] << 32) | L.ha0[i],
-                             ((uint64_t)L.hr1[i] << 32) | L.hr0[i]);
+                    uint64_t v0;
+                    (void)G.lookup(key - 1u, slot, v0);
+                    G.update(slot, key - 1u, ((uint64_t)L.hv1[i] << 32) | L.hv0[i]);
                 }
             }
             rc = walk(A, k, b, thr, sn, cs, G, P, st, lane);
@@ -949,13 +921,16 @@ template <bool kRest>
 __device__ __forceinline__ void explore_body(const FloodArgs& A, const BinTrig& trig, const uint32_t* __restrict__ act,
                                              uint32_t* __restrict__ big_list, uint32_t first) {
     __shared__ uint32_t s_ring[3][kRingT];
-    __shared__ uint32_t s_hash[7][kHashT];
+    __shared__ uint32_t s_hash[3][kHashT];
     __shared__ uint32_t s_pend[2][kPend];
     __shared__ uint8_t s_ord[kHashT];
+#ifdef LR_LDS_PAD  // experiment: fewer walks per CU (what does occupancy buy?)
+    __shared__ uint32_t s_pad[LR_LDS_PAD / 4];
+    asm volatile("" ::"v"(&s_pad[threadIdx.x]) : "memory");
+#endif
     const int lane = threadIdx.x & 63;
     const uint32_t n_act = uni(A.ctrl[kCtrlNAct]), window = uni(A.ctrl[kCtrlWindow]);
-    LdsStore L{s_ring[0], s_ring[1], s_ring[2], s_hash[0], s_hash[1], s_hash[2],
-               s_hash[3], s_hash[4], s_hash[5], s_hash[6], s_ord};
+    LdsStore L{s_ring[0], s_ring[1], s_ring[2], s_hash[0], s_hash[1], s_hash[2], s_ord};
     Pending P{s_pend[0], s_pend[1]};
     // The list is walked from its end: the first round's list is in seed order, strongest first, and the longest
     // walks belong to the weak seeds at its end (low thresholds, large footprints).  Started first, they run
@@ -985,7 +960,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void
 
 // Second storage tier: the same walk from the start with a 1024-record ring and a 2048-tile table (dynamic LDS,
 // kBigLdsBytes), for the seeds the first tier handed over this round.
-constexpr size_t kBigLdsBytes = (size_t)(3 * kRingBig + 7 * kHashBig + 2 * kPend) * 4 + (size_t)kHashBig * 2;
+constexpr size_t kBigLdsBytes = (size_t)(3 * kRingBig + 3 * kHashBig + 2 * kPend) * 4 + (size_t)kHashBig * 2;
 __global__ __launch_bounds__(64) void flood_explore_big_kernel(FloodArgs A, BinTrig trig,
                                                                uint32_t* __restrict__ big_list) {
     extern __shared__ uint32_t s_big[];
@@ -996,10 +971,9 @@ __global__ __launch_bounds__(64) void flood_explore_big_kernel(FloodArgs A, BinT
     const uint32_t k = uni(big_list[ai]);
     uint32_t* ring = s_big;
     uint32_t* hash = ring + 3 * kRingBig;
-    uint32_t* pend = hash + 7 * kHashBig;
+    uint32_t* pend = hash + 3 * kHashBig;
     uint16_t* ord = reinterpret_cast<uint16_t*>(pend + 2 * kPend);
-    LdsStoreBig L{ring, ring + kRingBig, ring + 2 * kRingBig, hash, hash + kHashBig, hash + 2 * kHashBig,
-                  hash + 3 * kHashBig, hash + 4 * kHashBig, hash + 5 * kHashBig, hash + 6 * kHashBig, ord};
+    LdsStoreBig L{ring, ring + kRingBig, ring + 2 * kRingBig, hash, hash + kHashBig, hash + 2 * kHashBig, ord};
     Pending P{pend, pend + kPend};
     explore_seed<LdsStoreBig, false>(A, trig, k, L, P, big_list, lane);
 }
