@@ -128,7 +128,7 @@ struct FloodBuffers {
     // natural image 8.6 -> ~5 ms, the long-edge stress frame 11 -> ~6 ms, frames without such walks untouched.
     int win_hold_pct = 80;
     bool second_tier = true;  // test hook: without it every walk that outgrows the first tier goes to a slab
-    // The second-tier kernel asks for 72 KB of LDS per workgroup: launched every round for nothing it waits behind
+    // The second-tier kernel asks for 41 KB of LDS per workgroup: launched every round for nothing it waits behind
     // other frames' walks (44 us per launch with 16 frames in flight).  So a flood starts WITH it only if the
     // context's previous frame needed it (or there was none), and turns it on at the next look at the control block
     // once a walk has had to go to a slab.

@@ -147,8 +147,8 @@ namespace {
 
 constexpr uint32_t kMarkBit = 0x80000000u;
 // Per-wave LDS storage of a walk, two tiers: every seed starts with a 128-record frontier ring and a 256-tile table
-// (9.5 KB: 16 walks per CU); the few walks that outgrow it (edges over ~1500 px) start again in a workgroup with a
-// 1024-record ring and a 2048-tile table (72 KB: 2 per CU) before the global slabs are the last resort.
+// (5.4 KB of LDS, 90 VGPRs: 20 walks per CU); the few walks that outgrow it (edges over ~1500 px) start again in a workgroup with a
+// 1024-record ring and a 2048-tile table (41 KB: 3 per CU) before the global slabs are the last resort.
 #ifndef LR_RING_T
 #define LR_RING_T 128
 #endif
@@ -949,6 +949,10 @@ __device__ __forceinline__ void explore_body(const FloodArgs& A, const BinTrig& 
         }
     }
 }
+// (90 VGPRs: five walks per SIMD, 20 per CU; the 5.4 KB of LDS would allow 30.  Capped at 80 or 72 registers (six or
+// seven per SIMD) the compiler spills 9 or 18 of them and the rounds and the batch rate stay within 2 %: not taken.  With
+// half the walks per CU -- LDS padded to 18.9 KB -- round one takes 600 us instead of 374 and the batch rate drops by a
+// quarter, so occupancy is what the bulk rounds live on up to about this point.)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void flood_explore_kernel(
     FloodArgs A, BinTrig trig, const uint32_t* __restrict__ act, uint32_t* __restrict__ big_list) {
     explore_body<false>(A, trig, act, big_list, 0u);
@@ -1459,7 +1463,7 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
     const int hold_pct = hold_env >= 0 ? hold_env : B.win_hold_pct;
     static const bool hold_start_env = std::getenv("LIBRECTIFY_FLOOD_HOLD_START") != nullptr;
     const bool hold_start = B.hold_from_start || hold_start_env;
-    // the opt-in for 72 KB of dynamic LDS is a per-device attribute of the kernel: once per device of this process
+    // the opt-in for more than 32 KB of dynamic LDS is a per-device attribute of the kernel: once per device of this process
     {
         static std::atomic<uint64_t> done_mask{0};
         int dev = 0;
