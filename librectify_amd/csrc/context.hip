@@ -169,6 +169,22 @@ int staging_threads(int num_threads) {
 
 }  // namespace
 
+// The copy stream of a context is made when it first uploads a frame: HIP maps streams onto a few hardware queues
+// (GPU_MAX_HW_QUEUES), commands of streams that share one run in order, and a batch's lanes never upload -- their
+// copy streams would only take queues away from the one that does (transfers were seen waiting 4-6 ms behind another
+// lane's kernels).
+static int ensure_copy_stream(lr_context* c) {
+    if (c->copy_stream) return 0;
+    LR_HIP(hipSetDevice(c->device));
+    // ... and at a higher priority than the lanes' streams: streams of different priorities do not share a queue
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
+    static const bool plain = std::getenv("LIBRECTIFY_COPY_STREAM_PLAIN") != nullptr;  // (measurement)
+    if (plain || hi == lo) LR_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    else LR_HIP(hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, hi));
+    return 0;
+}
+
 // Rows of a host frame (|stride| >= w; a negative stride addresses the same rows from the other end, reference
 // image.cpp:11-19) into a device buffer of w x h floats, on stream `up`.  Page-locked memory goes as it lies; pageable
 // memory goes through the page-locked buffer `stage` in 4 MB bands, copied by up to `num_threads` threads, each band's
@@ -233,6 +249,7 @@ int ctx_upload_frame(lr_context* c, int slot, const float* buffer, int w, int h,
         set_error("upload: |stride| smaller than the width");
         return 1;
     }
+    if (ensure_copy_stream(c)) return 1;
     hipStream_t up = c->copy_stream;
     const size_t npix = (size_t)w * h;
     if (c->cap_slot[slot] < npix) {
@@ -278,12 +295,6 @@ int ctx_create(int device, lr_context** out) {
         set_error("hipStreamCreate failed");
         return 1;
     }
-    if (hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) {
-        (void)hipStreamDestroy(c->stream);
-        delete c;
-        set_error("hipStreamCreate failed");
-        return 1;
-    }
     for (auto& e : c->ev) (void)hipEventCreate(&e);
     {
         static const bool lane_debug = std::getenv("LIBRECTIFY_LANE_DEBUG") != nullptr;  // (its timeline times the uploads)
@@ -325,7 +336,7 @@ void ctx_destroy(lr_context* c) {
                     c->d_gnorm, c->d_models, c->d_refine_table, c->d_refine_edges, c->d_cht_acc};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
-    (void)hipStreamSynchronize(c->copy_stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     for (float* p : c->h_stage)
         if (p) (void)hipHostFree(p);
     for (auto& e : c->ev_up)
@@ -336,7 +347,7 @@ void ctx_destroy(lr_context* c) {
         if (p) (void)hipHostFree(p);
     for (auto& e : c->ring_ev)
         if (e) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(c->copy_stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->h_res) (void)hipHostFree(c->h_res);
     if (c->h_model) (void)hipHostFree(c->h_model);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
@@ -1304,6 +1315,7 @@ int ctx_find_groups_device(lr_context* c, const float* d_image, int w, int h, in
 // the same batch without the transfers ran at 9.0; LIBRECTIFY_LANE_DEBUG prints each frame's lead.)  A lane makes its
 // stream wait for the frame's transfer and never touches host memory itself.
 static int ensure_upload_ring(lr_context* c, int R, size_t npix, bool staging) {
+    if (ensure_copy_stream(c)) return 1;
     if ((int)c->ring_img.size() < R || c->ring_cap_pix < npix) {
         LR_HIP(hipStreamSynchronize(c->copy_stream));
         for (float* p : c->ring_img)
@@ -1411,6 +1423,8 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
             slot_busy[(size_t)slot].store(1, std::memory_order_relaxed);
             float* stage = is_page_locked(h_frames[i]) ? nullptr : c->ring_stage[(size_t)slot];
             const double t_u0 = now_ms();
+            hipEvent_t e_dbg = nullptr;
+            if (lane_debug && hipEventCreate(&e_dbg) == hipSuccess) (void)hipEventRecord(e_dbg, c->copy_stream);
             if (upload_rows(c, c->ring_img[(size_t)slot], stage, h_frames[i], w, h, stride, num_threads, c->copy_stream) ||
                 hipEventRecord(c->ring_ev[(size_t)slot], c->copy_stream) != hipSuccess) {
                 up_err = get_error().empty() ? "upload failed" : get_error();
@@ -1418,7 +1432,16 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
                 return;
             }
             enq[(size_t)i].store(slot + 1, std::memory_order_release);
-            if (lane_debug) std::fprintf(stderr, "uploader frame %d: slot %d, waited %d naps for it, staged and enqueued in %.2f ms\n", i, slot, spins, now_ms() - t_u0);
+            if (lane_debug) {
+                const double t_u1 = now_ms();
+                float dma = 0.f;  // from the moment the link was free for this frame to the end of its last transfer
+                if (e_dbg) {
+                    (void)hipEventSynchronize(c->ring_ev[(size_t)slot]);
+                    if (hipEventElapsedTime(&dma, e_dbg, c->ring_ev[(size_t)slot]) != hipSuccess) (void)hipGetLastError();
+                    (void)hipEventDestroy(e_dbg);
+                }
+                std::fprintf(stderr, "uploader frame %d: slot %d, waited %d naps for it, staged and enqueued in %.2f ms, on the link %.2f ms\n", i, slot, spins, t_u1 - t_u0, dma);
+            }
         }
     };
     std::atomic<int> next_frame{0};
