@@ -371,8 +371,9 @@ def test_batch_entry_point_matches_single_calls(L, ctx):
 
 def test_host_batch_entry_point_pageable_pinned_and_strided(L, ctx):
     """lr_find_line_segment_groups_batch_host (the reference's kind of input, many frames at once): pageable frames
-    through the pinned staging ring, page-locked frames DMA-copied where they lie, row strides > width, a negative
-    stride, more frames than lanes (so every lane prefetches) and fewer; all equal to the single-frame call."""
+    through page-locked staging buffers, page-locked frames DMA-copied where they lie, both kinds mixed, row strides >
+    width, a negative stride, more frames than lanes and than slots of the upload pool, and fewer; all equal to the
+    single-frame call."""
     import ctypes as C
 
     from librectify_amd import synth
@@ -409,9 +410,18 @@ def test_host_batch_entry_point_pageable_pinned_and_strided(L, ctx):
     assert rc == 0
     for i in range(9):
         _assert_lines_equal(out[i][: n[i]], single[i])
+    # page-locked and pageable frames mixed in one call, five times more frames than the upload pool has slots
+    # (2 lanes + 6): every slot and staging buffer is reused several times, in whatever order the frames finish
+    ctx.set_batch_streams(2)
+    order = [(7 * k) % 9 for k in range(40)]
+    mixed = [pinned[i] if k % 3 else frames[i].copy() for k, i in enumerate(order)]
+    check(*ctx.find_line_segment_groups_batch_host(mixed, 3.3, capacity=1024, num_threads=4), order=order)
     ctx.host_free(pinned)
     with pytest.raises(Exception):
         ctx.find_line_segment_groups_batch_host(np.zeros((3, 4, 40), np.float32), 2.0)  # below the 5x5 filter: loud
+    # ... and the context is as good as before after the refused call
+    ctx.set_batch_streams(3)
+    check(*ctx.find_line_segment_groups_batch_host(frames, 3.3, capacity=1024))
 
 
 def test_batch_lanes_with_refine_and_with_prosac_and_concurrent_callers(L, ctx):
