@@ -230,6 +230,8 @@ int launch_filter_lines(const LineSegment* raw, const uint32_t* d_n_raw, uint32_
 int launch_lines_bbox(LineSegment* lines, uint32_t n, uint32_t* gctl, float* gnorm, hipStream_t s);
 int launch_pencil_model(const LineSegment* lines, const uint32_t* gctl, const float* gnorm, PencilTable all,
                         PencilTable round0, uint32_t line_cap, hipStream_t s);
+int launch_result_gather(const uint32_t* counts, const uint32_t* gctl, const float* models, const LineSegment* lines,
+                         uint32_t cap_lines, void* host_block, hipStream_t s);
 int launch_peel(PencilTable cur, PencilTable nxt, PencilTable all, const float* scores, uint32_t n_iter, uint64_t seed,
                 float tol, float garbage_tol, int max_models, uint32_t* gctl, float* stage4 /* 4 floats per line */,
                 LineSegment* lines, float* models, hipStream_t s);

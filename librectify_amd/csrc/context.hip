@@ -566,13 +566,9 @@ int enqueue_groups(lr_context* c, uint32_t line_cap, int max_models, float inlie
 
 // header (counts, peeling control block, refit models) and the first res_lines_cap grouped lines -> pinned host block
 int enqueue_result_copy(lr_context* c) {
-    uint8_t* h = c->h_res;
-    LR_HIP(hipMemcpyAsync(h, c->d_counts, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    LR_HIP(hipMemcpyAsync(h + 32, c->d_gctl, kGcWords * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    LR_HIP(hipMemcpyAsync(h + 64, c->d_models, 40 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    static_assert(kGcWords == 8 && kResHeaderBytes == 256, "layout of the result block (result_gather_kernel)");
     const size_t nl = std::min<size_t>(c->res_lines_cap, c->cap_flines);
-    LR_HIP(hipMemcpyAsync(h + kResHeaderBytes, c->d_flines, nl * sizeof(LineSegment), hipMemcpyDeviceToHost, c->stream));
-    return 0;
+    return launch_result_gather(c->d_counts, c->d_gctl, c->d_models, c->d_flines, (uint32_t)nl, c->h_res, c->stream);
 }
 
 void record_stage_times(lr_context* c, bool with_groups) {

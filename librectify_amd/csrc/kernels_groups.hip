@@ -496,4 +496,31 @@ int launch_peel(PencilTable cur, PencilTable nxt, PencilTable all, const float* 
     return 0;
 }
 
+// ---- a frame's results into the page-locked block the host reads after its one wait -------------------------------------
+// Layout (context.h kResHeaderBytes = 256): words 0..7 the stage counts, words 8..15 the peeling control block, words
+// 16..55 the refit models, from byte 256 on the grouped lines (as many as there are, up to the block's capacity).  One
+// launch instead of four device-to-host copies, and only the lines that exist cross the link.
+namespace {
+__global__ __launch_bounds__(256) void result_gather_kernel(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ gctl,
+                                                            const uint32_t* __restrict__ models,
+                                                            const uint32_t* __restrict__ lines, uint32_t cap_lines,
+                                                            uint32_t* __restrict__ dst) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < 8) dst[t] = counts[t];
+    else if (t < 16) dst[t] = gctl[t - 8];
+    else if (t < 56) dst[t] = models[t - 16];
+    const uint32_t n = min(gctl[kGcLines], cap_lines) * (uint32_t)(sizeof(LineSegment) / 4);
+    for (uint32_t i = t; i < n; i += gridDim.x * 256) dst[64 + i] = lines[i];
+}
+}  // namespace
+
+int launch_result_gather(const uint32_t* counts, const uint32_t* gctl, const float* models, const LineSegment* lines,
+                         uint32_t cap_lines, void* host_block, hipStream_t s) {
+    static_assert(sizeof(LineSegment) % 4 == 0, "LineSegment is copied word by word");
+    hipLaunchKernelGGL(result_gather_kernel, dim3(16), dim3(256), 0, s, counts, gctl, reinterpret_cast<const uint32_t*>(models),
+                       reinterpret_cast<const uint32_t*>(lines), cap_lines, static_cast<uint32_t*>(host_block));
+    LR_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace lramd
