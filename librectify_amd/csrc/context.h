@@ -28,6 +28,8 @@ struct lr_context {
     float* h_stage[2] = {nullptr, nullptr};
     size_t cap_stage[2] = {0, 0};
     hipEvent_t ev_up[2] = {};
+    hipEvent_t ev_wait = nullptr;  // (blocking-sync flag) what a batch lane sleeps on
+    bool sleep_in_wait = false;
     // Batch calls on host frames: a ring of device frames (and, for pageable frames, of page-locked staging buffers)
     // that ONE uploader fills in frame order on the copy stream, as far ahead of the lanes as the ring allows
     // (find_groups_batch).
