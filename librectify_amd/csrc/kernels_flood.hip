@@ -222,6 +222,17 @@ static_assert(kCtrlWords == kFloodCtrlWords, "control block size");
 // compiler keep them in SGPRs and run the bit-board logic on the scalar unit instead of the vector ALU.
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint64_t uni64(uint32_t lo, uint32_t hi) { return ((uint64_t)uni(hi) << 32) | uni(lo); }
+// Lane masks straight from the comparison (v_cmp writes the SGPR pair), and a lane mask used as a per-lane condition.
+// __ballot(a && b) goes through a 0/1 register and a second compare per ballot; the walk's conditions are combined as
+// masks on the scalar unit instead.  (All 64 lanes are active wherever these are used.)
+__device__ __forceinline__ uint64_t m_eq(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 32); }
+__device__ __forceinline__ uint64_t m_ne(uint32_t a, uint32_t b) { return __builtin_amdgcn_uicmp(a, b, 33); }
+__device__ __forceinline__ uint64_t m_ne64(uint64_t a, uint64_t b) { return __builtin_amdgcn_uicmpl(a, b, 33); }
+__device__ __forceinline__ uint64_t m_lt_s(int a, int b) { return __builtin_amdgcn_sicmp(a, b, 40); }
+__device__ __forceinline__ uint64_t m_ge_s(int a, int b) { return __builtin_amdgcn_sicmp(a, b, 39); }
+__device__ __forceinline__ uint64_t m_gt_s(int a, int b) { return __builtin_amdgcn_sicmp(a, b, 38); }
+__device__ __forceinline__ uint64_t m_gt_f(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 2); }
+__device__ __forceinline__ bool lane_of(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
 __device__ __forceinline__ uint64_t uni64(uint64_t v) { return uni64((uint32_t)v, (uint32_t)(v >> 32)); }
 
 struct WalkState {
@@ -441,55 +452,57 @@ __device__ __forceinline__ void push8(LdsStoreT<kRing, kHash, OrdT>& S, Pending&
     uint32_t hk0 = S.hk[ts];
     uint32_t v0 = S.hv0[ts], v1 = S.hv1[ts];
     const uint32_t pt = P.pt[hs], pi = P.pi[hs];
-    const bool want = c.dl && E != 0ull;
-    bool found = hk0 == key;
-    bool searching = want && !found && hk0 != 0u;
-    for (int probe = 1; probe < kHash && __ballot(searching) != 0ull; ++probe) {  // collisions: rare
-        if (searching) {
+    // lane masks from here on (lanes 0..7 carry a direction): what happens to a direction is decided on the scalar unit,
+    // and a whole branch is skipped when no lane takes it
+    const uint64_t m_want = m_ne64(E, 0ull) & 0xFFull;
+    uint64_t m_found = m_eq(hk0, key);
+    uint64_t m_search = m_want & ~m_found & m_ne(hk0, 0u);
+    for (int probe = 1; probe < kHash && m_search != 0ull; ++probe) {  // collisions: rare
+        if (lane_of(m_search)) {
             ts = (ts + 1) & (kHash - 1);
             hk0 = S.hk[ts];
-            if (hk0 == key) {
-                v0 = S.hv0[ts];
-                v1 = S.hv1[ts];
-                found = true;
-                searching = false;
-            } else if (hk0 == 0u) {
-                searching = false;
-            }
         }
+        const uint64_t hit = m_search & m_eq(hk0, key);
+        if (lane_of(hit)) {
+            v0 = S.hv0[ts];
+            v1 = S.hv1[ts];
+        }
+        m_found |= hit;
+        m_search &= ~hit & m_ne(hk0, 0u);
     }
     // A neighbour the wave already knows needs a record only for entry pixels it has not walked yet: every walked
     // set V is a union of whole in-tile components, so entries inside V could add nothing.  This drops the record
     // back into the tile a step came from (about half of all records otherwise).
-    if (found) E &= ~(((uint64_t)v1 << 32) | v0);
-    const bool active = want && E != 0ull;
+    if (lane_of(m_found)) E &= ~(((uint64_t)v1 << 32) | v0);
+    const uint64_t m_active = m_want & m_ne64(E, 0ull);
     // A record of the same tile that is still in the frontier (ring index in [head, tail)) takes the entries: the
     // pending entry was written with that record, and a ring slot is not reused while its index is in the window.
-    const bool merge = active && pt == key && (int32_t)(pi - st.head) >= 0 && (int32_t)(st.tail - pi) > 0;
-    if (merge) {
-        const uint32_t j = pi & (kRing - 1);
-        atomicOr(&S.rlo[j], (uint32_t)E);
-        atomicOr(&S.rhi[j], (uint32_t)(E >> 32));
+    const uint64_t m_merge = m_active & m_eq(pt, key) & m_ge_s((int32_t)(pi - st.head), 0) & m_gt_s((int32_t)(st.tail - pi), 0);
+    if (m_merge != 0ull) {
+        if (lane_of(m_merge)) {
+            const uint32_t j = pi & (kRing - 1);
+            atomicOr(&S.rlo[j], (uint32_t)E);
+            atomicOr(&S.rhi[j], (uint32_t)(E >> 32));
+        }
     }
-    const bool fresh = active && !merge;
-    const uint64_t mf = __ballot(fresh);
-    if (fresh) {
-        const uint32_t pos = st.tail + (uint32_t)__popcll(mf & ((1ull << lane) - 1ull));
-        const uint32_t j = pos & (kRing - 1);
-        S.rt[j] = nt;
-        S.rlo[j] = (uint32_t)E;
-        S.rhi[j] = (uint32_t)(E >> 32);
-        P.pt[hs] = key;
-        P.pi[hs] = pos;
-    }
+    const uint64_t mf = m_active & ~m_merge;  // directions that get a record of their own
     if (mf != 0ull) {
+        if (lane_of(mf)) {
+            const uint32_t pos = st.tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(mf >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mf, 0u));
+            const uint32_t j = pos & (kRing - 1);
+            S.rt[j] = nt;
+            S.rlo[j] = (uint32_t)E;
+            S.rhi[j] = (uint32_t)(E >> 32);
+            P.pt[hs] = key;
+            P.pi[hs] = pos;
+        }
         const int f = __builtin_ctzll(mf);  // the lane whose record went to index st.tail
         fw.valid = true;
         fw.tile = (uint32_t)__builtin_amdgcn_readlane((int)nt, f);
         fw.slot = (uint32_t)__builtin_amdgcn_readlane((int)ts, f);
         fw.entry = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(E >> 32), f) << 32) |
                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)E, f);
-        fw.known = (__ballot(found) >> f) & 1ull;
+        fw.known = (m_found >> f) & 1ull;
     }
     st.tail += (uint32_t)__popcll(mf);
 }
@@ -559,7 +572,8 @@ struct TileFetch {
     size_t q;
     float dx, dy, rdx, rdy;
     uint32_t dm, rdm;
-    bool known, inside, rinside;
+    bool known;
+    uint64_t inside, rinside;  // lane masks: the lane's pixel of the tile / of the ring lies in the frame
 };
 
 // `fw` (when valid) is the record at ring index i as the previous step's push8 left it in registers.
@@ -594,8 +608,8 @@ __device__ __forceinline__ TileFetch fetch_tile(const FloodArgs& A, const Store&
     // take a uniform base with a 32-bit byte offset (frames have fewer than 2^29 pixels: launch_filter checks).
     const int ty = (int)(f.tile >> 16), tx = (int)(f.tile & 0xFFFFu);  // tile id = ty << 16 | tx
     const uint32_t base = (uint32_t)(ty * 8) * (uint32_t)A.w + (uint32_t)(tx * 8);
-    f.inside = (ty * 8 + lr) < A.h && (tx * 8 + lc) < A.w;
-    const uint32_t q = f.inside ? base + G.off : 0u;
+    f.inside = m_lt_s(ty * 8 + lr, A.h) & m_lt_s(tx * 8 + lc, A.w);
+    const uint32_t q = lane_of(f.inside) ? base + G.off : 0u;
     f.q = q;
     // The pixels are requested whether or not the wave has been in this tile before (one step in fourteen is a
     // revisit): the table then holds the walked pixels only -- 12 bytes a tile instead of 28, which is what lets more
@@ -606,8 +620,10 @@ __device__ __forceinline__ TileFetch fetch_tile(const FloodArgs& A, const Store&
     f.dx = ldf(A.dx, q);
     f.dy = ldf(A.dy, q);
     const int rr = ty * 8 + ry, rc = tx * 8 + rx;
-    f.rinside = ring_lane && rr >= 0 && rr < A.h && rc >= 0 && rc < A.w;
-    const uint32_t rq = f.rinside ? base + G.roff : 0u;
+    // (one unsigned comparison per coordinate: a negative one reads as a huge number; lanes 36..63 have no ring pixel)
+    f.rinside = __builtin_amdgcn_uicmp((uint32_t)rr, (uint32_t)A.h, 36) & __builtin_amdgcn_uicmp((uint32_t)rc, (uint32_t)A.w, 36) &
+                0xFFFFFFFFFull;
+    const uint32_t rq = lane_of(f.rinside) ? base + G.roff : 0u;
     f.rdm = ld8(A.dmask, rq);
     f.rdx = ldf(A.dx, rq);
     f.rdy = ldf(A.dy, rq);
@@ -661,6 +677,7 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
     if (st.head == st.tail) return 0;
     if ((st.tail - st.head) + 8u > S.ring_cap() || st.ntiles + 2u > S.hash_limit()) return 1;
     const PushLane pc = push_lane(lane);
+    const uint32_t bin_bit = 1u << b;
     Forward fw;
     fw.valid = false;
     LaneGeom G;
@@ -679,10 +696,9 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
         nknown += cur.known ? 1u : 0u;
 #endif
         const uint32_t tile = cur.tile;
-        const bool acc = cur.inside && ((cur.dm >> b) & 1) && directional(cur.dx, cur.dy, sn, cs) > thr;
-        const uint64_t Am = __ballot(acc);  // acceptable pixels of the tile
-        const bool racc = cur.rinside && ((cur.rdm >> b) & 1) && directional(cur.rdx, cur.rdy, sn, cs) > thr;
-        const uint64_t Rg = __ballot(racc);  // ... of the 36-pixel ring around it (lane order, see ring_xy)
+        // acceptable pixels of the tile, and of the 36-pixel ring around it (lane order, see ring_xy)
+        const uint64_t Am = cur.inside & m_ne(cur.dm & bin_bit, 0u) & m_gt_f(directional(cur.dx, cur.dy, sn, cs), thr);
+        const uint64_t Rg = cur.rinside & m_ne(cur.rdm & bin_bit, 0u) & m_gt_f(directional(cur.rdx, cur.rdy, sn, cs), thr);
         LR_TICK(0)
         uint64_t R = cur.entry & Am;
         uint64_t New = 0ull;
@@ -690,9 +706,9 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
             // Connected closure of the entry pixels inside the tile.  One iteration is "8-neighbour dilation of R, restricted to Am", evaluated
             // with a pixel per lane (an acceptable pixel joins when its 3x3 neighbourhood meets R): three vector
             // instructions instead of sixteen on the scalar unit, which the rest of the step keeps busy.
-            const uint64_t reach = ((Am >> lane) & 1ull) ? nbr : 0ull;
+            const uint64_t reach = lane_of(Am) ? nbr : 0ull;
             for (;;) {
-                const uint64_t Rn = __ballot((R & reach) != 0ull);
+                const uint64_t Rn = m_ne64(R & reach, 0ull);
                 if (Rn == R) break;
                 R = Rn;
             }
@@ -713,8 +729,7 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
         if (New != 0ull) {
             if constexpr (!Store::kDeferStamps) {
                 uint32_t old = kLabelFree;
-                const bool issue = (New >> lane) & 1ull;
-                if (issue) {
+                if (lane_of(New)) {
                     old = atomicMin(&A.label[cur.q], mine);
                     A.dirty[cur.q >> 8] = 1;
                 }
@@ -727,7 +742,7 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
                 if (__ballot(foreign)) st.blocked = true;
             }
             // ring pixels that are acceptable and touch a newly walked pixel become entries of their own tiles
-            const uint64_t H = __ballot(((Rg >> lane) & 1ull) && (New & adj) != 0ull);
+            const uint64_t H = Rg & m_ne64(New & adj, 0ull);
             if (H != 0ull) push8(S, P, st, tile, H, lane, pc, fw);
         }
         fw.valid = fw.valid && was_empty;
