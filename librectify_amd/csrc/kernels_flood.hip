@@ -278,19 +278,18 @@ struct LdsStoreT {
     __device__ bool lookup(uint32_t tile, uint32_t& slot, uint64_t& V) const {
         const uint32_t key = tile + 1u;
         uint32_t hs = (key * 2654435761u) >> kHashShift;
-        for (int probe = 0; probe < kHash; ++probe) {
-            const uint32_t cur = uni(hk[hs]);
-            if (cur == key) {
-                slot = hs;
-                V = uni64(hv0[hs], hv1[hs]);
-                return true;
+        uint32_t cur = uni(hk[hs]);
+        if (cur != key && cur != 0u) {  // a collision: rare, and kept out of the straight path
+            for (int probe = 1; probe < kHash && cur != key && cur != 0u; ++probe) {
+                hs = (hs + 1) & (kHash - 1);
+                cur = uni(hk[hs]);
             }
-            if (cur == 0u) break;
-            hs = (hs + 1) & (kHash - 1);
         }
         slot = hs;
         V = 0ull;
-        return false;
+        if (cur != key) return false;  // (the table is never full: hash_limit)
+        V = uni64(hv0[hs], hv1[hs]);
+        return true;
     }
     __device__ void value(uint32_t slot, uint64_t& V) const { V = uni64(hv0[slot], hv1[slot]); }
     __device__ void update(uint32_t slot, uint32_t tile, uint64_t V) {
