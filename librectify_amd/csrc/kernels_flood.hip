@@ -706,10 +706,10 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
             // with a pixel per lane (an acceptable pixel joins when its 3x3 neighbourhood meets R): three vector
             // instructions instead of sixteen on the scalar unit, which the rest of the step keeps busy.
             const uint64_t reach = lane_of(Am) ? nbr : 0ull;
-            for (;;) {
-                const uint64_t Rn = m_ne64(R & reach, 0ull);
-                if (Rn == R) break;
-                R = Rn;
+            for (;;) {  // two dilations per convergence test: the test (compare -> scalar compare -> branch) is the slow part
+                const uint64_t R1 = m_ne64(R & reach, 0ull);
+                R = m_ne64(R1 & reach, 0ull);
+                if (R == R1) break;
             }
             New = R & ~cur.V;
         }
