@@ -1090,6 +1090,11 @@ __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift) {
     ctrl[kCtrlNBig] = 0u;
 }
 
+// (Commit pass and survivors pass in ONE launch -- blocked marks in two alternating buffers, counts and flags written
+// by every exploration instead of reset here, the survivors reading stamps as they find them, the workgroups counting
+// themselves off on a tree of counters -- was built and is exact, but saves nothing: 30, 23, 17, 13, 11, 10 us per
+// round against 16 + 13, 14 + 10, 9 + 9, ... for the two launches, single frames and batches unchanged.  With one
+// __threadfence per workgroup of the 4336 it took 65-140 us per round: the fence, not the atomics.)
 // After the commit: which seeds go on to the next round?
 __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, const uint32_t* __restrict__ act,
                                                               uint8_t* __restrict__ state,
