@@ -93,6 +93,9 @@ int launch_seed_select(const uint64_t* cand, const uint32_t* cand_count, const u
                        uint32_t key_cap, uint32_t* n_seeds, void* temp, size_t temp_bytes, hipStream_t s);
 int launch_seed_sort(uint64_t* keys_in, uint64_t* keys_out, uint32_t n, void* temp, size_t temp_bytes, hipStream_t s);
 // the seed count stays on the device (*n_seeds, clamped to cap); the launch covers `cap` seeds
+bool seed_order_is_fused(uint32_t cap);
+int launch_seed_order(uint64_t* keys, const uint32_t* n_seeds, uint32_t cap, const float* dx, const float* dy, BinTrig trig,
+                      float trace_tolerance, int32_t* seed_idx, int32_t* seed_bin, float* seed_thr, hipStream_t s);
 int launch_seed_setup(const uint64_t* keys_sorted, const uint32_t* n_seeds, uint32_t cap, const float* dx, const float* dy,
                       BinTrig trig, float trace_tolerance, int32_t* seed_idx, int32_t* seed_bin, float* seed_thr,
                       hipStream_t s);

@@ -481,10 +481,16 @@ int enqueue_seeds(lr_context* c) {
                            c->tile_pass, c->tile_off, c->keys_a, c->seed_cap, c->d_counts + kCntSeeds, c->temp,
                            c->temp_bytes, c->stream))
         return 1;
-    if (launch_seed_sort(c->keys_a, c->keys_b, c->seed_cap, c->temp, c->temp_bytes, c->stream)) return 1;
-    if (launch_seed_setup(c->keys_b, c->d_counts + kCntSeeds, c->seed_cap, c->dx, c->dy, c->trig, kTraceTolerance,
-                          c->seed_idx, c->seed_bin, c->seed_thr, c->stream))
-        return 1;
+    if (seed_order_is_fused(c->seed_cap)) {
+        if (launch_seed_order(c->keys_a, c->d_counts + kCntSeeds, c->seed_cap, c->dx, c->dy, c->trig, kTraceTolerance,
+                              c->seed_idx, c->seed_bin, c->seed_thr, c->stream))
+            return 1;
+    } else {
+        if (launch_seed_sort(c->keys_a, c->keys_b, c->seed_cap, c->temp, c->temp_bytes, c->stream)) return 1;
+        if (launch_seed_setup(c->keys_b, c->d_counts + kCntSeeds, c->seed_cap, c->dx, c->dy, c->trig, kTraceTolerance,
+                              c->seed_idx, c->seed_bin, c->seed_thr, c->stream))
+            return 1;
+    }
     LR_HIP(hipEventRecord(c->ev[2], c->stream));
     return 0;
 }

@@ -105,7 +105,98 @@ __global__ __launch_bounds__(256) void seed_setup_kernel(const uint64_t* __restr
     seed_thr[k] = (1 - trace_tolerance) * v;
 }
 
+// ---- the seed order in two launches (frames of up to kOwnSortCap seeds) -------------------------------------------------
+// rocPRIM sorts the 64-bit keys of a 4K frame in seven launches of 5-14 us, each far from filling the chip; with the
+// pad launch before and the set-up launch after, the sort was nine launches and 60 us of a 1.6 ms frame.  Here: every
+// workgroup sorts 4096 keys in LDS (slots past the seed count read as the largest key: no pad launch), then every key
+// finds its place by counting the smaller keys in each of the other sorted blocks (keys are unique: they end in the pixel
+// index) and writes the seed's record there directly (no sorted key array, no set-up launch).
+constexpr uint32_t kSortBlock = 4096;
+constexpr uint32_t kOwnSortBlocks = 32;
+constexpr uint32_t kOwnSortCap = kSortBlock * kOwnSortBlocks;
+
+__global__ __launch_bounds__(1024) void seed_block_sort_kernel(uint64_t* __restrict__ keys, uint32_t cap,
+                                                               const uint32_t* __restrict__ n_ptr) {
+    __shared__ uint64_t sk[kSortBlock];
+    const uint32_t n = min(*n_ptr, cap);
+    const uint32_t base = blockIdx.x * kSortBlock;
+    if (base >= n) return;  // nothing but padding (the ranking pass does not look at such a block)
+    for (uint32_t t = threadIdx.x; t < kSortBlock; t += 1024) sk[t] = (base + t < n) ? keys[base + t] : ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= kSortBlock; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t p = threadIdx.x; p < kSortBlock / 2; p += 1024) {
+                const uint32_t i = ((p & ~(j - 1u)) << 1) | (p & (j - 1u));  // the pair's lower index: bit log2(j) clear
+                const uint64_t a = sk[i], b = sk[i + j];
+                const bool up = (i & k) == 0u;
+                if ((a > b) == up) {
+                    sk[i] = b;
+                    sk[i + j] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (uint32_t t = threadIdx.x; t < kSortBlock; t += 1024)
+        if (base + t < cap) keys[base + t] = sk[t];
+}
+
+__global__ __launch_bounds__(256) void seed_rank_setup_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ n_ptr,
+                                                              uint32_t cap, const float* __restrict__ dx,
+                                                              const float* __restrict__ dy, BinTrig trig, float trace_tolerance,
+                                                              int32_t* __restrict__ seed_idx, int32_t* __restrict__ seed_bin,
+                                                              float* __restrict__ seed_thr) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t n = min(*n_ptr, cap);
+    const uint32_t n_blocks = (n + kSortBlock - 1) / kSortBlock;
+    const uint32_t mine = g / kSortBlock;
+    if (mine >= n_blocks) return;
+    const uint64_t key = keys[g];
+    if (key == ~0ull) return;  // padding of the last block
+    uint32_t rank = g - mine * kSortBlock;
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        if (b == mine) continue;
+        const uint64_t* __restrict__ blk = keys + (size_t)b * kSortBlock;
+        uint32_t lo = 0, len = kSortBlock;  // count of keys below `key` in a sorted block of 4096
+        while (len > 0) {
+            const uint32_t half = len >> 1;
+            if (blk[lo + half] < key) {
+                lo += half + 1;
+                len -= half + 1;
+            } else {
+                len = half;
+            }
+        }
+        rank += lo;
+    }
+    const uint32_t low = (uint32_t)key;
+    const uint32_t idx = low >> 3;
+    const int bin = (int)(low & 7u);
+    // flood(): min_val = (1 - tolerance) * image(seed) with image = grad[seed_bin] (filter.cpp:112-113)
+    const float v = directional(dx[idx], dy[idx], trig.st[bin], trig.ct[bin]);
+    seed_idx[rank] = (int32_t)idx;
+    seed_bin[rank] = bin;
+    seed_thr[rank] = (1 - trace_tolerance) * v;
+}
+
 }  // namespace
+
+// true when launch_seed_order handles this capacity itself (else: seed_pad + launch_seed_sort + launch_seed_setup)
+bool seed_order_is_fused(uint32_t cap) {
+    static const bool rocprim_only = std::getenv("LIBRECTIFY_SEED_SORT_ROCPRIM") != nullptr;  // (comparison knob)
+    return !rocprim_only && cap <= kOwnSortCap;
+}
+
+int launch_seed_order(uint64_t* keys, const uint32_t* n_seeds, uint32_t cap, const float* dx, const float* dy, BinTrig trig,
+                      float trace_tolerance, int32_t* seed_idx, int32_t* seed_bin, float* seed_thr, hipStream_t s) {
+    if (cap == 0) return 0;
+    const uint32_t nb = (cap + kSortBlock - 1) / kSortBlock;
+    hipLaunchKernelGGL(seed_block_sort_kernel, dim3(nb), dim3(1024), 0, s, keys, cap, n_seeds);
+    hipLaunchKernelGGL(seed_rank_setup_kernel, dim3((nb * kSortBlock + 255) / 256), dim3(256), 0, s, keys, n_seeds, cap, dx, dy,
+                       trig, trace_tolerance, seed_idx, seed_bin, seed_thr);
+    LR_HIP(hipGetLastError());
+    return 0;
+}
 
 size_t seeds_temp_bytes(int n_tiles, size_t max_seeds) {
     size_t a = 0, b = 0;
@@ -126,7 +217,8 @@ int launch_seed_select(const uint64_t* cand, const uint32_t* cand_count, const u
                                    rocprim::plus<uint32_t>(), s));
     hipLaunchKernelGGL(seed_write_kernel, dim3(blocks), dim3(256), 0, s, cand, cand_count, n_tiles, cand_cap, maxmag,
                        seed_keep_ratio, tile_pass, tile_off, keys, key_cap, n_seeds);
-    hipLaunchKernelGGL(seed_pad_kernel, dim3((key_cap + 255) / 256), dim3(256), 0, s, keys, key_cap, n_seeds);
+    if (!seed_order_is_fused(key_cap))
+        hipLaunchKernelGGL(seed_pad_kernel, dim3((key_cap + 255) / 256), dim3(256), 0, s, keys, key_cap, n_seeds);
     LR_HIP(hipGetLastError());
     return 0;
 }
