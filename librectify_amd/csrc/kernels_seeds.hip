@@ -115,30 +115,60 @@ constexpr uint32_t kSortBlock = 4096;
 constexpr uint32_t kOwnSortBlocks = 32;
 constexpr uint32_t kOwnSortCap = kSortBlock * kOwnSortBlocks;
 
+// Bitonic sort of 4096 keys by 1024 threads, four consecutive keys per thread: a compare-exchange at distance 1 or 2 is
+// inside a thread, at distance 4..128 inside a wavefront (shuffles, no barrier), and only the ten steps at distance
+// >= 256 go through LDS with a barrier (33 us for the ten blocks of a 4K frame; all 78 steps through LDS: 37 us).
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int lane_mask) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, lane_mask);
+    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), lane_mask);
+    return ((uint64_t)hi << 32) | lo;
+}
 __global__ __launch_bounds__(1024) void seed_block_sort_kernel(uint64_t* __restrict__ keys, uint32_t cap,
                                                                const uint32_t* __restrict__ n_ptr) {
     __shared__ uint64_t sk[kSortBlock];
     const uint32_t n = min(*n_ptr, cap);
     const uint32_t base = blockIdx.x * kSortBlock;
     if (base >= n) return;  // nothing but padding (the ranking pass does not look at such a block)
-    for (uint32_t t = threadIdx.x; t < kSortBlock; t += 1024) sk[t] = (base + t < n) ? keys[base + t] : ~0ull;
-    __syncthreads();
+    const uint32_t t = threadIdx.x, i0 = 4u * t;
+    uint64_t e[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) e[r] = (base + i0 + r < n) ? keys[base + i0 + r] : ~0ull;
+    // element i keeps the smaller of (own, partner) iff it is the lower one of an ascending pair or the upper one of a
+    // descending pair
+#define LR_KEEP(own, other, i, j, k) ((((((i) & (j)) == 0u) == (((i) & (k)) == 0u)) == ((other) < (own))) ? (other) : (own))
     for (uint32_t k = 2; k <= kSortBlock; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t p = threadIdx.x; p < kSortBlock / 2; p += 1024) {
-                const uint32_t i = ((p & ~(j - 1u)) << 1) | (p & (j - 1u));  // the pair's lower index: bit log2(j) clear
-                const uint64_t a = sk[i], b = sk[i + j];
-                const bool up = (i & k) == 0u;
-                if ((a > b) == up) {
-                    sk[i] = b;
-                    sk[i + j] = a;
+            if (j >= 256u) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sk[i0 + r] = e[r];
+                __syncthreads();
+                uint64_t o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = sk[(i0 + r) ^ j];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) e[r] = LR_KEEP(e[r], o[r], i0 + r, j, k);
+            } else if (j >= 4u) {
+                const int lm = (int)(j >> 2);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint64_t o = shfl_xor_u64(e[r], lm);
+                    e[r] = LR_KEEP(e[r], o, i0 + r, j, k);
                 }
+            } else {
+                const bool two = j == 2u;  // (no run-time index into the register array)
+                const uint64_t o0 = two ? e[2] : e[1], o1 = two ? e[3] : e[0], o2 = two ? e[0] : e[3], o3 = two ? e[1] : e[2];
+                e[0] = LR_KEEP(e[0], o0, i0 + 0u, j, k);
+                e[1] = LR_KEEP(e[1], o1, i0 + 1u, j, k);
+                e[2] = LR_KEEP(e[2], o2, i0 + 2u, j, k);
+                e[3] = LR_KEEP(e[3], o3, i0 + 3u, j, k);
             }
-            __syncthreads();
         }
     }
-    for (uint32_t t = threadIdx.x; t < kSortBlock; t += 1024)
-        if (base + t < cap) keys[base + t] = sk[t];
+#undef LR_KEEP
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (base + i0 + r < cap) keys[base + i0 + r] = e[r];
 }
 
 __global__ __launch_bounds__(256) void seed_rank_setup_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ n_ptr,
