@@ -239,6 +239,105 @@ static int upload_rows(lr_context* c, float* dst, float* stage, const float* buf
     return 0;
 }
 
+// The threads that stage pageable frames for a batch call: started once per call, not once per frame (seven thread
+// starts a frame were a tenth of a millisecond of the uploader's time and the larger part of its jitter).  A job is one
+// frame; its 4 MB bands are claimed through a counter that carries the job's number, so that a thread that is late for
+// one job cannot take a band of the next with the old job's pointers.
+struct StagingCrew {
+    lr_context* c = nullptr;
+    std::vector<std::thread> th;
+    std::atomic<uint32_t> job{0};
+    std::atomic<uint64_t> next{0};  // job number << 32 | next band
+    std::atomic<int> bands_left{0}, failed{0};
+    std::atomic<bool> quit{false};
+    // the job (written before `job` is advanced)
+    float* dst = nullptr;
+    float* stage = nullptr;
+    const float* src = nullptr;
+    int w = 0, h = 0, stride = 0, rows_per_band = 1, n_bands = 0;
+    hipStream_t up = nullptr;
+
+    void work(uint32_t gen) {
+        float* const d = dst;
+        float* const st = stage;
+        const float* const sr = src;
+        const int ww = w, hh = h, ss = stride, rpb = rows_per_band, nb = n_bands;
+        const size_t row_bytes = (size_t)ww * sizeof(float);
+        for (;;) {
+            uint64_t x = next.load(std::memory_order_acquire);
+            if ((uint32_t)(x >> 32) != gen || (int)(uint32_t)x >= nb) return;
+            if (!next.compare_exchange_weak(x, x + 1, std::memory_order_acq_rel)) continue;
+            const int k = (int)(uint32_t)x;
+            const int r0 = k * rpb, r1 = std::min(hh, r0 + rpb);
+            if (ss == ww) {
+                std::memcpy(st + (size_t)r0 * ww, sr + (size_t)r0 * ss, (size_t)(r1 - r0) * row_bytes);
+            } else {
+                for (int r = r0; r < r1; ++r) std::memcpy(st + (size_t)r * ww, sr + (size_t)r * ss, row_bytes);
+            }
+            if (hipMemcpyAsync(d + (size_t)r0 * ww, st + (size_t)r0 * ww, (size_t)(r1 - r0) * row_bytes, hipMemcpyHostToDevice,
+                               up) != hipSuccess) {
+                (void)hipGetLastError();
+                failed.store(1);
+            }
+            bands_left.fetch_sub(1, std::memory_order_acq_rel);
+        }
+    }
+    void start(lr_context* ctx, int helpers) {
+        c = ctx;
+        for (int t = 0; t < helpers; ++t)
+            th.emplace_back([this]() {
+                if (hipSetDevice(c->device) != hipSuccess) {
+                    failed.store(1);
+                    return;
+                }
+                uint32_t last = 0;
+                int spins = 0;
+                while (!quit.load(std::memory_order_acquire)) {
+                    const uint32_t g = job.load(std::memory_order_acquire);
+                    if (g == last) {
+                        if (++spins < 256) std::this_thread::yield();
+                        else std::this_thread::sleep_for(std::chrono::microseconds(20));
+                        continue;
+                    }
+                    spins = 0;
+                    last = g;
+                    work(g);
+                }
+            });
+    }
+    // stages one frame (rows as in upload_rows) and enqueues its transfers; returns when every band is enqueued
+    int run(float* dst_, float* stage_, const float* buffer, int w_, int h_, int stride_, hipStream_t up_) {
+        if (stride_ < 0) {
+            buffer = buffer + (std::ptrdiff_t)(h_ - 1) * stride_;
+            stride_ = -stride_;
+        }
+        dst = dst_;
+        stage = stage_;
+        src = buffer;
+        w = w_;
+        h = h_;
+        stride = stride_;
+        up = up_;
+        rows_per_band = (int)std::max<size_t>(1, ((size_t)4 << 20) / ((size_t)w_ * sizeof(float)));
+        n_bands = (h_ + rows_per_band - 1) / rows_per_band;
+        bands_left.store(n_bands, std::memory_order_relaxed);
+        const uint32_t g = job.load(std::memory_order_relaxed) + 1u;
+        next.store((uint64_t)g << 32, std::memory_order_release);
+        job.store(g, std::memory_order_release);
+        work(g);
+        int spins = 0;
+        while (bands_left.load(std::memory_order_acquire) > 0) {
+            if (++spins < 256) std::this_thread::yield();
+            else std::this_thread::sleep_for(std::chrono::microseconds(10));
+        }
+        return failed.load() ? 1 : 0;
+    }
+    ~StagingCrew() {
+        quit.store(true, std::memory_order_release);
+        for (auto& t : th) t.join();
+    }
+};
+
 int ctx_upload_frame(lr_context* c, int slot, const float* buffer, int w, int h, int stride, int num_threads) {
     LR_HIP(hipSetDevice(c->device));
     if (w < 1 || h < 1 || buffer == nullptr) {
@@ -1424,6 +1523,8 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
             abort_all.store(1);
             return;
         }
+        StagingCrew crew;
+        if (any_pageable) crew.start(c, staging_threads(num_threads) - 1);
         for (int i = 0; i < batch; ++i) {
             int slot = -1, spins = 0;
             // a slot whose frame is done (its transfer and its staging buffer are then free as well)
@@ -1438,8 +1539,9 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
             const double t_u0 = now_ms();
             hipEvent_t e_dbg = nullptr;
             if (lane_debug && hipEventCreate(&e_dbg) == hipSuccess) (void)hipEventRecord(e_dbg, c->copy_stream);
-            if (upload_rows(c, c->ring_img[(size_t)slot], stage, h_frames[i], w, h, stride, num_threads, c->copy_stream) ||
-                hipEventRecord(c->ring_ev[(size_t)slot], c->copy_stream) != hipSuccess) {
+            const int up_rc = stage ? crew.run(c->ring_img[(size_t)slot], stage, h_frames[i], w, h, stride, c->copy_stream)
+                                    : upload_rows(c, c->ring_img[(size_t)slot], nullptr, h_frames[i], w, h, stride, 1, c->copy_stream);
+            if (up_rc || hipEventRecord(c->ring_ev[(size_t)slot], c->copy_stream) != hipSuccess) {
                 up_err = get_error().empty() ? "upload failed" : get_error();
                 abort_all.store(1);
                 return;
