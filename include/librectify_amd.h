@@ -72,11 +72,16 @@ int lr_find_line_segment_groups_batch_device(lr_context* ctx, const float* d_ima
                                              const RectificationConfig* cfg, ImageTransform* transforms);
 
 /* Batch of `batch` HOST-resident frames of one size, frame b at frames + b*image_stride (elements), rows `stride`
- * elements apart (any sign, as image.cpp:11-19).  This is the reference's own kind of input, many frames at once:
- * each lane stages and uploads its next frame on a copy stream of its own while the kernels of its current frame run.
- * Pageable memory goes through a pinned staging buffer (copied in row bands by the lane's share of `num_threads`
- * host threads, the reference's knob); page-locked memory (lr_host_alloc, hipHostMalloc, hipHostRegister) is
- * DMA-copied where it lies.  Outputs as for the device batch. */
+ * elements apart (any sign, as image.cpp:11-19).  This is the reference's own kind of input, many frames at once.
+ * ONE uploader thread sends the frames, in frame order, on the context's (high-priority) copy stream into a pool of
+ * lanes + 6 device frames (LIBRECTIFY_RING_EXTRA overrides the 6; never more than 2 GiB or `batch` frames: 0.5 GiB
+ * of device memory for 4K frames with six lanes), so the link runs ahead of the lanes; a lane only makes its stream
+ * wait for its frame's transfer.  Page-locked memory (lr_host_alloc, hipHostMalloc, hipHostRegister) is DMA-copied
+ * where it lies.  Pageable memory goes through page-locked staging buffers -- as many as there are pool slots, i.e.
+ * the same amount again in pinned host memory, allocated when a call first meets a pageable frame -- filled in 4 MB
+ * row bands by `num_threads` host threads shared by the whole call (the reference's knob, threading.h:24-27: < 0 or
+ * 1 = the uploader alone; capped at 8 and at the host's cores), started once per call.  Outputs as for the device
+ * batch. */
 int lr_find_line_segment_groups_batch_host(lr_context* ctx, const float* frames, size_t image_stride, int batch,
                                            int width, int height, int stride, float min_length, int refine,
                                            int num_threads, LineSegment* out, int capacity, int* n_lines,
@@ -180,8 +185,20 @@ int lr_refine_lines(lr_context* ctx, const LineSegment* in, int n, LineSegment* 
 /* The reference compiles prosac.h and DirectEstimator (estimator.h:82-96) but never instantiates them (ChangeLog.md:
  * "pure RANSAC is used"), so RANSAC is the default here too.  kind: 0 = RANSAC, 1 = PROSAC with T_N iterations
  * (<= 0: the reference's niter_RANSAC(0.9, 0.5, 2) = 9, prosac.h:116), 2 = DirectEstimator (refit on the lines whose
- * Hough weight exceeds 0.95; prosac_T_N is ignored). */
-void lr_set_estimator(lr_context* ctx, int kind, int prosac_T_N);
+ * Hough weight exceeds 0.95; the parameter is ignored), 3 = the diamond-space accumulator (cht.h:13-24) with a
+ * param x param accumulator (<= 0: 128; 8..128), see lr_estimate_line_pencils_cht. */
+void lr_set_estimator(lr_context* ctx, int kind, int param);
+/* estimate_multiple_structures (estimator.h:99-145) around the diamond-space accumulator as cht.h:13-24 describes
+ * it: all lines vote once (length-weighted polylines, integer votes in LDS), every round takes the accumulator's
+ * strongest cell as the hypothesis, the remaining lines within `inlier_deg` of it decide the refit (fit_optimal), the
+ * refit's inliers get the round's id, near misses (< garbage_deg) are dropped, and the votes of both are taken back
+ * out of the accumulator ("the weights can be negative (so lines can be removed!)", cht.h:18).  Writes group_id in
+ * place (HOST array).  Optional outputs: models3 = refit of each round (3 floats, normalised coordinates),
+ * n_models = rounds run, peak_cells = winning cell (row * d + column) of each round, votes = accumulator cells voted
+ * for (added or taken back) during the call.  Parity unpinned: the reference's cht.cpp is an uncompilable sketch. */
+int lr_estimate_line_pencils_cht(lr_context* ctx, LineSegment* lines, int n, int max_models, float inlier_deg,
+                                 float garbage_deg, int d, float* models3, int* n_models, uint32_t* peak_cells,
+                                 uint64_t* votes);
 /* LinePencilModel::get_weights (line_pencil.cpp:47-86): 65x65 hemisphere accumulator (LDS, 64-bit integer
  * atomics), peak direction, inclination^4 per line listed in `indices`. */
 int lr_ht_weights(lr_context* ctx, const LineSegment* lines_norm, int n, const int32_t* indices, int n_idx, float* weights);

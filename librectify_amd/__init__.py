@@ -70,6 +70,7 @@ EXPORTS = [
     "lr_stage_counters", "lr_filter_kernel_ms", "lr_ransac_best", "lr_estimate_line_pencils",
     "lr_find_line_segment_groups_batch_host", "lr_find_line_segment_groups_batch_host_ptrs", "lr_host_alloc", "lr_host_free",
     "lr_set_seed_capacity", "lr_set_flood_blind_rounds", "lr_set_flood_staged", "lr_set_batch_streams", "lr_device_malloc", "lr_device_free", "lr_memcpy_h2d", "lr_cht_vanishing_point", "lr_refine_lines", "lr_set_estimator", "lr_ht_weights", "lr_prosac_solve", "lr_estimate_line_pencils_prosac", "lr_direct_solve", "lr_estimate_line_pencils_direct",
+    "lr_estimate_line_pencils_cht",
 ]
 
 _lib = None
@@ -150,6 +151,7 @@ def lib():
         L.lr_estimate_line_pencils_prosac.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_uint64]
         L.lr_direct_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.lr_estimate_line_pencils_direct.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
+        L.lr_estimate_line_pencils_cht.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
 
@@ -384,8 +386,19 @@ class Context:
         _check(lib().lr_refine_lines(self._h, _ptr(lines), len(lines), _ptr(out), C.byref(n)))
         return out[: n.value].copy()
 
-    def set_estimator(self, kind, prosac_T_N=-1):
-        lib().lr_set_estimator(self._h, int(kind), int(prosac_T_N))
+    def set_estimator(self, kind, param=-1):
+        """0 RANSAC (default), 1 PROSAC (param = T_N), 2 DirectEstimator, 3 diamond-space accumulator (param = its size d)."""
+        lib().lr_set_estimator(self._h, int(kind), int(param))
+
+    def estimate_line_pencils_cht(self, lines, max_models=4, inlier_deg=2.0, garbage_deg=4.0, d=128):
+        """-> (lines with group_id, refit models (k, 3), winning cells (k,), cells voted for)"""
+        lines = np.ascontiguousarray(lines, LINE_DTYPE).copy()
+        models = np.zeros((max(max_models, 1), 3), np.float32)
+        cells = np.zeros(max(max_models, 1), np.uint32)
+        k = C.c_int(0)
+        votes = C.c_uint64(0)
+        _check(lib().lr_estimate_line_pencils_cht(self._h, _ptr(lines), len(lines), max_models, inlier_deg, garbage_deg, d, _ptr(models), C.byref(k), _ptr(cells), C.byref(votes)))
+        return lines, models[: k.value].copy(), cells[: k.value].copy(), int(votes.value)
 
     def ht_weights(self, lines_norm, indices):
         lines_norm = np.ascontiguousarray(lines_norm, LINE_DTYPE)

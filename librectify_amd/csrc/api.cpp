@@ -328,9 +328,30 @@ int lr_refine_lines(lr_context* ctx, const LineSegment* in, int n, LineSegment* 
     return 0;
 }
 
-void lr_set_estimator(lr_context* ctx, int kind, int prosac_T_N) {
+void lr_set_estimator(lr_context* ctx, int kind, int param) {
     ctx->estimator = kind;
-    ctx->prosac_T_N = prosac_T_N;
+    if (kind == 3) ctx->cht_d = param > 0 ? param : 128;
+    else ctx->prosac_T_N = param;
+}
+
+int lr_estimate_line_pencils_cht(lr_context* ctx, LineSegment* lines, int n, int max_models, float inlier_deg,
+                                 float garbage_deg, int d, float* models3, int* n_models, uint32_t* peak_cells,
+                                 uint64_t* votes) {
+    std::vector<LineSegment> v(lines, lines + n);
+    ChtTrace tr;
+    if (ctx_estimate_line_pencils_cht(ctx, v, max_models, inlier_deg, garbage_deg, d, &tr)) return 1;
+    std::memcpy(lines, v.data(), sizeof(LineSegment) * (size_t)n);
+    for (size_t k = 0; k < tr.models.size(); ++k) {
+        if (models3) {
+            models3[3 * k + 0] = tr.models[k].x;
+            models3[3 * k + 1] = tr.models[k].y;
+            models3[3 * k + 2] = tr.models[k].z;
+        }
+        if (peak_cells) peak_cells[k] = tr.peak_cell[k];
+    }
+    if (n_models) *n_models = (int)tr.models.size();
+    if (votes) *votes = tr.votes;
+    return 0;
 }
 
 int lr_ht_weights(lr_context* ctx, const LineSegment* lines_norm, int n, const int32_t* indices, int n_idx, float* weights) {

@@ -12,6 +12,7 @@ namespace lramd {
 // reference config.h:23-59
 constexpr float kEps = 1e-6f;
 constexpr int kMaxModels = 4;
+constexpr int kMaxPeelModels = 5;  // peeling rounds the device buffers are sized for (d_models: words 16.. are timing slots)
 constexpr float kInlierDeg = 2.0f;
 constexpr float kGarbageDeg = 4.0f;
 constexpr int kRansacMaxIter = 10000;
@@ -240,6 +241,9 @@ int launch_peel(PencilTable cur, PencilTable nxt, PencilTable all, const float* 
                 LineSegment* lines, float* models, hipStream_t s);
 int launch_ransac_argmax(const float* scores, uint32_t n_iter, float* best_score, int32_t* best_iter, hipStream_t s);
 int launch_cht_accumulate(PencilSoA m, uint32_t n, int d, unsigned long long* acc, hipStream_t s);
+int launch_cht_votes(PencilSoA m, const uint32_t* idx, uint32_t n, int d, unsigned long long* acc, bool subtract,
+                     unsigned long long* n_votes, hipStream_t s);
+int launch_cht_peak(const unsigned long long* acc, int d, uint32_t* out3, hipStream_t s);
 // refine: seg = n records of 7 floats {x1,y1,x2,y2,dx,dy,len}; edges = pairs of uint32 (i<j); *n_edges may exceed cap
 int launch_refine_pairs(const void* seg, uint32_t n, void* edges, uint32_t* n_edges, uint32_t cap, hipStream_t s);
 int launch_prosac_count(PencilSoA m, uint32_t n, float tol, float degeneracy_tol, const uint32_t* sa,

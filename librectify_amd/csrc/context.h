@@ -94,6 +94,12 @@ struct lr_context {
     size_t cap_refine_edges = 0;
     unsigned long long* d_cht_acc = nullptr;
     size_t cap_cht = 0;
+    uint32_t* d_cht_idx = nullptr;   // lines a peeling round of the diamond-space estimator takes out of the accumulator
+    uint32_t* h_cht_idx = nullptr;   // pinned mirror
+    size_t cap_cht_idx = 0;
+    uint32_t* d_cht_peak = nullptr;  // {cell, value lo, value hi, -, votes lo, votes hi}
+    uint32_t* h_cht_peak = nullptr;  // pinned mirror
+    int cht_d = 128;                 // accumulator size of estimator 3
     // RANSAC
     size_t cap_lines = 0;
     float* d_model = nullptr;  // 8 arrays of cap_lines
@@ -116,7 +122,7 @@ struct lr_context {
     size_t cap_chunk = 0, cap_wlines = 0;
     std::vector<lr_context*> workers;  // extra contexts (own stream + workspace) for frames in flight in batch calls
     int batch_streams = 4;
-    int estimator = 0;            // 0 = RANSAC (reference default), 1 = PROSAC, 2 = DirectEstimator
+    int estimator = 0;            // 0 = RANSAC (reference default), 1 = PROSAC, 2 = DirectEstimator, 3 = diamond space (CHT)
     int prosac_T_N = -1;
     // pinned host scalars
     uint32_t* h_counts = nullptr;  // 8 words
@@ -174,6 +180,13 @@ int ctx_estimate_line_pencils_direct(lr_context* c, std::vector<LineSegment>& li
                                      float garbage_deg);
 int ctx_cht_vanishing_point(lr_context* c, const std::vector<LineSegment>& lines, int d, Vec3* vp,
                             std::vector<uint64_t>* acc_out);
+struct ChtTrace {
+    std::vector<Vec3> models;          // refit of each round (normalised coordinates)
+    std::vector<uint32_t> peak_cell;   // winning accumulator cell of each round
+    uint64_t votes = 0;                // cells voted for (added or taken back) over the call
+};
+int ctx_estimate_line_pencils_cht(lr_context* c, std::vector<LineSegment>& lines, int max_models, float inlier_deg,
+                                  float garbage_deg, int d, ChtTrace* trace);
 int ctx_refine(lr_context* c, std::vector<LineSegment>& lines);
 int ctx_find_groups_device(lr_context* c, const float* d_image, int w, int h, int stride, float min_length, bool refine,
                            std::vector<LineSegment>& out);

@@ -250,32 +250,32 @@ struct StagingCrew {
     std::atomic<uint64_t> next{0};  // job number << 32 | next band
     std::atomic<int> bands_left{0}, failed{0};
     std::atomic<bool> quit{false};
-    // the job (written before `job` is advanced)
-    float* dst = nullptr;
-    float* stage = nullptr;
-    const float* src = nullptr;
-    int w = 0, h = 0, stride = 0, rows_per_band = 1, n_bands = 0;
-    hipStream_t up = nullptr;
+    // Two job descriptors, used alternately (job number & 1): the one a late helper may still be reading is not the one
+    // the uploader fills for the next frame, and the one after that is only filled when every band of this one is done.
+    struct Job {
+        float* dst = nullptr;
+        float* stage = nullptr;
+        const float* src = nullptr;
+        int w = 0, h = 0, stride = 0, rows_per_band = 1, n_bands = 0;
+        hipStream_t up = nullptr;
+    } jobs[2];
 
     void work(uint32_t gen) {
-        float* const d = dst;
-        float* const st = stage;
-        const float* const sr = src;
-        const int ww = w, hh = h, ss = stride, rpb = rows_per_band, nb = n_bands;
-        const size_t row_bytes = (size_t)ww * sizeof(float);
+        const Job j = jobs[gen & 1u];
+        const size_t row_bytes = (size_t)j.w * sizeof(float);
         for (;;) {
             uint64_t x = next.load(std::memory_order_acquire);
-            if ((uint32_t)(x >> 32) != gen || (int)(uint32_t)x >= nb) return;
+            if ((uint32_t)(x >> 32) != gen || (int)(uint32_t)x >= j.n_bands) return;
             if (!next.compare_exchange_weak(x, x + 1, std::memory_order_acq_rel)) continue;
             const int k = (int)(uint32_t)x;
-            const int r0 = k * rpb, r1 = std::min(hh, r0 + rpb);
-            if (ss == ww) {
-                std::memcpy(st + (size_t)r0 * ww, sr + (size_t)r0 * ss, (size_t)(r1 - r0) * row_bytes);
+            const int r0 = k * j.rows_per_band, r1 = std::min(j.h, r0 + j.rows_per_band);
+            if (j.stride == j.w) {
+                std::memcpy(j.stage + (size_t)r0 * j.w, j.src + (size_t)r0 * j.stride, (size_t)(r1 - r0) * row_bytes);
             } else {
-                for (int r = r0; r < r1; ++r) std::memcpy(st + (size_t)r * ww, sr + (size_t)r * ss, row_bytes);
+                for (int r = r0; r < r1; ++r) std::memcpy(j.stage + (size_t)r * j.w, j.src + (size_t)r * j.stride, row_bytes);
             }
-            if (hipMemcpyAsync(d + (size_t)r0 * ww, st + (size_t)r0 * ww, (size_t)(r1 - r0) * row_bytes, hipMemcpyHostToDevice,
-                               up) != hipSuccess) {
+            if (hipMemcpyAsync(j.dst + (size_t)r0 * j.w, j.stage + (size_t)r0 * j.w, (size_t)(r1 - r0) * row_bytes,
+                               hipMemcpyHostToDevice, j.up) != hipSuccess) {
                 (void)hipGetLastError();
                 failed.store(1);
             }
@@ -286,10 +286,7 @@ struct StagingCrew {
         c = ctx;
         for (int t = 0; t < helpers; ++t)
             th.emplace_back([this]() {
-                if (hipSetDevice(c->device) != hipSuccess) {
-                    failed.store(1);
-                    return;
-                }
+                if (hipSetDevice(c->device) != hipSuccess) return;  // a helper less: the uploader stages every band itself if need be
                 uint32_t last = 0;
                 int spins = 0;
                 while (!quit.load(std::memory_order_acquire)) {
@@ -311,17 +308,19 @@ struct StagingCrew {
             buffer = buffer + (std::ptrdiff_t)(h_ - 1) * stride_;
             stride_ = -stride_;
         }
-        dst = dst_;
-        stage = stage_;
-        src = buffer;
-        w = w_;
-        h = h_;
-        stride = stride_;
-        up = up_;
-        rows_per_band = (int)std::max<size_t>(1, ((size_t)4 << 20) / ((size_t)w_ * sizeof(float)));
-        n_bands = (h_ + rows_per_band - 1) / rows_per_band;
-        bands_left.store(n_bands, std::memory_order_relaxed);
         const uint32_t g = job.load(std::memory_order_relaxed) + 1u;
+        Job& j = jobs[g & 1u];
+        j.dst = dst_;
+        j.stage = stage_;
+        j.src = buffer;
+        j.w = w_;
+        j.h = h_;
+        j.stride = stride_;
+        j.up = up_;
+        j.rows_per_band = (int)std::max<size_t>(1, ((size_t)4 << 20) / ((size_t)w_ * sizeof(float)));
+        j.n_bands = (h_ + j.rows_per_band - 1) / j.rows_per_band;
+        failed.store(0, std::memory_order_relaxed);  // (per frame: every band of the previous one has been accounted for)
+        bands_left.store(j.n_bands, std::memory_order_relaxed);
         next.store((uint64_t)g << 32, std::memory_order_release);
         job.store(g, std::memory_order_release);
         work(g);
@@ -433,7 +432,7 @@ void ctx_destroy(lr_context* c) {
                     c->fb.blocked, c->fb.count, c->fb.flags, c->fb.state, c->fb.tier, c->fb.act_a, c->fb.act_b,
                     c->fb.ctrl, c->fb.big_list, c->fb.dirty, c->fb.slab_ring, c->fb.slab_hash, c->d_pairs, c->d_peak, c->d_weights,
                     c->d_samples, c->d_hcounts, c->comp_large, c->d_tables, c->d_orig, c->d_inl, c->d_flines, c->d_gctl,
-                    c->d_gnorm, c->d_models, c->d_refine_table, c->d_refine_edges, c->d_cht_acc};
+                    c->d_gnorm, c->d_models, c->d_refine_table, c->d_refine_edges, c->d_cht_acc, c->d_cht_idx, c->d_cht_peak};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
@@ -457,6 +456,8 @@ void ctx_destroy(lr_context* c) {
     if (c->h_weights) (void)hipHostFree(c->h_weights);
     if (c->h_samples) (void)hipHostFree(c->h_samples);
     if (c->h_hcounts) (void)hipHostFree(c->h_hcounts);
+    if (c->h_cht_idx) (void)hipHostFree(c->h_cht_idx);
+    if (c->h_cht_peak) (void)hipHostFree(c->h_cht_peak);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
@@ -654,6 +655,10 @@ int enqueue_fit(lr_context* c) {
 // words a filter_lines / lines_bbox launch has left in d_gctl / d_gnorm.
 int enqueue_groups(lr_context* c, uint32_t line_cap, int max_models, float inlier_deg, float garbage_deg, int n_iter,
                    uint64_t seed) {
+    if (max_models > kMaxPeelModels) {  // the refit models and the diagnostics slots of a frame are sized for this many
+        set_error("estimate_line_pencils: max_models above " + std::to_string(kMaxPeelModels) + " (the reference uses 4, config.h:25)");
+        return 1;
+    }
     const float tol = cos_threshold(inlier_deg), garbage_tol = cos_threshold(garbage_deg);
     const PencilTable all = table_of(c, 0);
     PencilTable tab[2] = {table_of(c, 1), table_of(c, 2)};
@@ -1226,6 +1231,102 @@ int ctx_cht_vanishing_point(lr_context* c, const std::vector<LineSegment>& lines
     return 0;
 }
 
+// The diamond-space accumulator as an ESTIMATOR of the path (opt-in, lr_set_estimator(3, d); cht.h:13-24 describes
+// accumulate -> argmax -> de-normalise, "the weights can be negative (so lines can be removed!)"): the peeling loop of
+// estimate_multiple_structures (estimator.h:99-145) around a solve() that reads
+//     hypothesis = point of the accumulator's strongest cell (first maximum in row-major order)
+//     inliers    = remaining lines whose inclination error against it is below tol   (as estimator.h:74)
+//     model      = fit_optimal(inliers)                                              (as estimator.h:75-76)
+// The votes of every line go into the accumulator once; after a round the lines it has grouped or discarded are taken
+// back out of it with negative votes (exact: the votes are integers), instead of accumulating the rest again -- the
+// oracle re-accumulates, so the two check each other.  Accumulation and argmax run on the GPU, one 12-byte peak comes
+// back per round; the O(n) verdicts stay on the host like PROSAC's and Direct's.  Parity unpinned: the reference's
+// cht.cpp does not compile.
+int ctx_estimate_line_pencils_cht(lr_context* c, std::vector<LineSegment>& lines, int max_models, float inlier_deg,
+                                  float garbage_deg, int d, ChtTrace* trace) {
+    if (lines.empty()) return 0;
+    LR_HIP(hipSetDevice(c->device));
+    if (d <= 0) d = 128;
+    const Normalisation nrm = bbox_normalisation(lines);
+    const PencilModel model(normalise(lines, nrm));
+    const float tol = cos_threshold(inlier_deg), garbage_tol = cos_threshold(garbage_deg);
+    const int N = model.size();
+    std::vector<int> all(N);
+    for (int i = 0; i < N; ++i) all[i] = i;
+    PencilSoA soa;
+    if (upload_model(c, model, all, &soa)) return 1;
+    const size_t cells = (size_t)d * d;
+    if (cells > c->cap_cht) {
+        LR_HIP(hipStreamSynchronize(c->stream));
+        if (dev_alloc(c->d_cht_acc, cells)) return 1;
+        c->cap_cht = cells;
+    }
+    if ((size_t)N > c->cap_cht_idx) {
+        LR_HIP(hipStreamSynchronize(c->stream));
+        const size_t cl = std::max<size_t>((size_t)N, 4096);
+        if (dev_alloc(c->d_cht_idx, cl)) return 1;
+        if (c->h_cht_idx) (void)hipHostFree(c->h_cht_idx);
+        c->h_cht_idx = nullptr;
+        LR_HIP(hipHostMalloc((void**)&c->h_cht_idx, cl * sizeof(uint32_t)));
+        c->cap_cht_idx = cl;
+    }
+    if (!c->d_cht_peak) {
+        if (dev_alloc(c->d_cht_peak, 8)) return 1;
+        LR_HIP(hipHostMalloc((void**)&c->h_cht_peak, 8 * sizeof(uint32_t)));
+    }
+    unsigned long long* d_votes = reinterpret_cast<unsigned long long*>(c->d_cht_peak + 4);
+    LR_HIP(hipMemsetAsync(c->d_cht_peak, 0, 8 * sizeof(uint32_t), c->stream));
+    LR_HIP(hipMemsetAsync(c->d_cht_acc, 0, cells * sizeof(unsigned long long), c->stream));
+    if (launch_cht_votes(soa, nullptr, (uint32_t)N, d, c->d_cht_acc, false, d_votes, c->stream)) return 1;
+    std::vector<int> inlier_flag(N, -1), garbage_flag(N, 0);
+    int remaining = N, k = 0;
+    while (remaining >= 2 && k < max_models) {  // estimator.h:115
+        if (launch_cht_peak(c->d_cht_acc, d, c->d_cht_peak, c->stream)) return 1;
+        LR_HIP(hipMemcpyAsync(c->h_cht_peak, c->d_cht_peak, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        LR_HIP(hipStreamSynchronize(c->stream));
+        const uint32_t cell = c->h_cht_peak[0];
+        const int iy = (int)(cell / (uint32_t)d), ix = (int)(cell % (uint32_t)d);
+        const float u = (float)ix / (float)(d - 1) * 2.f - 1.f, v = (float)iy / (float)(d - 1) * 2.f - 1.f;
+        const Vec3 p{v, (u >= 0.f ? 1.f : -1.f) * u + (v >= 0.f ? 1.f : -1.f) * v - 1.f, u};
+        std::vector<int> inl;
+        for (int i = 0; i < N; ++i)
+            if (inlier_flag[i] < 0 && garbage_flag[i] == 0 && model.error(p, i) < tol) inl.push_back(i);
+        const Vec3 h = model.fit_optimal(inl);
+        if (trace) {
+            trace->models.push_back(h);
+            trace->peak_cell.push_back(cell);
+        }
+        uint32_t n_out = 0;
+        int n_in = 0, n_gb = 0;
+        for (int i = 0; i < N; ++i) {
+            if (inlier_flag[i] >= 0 || garbage_flag[i] != 0) continue;
+            const float e = model.error(h, i);
+            if (e < tol) {
+                inlier_flag[i] = k;
+                ++n_in;
+                c->h_cht_idx[n_out++] = (uint32_t)i;
+            } else if (e >= tol && e < garbage_tol) {
+                garbage_flag[i] = 1;
+                ++n_gb;
+                c->h_cht_idx[n_out++] = (uint32_t)i;
+            }
+        }
+        remaining -= n_in + n_gb;
+        ++k;
+        if (remaining >= 2 && k < max_models && n_out > 0) {  // the next round votes without them
+            LR_HIP(hipMemcpyAsync(c->d_cht_idx, c->h_cht_idx, (size_t)n_out * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            if (launch_cht_votes(soa, c->d_cht_idx, n_out, d, c->d_cht_acc, true, d_votes, c->stream)) return 1;
+        }
+    }
+    if (trace) {
+        LR_HIP(hipMemcpyAsync(c->h_cht_peak, c->d_cht_peak, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        LR_HIP(hipStreamSynchronize(c->stream));
+        trace->votes = ((uint64_t)c->h_cht_peak[5] << 32) | c->h_cht_peak[4];
+    }
+    for (int i = 0; i < N; ++i) lines[i].group_id = garbage_flag[i] == 1 ? -1 : inlier_flag[i];
+    return 0;
+}
+
 // postprocess_lines_segments (line_detector.cpp:332-444): pair test on the GPU for large n, graph walk and
 // merges on the host.
 int ctx_refine(lr_context* c, std::vector<LineSegment>& lines) {
@@ -1394,6 +1495,8 @@ static int run_frame(lr_context* c, const float* d_image, int w, int h, int stri
             return 1;
     } else if (c->estimator == 2) {
         if (ctx_estimate_line_pencils_direct(c, filtered, kMaxModels, kInlierDeg, kGarbageDeg)) return 1;
+    } else if (c->estimator == 3) {
+        if (ctx_estimate_line_pencils_cht(c, filtered, kMaxModels, kInlierDeg, kGarbageDeg, c->cht_d, nullptr)) return 1;
     } else if (ctx_estimate_line_pencils(c, filtered, kMaxModels, kInlierDeg, kGarbageDeg, n_iter, c->ransac_seed)) {
         return 1;
     }
@@ -1473,6 +1576,7 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
         l->flood_staged = c->flood_staged;  // (off unless lr_set_flood_staged: +6 % in round 1, -3 % now)
         l->estimator = c->estimator;
         l->prosac_T_N = c->prosac_T_N;
+        l->cht_d = c->cht_d;
         // LIBRECTIFY_LANES_SLEEP: the lanes sleep on an event instead of spinning in hipStreamSynchronize, for hosts
         // short of cores (on the 16-core share of a one-GPU box: pageable frames equal, page-locked ones 5 % slower)
         static const bool sleep_env = std::getenv("LIBRECTIFY_LANES_SLEEP") != nullptr;

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(kWG) void peel_kernel(PencilTable cur, PencilTable 
         s_h[0] = hx;
         s_h[1] = hy;
         s_h[2] = hz;
-        gctl[kGcBestIter0 + round] = (uint32_t)bi;
+        if (round < (uint32_t)(kGcWords - kGcBestIter0)) gctl[kGcBestIter0 + round] = (uint32_t)bi;  // (diagnostics: four slots)
     }
     __syncthreads();
     const float bx_ = s_h[0], by_ = s_h[1], bz_ = s_h[2];
@@ -407,9 +407,11 @@ __global__ __launch_bounds__(kWG) void peel_kernel(PencilTable cur, PencilTable 
             s_h[0] = hf[0];
             s_h[1] = hf[1];
             s_h[2] = hf[2];
-            models[round * 3 + 0] = hf[0];
-            models[round * 3 + 1] = hf[1];
-            models[round * 3 + 2] = hf[2];
+            if (round < (uint32_t)kMaxPeelModels) {  // (d_models holds kMaxPeelModels refits; enqueue_groups rejects more)
+                models[round * 3 + 0] = hf[0];
+                models[round * 3 + 1] = hf[1];
+                models[round * 3 + 2] = hf[2];
+            }
         }
     }
     __syncthreads();
@@ -454,7 +456,7 @@ __global__ __launch_bounds__(kWG) void peel_kernel(PencilTable cur, PencilTable 
 #ifdef LR_PEEL_TIMING
     if (threadIdx.x == 0) {
         tm[5] = wall_clock64();
-        for (int q = 0; q < 5; ++q) models[16 + round * 5 + q] = (float)(tm[q + 1] - tm[q]) * 0.01f;  // us (100 MHz clock)
+        for (int q = 0; q < 5 && round < 4u; ++q) models[16 + round * 5 + q] = (float)(tm[q + 1] - tm[q]) * 0.01f;  // us (100 MHz clock)
     }
 #endif
     if (threadIdx.x == 0) {

@@ -376,22 +376,32 @@ __global__ __launch_bounds__(256) void refine_pairs_kernel(const RefineSeg* __re
 }
 
 // ---- diamond-space (cascaded Hough) accumulator, opt-in (reference cht.h:13-24, cht.cpp: an uncompiled sketch) --
-// One thread per line; each workgroup keeps a d x d accumulator of 32-bit fixed-point votes in LDS (d <= 128:
-// 64 KB) and flushes it into the global 64-bit accumulator with integer atomics, so the result is independent
-// of scheduling.  Formulas and rasterisation: see the oracle's cht_accumulate.
+// One WAVEFRONT per line: the four corner points of the line's polyline are wave-uniform arithmetic, and the cells of
+// each of its three segments (up to d of them: cht.cpp:163-197 steps along the longer axis) are voted for by the lanes
+// side by side.  Each workgroup keeps a d x d accumulator of 32-bit fixed-point votes in LDS (d <= 128: 64 KB) and
+// flushes it into the global 64-bit accumulator with integer atomics, so the result does not depend on scheduling --
+// and votes can be TAKEN BACK exactly (cht.h:18: "the weights can be negative (so lines can be removed!)"): the
+// peeling loop subtracts the lines a round has removed instead of accumulating the rest again.
+// Formulas and rasterisation: see the oracle's cht_accumulate.
 __device__ inline float sgn1(float x) { return x >= 0.f ? 1.f : -1.f; }
 constexpr int kChtMax = 128;
-constexpr int kChtLinesPerBlock = 4096;  // keeps every LDS cell below 2^32 (<= 6 votes of < 2^17 per line)
+constexpr int kChtLinesPerBlock = 512;  // keeps every LDS cell below 2^32 (<= 6 votes of < 2^17 per line)
 
-__global__ __launch_bounds__(256) void cht_accumulate_kernel(PencilSoA m, uint32_t n, int d,
-                                                             unsigned long long* __restrict__ acc) {
+// idx == nullptr: lines 0..n-1 of the table; else lines idx[0..n-1].  kSub: the votes are taken back.
+template <bool kSub>
+__global__ __launch_bounds__(256) void cht_votes_kernel(PencilSoA m, const uint32_t* __restrict__ idx, uint32_t n, int d,
+                                                        unsigned long long* __restrict__ acc,
+                                                        unsigned long long* __restrict__ n_votes) {
     extern __shared__ uint32_t s_acc[];
     for (int i = threadIdx.x; i < d * d; i += 256) s_acc[i] = 0u;
     __syncthreads();
     const float sc = (float)(d - 1);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t lo = blockIdx.x * kChtLinesPerBlock;
     const uint32_t hi = min(n, lo + kChtLinesPerBlock);
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+    uint32_t cast = 0;
+    for (uint32_t li = lo + wv; li < hi; li += 4) {
+        const uint32_t i = idx ? idx[li] : li;
         const float a = m.hx[i], b = m.hy[i], c = m.hz[i];
         const float al = sgn1(a * b), be = sgn1(b * c), ga = sgn1(a * c);
         const float d1 = c + ga * a, d2 = c + be * b, d3 = a + al * b;
@@ -414,29 +424,96 @@ __global__ __launch_bounds__(256) void cht_accumulate_kernel(PencilSoA m, uint32
             const int steps = (int)roundf(fmaxf(fabsf(x1 - x0), fabsf(y1 - y0))) + 1;
             const float sx = steps > 1 ? (x1 - x0) / (float)(steps - 1) : 0.f;
             const float sy = steps > 1 ? (y1 - y0) / (float)(steps - 1) : 0.f;
-            for (int j = 0; j < steps; ++j) {
+            for (int j = lane; j < steps; j += 64) {
                 const int xi = (int)roundf(x0 + (float)j * sx), yi = (int)roundf(y0 + (float)j * sy);
                 atomicAdd(&s_acc[yi * d + xi], vote);
             }
+            cast += (uint32_t)steps;
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < d * d; i += 256) {
         const uint32_t v = s_acc[i];
-        if (v) atomicAdd(&acc[i], (unsigned long long)v);
+        if (v) atomicAdd(&acc[i], kSub ? (unsigned long long)0 - (unsigned long long)v : (unsigned long long)v);
+    }
+    if (n_votes && lane == 0 && cast) atomicAdd(n_votes, (unsigned long long)cast);
+}
+
+// argmax of the accumulator: the first maximum in row-major order (the oracle's cht_peak); out = {cell, value lo, value hi}
+__global__ __launch_bounds__(1024) void cht_peak_kernel(const unsigned long long* __restrict__ acc, uint32_t cells,
+                                                        uint32_t* __restrict__ out) {
+    __shared__ unsigned long long s_v[16];
+    __shared__ uint32_t s_i[16];
+    unsigned long long bv = 0ull;
+    uint32_t bi = 0xFFFFFFFFu;
+    for (uint32_t i = threadIdx.x; i < cells; i += 1024) {
+        const unsigned long long v = acc[i];
+        if (bi == 0xFFFFFFFFu || v > bv) {  // (ascending i per thread: a later equal value does not replace)
+            bv = v;
+            bi = i;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t olo = (uint32_t)__shfl_xor((int)(uint32_t)bv, off), ohi = (uint32_t)__shfl_xor((int)(uint32_t)(bv >> 32), off);
+        const unsigned long long ov = ((unsigned long long)ohi << 32) | olo;
+        const uint32_t oi = (uint32_t)__shfl_xor((int)bi, off);
+        if (oi != 0xFFFFFFFFu && (bi == 0xFFFFFFFFu || ov > bv || (ov == bv && oi < bi))) {
+            bv = ov;
+            bi = oi;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_v[threadIdx.x >> 6] = bv;
+        s_i[threadIdx.x >> 6] = bi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 16; ++k) {
+            const unsigned long long ov = s_v[k];
+            const uint32_t oi = s_i[k];
+            if (oi != 0xFFFFFFFFu && (bi == 0xFFFFFFFFu || ov > bv || (ov == bv && oi < bi))) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        out[0] = bi == 0xFFFFFFFFu ? 0u : bi;
+        out[1] = (uint32_t)bv;
+        out[2] = (uint32_t)(bv >> 32);
     }
 }
 
 }  // namespace
 
-int launch_cht_accumulate(PencilSoA m, uint32_t n, int d, unsigned long long* acc, hipStream_t s) {
+static int cht_check_size(int d) {
     if (d < 8 || d > kChtMax) {
-        set_error("launch_cht_accumulate: accumulator size must be in [8, 128]");
+        set_error("diamond-space accumulator: size must be in [8, 128]");
         return 1;
     }
+    return 0;
+}
+
+int launch_cht_accumulate(PencilSoA m, uint32_t n, int d, unsigned long long* acc, hipStream_t s) {
+    if (cht_check_size(d)) return 1;
     LR_HIP(hipMemsetAsync(acc, 0, (size_t)d * d * sizeof(unsigned long long), s));
+    return launch_cht_votes(m, nullptr, n, d, acc, false, nullptr, s);
+}
+
+// adds (or takes back) the votes of n lines (all of the table if idx == nullptr) to an accumulator that exists
+int launch_cht_votes(PencilSoA m, const uint32_t* idx, uint32_t n, int d, unsigned long long* acc, bool subtract,
+                     unsigned long long* n_votes, hipStream_t s) {
+    if (cht_check_size(d)) return 1;
+    if (n == 0) return 0;
     const uint32_t blocks = (n + kChtLinesPerBlock - 1) / kChtLinesPerBlock;
-    hipLaunchKernelGGL(cht_accumulate_kernel, dim3(blocks ? blocks : 1), dim3(256), (size_t)d * d * sizeof(uint32_t), s, m, n, d, acc);
+    const size_t lds = (size_t)d * d * sizeof(uint32_t);
+    if (subtract) hipLaunchKernelGGL(cht_votes_kernel<true>, dim3(blocks), dim3(256), lds, s, m, idx, n, d, acc, n_votes);
+    else hipLaunchKernelGGL(cht_votes_kernel<false>, dim3(blocks), dim3(256), lds, s, m, idx, n, d, acc, n_votes);
+    LR_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_cht_peak(const unsigned long long* acc, int d, uint32_t* out3, hipStream_t s) {
+    hipLaunchKernelGGL(cht_peak_kernel, dim3(1), dim3(1024), 0, s, acc, (uint32_t)(d * d), out3);
     LR_HIP(hipGetLastError());
     return 0;
 }

@@ -180,14 +180,17 @@ __global__ __launch_bounds__(256) void seed_rank_setup_kernel(const uint64_t* __
     const uint32_t n = min(*n_ptr, cap);
     const uint32_t n_blocks = (n + kSortBlock - 1) / kSortBlock;
     const uint32_t mine = g / kSortBlock;
-    if (mine >= n_blocks) return;
+    // The block sort writes (and pads with the largest key) only the slots below `cap`: a last block that `cap` cuts
+    // short has nothing of this frame beyond it (zeros of a fresh allocation or an earlier frame's keys), and when `cap`
+    // is the frame's pixel count there is no memory there at all.
+    if (mine >= n_blocks || g >= cap) return;
     const uint64_t key = keys[g];
     if (key == ~0ull) return;  // padding of the last block
     uint32_t rank = g - mine * kSortBlock;
     for (uint32_t b = 0; b < n_blocks; ++b) {
         if (b == mine) continue;
         const uint64_t* __restrict__ blk = keys + (size_t)b * kSortBlock;
-        uint32_t lo = 0, len = kSortBlock;  // count of keys below `key` in a sorted block of 4096
+        uint32_t lo = 0, len = min(kSortBlock, cap - b * kSortBlock);  // count of keys below `key` in a sorted block
         while (len > 0) {
             const uint32_t half = len >> 1;
             if (blk[lo + half] < key) {

@@ -1028,6 +1028,63 @@ V3 cht_peak(const std::vector<uint64_t>& acc, int d) {
     return {v, sgn1(u) * u + sgn1(v) * v - 1.f, u};
 }
 
+// The accumulator as an estimator (cht.h:13-24 + the loop of estimator.h:99-145; parity unpinned): every round
+// accumulates the votes of the lines still in the game FROM SCRATCH (the product takes the removed lines' votes back
+// out of one accumulator instead, cht.h:18 -- integer votes make the two identical), takes the strongest cell as the
+// hypothesis, refits on the remaining lines within tol of it (estimator.h:74-76) and applies the usual verdicts.
+void estimate_line_pencils_cht(std::vector<LineSegment>& lines, int max_models, float inlier_deg, float garbage_deg, int d,
+                               std::vector<V3>* models_out, std::vector<uint32_t>* cells_out) {
+    BBox bb = bounding_box(lines);
+    V2 p0 = bbox_center(bb);
+    V2 sz = bbox_size(bb);
+    float scale = std::max(sz.x, sz.y);
+    LinePencilModel model(normalize_lines(lines, p0, scale));
+    const float tol = cos_threshold(inlier_deg), garbage_tol = cos_threshold(garbage_deg);
+    const int N = model.size();
+    std::vector<int> inlier_flag(N, -1), garbage_flag(N, 0);
+    int num_observations = N, k = 0;
+    while (num_observations >= 2 && k < max_models) {
+        std::vector<int> obs;
+        for (int i = 0; i < N; ++i)
+            if (inlier_flag[i] < 0 && garbage_flag[i] == 0) obs.push_back(i);
+        std::vector<LineSegment> sub_lines;  // (the accumulator only reads h and length: a sub-model of the observations)
+        LinePencilModel sub = model;
+        sub.h.clear(); sub.anchor.clear(); sub.direction.clear(); sub.length.clear();
+        for (int i : obs) {
+            sub.h.push_back(model.h[i]);
+            sub.anchor.push_back(model.anchor[i]);
+            sub.direction.push_back(model.direction[i]);
+            sub.length.push_back(model.length[i]);
+        }
+        std::vector<uint64_t> acc;
+        cht_accumulate(sub, d, acc);
+        size_t best = 0;
+        for (size_t i = 1; i < acc.size(); ++i)
+            if (acc[i] > acc[best]) best = i;
+        const V3 p = cht_peak(acc, d);
+        std::vector<int> inl;
+        for (int i : obs)
+            if (model.error1(p, i) < tol) inl.push_back(i);
+        const V3 h = model.fit_optimal(inl);
+        if (models_out) models_out->push_back(h);
+        if (cells_out) cells_out->push_back(uint32_t(best));
+        int n_in = 0, n_gb = 0;
+        for (int i : obs) {
+            const float e = model.error1(h, i);
+            if (e < tol) {
+                inlier_flag[i] = k;
+                ++n_in;
+            } else if (e >= tol && e < garbage_tol) {
+                garbage_flag[i] = 1;
+                ++n_gb;
+            }
+        }
+        num_observations -= n_in + n_gb;
+        ++k;
+    }
+    for (int i = 0; i < N; ++i) lines[i].group_id = garbage_flag[i] == 1 ? -1 : inlier_flag[i];
+}
+
 // estimate_multiple_structures (estimator.h:99-145) driven by PROSAC instead of RANSAC
 // estimator.h:82-96 — DirectEstimator (compiled header, never instantiated: parity unpinned): the lines whose Hough
 // weight exceeds 0.95 (an empty set means all lines, line_pencil.cpp:114-117) decide the refit alone.
@@ -1767,6 +1824,25 @@ void orc_cht_vanishing_point(const LineSegment* lines, int n, int d, float* vp3,
     vp3[0] = p.x;
     vp3[1] = p.y;
     vp3[2] = p.z;
+}
+
+// returns the number of rounds; models3: max_models x 3 floats, cells: max_models words (both optional)
+int orc_estimate_line_pencils_cht(LineSegment* lines, int n, int max_models, float inlier_deg, float garbage_deg, int d,
+                                  float* models3, uint32_t* cells) {
+    std::vector<LineSegment> v(lines, lines + n);
+    std::vector<V3> models;
+    std::vector<uint32_t> cs;
+    estimate_line_pencils_cht(v, max_models, inlier_deg, garbage_deg, d, &models, &cs);
+    std::copy(v.begin(), v.end(), lines);
+    for (size_t k = 0; k < models.size(); ++k) {
+        if (models3) {
+            models3[3 * k + 0] = models[k].x;
+            models3[3 * k + 1] = models[k].y;
+            models3[3 * k + 2] = models[k].z;
+        }
+        if (cells) cells[k] = cs[k];
+    }
+    return int(models.size());
 }
 
 int orc_niter_ransac(double p, double eps, int s, int nmax) { return niter_RANSAC(p, eps, s, nmax); }

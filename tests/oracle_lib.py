@@ -278,6 +278,14 @@ def cht_vanishing_point(lines, d=128):
     return vp, acc
 
 
+def estimate_line_pencils_cht(lines, max_models=4, inlier_deg=2.0, garbage_deg=4.0, d=128):
+    lines = as_lines(lines).copy()
+    models = np.zeros((max(max_models, 1), 3), np.float32)
+    cells = np.zeros(max(max_models, 1), np.uint32)
+    k = lib().orc_estimate_line_pencils_cht(_p(lines), C.c_int(len(lines)), C.c_int(max_models), C.c_float(inlier_deg), C.c_float(garbage_deg), C.c_int(d), _p(models), _p(cells))
+    return lines, models[:k].copy(), cells[:k].copy()
+
+
 def niter_ransac(p, eps, s, nmax=-1):
     f = lib().orc_niter_ransac
     f.restype = C.c_int

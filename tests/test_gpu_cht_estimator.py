@@ -1,0 +1,160 @@
+"""The diamond-space ("cascaded Hough") accumulator as an estimator of the path — BASELINE.json configs[2] "full
+pipeline incl. RANSAC+CHT VP" and configs[4]'s "LDS/atomic stress" (VERDICT r02, row J1).
+
+PARITY UNPINNED: the reference's cht.cpp is an uncompilable sketch; the oracle restates what cht.h:13-24
+describes inside the peeling loop of estimator.h:99-145.  The product accumulates once and takes removed lines' votes
+back out (cht.h:18), the oracle accumulates the remaining lines from scratch every round: group ids bit-exact, winning
+cells equal, refit vanishing points within 1e-4 on unit-normalised homogeneous coordinates."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    import librectify_amd as L
+
+    L.lib()
+    assert L.device_count() > 0, "GPU tests need a GPU"
+    return L
+
+
+@pytest.fixture(scope="module")
+def ctx(L):
+    c = L.Context(0)
+    yield c
+    c.close()
+
+
+def _assert_lines_equal(a, b):
+    assert len(a) == len(b), (len(a), len(b))
+    av = np.frombuffer(np.ascontiguousarray(a).tobytes(), np.uint32).reshape(len(a), 7)
+    bv = np.frombuffer(np.ascontiguousarray(b).tobytes(), np.uint32).reshape(len(b), 7)
+    bad = np.nonzero((av != bv).any(axis=1))[0]
+    assert len(bad) == 0, "%d mismatching records, first at %d: %s vs %s" % (len(bad), bad[0], a[bad[0]], b[bad[0]])
+
+
+def _unit(v):
+    v = np.asarray(v, np.float64)
+    return v / np.linalg.norm(v)
+
+
+def _assert_models_close(got, ref):
+    assert len(got) == len(ref)
+    for g, r in zip(got, ref):
+        g, r = _unit(g), _unit(r)
+        assert min(np.abs(g - r).max(), np.abs(g + r).max()) < 1e-4, (g, r)
+
+
+@pytest.mark.parametrize("n,d", [(1000, 128), (1000, 64), (20000, 128), (3, 128), (2, 16)])
+def test_cht_estimator_on_synthetic_segments_self_golden_parity_unpinned(L, ctx, n, d):
+    from librectify_amd import synth
+
+    segs = synth.random_segments(n, 42)
+    ref, ref_m, ref_c = O.estimate_line_pencils_cht(segs, d=d)
+    got, got_m, got_c, votes = ctx.estimate_line_pencils_cht(segs, d=d)
+    np.testing.assert_array_equal(got_c, ref_c)
+    _assert_lines_equal(got, ref)
+    _assert_models_close(got_m, ref_m)
+    assert votes > 0
+    if n >= 1000:  # 60 % of the segments lie on three pencils: the first three rounds find them
+        ids, cnt = np.unique(got["group_id"], return_counts=True)
+        assert set(ids.tolist()) >= {0, 1, 2} and cnt[ids == 0][0] > 0.1 * n
+
+
+def test_cht_estimator_recovers_known_vanishing_points_parity_unpinned(L, ctx):
+    """Three pencils with known vanishing points + clutter: each round's refit, de-normalised, points at one of them."""
+    rng = np.random.RandomState(5)
+    vps = [np.array([3100.0, 400.0]), np.array([-2200.0, 700.0]), np.array([450.0, -5000.0])]
+    rows = []
+    for i in range(1500):
+        c = rng.uniform(50, 950, 2)
+        if i < 1200:
+            dirn = vps[i % 3] - c
+            dirn /= np.linalg.norm(dirn)
+            a = rng.normal(0, 0.002)
+            dirn = np.array([dirn[0] * np.cos(a) - dirn[1] * np.sin(a), dirn[0] * np.sin(a) + dirn[1] * np.cos(a)])
+        else:
+            t = rng.uniform(0, np.pi)
+            dirn = np.array([np.cos(t), np.sin(t)])
+        ln = rng.uniform(30, 120)
+        p1, p2 = c - dirn * ln / 2, c + dirn * ln / 2
+        rows.append([p1[0], p1[1], p2[0], p2[1], 1, 0, -1])
+    lines = O.lines_from_rows(np.array(rows))
+    got, models, cells, _ = ctx.estimate_line_pencils_cht(lines, d=128)
+    nrm, c0, sc = O.normalize_lines(lines)
+    found = set()
+    for m in models[:3]:
+        assert abs(m[2]) > 1e-6
+        p = np.array([m[0] / m[2], m[1] / m[2]]) * sc + c0
+        centre = np.array([500.0, 500.0])
+        best = max(range(3), key=lambda k: abs(np.dot(_unit(p - centre), _unit(vps[k] - centre))))
+        assert abs(np.dot(_unit(p - centre), _unit(vps[best] - centre))) > np.cos(np.radians(1.5)), (p, vps[best])
+        found.add(best)
+    assert found == {0, 1, 2}
+    for k in range(3):  # the lines drawn on a pencil share a group
+        ids = got["group_id"][k:1200:3]
+        assert (ids == np.bincount(ids[ids >= 0]).argmax()).mean() > 0.9
+
+
+def test_config_3_bench_frame_4k_full_path_with_cht_parity_unpinned(L, ctx):
+    """BASELINE configs[2]: frame(3840, 2160, 1) through find_line_segment_groups with the CHT estimator selected
+    (lr_set_estimator(3, 128)) + compute_rectification_transform, against detector -> filter_lines -> CHT peeling of
+    the oracle."""
+    from librectify_amd import synth
+
+    w, h = 3840, 2160
+    img = synth.frame(w, h, 1)
+    ml = max(w, h) / 100.0
+    T = O.max_threads()
+    det = O.find_line_segments(img, num_threads=T, want_label=False)
+    filt = O.filter_lines(det["lines"], ml)
+    ref, ref_m, ref_c = O.estimate_line_pencils_cht(filt, d=128)
+    ctx.set_estimator(3, 128)
+    try:
+        got = ctx.find_line_segment_groups(img, ml)
+        got_b, n_b, tf_b = ctx.find_line_segment_groups_batch_host(np.stack([img, img[::-1].copy()]), ml, capacity=4096)
+    finally:
+        ctx.set_estimator(0)
+    _assert_lines_equal(got, ref)
+    _assert_lines_equal(got_b[0][: n_b[0]], ref)  # the batch lanes carry the estimator too
+    assert len(got) > 500 and set(got["group_id"].tolist()) >= {0, 1, 2}
+    Tg = L.compute_rectification_transform(got, w, h).as_array()
+    Tr = O.transform_to_array(O.compute_rectification_transform(ref, w, h))
+    for k in (4, 5):
+        assert np.abs(_unit(Tg[k]) - _unit(Tr[k])).max() < 1e-4
+    np.testing.assert_allclose(Tg[:4], Tr[:4], rtol=1e-4, atol=1e-3)
+    np.testing.assert_array_equal(tf_b[0].as_array(), Tg)
+    # the same lines through the stand-alone entry: same groups, same cells
+    got2, got_m, got_c, votes = ctx.estimate_line_pencils_cht(filt, d=128)
+    _assert_lines_equal(got2, ref)
+    np.testing.assert_array_equal(got_c, ref_c)
+    _assert_models_close(got_m, ref_m)
+
+
+def test_config_5_8k_frame_segments_through_the_cht_accumulator_parity_unpinned(L, ctx):
+    """BASELINE configs[4]'s "LDS/atomic stress": the 8192^2 tiled frame's ~24 000 segments through the accumulator
+    (47 workgroups of LDS votes, four peeling rounds with votes taken back), as an estimator of the frame's own call."""
+    from librectify_amd import synth
+
+    w = h = 8192
+    img = synth.frame(w, h, 7, bars=6000, tile=512)
+    T = O.max_threads()
+    det = O.find_line_segments(img, num_threads=T, want_label=False)
+    filt = O.filter_lines(det["lines"], 20.0)
+    assert len(filt) > 20000
+    ref, ref_m, ref_c = O.estimate_line_pencils_cht(filt, d=128)
+    ctx.set_estimator(3, 128)
+    try:
+        got = ctx.find_line_segment_groups(img, 20.0, capacity=200000)
+    finally:
+        ctx.set_estimator(0)
+    _assert_lines_equal(got, ref)
+    got2, got_m, got_c, votes = ctx.estimate_line_pencils_cht(filt, d=128)
+    _assert_lines_equal(got2, ref)
+    np.testing.assert_array_equal(got_c, ref_c)
+    _assert_models_close(got_m, ref_m)
+    assert votes > 100 * len(filt)

@@ -240,6 +240,48 @@ def test_second_laps_of_the_one_wait_pipeline_are_exact(L, ctx):
     np.testing.assert_array_equal(ctx.download(L.BUF_LABEL), O.find_line_segments(img)["label"])
 
 
+def test_seed_order_with_a_capacity_that_cuts_the_last_sort_block(L, ctx):
+    """the fused seed order sorts blocks of 4096 keys; a capacity that is no multiple of 4096, with
+    the seed count in the last, partial block, used to rank against slots beyond the capacity (stale keys of an earlier
+    frame, or memory past the allocation).  A larger frame first leaves real keys beyond the slot, then the frame runs
+    with capacity = seeds + 37; and a frame of fewer than 4096 pixels on a fresh context (capacity = its pixel count)."""
+    from librectify_amd import synth
+
+    big = synth.frame(1600, 1200, 21)
+    img = synth.frame(1120, 840, 22)
+    ref = O.find_line_segments(img)
+    n = ref["n_seeds"]
+    assert 4096 < n < 8192, n  # two sort blocks, the second one partial
+    ctx.set_flood_mode(1)
+    ctx.set_seed(0)
+    for cap in (n + 37, n + 1, n):
+        ctx.find_line_segment_groups(big, 16.0)  # leaves its keys in every slot up to its own count (> 8192)
+        assert ctx.stage_counters()["seeds"] > 8192
+        ctx.set_seed_capacity(cap)
+        ctx.stage_filter_host(img)
+        assert ctx.stage_seeds() == n
+        ctx.stage_flood()
+        np.testing.assert_array_equal(ctx.download(L.BUF_LABEL), ref["label"])
+        _assert_lines_equal(ctx.stage_fit(), ref["lines"])
+        ctx.find_line_segment_groups(big, 16.0)
+        ctx.set_seed_capacity(cap)
+        got = ctx.find_line_segment_groups(img, 11.2)
+        assert ctx.stage_counters()["frame_laps"] == 1
+        _assert_lines_equal(got, O.find_line_segment_groups(img, 11.2, seed=0)[0])
+    small = synth.frame(62, 60, 23, bars=4)
+    ref_s, _ = O.find_line_segment_groups(small, 5.0, seed=0)
+    c2 = L.Context(0)
+    try:
+        c2.set_seed(0)
+        _assert_lines_equal(c2.find_line_segment_groups(small, 5.0), ref_s)
+        c2.stage_filter_host(small)
+        c2.stage_seeds()
+        c2.stage_flood()
+        np.testing.assert_array_equal(c2.download(L.BUF_LABEL), O.find_line_segments(small)["label"])
+    finally:
+        c2.close()
+
+
 def test_grouping_of_the_reference_golden_lines_on_the_gpu(L, ctx):
     """Pin 4 through the C ABI: the device peeling (kernels_groups.hip) on the reference's own 848 golden lines gives
     the oracle's group ids bit for bit, i.e. the reference's three pencils (tests/test_oracle_pins.py::test_pin4_*)."""

@@ -157,3 +157,21 @@ def test_oracle_threaded_equals_serial():
         ra, _ = O.find_line_segment_groups(img, 6.4, refine=refine, seed=0, num_threads=-1)
         rb, _ = O.find_line_segment_groups(img, 6.4, refine=refine, seed=0, num_threads=O.max_threads())
         assert ra.tobytes() == rb.tobytes()
+
+
+def test_cht_estimator_oracle_self_consistency_parity_unpinned():
+    """The oracle's diamond-space peeling (what cht.h:13-24 describes inside estimator.h:99-145): finds the three
+    pencils of the synthetic segments, is deterministic, and a finer accumulator agrees on the large groups."""
+    from librectify_amd import synth
+
+    segs = synth.random_segments(1000, 42)
+    a, ma, ca = O.estimate_line_pencils_cht(segs, d=128)
+    b, mb, cb = O.estimate_line_pencils_cht(segs, d=128)
+    assert a.tobytes() == b.tobytes() and (ca == cb).all()
+    ids, cnt = np.unique(a["group_id"], return_counts=True)
+    assert set(ids.tolist()) >= {0, 1, 2}
+    assert sorted(cnt[ids >= 0])[-3] > 120  # three pencils of ~200 lines each
+    assert len(ma) == len(ca) <= 4 and np.allclose(np.linalg.norm(ma, axis=1), 1.0, atol=1e-5)
+    # fewer than two lines: no round at all (estimator.h:115)
+    one, m1, c1 = O.estimate_line_pencils_cht(segs[:1])
+    assert len(m1) == 0 and one["group_id"][0] == -1
