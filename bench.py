@@ -24,7 +24,20 @@ Rank 0 prints ONE JSON line carrying, besides the contract's keys:
   config4_batch1080 — BASELINE configs[3]: 512 frames 1920x1080 sharded over the ranks (strong scaling),
                  host pointers, one gather.
 
+  single_frame — ONE frame through the reference's own six-symbol entry (find_line_segment_groups +
+                 compute_rectification_transform): wall ms and Mpix/s from a pageable and from a
+                 page-locked buffer, mean over the four bench frames;
+  flood        — the ordered flood of those frames: ms, component pixels per second, pixels walked per pixel labelled;
+  roofline_ransac — 15 flop per (hypothesis, line) x line evaluations per second against the fp32 vector peak;
+  roofline_8k  — the filter kernel on 8192x8192 frames (1.2 GB of algorithmic traffic per launch: nothing of it
+                 fits the 256 MiB Infinity Cache);
+  cht          — the diamond-space estimator (lr_estimate_line_pencils_cht): ms per grouping call and votes per second.
+
 `--config batch1080` makes that last workload the timed one (512 frames over N ranks, "scaling": "strong").
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process starts N ranks itself (`python -m
+torch.distributed.run --nproc-per-node N ... bench.py <same arguments>` as a child process, before anything here has
+touched the GPU) and relays rank 0's JSON line.  WORLD_SIZE set but different from --gpus is refused.
 """
 import argparse
 import json
@@ -145,7 +158,183 @@ def ransac_rates(ctx):
     return out
 
 
-def main():
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector peak (no MFMA on this path)
+RANSAC_FLOP_PER_EVAL = 15.0     # per (hypothesis, line)
+
+
+def spawn_command(argv, n, port):
+    """The child process that runs `n` ranks of this script on one node (one rank per GPU)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """--gpus N > 1 without a launcher: start the N ranks as a child process and relay rank 0's line.  Nothing in this
+    process has touched the GPU (and nothing will): no re-exec, the parent only waits."""
+    import subprocess
+
+    cmd = spawn_command(argv, args.gpus, free_port())
+    if args.dry_run_spawn:
+        print(json.dumps({"spawn": cmd}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in p.stdout:
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        else:
+            print(out, file=sys.stderr)
+    rc = p.wait()
+    if line is not None:
+        print(line)
+    elif rc == 0:
+        rc = 1
+    return rc
+
+
+def cpu_list(text):
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def rank_cpus(local_rank, world, pci_bus_id=None, available=None):
+    """Host cores for this rank's lanes and staging threads: the cores of its GPU's NUMA node (sysfs), split evenly
+    among the ranks whose GPUs share the node; without that information, the rank's contiguous share of the cores this
+    process may run on.  Returns (cores, how)."""
+    avail = sorted(available if available is not None else os.sched_getaffinity(0))
+    if world <= 1 or not avail:
+        return avail, "all"
+    share = max(1, len(avail) // world)
+    fallback = avail[local_rank * share : (local_rank + 1) * share] or avail
+    if pci_bus_id:
+        try:
+            node = int(open("/sys/bus/pci/devices/%s/numa_node" % pci_bus_id.lower()).read())
+            if node >= 0:
+                cpus = [c for c in cpu_list(open("/sys/devices/system/node/node%d/cpulist" % node).read()) if c in set(avail)]
+                n_nodes = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()])
+                per_node = max(1, world // max(1, n_nodes))  # ranks that share this node
+                k = local_rank % per_node
+                sh = max(1, len(cpus) // per_node)
+                mine = cpus[k * sh : (k + 1) * sh]
+                if mine:
+                    return mine, "numa node %d" % node
+        except (OSError, ValueError):
+            pass
+    return fallback, "contiguous share"
+
+
+def cht_rates(ctx):
+    """The diamond-space estimator (lr_estimate_line_pencils_cht: votes of all lines into the LDS accumulators, four
+    peeling rounds with argmax on the device and the removed lines' votes taken back): whole call."""
+    import librectify_amd as L
+    from librectify_amd import synth
+
+    out = {}
+    for n in (1000, 20000):
+        lines = np.ascontiguousarray(synth.random_segments(n, 42), L.LINE_DTYPE)
+        _, models, _, votes = ctx.estimate_line_pencils_cht(lines, d=128)
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.estimate_line_pencils_cht(lines, d=128)
+        dt = (time.perf_counter() - t0) / reps
+        out["N%d_d128" % n] = {"ms_per_call": round(dt * 1e3, 4), "rounds": int(len(models)), "ms_per_solve": round(dt * 1e3 / max(1, len(models)), 4),
+                               "votes_per_call": votes, "votes_per_s": round(votes / dt, 1)}
+    return out
+
+
+def single_frame_rates(L, ctx, frames, min_length):
+    """One frame at a time through the reference's own entry points (the drop-in symbols find_line_segment_groups,
+    compute_rectification_transform, release_line_segments): wall time from entry to return, pageable and page-locked
+    source, mean over the bench frames (SURVEY.md §8d-i is defined on exactly this call pair)."""
+    h, w = frames[0].shape
+    out = {"frames": len(frames), "entry": "find_line_segment_groups + compute_rectification_transform (librectify.h), num_threads = 8"}
+    pinned = ctx.host_alloc((len(frames), h, w))
+    pinned[:] = frames
+    for name, src in (("pageable", frames), ("page_locked", pinned)):
+        per = []
+        for f in src:
+            for rep in range(4):
+                t0 = time.perf_counter()
+                lines = L.find_line_segment_groups(f, min_length, num_threads=8)
+                L.compute_rectification_transform(lines, w, h)
+                dt = time.perf_counter() - t0
+                if rep > 0:
+                    per.append(dt)
+        ms = float(np.mean(per)) * 1e3
+        out[name] = {"wall_ms": round(ms, 4), "Mpix_per_s": round(w * h / ms / 1e3, 2), "min_ms": round(float(np.min(per)) * 1e3, 4), "max_ms": round(float(np.max(per)) * 1e3, 4)}
+    ctx.host_free(pinned)
+    return out
+
+
+def flood_rates(L, ctx, frames):
+    """The ordered flood (filter.cpp:110-153, line_detector.cpp:92-122) of the bench frames, one frame at a time through
+    the frame call: device ms of the flood stage, labelled component pixels per second, and how many pixels the rounds
+    walked for every pixel they labelled (re-walks of blocked seeds)."""
+    ms, px, walked, rounds = [], [], [], []
+    h, w = frames[0].shape
+    for f in frames:
+        for rep in range(3):
+            ctx.find_line_segment_groups(f, float(max(w, h)) / 100.0)
+            if rep > 0:
+                ms.append(float(ctx.stage_times()[L.T_FLOOD]))
+        c = ctx.stage_counters()
+        px.append(c["labelled_px"])
+        walked.append(c.get("walked_px", 0))
+        rounds.append(c["flood_rounds"])
+    m = float(np.mean(ms))
+    return {"ms": round(m, 4), "component_pixels_per_s": round(float(np.mean(px)) / (m * 1e-3), 1), "labelled_px": float(np.mean(px)),
+            "walked_px": float(np.mean(walked)), "walked_per_labelled": round(float(np.sum(walked)) / max(1.0, float(np.sum(px))), 3),
+            "rounds": float(np.mean(rounds)), "frames": len(frames)}
+
+
+def roofline_8k(L, ctx, torch, dev, base):
+    """The filter kernel on 8192 x 8192 frames (the primary HBM evidence -- 1.2 GB of algorithmic
+    traffic per launch, four times the Infinity Cache): three resident frames in turn, HIP events around each launch."""
+    w = h = 8192
+    if base is None:
+        from librectify_amd import synth
+
+        base = synth.frame(W4K, H4K, 1)
+    big = np.tile(base, (4, 3))[:h, :w]  # (content does not matter to a streaming kernel; every buffer is distinct memory)
+    d = torch.empty((3, h, w), dtype=torch.float32, device=dev)
+    for i in range(3):
+        d[i].copy_(torch.from_numpy(np.ascontiguousarray(np.roll(big, 17 * i, axis=1))))
+    torch.cuda.synchronize()
+    ms = []
+    for lap in range(4):
+        for b in range(3):
+            ctx.stage_filter_device(d.data_ptr() + b * h * w * 4, w, h)
+            ctx.synchronize()
+            if lap > 0:
+                ms.append(ctx.stage_times_partial())
+    del d
+    torch.cuda.empty_cache()
+    k = float(np.mean(ms))
+    ach = ALGO_BYTES_PER_PX * w * h / (k * 1e-3) / 1e9
+    return {"bound": "hbm", "frame": "8192x8192", "kernel_ms": round(k, 5), "launches": len(ms), "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PX * w * h}
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -167,8 +356,17 @@ def main():
     ap.add_argument("--flood-mode", type=int, default=None)
     ap.add_argument("--streams", type=int, default=6, help="frames in flight per GPU (one context + HIP stream + host thread each); "
                     "more than a handful only dilutes the 256 MB Infinity Cache that the flood's gathers live on")
-    ap.add_argument("--staging-threads", type=int, default=12, help="host threads that stage pageable frames (num_threads of the batch call)")
-    args = ap.parse_args()
+    ap.add_argument("--staging-threads", type=int, default=12, help="host threads that stage pageable frames (num_threads of the batch call); "
+                    "capped at this rank's share of the host cores")
+    ap.add_argument("--dry-run-spawn", action="store_true", help="with --gpus N > 1 and no WORLD_SIZE: print the launch command instead of running it")
+    args = ap.parse_args(argv)
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        return launch_ranks(args, argv)
+    if env_world is not None and int(env_world) != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%s: refusing to run a different number of ranks than asked for" % (args.gpus, env_world), file=sys.stderr)
+        return 2
 
     import torch
     import torch.distributed as dist
@@ -197,6 +395,26 @@ def main():
         else:
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
     n_gpus = world if world > 1 else 1
+    # host side of a rank: its lanes, its uploader and its staging threads stay on the cores of its GPU's NUMA node, and
+    # no rank asks for more staging threads than its share of the cores (threads inherit the affinity set here)
+    try:
+        bus = torch.cuda.get_device_properties(local_rank).pci_bus_id
+        bus_id = "%04x:%02x:%02x.0" % (torch.cuda.get_device_properties(local_rank).pci_domain_id, bus, torch.cuda.get_device_properties(local_rank).pci_device_id)
+    except Exception:
+        bus_id = None
+    cpus, cpus_how = rank_cpus(local_rank, world, bus_id)
+    if world > 1 and cpus:
+        try:
+            os.sched_setaffinity(0, cpus)
+        except OSError:
+            cpus_how += " (not applied)"
+    args.staging_threads = max(1, min(args.staging_threads, len(cpus) if cpus else args.staging_threads))
+    ranks_seen = world
+    if world > 1:  # did the collective backend see every rank?
+        t = torch.ones(1, dtype=torch.int32, device=cdev)
+        got = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        ranks_seen = int(sum(int(x.item()) for x in got))
 
     ctx = L.Context(local_rank)
     ctx.set_seed(0)
@@ -414,8 +632,25 @@ def main():
                 for k, i in [("filter", L.T_FILTER), ("seeds", L.T_SEEDS), ("flood", L.T_FLOOD), ("fit", L.T_FIT), ("ransac", L.T_RANSAC), ("total_device", L.T_TOTAL)]
             },
         }
+        res["ranks_seen"] = ranks_seen
+        res["host_cores_per_rank"] = {"count": len(cpus), "how": cpus_how, "staging_threads": args.staging_threads}
         if not args.no_extra_legs:
-            res["ransac_hypotheses_per_s"] = ransac_rates(ctx)
+            rr = ransac_rates(ctx)
+            res["ransac_hypotheses_per_s"] = rr
+            res["roofline_ransac"] = {
+                "bound": "fp32 vector ALU (no MFMA: no dense contraction on this path)",
+                "flop_per_line_evaluation": RANSAC_FLOP_PER_EVAL,
+                "peak": FP32_VECTOR_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                **{k: {"achieved": round(v["line_evaluations_per_s"] * RANSAC_FLOP_PER_EVAL / 1e12, 3),
+                       "frac": round(v["line_evaluations_per_s"] * RANSAC_FLOP_PER_EVAL / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4)} for k, v in rr.items()},
+                "note": "whole lr_ransac_best call: table upload, scoring kernel, argmax, one wait",
+            }
+            res["cht"] = cht_rates(ctx)
+            if args.config == "frames4k" and wl.B:
+                res["single_frame"] = single_frame_rates(L, ctx, wl.pageable[: min(4, wl.B)], wl.min_length)
+                res["flood"] = flood_rates(L, ctx, wl.pageable[: min(4, wl.B)])
+            res["roofline_8k"] = roofline_8k(L, ctx, torch, dev, wl.pageable[0] if wl.B and (wl.w, wl.h) == (W4K, H4K) else None)
         if not args.no_cpu_baseline and n_gpus == 1 and wl.B:
             res["cpu_baseline"] = cpu_baseline(wl.pageable[:2], w, h, wl.min_length)
         else:
@@ -427,4 +662,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

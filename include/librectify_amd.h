@@ -158,7 +158,8 @@ int lr_stage_times(lr_context* ctx, float* ms, int count);
 int lr_filter_kernel_ms(lr_context* ctx, float* ms);
 /* Extra counters of the last call: [0] seeds, [1] components, [2] flood rounds, [3] labelled pixels, and how the
  * flood's walks were stored: [4] seeds that moved to the second LDS tier, [5] global slabs used, [6] seeds finished by
- * the ordered single-wave tail (storage exhausted); [7] laps of the frame through the pipeline (1 normally). */
+ * the ordered single-wave tail (storage exhausted); [7] laps of the frame through the pipeline (1 normally); [8] pixels
+ * the flood's explorations walked in all rounds together (over [3]: the re-walk factor), [9] their 8x8-tile steps. */
 int lr_stage_counters(lr_context* ctx, int64_t* out, int count);
 
 /* ---- RANSAC --------------------------------------------------------------------------- */

@@ -262,10 +262,11 @@ class Context:
         return ms.value
 
     def stage_counters(self):
-        c = np.zeros(8, np.int64)
-        _check(lib().lr_stage_counters(self._h, _ptr(c), 8))
+        c = np.zeros(10, np.int64)
+        _check(lib().lr_stage_counters(self._h, _ptr(c), 10))
         return dict(seeds=int(c[0]), components=int(c[1]), flood_rounds=int(c[2]), labelled_px=int(c[3]),
-                    second_tier_seeds=int(c[4]), slabs=int(c[5]), ordered_tail_seeds=int(c[6]), frame_laps=int(c[7]))
+                    second_tier_seeds=int(c[4]), slabs=int(c[5]), ordered_tail_seeds=int(c[6]), frame_laps=int(c[7]),
+                    walked_px=int(c[8]), walk_steps=int(c[9]))
 
     # ---- full path ----
     def find_line_segment_groups(self, img, min_length, refine=False, num_threads=-1, capacity=None):

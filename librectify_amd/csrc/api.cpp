@@ -280,10 +280,12 @@ int lr_stage_times(lr_context* ctx, float* ms, int count) {
 }
 
 int lr_stage_counters(lr_context* ctx, int64_t* out, int count) {
-    const int64_t v[8] = {(int64_t)ctx->n_seeds,        (int64_t)ctx->n_comp,         (int64_t)ctx->flood_rounds,
-                          (int64_t)ctx->n_px,           (int64_t)ctx->flood_tiers[0], (int64_t)ctx->flood_tiers[1],
-                          (int64_t)ctx->flood_tiers[2], (int64_t)ctx->frame_laps};
-    for (int i = 0; i < count && i < 8; ++i) out[i] = v[i];
+    const int64_t v[10] = {(int64_t)ctx->n_seeds,        (int64_t)ctx->n_comp,         (int64_t)ctx->flood_rounds,
+                           (int64_t)ctx->n_px,           (int64_t)ctx->flood_tiers[0], (int64_t)ctx->flood_tiers[1],
+                           (int64_t)ctx->flood_tiers[2], (int64_t)ctx->frame_laps,
+                           (int64_t)(((uint64_t)ctx->flood_tiers[5] << 32) | ctx->flood_tiers[4]),
+                           (int64_t)(((uint64_t)ctx->flood_tiers[7] << 32) | ctx->flood_tiers[6])};
+    for (int i = 0; i < count && i < 10; ++i) out[i] = v[i];
     return 0;
 }
 

@@ -172,8 +172,8 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
 // After the stream has been synchronised: completes the flood if the first batch did not (more rounds, ordered tail;
 // synchronises).  *extra = the label image changed after flood_enqueue's rounds, so later stages must run again.
 int flood_finish(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, uint32_t* h_ctrl, int* rounds_out,
-                 uint32_t* tiers_out /* [4]: seeds moved to the second tier, slabs used, seeds left to the ordered tail,
-                                        hold-back engaged */,
+                 uint32_t* tiers_out /* [8]: seeds moved to the second tier, slabs used, seeds left to the ordered tail,
+                                        hold-back engaged, pixels walked (lo, hi), tile steps (lo, hi) */,
                  bool* extra, hipStream_t s);
 
 // kernels_fit.hip (all counts stay on the device: launches cover seed_cap / comp_cap)

@@ -142,7 +142,7 @@ struct lr_context {
     int flood_mode = 1;
     bool flood_big_hint = true;  // did the last frame's walks outgrow the first storage tier? (none yet: assume so)
     bool flood_hold_hint = false;  // did the last frame hold its weakest seeds back?
-    uint32_t flood_tiers[4] = {0, 0, 0, 0};  // last flood: seeds in the second tier, slabs used, seeds of the ordered tail
+    uint32_t flood_tiers[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // last flood: seeds in the second tier, slabs used, seeds of the ordered tail, hold-back, walked px (lo, hi), steps (lo, hi)
     bool flood_staged = false;  // lr_set_flood_staged: the rounds start on the strongest eighth of the seeds (test / experiment hook)
     hipEvent_t ev[16] = {};
     float stage_ms[LR_T_COUNT] = {};

@@ -214,6 +214,8 @@ enum {
     // is worked out by flood_init_seeds_kernel and kept here.
     kCtrlNSeeds = 16,   // seeds of this frame (clamped to the capacity the seed sort ran with)
     kCtrlWinHold = 17,  // the window stops here while the weakest seeds are held back
+    kCtrlWalked = 18,   // [18..19] 64-bit: pixels walked by all explorations of the frame (diagnostics: re-walk factor)
+    kCtrlSteps = 20,    // [20..21] 64-bit: tile steps of all explorations
     kCtrlWords = 32,
 };
 static_assert(kCtrlWords == kFloodCtrlWords, "control block size");
@@ -1106,14 +1108,16 @@ __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, const
     const uint32_t barrier = A.ctrl[kCtrlBarrier];
     // Counters of the control block are added to once per workgroup: an atomic per wavefront was 640 atomics on one
     // address in the first round, which the L2 executes one after the other (28 us for 40 000 seeds; 10 us now).
-    __shared__ uint32_t s_cnt[4][3];  // per wavefront: survivors, committed, survivors below the window
+    __shared__ uint32_t s_cnt[4][5];  // per wavefront: survivors, committed, survivors below the window, pixels and steps walked
     __shared__ uint32_t s_base;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (uint32_t ai = blockIdx.x * 256 + threadIdx.x; ai < n_pad; ai += gridDim.x * 256) {
         bool a = false, done = false;
-        uint32_t k = 0;
+        uint32_t k = 0, wpx = 0, wst = 0;
         if (ai < n_act) {
             k = act[ai];
+            wpx = A.count[k];        // what this round's exploration of k walked (0 if it did not walk)
+            wst = A.flags[k] >> 8;
             if (A.flags[k] & kFlagSelfFail) {  // flood() accepted nothing, not even the seed
                 state[k] = 2;
                 seed_size[k] = 0;
@@ -1135,10 +1139,17 @@ __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, const
         }
         // next round's active list: the order of the list does not matter
         const uint64_t m = __ballot(a), md = __ballot(done), mb = __ballot(a && k < window);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            wpx += (uint32_t)__shfl_xor((int)wpx, off);
+            wst += (uint32_t)__shfl_xor((int)wst, off);
+        }
         if (lane == 0) {
             s_cnt[wave][0] = (uint32_t)__popcll(m);
             s_cnt[wave][1] = (uint32_t)__popcll(md);
             s_cnt[wave][2] = (uint32_t)__popcll(mb);
+            s_cnt[wave][3] = wpx;
+            s_cnt[wave][4] = wst;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -1148,6 +1159,10 @@ __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, const
             s_base = na ? atomicAdd(&A.ctrl[kCtrlNNext], na) : 0u;
             if (nd) atomicAdd(&A.ctrl[kCtrlNCommit], nd);
             if (nb) atomicAdd(&A.ctrl[kCtrlBelow], nb);
+            const uint32_t np_ = s_cnt[0][3] + s_cnt[1][3] + s_cnt[2][3] + s_cnt[3][3];
+            const uint32_t ns_ = s_cnt[0][4] + s_cnt[1][4] + s_cnt[2][4] + s_cnt[3][4];
+            if (np_) atomicAdd(reinterpret_cast<unsigned long long*>(&A.ctrl[kCtrlWalked]), (unsigned long long)np_);
+            if (ns_) atomicAdd(reinterpret_cast<unsigned long long*>(&A.ctrl[kCtrlSteps]), (unsigned long long)ns_);
         }
         __syncthreads();
         if (a) {
@@ -1204,6 +1219,8 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
         ctrl[kCtrlRounds] = 0u;
         ctrl[kCtrlStall] = 0u;
         ctrl[kCtrlNRemain] = n_seeds;
+        ctrl[kCtrlWalked] = ctrl[kCtrlWalked + 1] = 0u;
+        ctrl[kCtrlSteps] = ctrl[kCtrlSteps + 1] = 0u;
     }
     for (uint32_t r = k; r < n_runs; r += gridDim.x * 256) dirty[r] = 0;  // (all clear after a flood that ran to its end)
     if (k >= n_seeds) return;
@@ -1565,6 +1582,10 @@ int flood_finish(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, u
         tiers_out[1] = h_ctrl[kCtrlSlabTotal];
         tiers_out[2] = (h_ctrl[kCtrlStall] != 0u && h_ctrl[kCtrlNRemain] > 0u) ? h_ctrl[kCtrlNRemain] : 0u;
         tiers_out[3] = h_ctrl[kCtrlPhase];
+        tiers_out[4] = h_ctrl[kCtrlWalked];
+        tiers_out[5] = h_ctrl[kCtrlWalked + 1];
+        tiers_out[6] = h_ctrl[kCtrlSteps];
+        tiers_out[7] = h_ctrl[kCtrlSteps + 1];
     }
     return 0;
 }

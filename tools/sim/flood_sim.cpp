@@ -1,0 +1,536 @@
+// Experiment tooling (NOT product, NOT oracle): pixel-level simulator of the flood's round schemes on a dumped frame
+// (tools/sim/dump_frame.py), to count rounds, walked pixels, tile steps and the per-round critical path of candidate
+// commit rules before any of them is written in HIP.  The ordered semantics are those of filter.cpp:110-153 /
+// line_detector.cpp:92-122; every scheme is checked against the sequential result.
+//
+//   g++ -O2 -std=c++17 -o /tmp/flood_sim tools/sim/flood_sim.cpp && /tmp/flood_sim /tmp/sim4k <scheme>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+static std::vector<float> dx, dy, thr;
+static std::vector<uint8_t> dmask;
+static std::vector<int32_t> sidx, sbin;
+static float st[8], ct[8];
+static int W, H, NS;
+
+template <class T>
+static std::vector<T> load(const std::string& p) {
+    FILE* f = fopen(p.c_str(), "rb");
+    if (!f) {
+        perror(p.c_str());
+        exit(1);
+    }
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<T> v(n / sizeof(T));
+    if (fread(v.data(), 1, n, f) != (size_t)n) exit(1);
+    fclose(f);
+    return v;
+}
+
+static inline float resp(int q, int b) { return std::fabs(fmaf(dx[q], st[b], dy[q] * ct[b])); }
+
+struct Walk {
+    std::vector<int> px;
+    int tiles = 0;
+};
+
+static std::vector<int> g_seen;  // epoch marks
+static int g_epoch = 0;
+static std::vector<int> g_tile_seen;
+
+// footprint of seed k w.r.t. the committed pixels (their dmask is cleared)
+static void footprint(int k, const std::vector<uint8_t>& dm, Walk& out) {
+    out.px.clear();
+    out.tiles = 0;
+    const int b = sbin[k];
+    const float t = thr[k];
+    const int s = sidx[k];
+    if (!(((dm[s] >> b) & 1) && resp(s, b) > t)) return;
+    ++g_epoch;
+    g_seen[s] = g_epoch;
+    out.px.push_back(s);
+    const int tw = (W + 7) / 8;
+    for (size_t head = 0; head < out.px.size(); ++head) {
+        const int p = out.px[head];
+        const int ti = (p / W / 8) * tw + (p % W) / 8;
+        if (g_tile_seen[ti] != g_epoch) {
+            g_tile_seen[ti] = g_epoch;
+            out.tiles++;
+        }
+        const int r = p / W, c = p % W;
+        for (int dr = -1; dr <= 1; ++dr)
+            for (int dc = -1; dc <= 1; ++dc) {
+                if (!dr && !dc) continue;
+                const int rr = r + dr, cc = c + dc;
+                if (rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
+                const int q = rr * W + cc;
+                if (g_seen[q] == g_epoch) continue;
+                if (((dm[q] >> b) & 1) && resp(q, b) > t) {
+                    g_seen[q] = g_epoch;
+                    out.px.push_back(q);
+                }
+            }
+    }
+}
+
+// sequential reference
+static std::vector<int> sequential(std::vector<int>& sizes) {
+    std::vector<uint8_t> dm = dmask;
+    std::vector<int> label((size_t)W * H, -1);
+    sizes.assign(NS, 0);
+    Walk w;
+    for (int k = 0; k < NS; ++k) {
+        if (label[sidx[k]] >= 0) continue;
+        footprint(k, dm, w);
+        for (int p : w.px) {
+            label[p] = k;
+            dm[p] = 0;
+        }
+        sizes[k] = (int)w.px.size();
+    }
+    return label;
+}
+
+struct RoundStat {
+    long walked_px = 0, steps = 0;
+    int longest = 0, longest_commit = 0, n_walk = 0, n_commit = 0, n_dead = 0, n_active = 0, phases = 1, longest_sum = 0;
+};
+
+static void print_round(int r, const RoundStat& s) {
+    printf("round %d: active %d, walked %d seeds, %ld px in %ld steps, longest walk %d (committing: %d), sum of per-phase longest %d, phases %d; commit %d, dead %d\n", r,
+           s.n_active, s.n_walk, s.walked_px, s.steps, s.longest, s.longest_commit, s.longest_sum, s.phases, s.n_commit, s.n_dead);
+}
+
+// ---- schemes 3, 4: pixel-level commits -------------------------------------------------------------------------------
+// A seed commits, every round, the part G of its footprint that is connected to what it already owns (or to its seed
+// pixel) through pixels that carry no lower stamp: no lower alive seed can reach those, so they belong to its final
+// flood whatever happens elsewhere.  It stays active while its footprint still has contested pixels.  In later rounds it
+// explores from what it owns.  scheme 3: every alive seed walks its whole footprint every round; scheme 4: seeds whose
+// pixel lies in a part committed in this round (by a lower seed) are dead without walking (perfect deferral).
+static int g_win_first_shift = 0, g_win_growth = 2;
+static bool g_seed_level = false;
+static int pixel_level(int scheme, const std::vector<int>& ref, long labelled) {
+    std::vector<uint8_t> dm = dmask;
+    std::vector<int> label((size_t)W * H, -1);
+    const int INF = 0x7fffffff;
+    std::vector<int> stamp((size_t)W * H, INF);
+    std::vector<int> active(NS);
+    for (int k = 0; k < NS; ++k) active[k] = k;
+    std::vector<std::vector<int>> own(NS);  // committed pixels of a seed that is still active
+    std::vector<int> cmark((size_t)W * H, 0);
+    long tot_px = 0, tot_steps = 0;
+    int rounds = 0, crit = 0;
+    std::vector<int> q;
+    while (!active.empty()) {
+        ++rounds;
+        RoundStat rs;
+        rs.n_active = (int)active.size();
+        std::vector<int> touched, next;
+        std::vector<std::pair<int, std::vector<int>>> commits;  // applied at the end of the round (walks see the round-start state)
+        // staged window: only seeds below it walk (any prefix of the seed order is a valid window)
+        long window = NS;
+        if (g_win_first_shift > 0) {
+            window = std::max<long>(1024, NS >> g_win_first_shift);
+            for (int r = 1; r < rounds && window < NS; ++r) window <<= g_win_growth;
+        }
+        for (int k : active) {  // ascending
+            if (k >= window) {
+                if (label[sidx[k]] >= 0 && own[k].empty()) rs.n_dead++;
+                else next.push_back(k);
+                continue;
+            }
+            const int b = sbin[k];
+            const float t = thr[k];
+            const int s = sidx[k];
+            const bool has_own = !own[k].empty();
+            if (!has_own) {
+                if (label[s] >= 0 || cmark[s] == rounds) {  // taken by an earlier flood (this round: only scheme 4 knows before walking)
+                    if (label[s] >= 0 || scheme == 4) {
+                        rs.n_dead++;
+                        continue;
+                    }
+                }
+                if (!(((dm[s] >> b) & 1) && resp(s, b) > t)) {
+                    rs.n_dead++;
+                    continue;
+                }
+            }
+            // explore from the owned pixels (or the seed) through uncommitted acceptable pixels
+            ++g_epoch;
+            q.clear();
+            std::vector<int> fpx;  // uncommitted pixels reached
+            if (has_own) {
+                for (int p : own[k]) {
+                    g_seen[p] = g_epoch;
+                    q.push_back(p);
+                }
+            } else {
+                g_seen[s] = g_epoch;
+                q.push_back(s);
+                fpx.push_back(s);
+            }
+            int tiles = 0;
+            const int tw = (W + 7) / 8;
+            for (size_t head = 0; head < q.size(); ++head) {
+                const int p = q[head];
+                const int r = p / W, c = p % W;
+                for (int dr = -1; dr <= 1; ++dr)
+                    for (int dc = -1; dc <= 1; ++dc) {
+                        if (!dr && !dc) continue;
+                        const int rr = r + dr, cc = c + dc;
+                        if (rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
+                        const int x = rr * W + cc;
+                        if (g_seen[x] == g_epoch) continue;
+                        if (((dm[x] >> b) & 1) && resp(x, b) > t) {
+                            g_seen[x] = g_epoch;
+                            q.push_back(x);
+                            fpx.push_back(x);
+                        }
+                    }
+            }
+            for (int p : fpx) {
+                const int ti = (p / W / 8) * tw + (p % W) / 8;
+                if (g_tile_seen[ti] != g_epoch) {
+                    g_tile_seen[ti] = g_epoch;
+                    tiles++;
+                }
+            }
+            rs.n_walk++;
+            rs.walked_px += (long)fpx.size();
+            rs.steps += tiles;
+            rs.longest = std::max(rs.longest, tiles);
+            // G: reachable from the sources through pixels of fpx without a lower stamp
+            bool contested = false;
+            std::vector<int> G;
+            ++g_epoch;
+            q.clear();
+            if (has_own) {
+                for (int p : own[k]) {
+                    g_seen[p] = g_epoch;
+                    q.push_back(p);
+                }
+            } else if (stamp[s] > k) {
+                g_seen[s] = g_epoch;
+                q.push_back(s);
+                G.push_back(s);
+            }
+            for (int p : fpx)
+                if (stamp[p] < k) contested = true;
+            for (size_t head = 0; head < q.size(); ++head) {
+                const int p = q[head];
+                const int r = p / W, c = p % W;
+                for (int dr = -1; dr <= 1; ++dr)
+                    for (int dc = -1; dc <= 1; ++dc) {
+                        if (!dr && !dc) continue;
+                        const int rr = r + dr, cc = c + dc;
+                        if (rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
+                        const int x = rr * W + cc;
+                        if (g_seen[x] == g_epoch) continue;
+                        if (((dm[x] >> b) & 1) && resp(x, b) > t && stamp[x] > k) {
+                            g_seen[x] = g_epoch;
+                            q.push_back(x);
+                            G.push_back(x);
+                        }
+                    }
+            }
+            for (int p : fpx) {
+                if (stamp[p] == INF) touched.push_back(p);
+                stamp[p] = std::min(stamp[p], k);
+            }
+            if (g_seed_level && contested) G.clear();  // seed-level commits: all or nothing
+            for (int p : G) cmark[p] = rounds;
+            if (!G.empty()) rs.longest_commit = std::max(rs.longest_commit, tiles);
+            if (contested) {
+                next.push_back(k);
+                if (!G.empty()) own[k].insert(own[k].end(), G.begin(), G.end());
+            } else {
+                rs.n_commit++;
+                own[k].clear();
+                own[k].shrink_to_fit();
+            }
+            commits.emplace_back(k, std::move(G));
+        }
+        for (auto& c : commits)
+            for (int p : c.second) {
+                label[p] = c.first;
+                dm[p] = 0;
+            }
+        for (int p : touched) stamp[p] = INF;
+        rs.longest_sum = rs.longest;
+        print_round(rounds, rs);
+        tot_px += rs.walked_px;
+        tot_steps += rs.steps;
+        crit += rs.longest;
+        active.swap(next);
+        if (rounds > 200) break;
+    }
+    long bad = 0;
+    for (size_t i = 0; i < ref.size(); ++i) bad += ref[i] != label[i];
+    printf("scheme %d: %d rounds, %ld px walked (%.2fx labelled), %ld steps, critical path %d steps; label mismatches vs sequential: %ld\n", scheme,
+           rounds, tot_px, (double)tot_px / labelled, tot_steps, crit, bad);
+    return bad != 0;
+}
+
+// scheme 0: every active seed walks every round (what kernels_flood.hip did in r02)
+// scheme 1: perfect deferral -- seeds that die in the round never walk or stamp (lower bound of the deferral family)
+// scheme 2: opportunistic deferral in dispatch batches of `conc` walks (strongest first), phases until nothing is left
+//           to walk; a deferred seed is one whose own pixel carries a lower stamp when its batch starts
+int main(int argc, char** argv) {
+    const std::string dir = argv[1];
+    const int scheme = argc > 2 ? atoi(argv[2]) : 0;
+    const int conc = argc > 3 ? atoi(argv[3]) : 5120;
+    const int max_phases = argc > 4 ? atoi(argv[4]) : 100;
+    FILE* m = fopen((dir + "/meta.txt").c_str(), "r");
+    if (fscanf(m, "%d %d %d", &W, &H, &NS) != 3) return 1;
+    fclose(m);
+    dx = load<float>(dir + "/dx.f32");
+    dy = load<float>(dir + "/dy.f32");
+    dmask = load<uint8_t>(dir + "/dmask.u8");
+    sidx = load<int32_t>(dir + "/seed_idx.i32");
+    sbin = load<int32_t>(dir + "/seed_bin.i32");
+    thr = load<float>(dir + "/seed_thr.f32");
+    auto tr = load<float>(dir + "/trig.f32");
+    for (int i = 0; i < 8; ++i) st[i] = tr[i], ct[i] = tr[8 + i];
+    g_seen.assign((size_t)W * H, 0);
+    g_tile_seen.assign((size_t)((W + 7) / 8) * ((H + 7) / 8), 0);
+
+    std::vector<int> ref_sizes;
+    const std::vector<int> ref = sequential(ref_sizes);
+    long labelled = 0;
+    for (int v : ref) labelled += v >= 0;
+    printf("%dx%d, %d seeds, %ld labelled px\n", W, H, NS, labelled);
+    if (scheme >= 3 && scheme <= 6) {
+        // 3: pixel-level, all walk; 4: + perfect deferral; 5: seed-level commits + perfect deferral (= scheme 1); 6: seed-level, all walk
+        if (argc > 3) g_win_first_shift = atoi(argv[3]);
+        if (argc > 4) g_win_growth = atoi(argv[4]);
+        g_seed_level = scheme >= 5;
+        return pixel_level(scheme == 5 ? 4 : (scheme == 6 ? 3 : scheme), ref, labelled);
+    }
+
+    std::vector<uint8_t> dm = dmask;
+    std::vector<int> label((size_t)W * H, -1);
+    std::vector<int> active(NS);
+    for (int k = 0; k < NS; ++k) active[k] = k;
+    const int INF = 0x7fffffff;
+    std::vector<int> stamp((size_t)W * H, INF);
+    std::vector<Walk> fp(NS);
+    long tot_px = 0, tot_steps = 0;
+    int crit = 0, crit_commit = 0, rounds = 0, tot_phases = 0;
+    while (!active.empty()) {
+        ++rounds;
+        RoundStat rs;
+        rs.n_active = (int)active.size();
+        std::vector<int> commit, dead;
+        std::vector<uint8_t> walked(NS, 0);
+        std::vector<int> touched;  // pixels stamped this round
+        auto do_walk = [&](int k) {
+            footprint(k, dm, fp[k]);
+            walked[k] = 1;
+            rs.n_walk++;
+            rs.walked_px += (long)fp[k].px.size();
+            rs.steps += fp[k].tiles;
+            rs.longest = std::max(rs.longest, fp[k].tiles);
+            for (int p : fp[k].px) {
+                if (stamp[p] == INF) touched.push_back(p);
+                stamp[p] = std::min(stamp[p], k);
+            }
+        };
+        if (scheme == 0) {
+            for (int k : active) do_walk(k);
+            rs.longest_sum = rs.longest;
+            for (int k : active) {
+                if (fp[k].px.empty()) {
+                    dead.push_back(k);  // accepts nothing, not even itself
+                    continue;
+                }
+                bool blocked = false;
+                for (int p : fp[k].px)
+                    if (stamp[p] < k) {
+                        blocked = true;
+                        break;
+                    }
+                if (!blocked) commit.push_back(k);
+            }
+        } else if (scheme == 1) {
+            // ascending order: a seed whose pixel lies in a footprint committed in this round is dead and leaves no stamp
+            std::vector<uint8_t> ccov;  // marks via stamp2
+            std::vector<int> cover((size_t)0);
+            static std::vector<int> cmark;
+            if (cmark.empty()) cmark.assign((size_t)W * H, 0);
+            for (int k : active) {  // (active is ascending)
+                if (cmark[sidx[k]] == rounds) {
+                    dead.push_back(k);
+                    continue;
+                }
+                footprint(k, dm, fp[k]);
+                walked[k] = 1;
+                rs.n_walk++;
+                rs.walked_px += (long)fp[k].px.size();
+                rs.steps += fp[k].tiles;
+                rs.longest = std::max(rs.longest, fp[k].tiles);
+                if (fp[k].px.empty()) {
+                    dead.push_back(k);
+                    continue;
+                }
+                bool blocked = false;
+                for (int p : fp[k].px)
+                    if (stamp[p] < k) {
+                        blocked = true;
+                        break;
+                    }
+                for (int p : fp[k].px) {
+                    if (stamp[p] == INF) touched.push_back(p);
+                    stamp[p] = std::min(stamp[p], k);
+                }
+                if (!blocked) {
+                    commit.push_back(k);
+                    for (int p : fp[k].px) cmark[p] = rounds;
+                }
+            }
+            rs.longest_sum = rs.longest;
+        } else {
+            // opportunistic deferral.  status: 0 not yet considered, 1 walked, 2 deferred
+            std::vector<uint8_t> status(NS, 0);
+            std::vector<int> to_walk = active;
+            rs.phases = 0;
+            rs.longest_sum = 0;
+            std::vector<uint8_t> blocked(NS, 0);
+            std::vector<int> deferred;
+            while (!to_walk.empty() && rs.phases < max_phases) {
+                rs.phases++;
+                int phase_longest = 0;
+                // batches of `conc`: a seed sees the stamps of earlier batches (and earlier phases) only
+                for (size_t b0 = 0; b0 < to_walk.size(); b0 += conc) {
+                    const size_t b1 = std::min(to_walk.size(), b0 + (size_t)conc);
+                    std::vector<int> go;
+                    for (size_t i = b0; i < b1; ++i) {
+                        const int k = to_walk[i];
+                        if (stamp[sidx[k]] < k && rs.phases == 1) {  // its own pixel is reached by a lower seed: deferred
+                            status[k] = 2;
+                            deferred.push_back(k);
+                        } else {
+                            go.push_back(k);
+                        }
+                    }
+                    for (int k : go) {
+                        footprint(k, dm, fp[k]);
+                        status[k] = 1;
+                        walked[k] = 1;
+                        rs.n_walk++;
+                        rs.walked_px += (long)fp[k].px.size();
+                        rs.steps += fp[k].tiles;
+                        phase_longest = std::max(phase_longest, fp[k].tiles);
+                    }
+                    for (int k : go)
+                        for (int p : fp[k].px) {
+                            if (stamp[p] == INF) touched.push_back(p);
+                            stamp[p] = std::min(stamp[p], k);
+                        }
+                }
+                rs.longest = std::max(rs.longest, phase_longest);
+                rs.longest_sum += phase_longest;
+                // decide: tentative commits = walked, unblocked; deferred seeds whose pixel's lowest stamper commits are dead;
+                // the other deferred seeds must walk in the next phase
+                std::vector<uint8_t> tent(NS, 0);
+                for (int k : active)
+                    if (status[k] == 1 && !fp[k].px.empty()) {
+                        bool bl = false;
+                        for (int p : fp[k].px)
+                            if (stamp[p] < k) {
+                                bl = true;
+                                break;
+                            }
+                        tent[k] = !bl;
+                    }
+                to_walk.clear();
+                std::vector<int> still;
+                for (int k : deferred) {
+                    const int o = stamp[sidx[k]];
+                    if (o < k && tent[o]) {
+                        still.push_back(k);  // dead if o really commits: stays deferred
+                    } else {
+                        to_walk.push_back(k);
+                    }
+                }
+                deferred.swap(still);
+            }
+            // final decision (barrier: the lowest active seed that neither walked nor is dead)
+            std::vector<uint8_t> tent(NS, 0);
+            for (int k : active)
+                if (status[k] == 1 && !fp[k].px.empty()) {
+                    bool bl = false;
+                    for (int p : fp[k].px)
+                        if (stamp[p] < k) {
+                            bl = true;
+                            break;
+                        }
+                    tent[k] = !bl;
+                }
+            int barrier = INF;
+            for (int k : to_walk) barrier = std::min(barrier, k);  // phases exhausted: these never walked
+            // deferred whose owner does not commit below the barrier are alive and un-walked: lower the barrier (fixpoint)
+            for (bool again = true; again;) {
+                again = false;
+                for (int k : deferred) {
+                    const int o = stamp[sidx[k]];
+                    const bool owner_commits = o < k && tent[o] && o < barrier;
+                    if (!owner_commits && k < barrier) {
+                        barrier = k;
+                        again = true;
+                    }
+                }
+            }
+            for (int k : active) {
+                if (status[k] == 1 && fp[k].px.empty()) dead.push_back(k);
+                else if (tent[k] && k < barrier) commit.push_back(k);
+            }
+        }
+        for (int k : commit) {
+            rs.longest_commit = std::max(rs.longest_commit, fp[k].tiles);
+            for (int p : fp[k].px) {
+                label[p] = k;
+                dm[p] = 0;
+            }
+        }
+        for (int p : touched) stamp[p] = INF;
+        std::vector<int> next;
+        std::vector<uint8_t> gone(NS, 0);
+        for (int k : commit) gone[k] = 1;
+        for (int k : dead) gone[k] = 1;
+        for (int k : active) {
+            if (gone[k]) continue;
+            if (label[sidx[k]] >= 0) {
+                rs.n_dead++;
+                continue;
+            }
+            next.push_back(k);
+        }
+        rs.n_commit = (int)commit.size();
+        rs.n_dead += (int)dead.size();
+        print_round(rounds, rs);
+        tot_px += rs.walked_px;
+        tot_steps += rs.steps;
+        crit += rs.longest_sum;
+        crit_commit += rs.longest_commit;
+        tot_phases += rs.phases;
+        if (commit.empty() && next.size() == active.size()) {
+            printf("STALL\n");
+            break;
+        }
+        active.swap(next);
+    }
+    long bad = 0;
+    for (size_t i = 0; i < ref.size(); ++i) bad += ref[i] != label[i];
+    printf("scheme %d: %d rounds (%d phases), %ld px walked (%.2fx labelled), %ld steps, critical path %d steps (committing walks only: %d); label mismatches vs sequential: %ld\n",
+           scheme, rounds, tot_phases, tot_px, (double)tot_px / labelled, tot_steps, crit, crit_commit, bad);
+    return bad != 0;
+}
