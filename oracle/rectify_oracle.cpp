@@ -1434,7 +1434,15 @@ LineSegment merge_lines(const std::vector<LineSegment>& lines) {  // :254-274
     return merged;
 }
 
-std::vector<LineSegment> postprocess_lines_segments(const std::vector<LineSegment>& lines, const ThreadContext& ctx) {  // :332-444
+// The four constants of the pair test (line_detector.cpp:369,382,385): today's values are the defaults; the sweep of
+// tools/sweep_refine_pins.py varies them to look for the older set the doc/ artefacts were made with.
+struct RefineParams {
+    float cos_gate = 0.99f;   // |d_i . d_j| below this: not parallel enough           (:369, a double literal there)
+    float max_offset = 0.02f; // normal offset of both endpoints, in units of the longer segment's length (:382)
+    float lo = -0.5f, hi = 1.5f;  // overlap window along the longer segment (:385)
+};
+std::vector<LineSegment> postprocess_lines_segments(const std::vector<LineSegment>& lines, const ThreadContext& ctx,
+                                                    const RefineParams& P = RefineParams()) {  // :332-444
     int n = int(lines.size());
     std::vector<V2> d(n), nn(n);
     std::vector<float> l(n);
@@ -1451,7 +1459,7 @@ std::vector<LineSegment> postprocess_lines_segments(const std::vector<LineSegmen
         const auto& li = lines[i];
         for (int j = i + 1; j < n; ++j) {
             const auto& lj = lines[j];
-            if (std::fabs(d[i].x * d[j].x + d[i].y * d[j].y) < 0.99) continue;
+            if (std::fabs(d[i].x * d[j].x + d[i].y * d[j].y) < (double)P.cos_gate) continue;
             float w00, w01, w10, w11;  // W(row, col): rows = the two endpoints, col0 = along, col1 = normal
             if (l[i] < l[j]) {
                 float ax = li.x1 - lj.x1, ay = li.y1 - lj.y1, bx = li.x2 - lj.x1, by = li.y2 - lj.y1;
@@ -1466,9 +1474,9 @@ std::vector<LineSegment> postprocess_lines_segments(const std::vector<LineSegmen
                 w10 = (bx * d[i].x + by * d[i].y) / l[i];
                 w11 = (bx * nn[i].x + by * nn[i].y) / l[i];
             }
-            if (std::max(std::fabs(w01), std::fabs(w11)) < 0.02) {
-                bool any_gt = (w00 > -0.5) || (w10 > -0.5);
-                bool any_lt = (w00 < 1.5) || (w10 < 1.5);
+            if (std::max(std::fabs(w01), std::fabs(w11)) < (double)P.max_offset) {
+                bool any_gt = (w00 > (double)P.lo) || (w10 > (double)P.lo);
+                bool any_lt = (w00 < (double)P.hi) || (w10 < (double)P.hi);
                 if (any_gt && any_lt) adj[i].push_back(j);
             }
         }
@@ -1586,6 +1594,18 @@ int orc_filter_lines(const LineSegment* in, int n, float min_length, LineSegment
     auto f = filter_lines(std::vector<LineSegment>(in, in + n), min_length);
     std::copy(f.begin(), f.end(), out);
     return int(f.size());
+}
+
+// refine with other constants than today's (experiment / pin sweep only)
+int orc_refine_lines_params(const LineSegment* in, int n, float cos_gate, float max_offset, float lo, float hi, LineSegment* out) {
+    RefineParams P;
+    P.cos_gate = cos_gate;
+    P.max_offset = max_offset;
+    P.lo = lo;
+    P.hi = hi;
+    auto r = postprocess_lines_segments(std::vector<LineSegment>(in, in + n), ThreadContext(-1), P);
+    std::copy(r.begin(), r.end(), out);
+    return int(r.size());
 }
 
 int orc_refine_lines(const LineSegment* in, int n, int num_threads, LineSegment* out) {

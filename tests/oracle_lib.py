@@ -170,6 +170,14 @@ def refine_lines(lines, num_threads=-1):
     return out[:n].copy()
 
 
+def refine_lines_params(lines, cos_gate=0.99, max_offset=0.02, lo=-0.5, hi=1.5):
+    """postprocess_lines_segments with other constants than today's (pin sweep, tests/test_oracle_pins.py)"""
+    lines = as_lines(lines)
+    out = np.zeros(len(lines), LINE_DTYPE)
+    n = lib().orc_refine_lines_params(_p(lines), C.c_int(len(lines)), C.c_float(cos_gate), C.c_float(max_offset), C.c_float(lo), C.c_float(hi), _p(out))
+    return out[:n].copy()
+
+
 def estimate_line_pencils(lines, max_models=4, inlier_deg=2.0, garbage_deg=4.0, n_iter=10000, seed=0, num_threads=-1):
     lines = as_lines(lines).copy()
     models = np.zeros((max_models, 3), np.float32)

@@ -127,11 +127,13 @@ static int pixel_level(int scheme, const std::vector<int>& ref, long labelled) {
     for (int k = 0; k < NS; ++k) active[k] = k;
     std::vector<std::vector<int>> own(NS);  // committed pixels of a seed that is still active
     std::vector<int> cmark((size_t)W * H, 0);
-    long tot_px = 0, tot_steps = 0;
-    int rounds = 0, crit = 0;
+    long tot_px = 0, tot_steps = 0, first_px = 0, first_steps = 0;
+    int rounds = 0, crit = 0, crit_first = 0;
+    std::vector<uint8_t> has_walked(NS, 0);
     std::vector<int> q;
     while (!active.empty()) {
         ++rounds;
+        int longest_first = 0;
         RoundStat rs;
         rs.n_active = (int)active.size();
         std::vector<int> touched, next;
@@ -208,6 +210,12 @@ static int pixel_level(int scheme, const std::vector<int>& ref, long labelled) {
             rs.walked_px += (long)fpx.size();
             rs.steps += tiles;
             rs.longest = std::max(rs.longest, tiles);
+            if (!has_walked[k]) {  // a first walk: the dependent chain through memory; later ones can replay the saved tile list
+                has_walked[k] = 1;
+                first_px += (long)fpx.size();
+                first_steps += tiles;
+                longest_first = std::max(longest_first, tiles);
+            }
             // G: reachable from the sources through pixels of fpx without a lower stamp
             bool contested = false;
             std::vector<int> G;
@@ -249,6 +257,21 @@ static int pixel_level(int scheme, const std::vector<int>& ref, long labelled) {
             if (g_seed_level && contested) G.clear();  // seed-level commits: all or nothing
             for (int p : G) cmark[p] = rounds;
             if (!G.empty()) rs.longest_commit = std::max(rs.longest_commit, tiles);
+            if (contested && rounds == 1 && getenv("SIM_DIAG")) {
+                // who is it that stays?  own pixel stamped by a lower seed (dominated) or not; bin of the dominator
+                static long n_dom = 0, n_dom_samebin = 0, n_free = 0, px_dom = 0, px_free = 0, n_dom_ownG = 0, px_dom_same = 0;
+                const int o = stamp[s];
+                if (!has_own && o < k) {
+                    n_dom++;
+                    px_dom += (long)fpx.size();
+                    if (sbin[o] == b) n_dom_samebin++, px_dom_same += (long)fpx.size();
+                } else {
+                    n_free++;
+                    px_free += (long)fpx.size();
+                }
+                if (k == active.back() || (n_dom + n_free) % 2000 == 0)
+                    fprintf(stderr, "diag: contested alive so far %ld dominated (%ld same bin as dominator; px %ld / %ld), %ld undominated (px %ld)\n", n_dom, n_dom_samebin, px_dom, px_dom_same, n_free, px_free);
+            }
             if (contested) {
                 next.push_back(k);
                 if (!G.empty()) own[k].insert(own[k].end(), G.begin(), G.end());
@@ -270,13 +293,15 @@ static int pixel_level(int scheme, const std::vector<int>& ref, long labelled) {
         tot_px += rs.walked_px;
         tot_steps += rs.steps;
         crit += rs.longest;
+        crit_first += longest_first;
+        printf("   first walks of this round: longest %d\n", longest_first);
         active.swap(next);
         if (rounds > 200) break;
     }
     long bad = 0;
     for (size_t i = 0; i < ref.size(); ++i) bad += ref[i] != label[i];
-    printf("scheme %d: %d rounds, %ld px walked (%.2fx labelled), %ld steps, critical path %d steps; label mismatches vs sequential: %ld\n", scheme,
-           rounds, tot_px, (double)tot_px / labelled, tot_steps, crit, bad);
+    printf("scheme %d: %d rounds, %ld px walked (%.2fx labelled), %ld steps, critical path %d steps; FIRST walks only: %ld px (%.2fx), %ld steps, critical path %d; label mismatches vs sequential: %ld\n", scheme,
+           rounds, tot_px, (double)tot_px / labelled, tot_steps, crit, first_px, (double)first_px / labelled, first_steps, crit_first, bad);
     return bad != 0;
 }
 

@@ -1,0 +1,60 @@
+"""can `refine` be pinned to the reference's own rows?
+
+135 of the 848 rows of doc/image.jpg_warp_lines.csv are products of the reference's postprocess_lines_segments
+(line_detector.cpp:332-444) run with OLDER constants than today's.  With the oracle's detector at
+TRACE_TOLERANCE 0.3 (what pin 2 needs) this sweeps the four constants of the pair test and counts how many golden rows
+the pipeline detector -> refine(params) -> filter_lines(10) reproduces within 0.01 px on all four endpoints.
+CPU only; test tooling (uses the oracle)."""
+import itertools
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O  # noqa: E402
+
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def hits_of(lines, gold):
+    mine = np.stack([lines["x1"], lines["y1"], lines["x2"], lines["y2"]], 1).astype(np.float64)
+    swapped = mine[:, [2, 3, 0, 1]]
+    hit = np.zeros(len(gold), bool)
+    for i, g in enumerate(gold):
+        d = min(np.abs(mine - g).max(axis=1).min(), np.abs(swapped - g).max(axis=1).min())
+        hit[i] = d <= 0.01
+    return hit
+
+
+GRID = list(itertools.product([0.98, 0.985, 0.99, 0.995], [0.02, 0.025, 0.03, 0.035, 0.04, 0.05], [-0.5, -0.25, 0.0], [1.5, 1.25, 1.0]))
+if len(sys.argv) > 1 and sys.argv[1] == 'fine':
+    GRID = list(itertools.product([0.97, 0.98, 0.99, 0.995], [0.045, 0.05, 0.06, 0.075, 0.1], [-0.3, -0.25, -0.2, -0.1], [1.1, 1.2, 1.25, 1.3]))
+
+
+def main():
+    gray = np.load(os.path.join(G, "doc_image_gray.npy"))
+    img = gray.astype(np.float32) / np.float32(256.0)
+    gold = np.loadtxt(os.path.join(G, "doc_warp_lines.csv"), delimiter=",")[:, :4]
+    raw = O.find_line_segments(img, tolerance=0.3, want_label=False)["lines"]
+    base = hits_of(O.filter_lines(raw, 10.0), gold)
+    print("no refine: %d of %d golden rows; the other %d are the refine products" % (base.sum(), len(gold), (~base).sum()))
+    best = (0, None)
+    rows = []
+    for cg, off, lo, hi in GRID:
+        ref = O.refine_lines_params(raw, cg, off, lo, hi)
+        h = hits_of(O.filter_lines(ref, 10.0), gold)
+        new = int((h & ~base).sum())
+        rows.append((new, int(h.sum()), cg, off, lo, hi, len(ref)))
+        if new > best[0]:
+            best = (new, (cg, off, lo, hi))
+    rows.sort(reverse=True)
+    for r in rows[:12]:
+        print("refine-only rows matched %3d (all rows %3d)  cos_gate %.3f offset %.3f window [%.2f, %.2f]  -> %d lines" % r)
+    print("today's constants:", [r for r in rows if r[2:6] == (0.99, 0.02, -0.5, 1.5)])
+    print("best:", best)
+
+
+main()
