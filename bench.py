@@ -290,6 +290,7 @@ def flood_rates(L, ctx, frames):
     walked for every pixel they labelled (re-walks of blocked seeds)."""
     ms, px, walked, rounds = [], [], [], []
     h, w = frames[0].shape
+    ctx.set_stage_timing(True)
     for f in frames:
         for rep in range(3):
             ctx.find_line_segment_groups(f, float(max(w, h)) / 100.0)
@@ -299,6 +300,7 @@ def flood_rates(L, ctx, frames):
         px.append(c["labelled_px"])
         walked.append(c.get("walked_px", 0))
         rounds.append(c["flood_rounds"])
+    ctx.set_stage_timing(False)
     m = float(np.mean(ms))
     return {"ms": round(m, 4), "component_pixels_per_s": round(float(np.mean(px)) / (m * 1e-3), 1), "labelled_px": float(np.mean(px)),
             "walked_px": float(np.mean(walked)), "walked_per_labelled": round(float(np.sum(walked)) / max(1.0, float(np.sum(px))), 3),
@@ -513,12 +515,19 @@ def main(argv=None):
 
     def timed_step():
         wl.step(kind, n_total)
-        t = ctx.stage_times()  # lane 0's last frame of this step
-        filt_ms.append(float(t[L.T_FILTER_KERNEL]))
-        stage_acc[:] += t
 
     el = timed(timed_step, args.steps)
     segs = float(np.mean(wl.n_lines[: max(wl.B, 1)]))
+    # stage times of frames inside the pipeline: two extra steps with the stage timers on (they cost the frame seven event
+    # records, some 40 us of idle GPU: not inside the timed region)
+    if args.steps > 0 and not args.roofline_only:
+        ctx.set_stage_timing(True)
+        for _ in range(2):
+            wl.step(kind, n_total)
+            t = ctx.stage_times()  # lane 0's last frame of this step
+            filt_ms.append(float(t[L.T_FILTER_KERNEL]))
+            stage_acc[:] += t
+        ctx.set_stage_timing(False)
 
     # ---- extra legs (outside the timed region; each bracketed like it) ------------------------------------------
     extra = {}

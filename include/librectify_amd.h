@@ -153,6 +153,11 @@ enum lr_stage_id {
 };
 /* HIP-event times (ms) of the stages of the last call on this context. */
 int lr_stage_times(lr_context* ctx, float* ms, int count);
+/* The frame calls (lr_find_line_segment_groups_*, the batch entries and the drop-in symbol) record their stage timers
+ * only when asked: lr_set_stage_timing(ctx, 1) or LIBRECTIFY_STAGE_TIMES in the environment (seven event records per
+ * frame cost some 40 us of idle GPU).  lr_stage_times then returns the last frame's stages; the staged API below always
+ * times its stages. */
+void lr_set_stage_timing(lr_context* ctx, int on);
 /* Duration (ms) of the last fused filter kernel alone (HIP events around its launch); valid right after
  * lr_stage_filter*, without running the later stages. */
 int lr_filter_kernel_ms(lr_context* ctx, float* ms);

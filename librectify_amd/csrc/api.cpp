@@ -70,8 +70,7 @@ LineSegment* find_line_segment_groups(float* buffer, int width, int height, int 
         set_error("image smaller than the 5x5 filter");
         return fail();
     }
-    if (upload_host_image(c, buffer, width, height, stride, num_threads)) return fail();
-    if (ctx_find_groups_device(c, c->d_img_slot[0], width, height, width, min_length, refine, res)) return fail();
+    if (ctx_find_groups_host(c, buffer, width, height, stride, min_length, refine, num_threads, res)) return fail();
     if (res.empty()) return nullptr;
     LineSegment* out = new (std::nothrow) LineSegment[res.size()];
     if (!out) return nullptr;
@@ -116,6 +115,7 @@ int lr_synchronize(lr_context* ctx) {
     return 0;
 }
 void lr_set_ransac_seed(lr_context* ctx, uint64_t seed) { ctx->ransac_seed = seed; }
+void lr_set_stage_timing(lr_context* ctx, int on) { ctx->timing_on = on != 0; }
 void lr_set_ransac_iterations(lr_context* ctx, int n_iter) { ctx->ransac_iters = n_iter; }
 void lr_set_flood_mode(lr_context* ctx, int mode) {
     ctx->flood_mode = mode;
@@ -144,9 +144,8 @@ int lr_find_line_segment_groups_host(lr_context* ctx, const float* buffer, int w
         set_error("image smaller than the 5x5 filter");
         return 1;
     }
-    if (upload_host_image(ctx, buffer, width, height, stride, num_threads)) return 1;
     std::vector<LineSegment> res;
-    if (ctx_find_groups_device(ctx, ctx->d_img_slot[0], width, height, width, min_length, refine != 0, res)) return 1;
+    if (ctx_find_groups_host(ctx, buffer, width, height, stride, min_length, refine != 0, num_threads, res)) return 1;
     return copy_out(res, out, capacity, n_lines);
 }
 

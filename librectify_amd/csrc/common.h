@@ -81,6 +81,10 @@ void set_error(const std::string& msg);
 // kernels_filter.hip
 int launch_filter(const float* img, int w, int h, int stride, const FilterConsts& fc, float* dx, float* dy,
                   uint8_t* dmask, uint64_t* cand, uint32_t* cand_count, uint32_t* tile_max, hipStream_t s);
+int filter_band_rows();  // image rows per band of the filter kernel (a band reads four rows above and 33 below its first)
+int launch_filter_rows(const float* img, int w, int h, int stride, const FilterConsts& fc, float* dx, float* dy,
+                       uint8_t* dmask, uint64_t* cand, uint32_t* cand_count, uint32_t* tile_max, int by_begin, int by_end,
+                       hipStream_t s);
 struct FilterGeom {
     int n_tiles;   // candidate lists written by the filter (tiles or bands, by kernel variant)
     int cand_cap;  // slots per list
@@ -91,7 +95,7 @@ FilterGeom filter_geometry(int w, int h);
 size_t seeds_temp_bytes(int n_tiles, size_t max_seeds);
 int launch_seed_select(const uint64_t* cand, const uint32_t* cand_count, const uint32_t* tile_max, int n_tiles,
                        int cand_cap, float seed_keep_ratio, float* maxmag, uint32_t* tile_pass, uint32_t* tile_off, uint64_t* keys,
-                       uint32_t key_cap, uint32_t* n_seeds, void* temp, size_t temp_bytes, hipStream_t s);
+                       uint32_t key_cap, uint32_t* n_seeds, uint32_t* ticket, hipStream_t s);
 int launch_seed_sort(uint64_t* keys_in, uint64_t* keys_out, uint32_t n, void* temp, size_t temp_bytes, hipStream_t s);
 // the seed count stays on the device (*n_seeds, clamped to cap); the launch covers `cap` seeds
 bool seed_order_is_fused(uint32_t cap);

@@ -29,6 +29,9 @@ struct lr_context {
     size_t cap_stage[2] = {0, 0};
     hipEvent_t ev_up[2] = {};
     hipEvent_t ev_wait = nullptr;  // (blocking-sync flag) what a batch lane sleeps on
+    std::vector<hipEvent_t> band_ev;  // single host frames: one event per 4 MB upload band (the filter follows the bands)
+    void* crew = nullptr;             // StagingCrew of single host frames: threads kept from call to call
+    int crew_helpers = 0;
     bool sleep_in_wait = false;
     // Batch calls on host frames: a ring of device frames (and, for pageable frames, of page-locked staging buffers)
     // that ONE uploader fills in frame order on the copy stream, as far ahead of the lanes as the ring allows
@@ -144,6 +147,10 @@ struct lr_context {
     bool flood_hold_hint = false;  // did the last frame hold its weakest seeds back?
     uint32_t flood_tiers[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // last flood: seeds in the second tier, slabs used, seeds of the ordered tail, hold-back, walked px (lo, hi), steps (lo, hi)
     bool flood_staged = false;  // lr_set_flood_staged: the rounds start on the strongest eighth of the seeds (test / experiment hook)
+    // Stage timers (HIP events between the stages of a frame): off in the frame calls unless lr_set_stage_timing or
+    // LIBRECTIFY_STAGE_TIMES asks -- every event record is a barrier packet in the stream, some 6 us of idle GPU each,
+    // seven of them per frame.  The staged API (lr_stage_*) always times its stages.
+    bool timing_on = false;
     hipEvent_t ev[16] = {};
     float stage_ms[LR_T_COUNT] = {};
     double host_ms[3] = {0, 0, 0};  // last frame: enqueue, next-frame staging + upload, wait (LIBRECTIFY_LANE_DEBUG)
@@ -190,6 +197,8 @@ int ctx_estimate_line_pencils_cht(lr_context* c, std::vector<LineSegment>& lines
 int ctx_refine(lr_context* c, std::vector<LineSegment>& lines);
 int ctx_find_groups_device(lr_context* c, const float* d_image, int w, int h, int stride, float min_length, bool refine,
                            std::vector<LineSegment>& out);
+int ctx_find_groups_host(lr_context* c, const float* buffer, int w, int h, int stride, float min_length, bool refine,
+                         int num_threads, std::vector<LineSegment>& out);
 int ctx_find_groups_batch_device(lr_context* c, const float* d_images, size_t image_stride, int batch, int w, int h,
                                  int stride, float min_length, bool refine, LineSegment* out, int capacity, int* n_lines,
                                  const RectificationConfig* cfg, ImageTransform* transforms);

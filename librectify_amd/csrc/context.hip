@@ -258,6 +258,8 @@ struct StagingCrew {
         const float* src = nullptr;
         int w = 0, h = 0, stride = 0, rows_per_band = 1, n_bands = 0;
         hipStream_t up = nullptr;
+        hipEvent_t* band_ev = nullptr;        // optional: recorded after each band's transfer is enqueued ...
+        std::atomic<int>* ready = nullptr;    // ... and then ready[k] = 1 (-1 if the band failed)
     } jobs[2];
 
     void work(uint32_t gen) {
@@ -274,11 +276,14 @@ struct StagingCrew {
             } else {
                 for (int r = r0; r < r1; ++r) std::memcpy(j.stage + (size_t)r * j.w, j.src + (size_t)r * j.stride, row_bytes);
             }
-            if (hipMemcpyAsync(j.dst + (size_t)r0 * j.w, j.stage + (size_t)r0 * j.w, (size_t)(r1 - r0) * row_bytes,
-                               hipMemcpyHostToDevice, j.up) != hipSuccess) {
+            bool ok = hipMemcpyAsync(j.dst + (size_t)r0 * j.w, j.stage + (size_t)r0 * j.w, (size_t)(r1 - r0) * row_bytes,
+                                     hipMemcpyHostToDevice, j.up) == hipSuccess;
+            if (ok && j.band_ev) ok = hipEventRecord(j.band_ev[k], j.up) == hipSuccess;
+            if (!ok) {
                 (void)hipGetLastError();
                 failed.store(1);
             }
+            if (j.ready) j.ready[k].store(ok ? 1 : -1, std::memory_order_release);
             bands_left.fetch_sub(1, std::memory_order_acq_rel);
         }
     }
@@ -304,6 +309,13 @@ struct StagingCrew {
     }
     // stages one frame (rows as in upload_rows) and enqueues its transfers; returns when every band is enqueued
     int run(float* dst_, float* stage_, const float* buffer, int w_, int h_, int stride_, hipStream_t up_) {
+        const uint32_t g = begin(dst_, stage_, buffer, w_, h_, stride_, up_, nullptr, nullptr);
+        work(g);
+        return finish();
+    }
+    // the two halves of run(): publish the job (the helpers start on it), and wait for its last band
+    uint32_t begin(float* dst_, float* stage_, const float* buffer, int w_, int h_, int stride_, hipStream_t up_,
+                   hipEvent_t* band_ev_, std::atomic<int>* ready_, size_t band_bytes = (size_t)4 << 20) {
         if (stride_ < 0) {
             buffer = buffer + (std::ptrdiff_t)(h_ - 1) * stride_;
             stride_ = -stride_;
@@ -317,13 +329,17 @@ struct StagingCrew {
         j.h = h_;
         j.stride = stride_;
         j.up = up_;
-        j.rows_per_band = (int)std::max<size_t>(1, ((size_t)4 << 20) / ((size_t)w_ * sizeof(float)));
+        j.band_ev = band_ev_;
+        j.ready = ready_;
+        j.rows_per_band = (int)std::max<size_t>(1, band_bytes / ((size_t)w_ * sizeof(float)));
         j.n_bands = (h_ + j.rows_per_band - 1) / j.rows_per_band;
         failed.store(0, std::memory_order_relaxed);  // (per frame: every band of the previous one has been accounted for)
         bands_left.store(j.n_bands, std::memory_order_relaxed);
         next.store((uint64_t)g << 32, std::memory_order_release);
         job.store(g, std::memory_order_release);
-        work(g);
+        return g;
+    }
+    int finish() {
         int spins = 0;
         while (bands_left.load(std::memory_order_acquire) > 0) {
             if (++spins < 256) std::this_thread::yield();
@@ -413,6 +429,7 @@ int ctx_create(int device, lr_context** out) {
     init_constants(c);
     const char* env = std::getenv("LIBRECTIFY_SEED");
     c->ransac_seed = env ? std::strtoull(env, nullptr, 0) : 0ull;
+    c->timing_on = std::getenv("LIBRECTIFY_STAGE_TIMES") != nullptr;
     const char* fm = std::getenv("LIBRECTIFY_FLOOD_MODE");
     if (fm) c->flood_mode = std::atoi(fm);
     *out = c;
@@ -435,7 +452,11 @@ void ctx_destroy(lr_context* c) {
                     c->d_gnorm, c->d_models, c->d_refine_table, c->d_refine_edges, c->d_cht_acc, c->d_cht_idx, c->d_cht_peak};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    delete static_cast<StagingCrew*>(c->crew);
+    c->crew = nullptr;
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    for (auto& e : c->band_ev)
+        if (e) (void)hipEventDestroy(e);
     for (float* p : c->h_stage)
         if (p) (void)hipHostFree(p);
     for (auto& e : c->ev_up)
@@ -475,7 +496,7 @@ void ctx_destroy(lr_context* c) {
 namespace {
 
 // d_counts words
-enum { kCntSeeds = 0, kCntComp = 1, kCntPx = 2, kCntLarge = 4 };
+enum { kCntSeeds = 0, kCntComp = 1, kCntPx = 2, kCntLarge = 4, kCntTicket = 12 /* seed_count_scan_kernel's ticket counter: zero between launches */ };
 
 uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
@@ -550,7 +571,8 @@ FloodFrame flood_frame_for(lr_context* c) {
                       c->d_counts + kCntSeeds, c->seed_cap, c->trig, c->label, c->seed_size, c->queue};
 }
 
-int enqueue_filter(lr_context* c, const float* d_image, int w, int h, int stride) {
+// everything of a frame's first stage but the launch: workspace, seed-sort capacity, state of the last run
+int prepare_frame(lr_context* c, int w, int h) {
     LR_HIP(hipSetDevice(c->device));
     if (w < 5 || h < 5) {
         set_error("image smaller than the 5x5 filter");
@@ -567,19 +589,24 @@ int enqueue_filter(lr_context* c, const float* d_image, int w, int h, int stride
     c->n_seeds = c->n_comp = c->n_px = 0;
     c->dmask_consumed = false;
     for (bool& v : c->stage_valid) v = false;
-    LR_HIP(hipEventRecord(c->ev[0], c->stream));
+    return 0;
+}
+
+int enqueue_filter(lr_context* c, const float* d_image, int w, int h, int stride) {
+    if (prepare_frame(c, w, h)) return 1;
+    if (c->timing_on) LR_HIP(hipEventRecord(c->ev[0], c->stream));
     if (launch_filter(d_image, w, h, stride, c->fconsts, c->dx, c->dy, c->dmask, c->cand, c->cand_count, c->tile_max,
                       c->stream))
         return 1;
-    LR_HIP(hipEventRecord(c->ev[1], c->stream));
+    if (c->timing_on) LR_HIP(hipEventRecord(c->ev[1], c->stream));
     return 0;
 }
 
 int enqueue_seeds(lr_context* c) {
     const FilterGeom fg = filter_geometry(c->w, c->h);
     if (launch_seed_select(c->cand, c->cand_count, c->tile_max, fg.n_tiles, fg.cand_cap, c->seed_keep_ratio, c->maxmag,
-                           c->tile_pass, c->tile_off, c->keys_a, c->seed_cap, c->d_counts + kCntSeeds, c->temp,
-                           c->temp_bytes, c->stream))
+                           c->tile_pass, c->tile_off, c->keys_a, c->seed_cap, c->d_counts + kCntSeeds, c->d_counts + kCntTicket,
+                           c->stream))
         return 1;
     if (seed_order_is_fused(c->seed_cap)) {
         if (launch_seed_order(c->keys_a, c->d_counts + kCntSeeds, c->seed_cap, c->dx, c->dy, c->trig, kTraceTolerance,
@@ -591,7 +618,7 @@ int enqueue_seeds(lr_context* c) {
                               c->seed_idx, c->seed_bin, c->seed_thr, c->stream))
             return 1;
     }
-    LR_HIP(hipEventRecord(c->ev[2], c->stream));
+    if (c->timing_on) LR_HIP(hipEventRecord(c->ev[2], c->stream));
     return 0;
 }
 
@@ -612,7 +639,7 @@ int enqueue_flood(lr_context* c) {
         c->stage_valid[0] = c->stage_valid[1] = false;
         c->dmask_consumed = true;
     }
-    LR_HIP(hipEventRecord(c->ev[3], c->stream));
+    if (c->timing_on) LR_HIP(hipEventRecord(c->ev[3], c->stream));
     return 0;
 }
 
@@ -647,7 +674,7 @@ int enqueue_fit(lr_context* c) {
     if (launch_fit(c->px_b, c->comp_off, c->comp_seed, c->d_counts + kCntComp, comp_cap, c->seed_bin, c->dx, c->dy, c->w,
                    c->trig, c->scratch_w, c->d_lines, c->stream))
         return 1;
-    LR_HIP(hipEventRecord(c->ev[4], c->stream));
+    if (c->timing_on) LR_HIP(hipEventRecord(c->ev[4], c->stream));
     return 0;
 }
 
@@ -684,6 +711,7 @@ int enqueue_result_copy(lr_context* c) {
 }
 
 void record_stage_times(lr_context* c, bool with_groups) {
+    if (!c->timing_on) return;
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
     c->stage_ms[LR_T_FILTER] = ms;
@@ -715,7 +743,16 @@ void adapt_seed_cap(lr_context* c, uint32_t n_seeds) {
 
 }  // namespace
 
+// (the staged API exists for tests and measurements: its stages are always timed)
+struct TimingOn {
+    lr_context* c;
+    bool was;
+    explicit TimingOn(lr_context* ctx) : c(ctx), was(ctx->timing_on) { c->timing_on = true; }
+    ~TimingOn() { c->timing_on = was; }
+};
+
 int ctx_stage_filter(lr_context* c, const float* d_image, int w, int h, int stride) {
+    TimingOn t(c);
     if (enqueue_filter(c, d_image, w, h, stride)) return 1;
     c->stage_valid[0] = true;
     return 0;
@@ -726,6 +763,7 @@ int ctx_stage_seeds(lr_context* c) {
         set_error("lr_stage_seeds: run lr_stage_filter first");
         return 1;
     }
+    TimingOn t(c);
     for (int attempt = 0;; ++attempt) {
         if (enqueue_seeds(c)) return 1;
         LR_HIP(hipMemcpyAsync(c->h_counts, c->d_counts, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -748,6 +786,7 @@ int ctx_stage_flood(lr_context* c) {
                                     : "lr_stage_flood: run lr_stage_seeds first");
         return 1;
     }
+    TimingOn t(c);
     if (enqueue_flood(c)) return 1;
     LR_HIP(hipStreamSynchronize(c->stream));
     bool extra;
@@ -762,6 +801,7 @@ int ctx_stage_fit(lr_context* c, std::vector<LineSegment>& out) {
         return 1;
     }
     out.clear();
+    TimingOn t(c);
     if (enqueue_fit(c)) return 1;
     LR_HIP(hipMemcpyAsync(c->h_counts, c->d_counts, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     LR_HIP(hipStreamSynchronize(c->stream));
@@ -1386,7 +1426,7 @@ int ctx_refine(lr_context* c, std::vector<LineSegment>& lines) {
 // that needs more rounds than were enqueued blindly (the rounds are completed, the stages after the flood repeated).
 // With refine or PROSAC the raw segments go to the host after the fit, as before.
 static int run_frame(lr_context* c, const float* d_image, int w, int h, int stride, float min_length, bool refine,
-                     std::vector<LineSegment>& out) {
+                     std::vector<LineSegment>& out, bool filter_enqueued = false) {
     out.clear();
     const double t_begin = now_ms();
     const bool fused = !refine && c->estimator == 0;
@@ -1395,18 +1435,20 @@ static int run_frame(lr_context* c, const float* d_image, int w, int h, int stri
         const uint32_t lc = line_cap_for(c);
         if (ensure_group_capacity(c, lc, (size_t)std::max(n_iter, 1))) return 1;
         if (ensure_result_block(c, std::max<size_t>(c->res_lines_cap, 4096))) return 1;
-        LR_HIP(hipEventRecord(c->ev[5], c->stream));
+        if (c->timing_on) LR_HIP(hipEventRecord(c->ev[5], c->stream));
         if (launch_filter_lines(c->d_lines, c->d_counts + kCntComp, lc, min_length, c->d_flines, c->d_gctl, c->d_gnorm,
                                 c->stream))
             return 1;
         if (enqueue_groups(c, lc, kMaxModels, kInlierDeg, kGarbageDeg, n_iter, c->ransac_seed)) return 1;
-        LR_HIP(hipEventRecord(c->ev[6], c->stream));
+        if (c->timing_on) LR_HIP(hipEventRecord(c->ev[6], c->stream));
         return enqueue_result_copy(c);
     };
     c->frame_laps = 0;
     for (int attempt = 0;; ++attempt) {
         c->frame_laps += 1;
-        if (enqueue_filter(c, d_image, w, h, stride)) return 1;
+        // (a frame that came from a host buffer has had its filter launched band by band as its rows arrived:
+        // ctx_find_groups_host; a second lap takes the whole frame from the device slot)
+        if (!(filter_enqueued && attempt == 0) && enqueue_filter(c, d_image, w, h, stride)) return 1;
         if (enqueue_seeds(c)) return 1;
         if (enqueue_flood(c)) return 1;
         if (enqueue_fit(c)) return 1;
@@ -1488,7 +1530,7 @@ static int run_frame(lr_context* c, const float* d_image, int w, int h, int stri
     if (refine && ctx_refine(c, raw)) return 1;
     std::vector<LineSegment> filtered = filter_lines(raw, min_length);
     if (filtered.empty()) return 0;
-    LR_HIP(hipEventRecord(c->ev[5], c->stream));
+    if (c->timing_on) LR_HIP(hipEventRecord(c->ev[5], c->stream));
     if (c->estimator == 1) {
         if (ctx_estimate_line_pencils_prosac(c, filtered, kMaxModels, kInlierDeg, kGarbageDeg, c->prosac_T_N,
                                              c->ransac_seed))
@@ -1500,7 +1542,7 @@ static int run_frame(lr_context* c, const float* d_image, int w, int h, int stri
     } else if (ctx_estimate_line_pencils(c, filtered, kMaxModels, kInlierDeg, kGarbageDeg, n_iter, c->ransac_seed)) {
         return 1;
     }
-    LR_HIP(hipEventRecord(c->ev[6], c->stream));
+    if (c->timing_on) LR_HIP(hipEventRecord(c->ev[6], c->stream));
     LR_HIP(hipStreamSynchronize(c->stream));
     record_stage_times(c, true);
     out.swap(filtered);
@@ -1511,6 +1553,143 @@ int ctx_find_groups_device(lr_context* c, const float* d_image, int w, int h, in
                            std::vector<LineSegment>& out) {
     const int rc = run_frame(c, d_image, w, h, stride, min_length, refine, out);
     return rc;
+}
+
+// find_line_segment_groups on a HOST buffer (the reference's only kind of input: interface.cpp:43-48, image.cpp:11-19),
+// one frame.  The upload, the filter and the host's enqueueing of the rest of the frame overlap:
+//  - the frame goes up in 4 MB row bands (pageable memory through the page-locked staging buffer, filled by the
+//    context's staging threads; page-locked memory straight from where it lies), an event after every band;
+//  - the filter is launched band by band: a band row of the filter reads the image rows 30 by - 4 .. 30 by + 33, so the
+//    band rows whose last image row lies in upload band k are launched as soon as that band's transfer is enqueued,
+//    behind a wait for its event -- when the last transfer ends, all but the last ninth of the filter has run;
+//  - the calling thread only drives (waits for "band k enqueued", launches its filter rows) and then enqueues the rest
+//    of the frame while the last transfers are still on the link.
+// What cannot overlap: everything after the filter needs the frame's largest magnitude, i.e. the whole frame.
+int ctx_find_groups_host(lr_context* c, const float* buffer, int w, int h, int stride, float min_length, bool refine,
+                         int num_threads, std::vector<LineSegment>& out) {
+    LR_HIP(hipSetDevice(c->device));
+    if (w < 5 || h < 5 || buffer == nullptr) {
+        set_error("image smaller than the 5x5 filter");
+        return 1;
+    }
+    if ((stride < 0 ? -stride : stride) < w) {
+        set_error("upload: |stride| smaller than the width");
+        return 1;
+    }
+    if (ensure_copy_stream(c)) return 1;
+    hipStream_t up = c->copy_stream;
+    const size_t npix = (size_t)w * h;
+    const int slot = 0;
+    if (c->cap_slot[slot] < npix) {
+        LR_HIP(hipStreamSynchronize(c->stream));
+        LR_HIP(hipStreamSynchronize(up));
+        if (dev_alloc(c->d_img_slot[slot], npix)) return 1;
+        c->cap_slot[slot] = npix;
+    }
+    float* stage = nullptr;
+    if (!is_page_locked(buffer)) {
+        if (c->cap_stage[slot] < npix) {
+            LR_HIP(hipStreamSynchronize(up));
+            if (c->h_stage[slot]) (void)hipHostFree(c->h_stage[slot]);
+            c->h_stage[slot] = nullptr;
+            c->cap_stage[slot] = 0;
+            LR_HIP(hipHostMalloc((void**)&c->h_stage[slot], npix * sizeof(float)));
+            c->cap_stage[slot] = npix;
+        }
+        LR_HIP(hipEventSynchronize(c->ev_up[slot]));  // (the transfer that last read the staging buffer: long finished)
+        stage = c->h_stage[slot];
+    }
+    if (prepare_frame(c, w, h)) return 1;
+    const float* src = buffer;
+    int sstride = stride;
+    if (sstride < 0) {  // image.cpp:14-18: the same rows, addressed from the other end (no flip)
+        src = buffer + (std::ptrdiff_t)(h - 1) * sstride;
+        sstride = -sstride;
+    }
+    const size_t row_bytes = (size_t)w * sizeof(float);
+    // Upload bands of 1 MB: with eight staging threads the first transfers start after a sixteenth of a millisecond
+    // instead of after a whole 4 MB band per thread (which is when ALL of them are ready: the link would idle for the
+    // first 0.4 ms); the filter follows every fourth band (4 MB of rows per launch, about a ninth of a 4K frame).
+    static const size_t band_bytes = std::getenv("LIBRECTIFY_UPLOAD_BAND_KB") ? (size_t)std::max(64, std::atoi(std::getenv("LIBRECTIFY_UPLOAD_BAND_KB"))) << 10 : (size_t)1 << 20;
+    static const int filter_every = std::getenv("LIBRECTIFY_FILTER_EVERY") ? std::max(1, std::atoi(std::getenv("LIBRECTIFY_FILTER_EVERY"))) : 4;
+    const int rpb = (int)std::max<size_t>(1, band_bytes / row_bytes);
+    const int n_bands = (h + rpb - 1) / rpb;
+    while ((int)c->band_ev.size() < n_bands) {
+        hipEvent_t e = nullptr;
+        LR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->band_ev.push_back(e);
+    }
+    float* dst = c->d_img_slot[slot];
+    const int fb = filter_band_rows(), band_rows = (h + fb - 1) / fb;
+    int by_next = 0;
+    // filter rows that upload band k completes, behind that band's event
+    auto filter_after_band = [&](int k) -> int {
+        // the compute stream waits for EVERY band's own event: the bands are enqueued by several threads in no particular
+        // order, so a later band's event says nothing about an earlier band
+        LR_HIP(hipStreamWaitEvent(c->stream, c->band_ev[(size_t)k], 0));
+        if ((k + 1) % filter_every != 0 && k != n_bands - 1) return 0;
+        const int last_row = std::min(h, (k + 1) * rpb) - 1;  // last image row on the device once bands 0..k are
+        int by_end = by_next;
+        while (by_end < band_rows && std::min(h - 1, fb * by_end + 33) <= last_row) ++by_end;
+        if (k == n_bands - 1) by_end = band_rows;
+        if (launch_filter_rows(dst, w, h, w, c->fconsts, c->dx, c->dy, c->dmask, c->cand, c->cand_count, c->tile_max, by_next,
+                               by_end, c->stream))
+            return 1;
+        by_next = by_end;
+        return 0;
+    };
+    if (c->timing_on) LR_HIP(hipEventRecord(c->ev[0], c->stream));
+    const int T = stage ? std::min(staging_threads(num_threads), n_bands) : 1;
+    if (T <= 1) {
+        // the calling thread alone (the reference's serial mode, or a page-locked source that needs no staging)
+        for (int k = 0; k < n_bands; ++k) {
+            const int r0 = k * rpb, r1 = std::min(h, r0 + rpb);
+            if (stage) {
+                if (sstride == w) std::memcpy(stage + (size_t)r0 * w, src + (size_t)r0 * sstride, (size_t)(r1 - r0) * row_bytes);
+                else
+                    for (int r = r0; r < r1; ++r) std::memcpy(stage + (size_t)r * w, src + (size_t)r * sstride, row_bytes);
+                LR_HIP(hipMemcpyAsync(dst + (size_t)r0 * w, stage + (size_t)r0 * w, (size_t)(r1 - r0) * row_bytes,
+                                      hipMemcpyHostToDevice, up));
+            } else if (sstride == w) {
+                LR_HIP(hipMemcpyAsync(dst + (size_t)r0 * w, src + (size_t)r0 * w, (size_t)(r1 - r0) * row_bytes,
+                                      hipMemcpyHostToDevice, up));
+            } else {
+                LR_HIP(hipMemcpy2DAsync(dst + (size_t)r0 * w, row_bytes, src + (size_t)r0 * sstride, (size_t)sstride * sizeof(float),
+                                        row_bytes, (size_t)(r1 - r0), hipMemcpyHostToDevice, up));
+            }
+            LR_HIP(hipEventRecord(c->band_ev[(size_t)k], up));
+            if (filter_after_band(k)) return 1;
+        }
+    } else {
+        // the context's staging threads fill and send the bands; this thread follows them with the filter
+        if (!c->crew || c->crew_helpers != T) {
+            delete static_cast<StagingCrew*>(c->crew);
+            StagingCrew* cr = new StagingCrew();
+            cr->start(c, T);
+            c->crew = cr;
+            c->crew_helpers = T;
+        }
+        StagingCrew* cr = static_cast<StagingCrew*>(c->crew);
+        std::vector<std::atomic<int>> ready((size_t)n_bands);
+        for (auto& a : ready) a.store(0, std::memory_order_relaxed);
+        (void)cr->begin(dst, stage, src, w, h, sstride, up, c->band_ev.data(), ready.data(), band_bytes);
+        int rc = 0;
+        for (int k = 0; k < n_bands && rc == 0; ++k) {
+            int spins = 0, r;
+            while ((r = ready[(size_t)k].load(std::memory_order_acquire)) == 0) {
+                if (++spins < 2048) std::this_thread::yield();
+                else std::this_thread::sleep_for(std::chrono::microseconds(5));
+            }
+            if (r < 0 || filter_after_band(k)) rc = 1;
+        }
+        if (cr->finish() || rc) {  // (every band accounted for before `ready` goes out of scope)
+            if (get_error().empty()) set_error("upload: staging copy failed");
+            return 1;
+        }
+    }
+    if (c->timing_on) LR_HIP(hipEventRecord(c->ev[1], c->stream));
+    LR_HIP(hipEventRecord(c->ev_up[slot], up));
+    return run_frame(c, dst, w, h, w, min_length, refine, out, true);
 }
 
 // Batch of independent frames: the stages of one frame are latency-bound (flood rounds,
@@ -1577,6 +1756,7 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
         l->estimator = c->estimator;
         l->prosac_T_N = c->prosac_T_N;
         l->cht_d = c->cht_d;
+        l->timing_on = c->timing_on;
         // LIBRECTIFY_LANES_SLEEP: the lanes sleep on an event instead of spinning in hipStreamSynchronize, for hosts
         // short of cores (on the 16-core share of a one-GPU box: pageable frames equal, page-locked ones 5 % slower)
         static const bool sleep_env = std::getenv("LIBRECTIFY_LANES_SLEEP") != nullptr;

@@ -17,6 +17,7 @@
 // barrier.  Arithmetic is the canonical form shared with the CPU oracle: the separable evaluation
 // of the 5x5 Gaussian-derivative correlation (row pass hx, hs; column pass dx, dy; explicit fmaf),
 // mag = sqrtf(dx*dx + dy*dy) without contraction, bin = first strict argmax of |fmaf(dx, sin, dy*cos)|.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -88,9 +89,7 @@ __device__ __forceinline__ float load_px_in(const float* __restrict__ img, int s
     return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(row) + (unsigned)xcl * 4u);
 }
 
-// INTERIOR: every column of the 64 lanes and every row the band touches is at least 2 px inside the image, so all
-// border, clamp and zero-border tests are compile-time true (the common case: all but the outer ring of bands).
-template <int K10, bool INTERIOR>
+template <int K10>
 __device__ __forceinline__ void lane_step(Roll1& R, const int t, const float* __restrict__ img, const int w, const int h,
                                           const int stride, const FilterTaps& fc, float* __restrict__ dx_out,
                                           float* __restrict__ dy_out, uint8_t* __restrict__ dmask_out,
@@ -118,7 +117,7 @@ __device__ __forceinline__ void lane_step(Roll1& R, const int t, const float* __
     const float ax = fmaf(R.hx[K] + R.hx[(K + 1) % 5], fc.g2,
                           fmaf(R.hx[(K + 4) % 5] + R.hx[(K + 2) % 5], fc.g1, R.hx[(K + 3) % 5]));
     const float ay = fmaf(R.hs[K] - R.hs[(K + 1) % 5], fc.d2, (R.hs[(K + 4) % 5] - R.hs[(K + 2) % 5]) * fc.d1);
-    const bool ok = INTERIOR || ((yc >= 2) && (yc < h - 2) && (x >= 2) && (x < w - 2));  // conv_2d's zero border (filter.cpp:89-97)
+    const bool ok = (yc >= 2) && (yc < h - 2) && (x >= 2) && (x < w - 2);  // conv_2d's zero border (filter.cpp:89-97)
     const float vx = ok ? ax : 0.f;
     const float vy = ok ? ay : 0.f;
     R.mag[K] = sqrtf(vx * vx + vy * vy);
@@ -132,8 +131,8 @@ __device__ __forceinline__ void lane_step(Roll1& R, const int t, const float* __
 #pragma unroll
     for (int b = kBins - 2; b >= 0; --b) bit = (g[b] == gm) ? (1u << b) : bit;
     R.bits[K] = bit;
-    const bool in_img = useful && (INTERIOR || x < w);
-    if (t >= 6 && t < 6 + kBandRows && (INTERIOR || yc < h)) {  // yc in [y0, y0+32): wave-uniform, compile-time in t
+    const bool in_img = useful && x < w;
+    if (t >= 6 && t < 6 + kBandRows && yc < h) {  // yc in [y0, y0+32): wave-uniform, compile-time in t
         if (in_img) {
             const unsigned row = (unsigned)yc * (unsigned)w * 4u;
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, vx), r_dx, (unsigned)x * 4u, row, 0);
@@ -143,7 +142,7 @@ __device__ __forceinline__ void lane_step(Roll1& R, const int t, const float* __
     if (t < 8) return;  // wave-uniform
 
     const int yo = yc - 2;  // output row of the NMS / dilation
-    if (!INTERIOR && yo >= h) return;  // wave-uniform
+    if (yo >= h) return;  // wave-uniform
     const float cm = fmaxf(fmaxf(fmaxf(R.mag[0], R.mag[1]), fmaxf(R.mag[2], R.mag[3])), R.mag[4]);
     const float cl1 = from_lower(cm), cr1 = from_upper(cm);
     const float cl2 = from_lower(cl1), cr2 = from_upper(cr1);
@@ -152,12 +151,12 @@ __device__ __forceinline__ void lane_step(Roll1& R, const int t, const float* __
     const uint32_t cb = R.bits[(K + 3) % 5];
     const uint32_t v = R.bits[(K + 2) % 5] | cb | R.bits[(K + 4) % 5];
     uint32_t dm = from_lower(v) | v | from_upper(v);
-    if (!INTERIOR && (yo == 0 || yo == h - 1 || x == 0 || x == w - 1)) dm = 0;  // binary_dilate's 1-px zero border (filter.cpp:52-61)
+    if (yo == 0 || yo == h - 1 || x == 0 || x == w - 1) dm = 0;  // binary_dilate's 1-px zero border (filter.cpp:52-61)
     if (in_img) {
         lmax = fmaxf(lmax, c);
         __builtin_amdgcn_raw_buffer_store_b8((unsigned char)dm, r_dm, (unsigned)x, (unsigned)yo * (unsigned)w, 0);
     }
-    const bool peak = in_img && (INTERIOR || ((yo >= 2) && (yo < h - 2) && (x >= 2) && (x < w - 2))) && (c > 0.f) && (c == mx);
+    const bool peak = in_img && (yo >= 2) && (yo < h - 2) && (x >= 2) && (x < w - 2) && (c > 0.f) && (c == mx);
     const uint64_t m = __ballot(peak);
     if (m) {  // wave-uniform, rare
         if (peak) {
@@ -174,7 +173,8 @@ __global__ __launch_bounds__(256) void filter_lanes_kernel(const float* __restri
                                                            FilterTaps fc, float* __restrict__ dx_out,
                                                            float* __restrict__ dy_out, uint8_t* __restrict__ dmask_out,
                                                            uint64_t* __restrict__ cand, uint32_t* __restrict__ cand_count,
-                                                           uint32_t* __restrict__ tile_max, int bands_x, int n_bands) {
+                                                           uint32_t* __restrict__ tile_max, int bands_x, int band_begin,
+                                                           int band_end) {
     const int lane = threadIdx.x & 63;
     // the band index is the same in all 64 lanes: say so, and every row pointer, row test and loop bound below
     // lives in SGPRs (scalar base + 32-bit lane offset addressing) instead of 64-bit VGPR arithmetic
@@ -187,8 +187,10 @@ __global__ __launch_bounds__(256) void filter_lanes_kernel(const float* __restri
 #else
     const int wg = (int)blockIdx.x;
 #endif
-    const int band = __builtin_amdgcn_readfirstlane(wg * 4 + (int)(threadIdx.x >> 6));
-    if (band >= n_bands) return;
+    // (a launch covers the bands [band_begin, band_end): all of a frame, or the rows of it that have arrived -- see
+    // launch_filter_rows)
+    const int band = __builtin_amdgcn_readfirstlane(band_begin + wg * 4 + (int)(threadIdx.x >> 6));
+    if (band >= band_end) return;
     const int by = band / bands_x, bx = band - by * bands_x;
     const int y0 = by * kBandRows;
     const int x = bx * kLaneCols - 4 + lane;
@@ -210,16 +212,16 @@ __global__ __launch_bounds__(256) void filter_lanes_kernel(const float* __restri
     const uint32_t npx = (uint32_t)w * (uint32_t)h;
     const BufRsrc r_img = make_rsrc(img, ((uint32_t)(h - 1) * (uint32_t)stride + (uint32_t)w) * 4u);
     const BufRsrc r_dx = make_rsrc(dx_out, npx * 4u), r_dy = make_rsrc(dy_out, npx * 4u), r_dm = make_rsrc(dmask_out, npx);
-#define LR_STEP(k, I) lane_step<k, I>(R, t0 + k, img, w, h, stride, fc, dx_out, dy_out, dmask_out, cand_band, ncand, lmax, y0, x, xcl, lane, useful, r_img, r_dx, r_dy, r_dm)
+#define LR_STEP(k) lane_step<k>(R, t0 + k, img, w, h, stride, fc, dx_out, dy_out, dmask_out, cand_band, ncand, lmax, y0, x, xcl, lane, useful, r_img, r_dx, r_dy, r_dm)
     // fully unrolled: across a loop back-edge the compiler can only wait for vmcnt(0), which would expose the
     // latency of every store in flight once per iteration.
-    // (An INTERIOR = true instantiation for the bands away from the image border -- no border test, clamp or predicate,
-    // some 55 scalar instructions per row fewer -- was measured twice, with the 25-tap and with the separable filter:
-    // no gain either time, twice the code.)
+    // (An instantiation without border tests, clamps and predicates for the bands away from the image border -- some 55
+    // scalar instructions per row fewer -- was measured twice, with the 25-tap and with the separable filter: no gain
+    // either time, twice the code.  Removed in round 3.)
 #pragma unroll
     for (int t0 = 0; t0 < (kBandSteps + 9) / 10 * 10; t0 += 10) {
-        LR_STEP(0, false); LR_STEP(1, false); LR_STEP(2, false); LR_STEP(3, false); LR_STEP(4, false);
-        LR_STEP(5, false); LR_STEP(6, false); LR_STEP(7, false); LR_STEP(8, false); LR_STEP(9, false);
+        LR_STEP(0); LR_STEP(1); LR_STEP(2); LR_STEP(3); LR_STEP(4);
+        LR_STEP(5); LR_STEP(6); LR_STEP(7); LR_STEP(8); LR_STEP(9);
     }
 #undef LR_STEP
 #pragma unroll
@@ -239,23 +241,13 @@ FilterGeom filter_geometry(int w, int h) {
     return g;
 }
 
-int launch_filter(const float* img, int w, int h, int stride, const FilterConsts& fc, float* dx, float* dy,
-                  uint8_t* dmask, uint64_t* cand, uint32_t* cand_count, uint32_t* tile_max, hipStream_t s) {
-    if (w < 1 || h < 1 || stride < w) {
-        set_error("launch_filter: bad geometry");
-        return 1;
-    }
-    if ((uint64_t)w * (uint64_t)h >= (1ull << 29)) {
-        set_error("launch_filter: image larger than 2^29 pixels is not supported (seed key packs index in 29 bits)");
-        return 1;
-    }
+static int filter_taps(const FilterConsts& fc, FilterTaps& ft) {
     // the (anti)symmetry the separable form relies on is a property of the host's libm results: verify, never assume
     if (!(fc.d[2] == 0.f && fc.g[2] == 1.f && fc.d[1] == -fc.d[3] && fc.d[0] == -fc.d[4] && fc.g[1] == fc.g[3] &&
           fc.g[0] == fc.g[4])) {
         set_error("launch_filter: derivative factors are not (anti)symmetric on this host");
         return 1;
     }
-    FilterTaps ft;
     ft.d1 = fc.d[3];
     ft.d2 = fc.d[4];
     ft.g1 = fc.g[3];
@@ -264,13 +256,43 @@ int launch_filter(const float* img, int w, int h, int stride, const FilterConsts
         ft.st[b] = fc.st[b];
         ft.ct[b] = fc.ct[b];
     }
+    return 0;
+}
+
+int filter_band_rows() { return kBandRows; }
+
+// The bands whose image rows lie in [row_begin, row_end) -- band row `by` reads the image rows 30 by - 4 .. 30 by + 33 --
+// i.e. the band rows [by_begin, by_end).  A frame that is still arriving over the link is filtered in a few such
+// launches, each as soon as its rows are on the device (context.hip: find_groups_host).
+int launch_filter_rows(const float* img, int w, int h, int stride, const FilterConsts& fc, float* dx, float* dy,
+                       uint8_t* dmask, uint64_t* cand, uint32_t* cand_count, uint32_t* tile_max, int by_begin, int by_end,
+                       hipStream_t s) {
+    if (w < 1 || h < 1 || stride < w) {
+        set_error("launch_filter: bad geometry");
+        return 1;
+    }
+    if ((uint64_t)w * (uint64_t)h >= (1ull << 29)) {
+        set_error("launch_filter: image larger than 2^29 pixels is not supported (seed key packs index in 29 bits)");
+        return 1;
+    }
+    FilterTaps ft;
+    if (filter_taps(fc, ft)) return 1;
     const int bands_x = (w + kLaneCols - 1) / kLaneCols;
-    const int n_bands = bands_x * ((h + kBandRows - 1) / kBandRows);
-    const int n_wg = ((n_bands + 3) / 4 + 7) / 8 * 8;  // a multiple of eight: see the XCD mapping in the kernel
+    const int band_rows = (h + kBandRows - 1) / kBandRows;
+    by_begin = std::max(by_begin, 0);
+    by_end = std::min(by_end, band_rows);
+    if (by_end <= by_begin) return 0;
+    const int band_begin = by_begin * bands_x, band_end = by_end * bands_x;
+    const int n_wg = ((band_end - band_begin + 3) / 4 + 7) / 8 * 8;  // a multiple of eight: see the XCD mapping in the kernel
     hipLaunchKernelGGL(filter_lanes_kernel, dim3(n_wg), dim3(256), 0, s, img, w, h, stride, ft, dx, dy, dmask,
-                       cand, cand_count, tile_max, bands_x, n_bands);
+                       cand, cand_count, tile_max, bands_x, band_begin, band_end);
     LR_HIP(hipGetLastError());
     return 0;
+}
+
+int launch_filter(const float* img, int w, int h, int stride, const FilterConsts& fc, float* dx, float* dy,
+                  uint8_t* dmask, uint64_t* cand, uint32_t* cand_count, uint32_t* tile_max, hipStream_t s) {
+    return launch_filter_rows(img, w, h, stride, fc, dx, dy, dmask, cand, cand_count, tile_max, 0, (h + kBandRows - 1) / kBandRows, s);
 }
 
 }  // namespace lramd

@@ -82,49 +82,155 @@ __device__ __forceinline__ void hyp_v(const Hyp& h, float ax, float ay, float& v
     vy = h.sub != 0.f ? h.cy - ay : h.cy;
 }
 
-// One wavefront scores kH hypotheses at a time: each lane loads its lines' (anchor, direction, length) once and tests
-// them against all kH (whose parameters are wave-uniform), so the table is read kH times less often; the score of
-// each hypothesis is the canonical tree T() over the lines (lane-strided partial sums in ascending line order, then
-// the xor butterfly), exactly as when a wavefront owned a single hypothesis.
+// The estimate of the inlier test without a branch, a division or a square root.  With v = c - sub * anchor (two FMAs:
+// sub is 0 or 1, fma(-1, a, c) is the rounded difference and fma(-0, a, c) is c itself), nn = |v|^2 and dot = v . d, the
+// canonical error err = 1 - |dot| / |v| is below tol iff dot^2 > (1 - tol)^2 nn.  The estimate tests that inequality
+// with a safety band around the threshold: `in` where dot^2 > k_in nn with k_in = (1 - tol + band)^2, "surely out"
+// where dot^2 < k_out nn with k_out = (1 - tol - band)^2, and everything else -- inside the band, not a number,
+// |v| = 0, or |v|^2 so small that the products could underflow -- is `unsure` and decided by the canonical expression.
+// The six products and sums carry a relative error below 2^-21 together, i.e. less than 5e-7 on |dot| / |v| <= 1, and
+// the canonical float expression is within 13 x 2^-24 = 8e-7 of the real quotient: with
+// band = 3e-6 a sure decision is the canonical decision.  Scores and counts are therefore bit-identical.
+constexpr float kTiny = 1e-30f;
+struct EstConst {
+    float k_in, k_out;
+};
+__device__ __forceinline__ EstConst est_const(float tol) {
+    const float a = (1.0f - tol) + kErrBand, b = (1.0f - tol) - kErrBand;
+    return EstConst{a * a, b * b};
+}
+__device__ __forceinline__ void inlier_estimate(const float cx, const float cy, const float nsub, float ax, float ay, float dx,
+                                                float dy, const EstConst& K, uint64_t& m_in, uint64_t& m_unsure) {
+    const float vx = __builtin_fmaf(nsub, ax, cx), vy = __builtin_fmaf(nsub, ay, cy);
+    const float nn = __builtin_fmaf(vx, vx, vy * vy);
+    const float dot = __builtin_fmaf(vx, dx, vy * dy);
+    const float dd = dot * dot;
+    // thresholds with a floor of kTiny on either side: for |v|^2 below it neither comparison can hold (dot^2 <= |v|^2),
+    // so such a line is unsure without a comparison of its own; for any |v|^2 the floor only makes a decision less sure
+    const float t_in = __builtin_fmaf(nn, K.k_in, kTiny), t_out = __builtin_fmaf(nn, K.k_out, -kTiny);
+    // lane masks straight from the comparisons (v_cmp writes an SGPR pair); they are combined on the scalar unit
+    m_in = __builtin_amdgcn_fcmpf(dd, t_in, 2 /* > (ordered) */);
+    const uint64_t m_out = __builtin_amdgcn_fcmpf(dd, t_out, 4 /* < (ordered) */);
+    m_unsure = ~(m_in | m_out);
+}
+
+// The same for TWO hypotheses at once in packed fp32 (v_pk_fma_f32 / v_pk_mul_f32: both halves are the IEEE operations
+// of the scalar form, so the masks are the same bits): nine packed instructions instead of eighteen.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void inlier_estimate2(const f2 cx, const f2 cy, const f2 nsub, float ax, float ay, float dx, float dy,
+                                                 const EstConst& K, uint64_t& m_in0, uint64_t& m_un0, uint64_t& m_in1,
+                                                 uint64_t& m_un1) {
+    const f2 vx = __builtin_elementwise_fma(nsub, (f2){ax, ax}, cx), vy = __builtin_elementwise_fma(nsub, (f2){ay, ay}, cy);
+    const f2 nn = __builtin_elementwise_fma(vx, vx, vy * vy);
+    const f2 dot = __builtin_elementwise_fma(vx, (f2){dx, dx}, vy * (f2){dy, dy});
+    const f2 dd = dot * dot;
+    const f2 t_in = __builtin_elementwise_fma(nn, (f2){K.k_in, K.k_in}, (f2){kTiny, kTiny});
+    const f2 t_out = __builtin_elementwise_fma(nn, (f2){K.k_out, K.k_out}, (f2){-kTiny, -kTiny});
+    m_in0 = __builtin_amdgcn_fcmpf(dd.x, t_in.x, 2);
+    m_in1 = __builtin_amdgcn_fcmpf(dd.y, t_in.y, 2);
+    m_un0 = ~(m_in0 | __builtin_amdgcn_fcmpf(dd.x, t_out.x, 4));
+    m_un1 = ~(m_in1 | __builtin_amdgcn_fcmpf(dd.y, t_out.y, 4));
+}
+
+// One wavefront scores kH hypotheses at a time, and the four wavefronts of a workgroup share one pass over the line
+// table: it is staged through LDS in chunks of kScoreChunk lines (two buffers, one barrier per chunk), so 4 x kH
+// hypotheses cost one read of the table from L2 (it used to be read once per wavefront: at N = 20 000 and 100 000
+// hypotheses that was 5 GB per solve).  Each lane tests its lines against all kH hypotheses (whose parameters are
+// wave-uniform) in one straight-line block; the rare lines for which an estimate is not sure are decided by the
+// canonical expression afterwards.  The score of each hypothesis is the canonical tree T() over the lines (lane-strided
+// partial sums in ascending line order, then the xor butterfly), exactly as when a wavefront owned a single hypothesis.
 // gctl != nullptr: line count and round come from the device (peeling rounds enqueued blindly, kernels_groups.hip);
 // the kernel then leaves at once when the peeling is over.
+constexpr int kScoreChunk = 512;
 template <int kH>
 __global__ __launch_bounds__(256) void ransac_score_kernel(PencilSoA m, uint32_t n_host, float tol, float degeneracy_tol,
                                                            uint32_t n_iter, uint64_t seed, uint32_t round_host,
                                                            const uint32_t* __restrict__ gctl, int max_models,
                                                            float* __restrict__ scores) {
+    __shared__ float s_tab[2][5][kScoreChunk];
     const int lane = threadIdx.x & 63;
     const uint32_t hyp0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kH;
-    if (hyp0 >= n_iter) return;
+    if (blockIdx.x * 4u * kH >= n_iter) return;  // (whole workgroup)
     uint32_t n = n_host, round = round_host;
     if (gctl) {
         n = gctl[kGcActive];
         round = gctl[kGcRound];
         if (gctl[kGcRemaining] < 2u || round >= (uint32_t)max_models) return;
     }
-    Hyp H[kH];
+    float cx[kH], cy[kH], nsub[kH];
+    bool valid[kH];
 #pragma unroll
     for (int j = 0; j < kH; ++j) {
         uint32_t a, b;
         sample_pair(seed, round, min(hyp0 + (uint32_t)j, n_iter - 1u), n, a, b);
-        H[j] = make_hyp(m, a, b, degeneracy_tol);
+        const Hyp h = make_hyp(m, a, b, degeneracy_tol);
+        cx[j] = h.cx;
+        cy[j] = h.cy;
+        nsub[j] = -h.sub;
+        valid[j] = h.valid;
     }
+    const EstConst K = est_const(tol);
     float acc[kH];
 #pragma unroll
     for (int j = 0; j < kH; ++j) acc[j] = 0.f;
-    for (uint32_t i = lane; i < n; i += 64) {
-        const float ax = m.ax[i], ay = m.ay[i], dx = m.dx[i], dy = m.dy[i], len = m.len[i];
+    auto stage = [&](int buf, uint32_t c0) {
+        for (uint32_t t = threadIdx.x; t < (uint32_t)kScoreChunk; t += 256) {
+            const uint32_t i = c0 + t;
+            if (i < n) {
+                s_tab[buf][0][t] = m.ax[i];
+                s_tab[buf][1][t] = m.ay[i];
+                s_tab[buf][2][t] = m.dx[i];
+                s_tab[buf][3][t] = m.dy[i];
+                s_tab[buf][4][t] = m.len[i];
+            }
+        }
+    };
+    stage(0, 0u);
+    int buf = 0;
+    for (uint32_t c0 = 0; c0 < n; c0 += kScoreChunk, buf ^= 1) {
+        __syncthreads();  // this chunk is in LDS; the other buffer is no longer being read
+        if (c0 + kScoreChunk < n) stage(buf ^ 1, c0 + kScoreChunk);
+        const uint32_t cn = min((uint32_t)kScoreChunk, n - c0);
+        for (uint32_t t = lane; t < cn; t += 64) {
+            const float ax = s_tab[buf][0][t], ay = s_tab[buf][1][t], dx = s_tab[buf][2][t], dy = s_tab[buf][3][t];
+            const float len = s_tab[buf][4][t];
+            uint64_t any_unsure = 0ull, mu[kH];
+#ifndef LR_SCORE_SCALAR
+            static_assert(kH % 2 == 0, "hypotheses are scored in pairs");
 #pragma unroll
-        for (int j = 0; j < kH; ++j) {
-            float vx, vy;
-            hyp_v(H[j], ax, ay, vx, vy);
-            acc[j] = acc[j] + (inlier_test(vx, vy, dx, dy, tol) ? len : 0.0f);
+            for (int j = 0; j < kH; j += 2) {
+                uint64_t mi0, mi1;
+                inlier_estimate2((f2){cx[j], cx[j + 1]}, (f2){cy[j], cy[j + 1]}, (f2){nsub[j], nsub[j + 1]}, ax, ay, dx, dy, K, mi0,
+                                 mu[j], mi1, mu[j + 1]);
+                // (an unsure line adds nothing here; the canonical test below adds it if it is an inlier)
+                acc[j] = acc[j] + (__builtin_amdgcn_inverse_ballot_w64(mi0 & ~mu[j]) ? len : 0.0f);
+                acc[j + 1] = acc[j + 1] + (__builtin_amdgcn_inverse_ballot_w64(mi1 & ~mu[j + 1]) ? len : 0.0f);
+                any_unsure |= mu[j] | mu[j + 1];
+            }
+#else
+#pragma unroll
+            for (int j = 0; j < kH; ++j) {
+                uint64_t mi;
+                inlier_estimate(cx[j], cy[j], nsub[j], ax, ay, dx, dy, K, mi, mu[j]);
+                // (an unsure line adds nothing here; the canonical test below adds it if it is an inlier)
+                acc[j] = acc[j] + (__builtin_amdgcn_inverse_ballot_w64(mi & ~mu[j]) ? len : 0.0f);
+                any_unsure |= mu[j];
+            }
+#endif
+            if (__builtin_expect(any_unsure != 0ull, 0)) {  // wave-uniform, rare
+#pragma unroll
+                for (int j = 0; j < kH; ++j)
+                    if (__builtin_amdgcn_inverse_ballot_w64(mu[j])) {
+                        const float vx = __builtin_fmaf(nsub[j], ax, cx[j]), vy = __builtin_fmaf(nsub[j], ay, cy[j]);
+                        acc[j] = acc[j] + (inlier_exact(vx, vy, dx, dy, tol) ? len : 0.0f);
+                    }
+            }
         }
     }
 #pragma unroll
     for (int j = 0; j < kH; ++j) {
         const float score = wave_tree(acc[j]);
-        if (lane == 0 && hyp0 + (uint32_t)j < n_iter) scores[hyp0 + j] = H[j].valid ? score : -1.0f;
+        if (lane == 0 && hyp0 + (uint32_t)j < n_iter) scores[hyp0 + j] = valid[j] ? score : -1.0f;
     }
 }
 
@@ -174,31 +280,79 @@ __global__ __launch_bounds__(1024) void ransac_argmax_kernel(const float* __rest
 // ---- PROSAC support (reference prosac.h, line_pencil.cpp:47-86; opt-in) ----------
 
 // Inlier COUNT (prosac.h:208-210) of explicit two-line samples over the quality-sorted line table.
-// One wavefront per hypothesis; the count is an integer, so its reduction order is immaterial.
+// kH hypotheses per wavefront, the table staged through LDS for the workgroup's four wavefronts (as ransac_score_kernel);
+// the count is an integer, so its reduction order is immaterial.
 template <int kH>
 __global__ __launch_bounds__(256) void prosac_count_kernel(PencilSoA m, uint32_t n, float tol, float degeneracy_tol,
                                                            const uint32_t* __restrict__ sa,
                                                            const uint32_t* __restrict__ sb, uint32_t n_hyp,
                                                            uint32_t* __restrict__ counts) {
+    __shared__ float s_tab[2][4][kScoreChunk];
     const int lane = threadIdx.x & 63;
     const uint32_t hyp0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kH;
-    if (hyp0 >= n_hyp) return;
-    Hyp H[kH];
+    if (blockIdx.x * 4u * kH >= n_hyp) return;  // (whole workgroup)
+    float cx[kH], cy[kH], nsub[kH];
+    bool valid[kH];
 #pragma unroll
     for (int j = 0; j < kH; ++j) {
         const uint32_t h = min(hyp0 + (uint32_t)j, n_hyp - 1u);
-        H[j] = make_hyp(m, sa[h], sb[h], degeneracy_tol);
+        const Hyp hy = make_hyp(m, sa[h], sb[h], degeneracy_tol);
+        cx[j] = hy.cx;
+        cy[j] = hy.cy;
+        nsub[j] = -hy.sub;
+        valid[j] = hy.valid;
     }
+    const EstConst K = est_const(tol);
     uint32_t cnt[kH];
 #pragma unroll
     for (int j = 0; j < kH; ++j) cnt[j] = 0u;
-    for (uint32_t i = lane; i < n; i += 64) {
-        const float ax = m.ax[i], ay = m.ay[i], dx = m.dx[i], dy = m.dy[i];
+    auto stage = [&](int buf, uint32_t c0) {
+        for (uint32_t t = threadIdx.x; t < (uint32_t)kScoreChunk; t += 256) {
+            const uint32_t i = c0 + t;
+            if (i < n) {
+                s_tab[buf][0][t] = m.ax[i];
+                s_tab[buf][1][t] = m.ay[i];
+                s_tab[buf][2][t] = m.dx[i];
+                s_tab[buf][3][t] = m.dy[i];
+            }
+        }
+    };
+    stage(0, 0u);
+    int buf = 0;
+    for (uint32_t c0 = 0; c0 < n; c0 += kScoreChunk, buf ^= 1) {
+        __syncthreads();
+        if (c0 + kScoreChunk < n) stage(buf ^ 1, c0 + kScoreChunk);
+        const uint32_t cn = min((uint32_t)kScoreChunk, n - c0);
+        for (uint32_t t = lane; t < cn; t += 64) {
+            const float ax = s_tab[buf][0][t], ay = s_tab[buf][1][t], dx = s_tab[buf][2][t], dy = s_tab[buf][3][t];
+            uint64_t any_unsure = 0ull, mu[kH];
+#ifndef LR_SCORE_SCALAR
 #pragma unroll
-        for (int j = 0; j < kH; ++j) {
-            float vx, vy;
-            hyp_v(H[j], ax, ay, vx, vy);
-            cnt[j] += inlier_test(vx, vy, dx, dy, tol) ? 1u : 0u;
+            for (int j = 0; j < kH; j += 2) {
+                uint64_t mi0, mi1;
+                inlier_estimate2((f2){cx[j], cx[j + 1]}, (f2){cy[j], cy[j + 1]}, (f2){nsub[j], nsub[j + 1]}, ax, ay, dx, dy, K, mi0,
+                                 mu[j], mi1, mu[j + 1]);
+                cnt[j] += __builtin_amdgcn_inverse_ballot_w64(mi0 & ~mu[j]) ? 1u : 0u;
+                cnt[j + 1] += __builtin_amdgcn_inverse_ballot_w64(mi1 & ~mu[j + 1]) ? 1u : 0u;
+                any_unsure |= mu[j] | mu[j + 1];
+            }
+#else
+#pragma unroll
+            for (int j = 0; j < kH; ++j) {
+                uint64_t mi;
+                inlier_estimate(cx[j], cy[j], nsub[j], ax, ay, dx, dy, K, mi, mu[j]);
+                cnt[j] += __builtin_amdgcn_inverse_ballot_w64(mi & ~mu[j]) ? 1u : 0u;
+                any_unsure |= mu[j];
+            }
+#endif
+            if (__builtin_expect(any_unsure != 0ull, 0)) {  // wave-uniform, rare
+#pragma unroll
+                for (int j = 0; j < kH; ++j)
+                    if (__builtin_amdgcn_inverse_ballot_w64(mu[j])) {
+                        const float vx = __builtin_fmaf(nsub[j], ax, cx[j]), vy = __builtin_fmaf(nsub[j], ay, cy[j]);
+                        cnt[j] += inlier_exact(vx, vy, dx, dy, tol) ? 1u : 0u;
+                    }
+            }
         }
     }
 #pragma unroll
@@ -207,7 +361,7 @@ __global__ __launch_bounds__(256) void prosac_count_kernel(PencilSoA m, uint32_t
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) c += (uint32_t)__shfl_xor((int)c, off);
         // sample_check failed: the reference skips the iteration
-        if (lane == 0 && hyp0 + (uint32_t)j < n_hyp) counts[hyp0 + j] = H[j].valid ? c : 0xFFFFFFFFu;
+        if (lane == 0 && hyp0 + (uint32_t)j < n_hyp) counts[hyp0 + j] = valid[j] ? c : 0xFFFFFFFFu;
     }
 }
 

@@ -16,34 +16,79 @@
 namespace lramd {
 namespace {
 
-__global__ __launch_bounds__(256) void reduce_max_kernel(const uint32_t* __restrict__ tile_max, int n_tiles,
-                                                         float* __restrict__ maxmag) {
-    __shared__ uint32_t s[4];
+__device__ __forceinline__ uint32_t ld_agent_u32(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Seed threshold, per-band counts and their exclusive scan in ONE launch (it used to be four: a one-workgroup max
+// reduction, the counts, and rocPRIM's scan with its own initialisation kernel -- each some 4.5 us of launch floor in a
+// chain that the flood waits for).
+//  - min_seed_value needs the frame's largest magnitude (line_detector.cpp:209): every workgroup reduces ALL the per-band
+//    maxima itself (20 KB from L2 for a 4K frame) instead of waiting for a kernel that does it once;
+//  - one wavefront per band counts the band's candidates above the threshold (filter.cpp:168);
+//  - the workgroup that finishes last (a ticket counter) scans the counts into offsets and writes the seed count.
+__global__ __launch_bounds__(256) void seed_count_scan_kernel(const uint64_t* __restrict__ cand,
+                                                              const uint32_t* __restrict__ cand_count,
+                                                              const uint32_t* __restrict__ tile_max, int n_tiles,
+                                                              int cand_cap, float keep_ratio, float* __restrict__ maxmag,
+                                                              uint32_t* __restrict__ tile_pass, uint32_t* __restrict__ tile_off,
+                                                              uint32_t* __restrict__ n_seeds, uint32_t* __restrict__ ticket) {
+    __shared__ uint32_t s_red[4];
+    __shared__ uint32_t s_scan[256];
+    __shared__ uint32_t s_last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t m = 0;  // magnitudes are >= 0, so their bit patterns order like the floats
     for (int i = threadIdx.x; i < n_tiles; i += 256) m = max(m, tile_max[i]);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
+    if (lane == 0) s_red[wave] = m;
     __syncthreads();
-    if (threadIdx.x == 0) *maxmag = __uint_as_float(max(max(s[0], s[1]), max(s[2], s[3])));
-}
-
-// one wave per tile
-__global__ __launch_bounds__(256) void seed_count_kernel(const uint64_t* __restrict__ cand,
-                                                         const uint32_t* __restrict__ cand_count, int n_tiles,
-                                                         int cand_cap, const float* __restrict__ maxmag,
-                                                         float keep_ratio, uint32_t* __restrict__ tile_pass) {
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (tile >= n_tiles) return;
-    const float thr = *maxmag * keep_ratio;
-    const uint32_t n = cand_count[tile];
-    const uint64_t* c = cand + (size_t)tile * cand_cap;
-    uint32_t cnt = 0;
-    for (uint32_t i = lane; i < n; i += 64) cnt += (__uint_as_float((uint32_t)(c[i] >> 32)) > thr) ? 1u : 0u;
+    const float mx = __uint_as_float(max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3])));
+    if (blockIdx.x == 0 && threadIdx.x == 0) *maxmag = mx;
+    const float thr = mx * keep_ratio;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile < n_tiles) {
+        const uint32_t n = cand_count[tile];
+        const uint64_t* c = cand + (size_t)tile * cand_cap;
+        uint32_t cnt = 0;
+        for (uint32_t i = lane; i < n; i += 64) cnt += (__uint_as_float((uint32_t)(c[i] >> 32)) > thr) ? 1u : 0u;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, off);
-    if (lane == 0) tile_pass[tile] = cnt;
+        for (int off = 32; off >= 1; off >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, off);
+        if (lane == 0) tile_pass[tile] = cnt;
+    }
+    // the last workgroup to get here scans (every other one has written its counts before taking its ticket)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const int chunk = (n_tiles + 255) / 256;
+    const int i0 = (int)threadIdx.x * chunk, i1 = min(n_tiles, i0 + chunk);
+    uint32_t sum = 0;
+    for (int i = i0; i < i1; ++i) sum += ld_agent_u32(&tile_pass[i]);
+    s_scan[threadIdx.x] = sum;
+    __syncthreads();
+    // exclusive scan of the 256 chunk sums (Hillis-Steele in LDS: eight steps)
+    uint32_t v = sum;
+    for (int off = 1; off < 256; off <<= 1) {
+        const uint32_t o = threadIdx.x >= (unsigned)off ? s_scan[threadIdx.x - off] : 0u;
+        __syncthreads();
+        v += o;
+        s_scan[threadIdx.x] = v;
+        __syncthreads();
+    }
+    uint32_t run = v - sum;
+    for (int i = i0; i < i1; ++i) {
+        tile_off[i] = run;
+        run += ld_agent_u32(&tile_pass[i]);
+    }
+    if (threadIdx.x == 255) {
+        *n_seeds = v;
+        *ticket = 0u;  // for the next frame
+    }
 }
 
 __global__ __launch_bounds__(256) void seed_write_kernel(const uint64_t* __restrict__ cand,
@@ -51,8 +96,7 @@ __global__ __launch_bounds__(256) void seed_write_kernel(const uint64_t* __restr
                                                          int cand_cap, const float* __restrict__ maxmag,
                                                          float keep_ratio, const uint32_t* __restrict__ tile_pass,
                                                          const uint32_t* __restrict__ tile_off,
-                                                         uint64_t* __restrict__ keys, uint32_t cap,
-                                                         uint32_t* __restrict__ n_seeds) {
+                                                         uint64_t* __restrict__ keys, uint32_t cap) {
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (tile >= n_tiles) return;
@@ -76,7 +120,6 @@ __global__ __launch_bounds__(256) void seed_write_kernel(const uint64_t* __restr
         }
         base += (uint32_t)__popcll(m);
     }
-    if (tile == n_tiles - 1 && lane == 0) *n_seeds = tile_off[tile] + tile_pass[tile];
 }
 
 // The sort runs on a fixed number of keys (`cap`, chosen by the host before it knows the seed count, so that no
@@ -232,24 +275,21 @@ int launch_seed_order(uint64_t* keys, const uint32_t* n_seeds, uint32_t cap, con
 }
 
 size_t seeds_temp_bytes(int n_tiles, size_t max_seeds) {
-    size_t a = 0, b = 0;
-    (void)rocprim::exclusive_scan(nullptr, a, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)n_tiles,
-                                  rocprim::plus<uint32_t>());
+    (void)n_tiles;
+    size_t b = 0;
     (void)rocprim::radix_sort_keys(nullptr, b, (uint64_t*)nullptr, (uint64_t*)nullptr, max_seeds, 0u, 64u);
-    return (a > b ? a : b) + 256;
+    return b + 256;
 }
 
+// `ticket`: one zero-initialised word of the context (the last workgroup of a launch resets it)
 int launch_seed_select(const uint64_t* cand, const uint32_t* cand_count, const uint32_t* tile_max, int n_tiles,
                        int cand_cap, float seed_keep_ratio, float* maxmag, uint32_t* tile_pass, uint32_t* tile_off, uint64_t* keys,
-                       uint32_t key_cap, uint32_t* n_seeds, void* temp, size_t temp_bytes, hipStream_t s) {
-    hipLaunchKernelGGL(reduce_max_kernel, dim3(1), dim3(256), 0, s, tile_max, n_tiles, maxmag);
+                       uint32_t key_cap, uint32_t* n_seeds, uint32_t* ticket, hipStream_t s) {
     const int blocks = (n_tiles + 3) / 4;
-    hipLaunchKernelGGL(seed_count_kernel, dim3(blocks), dim3(256), 0, s, cand, cand_count, n_tiles, cand_cap, maxmag,
-                       seed_keep_ratio, tile_pass);
-    LR_HIP(rocprim::exclusive_scan(temp, temp_bytes, tile_pass, tile_off, 0u, (size_t)n_tiles,
-                                   rocprim::plus<uint32_t>(), s));
+    hipLaunchKernelGGL(seed_count_scan_kernel, dim3(blocks), dim3(256), 0, s, cand, cand_count, tile_max, n_tiles, cand_cap,
+                       seed_keep_ratio, maxmag, tile_pass, tile_off, n_seeds, ticket);
     hipLaunchKernelGGL(seed_write_kernel, dim3(blocks), dim3(256), 0, s, cand, cand_count, n_tiles, cand_cap, maxmag,
-                       seed_keep_ratio, tile_pass, tile_off, keys, key_cap, n_seeds);
+                       seed_keep_ratio, tile_pass, tile_off, keys, key_cap);
     if (!seed_order_is_fused(key_cap))
         hipLaunchKernelGGL(seed_pad_kernel, dim3((key_cap + 255) / 256), dim3(256), 0, s, keys, key_cap, n_seeds);
     LR_HIP(hipGetLastError());

@@ -17,6 +17,7 @@ elif which == "doc":
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "doc_image_gray.npy")).astype(np.float32) / np.float32(256.0)
     img = np.ascontiguousarray(ndi.zoom(g, (2160 / g.shape[0], 3840 / g.shape[1]), order=3).astype(np.float32)[:2160, :3840])
 ctx = L.Context(0)
+ctx.set_stage_timing(True)
 h, w = img.shape
 for rep in range(2):
     sys.stderr.write("---- pass %d\n" % rep)

@@ -3,6 +3,7 @@ import numpy as np, time, sys
 import librectify_amd as L
 from librectify_amd import synth
 ctx=L.Context(0)
+ctx.set_stage_timing(True)
 W,H=3840,2160
 img=synth.frame(W,H,1)
 for rep in range(3):

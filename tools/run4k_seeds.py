@@ -4,6 +4,7 @@ import numpy as np, time
 import librectify_amd as L
 from librectify_amd import synth
 ctx = L.Context(0)
+ctx.set_stage_timing(True)
 W, H = 3840, 2160
 for seed in [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]:
     img = synth.frame(W, H, seed)

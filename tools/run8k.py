@@ -5,6 +5,7 @@ from librectify_amd import synth
 W = H = 8192
 t = time.time(); img = synth.frame(W, H, 7, bars=6000, tile=512); print("gen %.1fs" % (time.time() - t), flush=True)
 ctx = L.Context(0)
+ctx.set_stage_timing(True)
 ctx.set_seed(0)
 for est in (0, 1):
     ctx.set_estimator(est, 100000)

@@ -11,6 +11,7 @@ img = ndi.zoom(g, (H / g.shape[0], W / g.shape[1]), order=3).astype(np.float32)
 img = np.ascontiguousarray(img[:H, :W])
 print("frame", img.shape, flush=True)
 ctx = L.Context(0)
+ctx.set_stage_timing(True)
 ctx.set_seed(0)
 for rep in range(3):
     t = time.time(); got = ctx.find_line_segment_groups(img, max(W, H) / 100.0); dt = time.time() - t

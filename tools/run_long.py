@@ -25,6 +25,7 @@ def long_frame(W, H, seed, K=60):
 W, H = 3840, 2160
 img = long_frame(W, H, 3)
 ctx = L.Context(0)
+ctx.set_stage_timing(True)
 for rep in range(3):
     t = time.time(); got = ctx.find_line_segment_groups(img, max(W, H) / 100.0); dt = time.time() - t
     print(W, H, "total %.1f ms" % (dt * 1e3), "lines", len(got), ctx.stage_counters(), ctx.stage_times().round(3), flush=True)
