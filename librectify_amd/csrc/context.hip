@@ -1607,11 +1607,12 @@ int ctx_find_groups_host(lr_context* c, const float* buffer, int w, int h, int s
         sstride = -sstride;
     }
     const size_t row_bytes = (size_t)w * sizeof(float);
-    // Upload bands of 1 MB: with eight staging threads the first transfers start after a sixteenth of a millisecond
-    // instead of after a whole 4 MB band per thread (which is when ALL of them are ready: the link would idle for the
-    // first 0.4 ms); the filter follows every fourth band (4 MB of rows per launch, about a ninth of a 4K frame).
-    static const size_t band_bytes = std::getenv("LIBRECTIFY_UPLOAD_BAND_KB") ? (size_t)std::max(64, std::atoi(std::getenv("LIBRECTIFY_UPLOAD_BAND_KB"))) << 10 : (size_t)1 << 20;
-    static const int filter_every = std::getenv("LIBRECTIFY_FILTER_EVERY") ? std::max(1, std::atoi(std::getenv("LIBRECTIFY_FILTER_EVERY"))) : 4;
+    // Upload bands of 4 MB, the filter behind every band.  Smaller bands would start the link earlier (with eight staging
+    // threads the first 4 MB bands are all ready at the same moment, 0.4 ms in), but every band costs about 18 us of its
+    // own -- transfer submission, event, cross-stream wait -- on the stream that carries the frame: measured on 4K frames
+    // 3.01 ms per call with 4 MB bands, 3.49 with 1 MB, 4.07 with 512 KB (profiles/r03_single_call_sweep.txt).
+    static const size_t band_bytes = std::getenv("LIBRECTIFY_UPLOAD_BAND_KB") ? (size_t)std::max(64, std::atoi(std::getenv("LIBRECTIFY_UPLOAD_BAND_KB"))) << 10 : (size_t)4 << 20;
+    static const int filter_every = std::getenv("LIBRECTIFY_FILTER_EVERY") ? std::max(1, std::atoi(std::getenv("LIBRECTIFY_FILTER_EVERY"))) : 1;
     const int rpb = (int)std::max<size_t>(1, band_bytes / row_bytes);
     const int n_bands = (h + rpb - 1) / rpb;
     while ((int)c->band_ev.size() < n_bands) {

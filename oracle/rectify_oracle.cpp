@@ -197,6 +197,31 @@ void conv_gradients(const float* img, int w, int h, float* dx, float* dy, const 
         }
 }
 
+// The reference's own form (filter.cpp:81-98 with the taps of :65-78): out(i+2, j+2) = sum over the 5x5 block of
+// block(a, b) * H(a, b), every tap H(a, b) = z / a * exp(-(x^2 + y^2) / 2 s^2) rounded on its own, summed here in
+// row-major tap order with double accumulation (Eigen's order under -ffast-math is unspecified).  Not the canonical
+// arithmetic of this build: kept as a second path so that tests/test_oracle_pins.py can bound what the separable form
+// (which the product mirrors) may differ from it.
+void conv_gradients_25tap(const float* img, int w, int h, float* dx, float* dy) {
+    float Hx[25], Hy[25];
+    gauss_deriv_kernel(EDGE_KERNEL_SIZE, EDGE_KERNEL_SIGMA, true, Hx);
+    gauss_deriv_kernel(EDGE_KERNEL_SIZE, EDGE_KERNEL_SIGMA, false, Hy);
+    std::fill(dx, dx + size_t(w) * h, 0.0f);
+    std::fill(dy, dy + size_t(w) * h, 0.0f);
+    for (int y = 2; y < h - 2; ++y)
+        for (int x = 2; x < w - 2; ++x) {
+            double sx = 0.0, sy = 0.0;
+            for (int a = 0; a < 5; ++a)
+                for (int b = 0; b < 5; ++b) {
+                    const float v = img[size_t(y + a - 2) * w + (x + b - 2)];
+                    sx += double(v * Hx[a * 5 + b]);
+                    sy += double(v * Hy[a * 5 + b]);
+                }
+            dx[size_t(y) * w + x] = float(sx);
+            dy[size_t(y) * w + x] = float(sy);
+        }
+}
+
 // line_detector.cpp:41-49
 void image_gradients(const float* img, int w, int h, float* dx, float* dy, float* mag, const ThreadContext& ctx) {
     conv_gradients(img, w, h, dx, dy, ctx);
@@ -1517,6 +1542,9 @@ extern "C" {
 void orc_gauss_deriv_kernel(int size, float sigma, int dir_x, float* out) { gauss_deriv_kernel(size, sigma, dir_x != 0, out); }
 
 void orc_bin_trig(int n_bins, float* st, float* ct) { bin_trig(n_bins, st, ct); }
+
+// the reference's 25-tap correlation (second path, see conv_gradients_25tap)
+void orc_conv_gradients_25tap(const float* img, int w, int h, float* dx, float* dy) { conv_gradients_25tap(img, w, h, dx, dy); }
 
 // dx, dy, mag: w*h floats; bin: w*h int32; dmask: w*h uint8 (bit b set iff the 3x3 dilation
 // of grad_bin==b covers the pixel; 0 on the 1-px border) — the lazily evaluated form of the

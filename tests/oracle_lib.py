@@ -120,6 +120,16 @@ def filter_stage(img, num_threads=-1, planes=False):
     return dict(dx=dx, dy=dy, mag=mag, bin=bins, dmask=dmask, planes=pl)
 
 
+def conv_gradients_25tap(img):
+    """the reference's 25-tap correlation (filter.cpp:65-98), second path of the oracle"""
+    img = np.ascontiguousarray(img, np.float32)
+    h, w = img.shape
+    dx = np.zeros((h, w), np.float32)
+    dy = np.zeros((h, w), np.float32)
+    lib().orc_conv_gradients_25tap(_p(img), C.c_int(w), C.c_int(h), _p(dx), _p(dy))
+    return dx, dy
+
+
 def find_seeds(mag, bins, cap=None):
     h, w = mag.shape
     cap = cap or (h * w // 4 + 16)

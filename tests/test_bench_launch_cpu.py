@@ -1,0 +1,51 @@
+"""bench.py's launch logic, without a GPU: `--gpus N` with no WORLD_SIZE starts N ranks as a child
+process (torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1) -- checked through the dry-run flag -- and a
+WORLD_SIZE that disagrees with --gpus is refused.  Also the rank -> host cores mapping."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + args, env=env, capture_output=True, text=True, timeout=120)
+
+
+def test_gpus_n_without_a_launcher_spawns_n_ranks():
+    p = _run(["--gpus", "4", "--steps", "3", "--warmup", "1", "--dry-run-spawn"])
+    assert p.returncode == 0, p.stderr
+    cmd = json.loads(p.stdout.strip().splitlines()[-1])["spawn"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(BENCH)
+    assert cmd[i + 1 :] == ["--gpus", "4", "--steps", "3", "--warmup", "1", "--dry-run-spawn"]  # the ranks get the same arguments
+
+
+def test_world_size_that_disagrees_with_gpus_is_refused():
+    p = _run(["--gpus", "8"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0
+    assert "refusing" in p.stderr and '"metric"' not in p.stdout
+    p = _run(["--gpus", "1"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0
+
+
+def test_rank_cpus_splits_the_cores_evenly():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    avail = list(range(64))
+    seen = []
+    for r in range(8):
+        cpus, how = bench.rank_cpus(r, 8, None, avail)
+        assert len(cpus) == 8 and how == "contiguous share"
+        seen += cpus
+    assert sorted(seen) == avail
+    assert bench.rank_cpus(0, 1, None, avail)[0] == avail
+    assert bench.cpu_list("0-3,8,10-11") == [0, 1, 2, 3, 8, 10, 11]

@@ -210,3 +210,38 @@ def test_cht_estimator_oracle_self_consistency_parity_unpinned():
     # fewer than two lines: no round at all (estimator.h:115)
     one, m1, c1 = O.estimate_line_pencils_cht(segs[:1])
     assert len(m1) == 0 and one["group_id"][0] == -1
+
+
+def test_separable_gradient_stays_within_ulps_of_the_reference_25_tap_form():
+    """the canonical gradient of this build is the separable evaluation of the reference's taps (which the
+    HIP kernel mirrors); the reference itself sums 25 separately rounded taps (filter.cpp:65-98).  The two are kept side
+    by side in the oracle: on the doc image and on a synthetic frame they differ by a few ulp of the largest magnitude,
+    the bin decision agrees wherever the two best directional responses are not within that distance of each other, and
+    the seeds are the same but for such ties."""
+    from librectify_amd import synth
+
+    gray = np.load(os.path.join(G, "doc_image_gray.npy"))
+    for img in (gray.astype(np.float32) / np.float32(256.0), synth.frame(640, 480, 3)):
+        f = O.filter_stage(img, planes=True)
+        dx25, dy25 = O.conv_gradients_25tap(img)
+        scale = float(max(np.abs(f["dx"]).max(), np.abs(f["dy"]).max()))
+        ulp = scale * 2.0 ** -23
+        assert np.abs(f["dx"] - dx25).max() <= 8 * ulp, np.abs(f["dx"] - dx25).max() / ulp
+        assert np.abs(f["dy"] - dy25).max() <= 8 * ulp, np.abs(f["dy"] - dy25).max() / ulp
+        assert (dx25[:2] == 0).all() and (dx25[-2:] == 0).all() and (dx25[:, :2] == 0).all() and (dx25[:, -2:] == 0).all()
+        # bins from the 25-tap gradients: the same first-strict-argmax rule
+        st, ct = O.bin_trig()
+        planes25 = np.abs(dx25[None] * st[:, None, None] + dy25[None] * ct[:, None, None])
+        bin25 = planes25.argmax(axis=0)
+        differ = bin25 != f["bin"]
+        # (the masked planes of the oracle are zero outside their dilated masks: the unmasked 25-tap responses give the gap)
+        srt = np.sort(planes25, axis=0)
+        gap = srt[-1] - srt[-2]
+        assert (gap[differ] <= 32 * ulp).all(), float(gap[differ].max() / ulp)
+        assert differ.mean() < 2e-3
+        mag25 = np.sqrt(dx25 * dx25 + dy25 * dy25)
+        s_can = O.find_seeds(f["mag"], f["bin"])
+        s_25 = O.find_seeds(mag25.astype(np.float32), bin25.astype(np.int32))
+        a = set(zip(s_can["rows"].tolist(), s_can["cols"].tolist()))
+        b = set(zip(s_25["rows"].tolist(), s_25["cols"].tolist()))
+        assert len(a ^ b) <= 0.02 * len(a), (len(a), len(b), len(a ^ b))
