@@ -253,6 +253,9 @@ int launch_refine_pairs(const void* seg, uint32_t n, void* edges, uint32_t* n_ed
 int launch_prosac_count(PencilSoA m, uint32_t n, float tol, float degeneracy_tol, const uint32_t* sa,
                         const uint32_t* sb, uint32_t n_hyp, uint32_t* counts, hipStream_t s);
 int launch_prosac_flags(PencilSoA m, uint32_t n, float px, float py, float pz, float tol, uint8_t* flags, hipStream_t s);
+// new-best iterations of a chunk (from its counts and the best count it starts with) and their inlier flags
+int launch_prosac_records(PencilSoA m, uint32_t n, const uint32_t* sa, const uint32_t* sb, const uint32_t* counts,
+                          uint32_t n_hyp, uint32_t best_in, float tol, uint32_t* rec, uint32_t cap, uint8_t* flags, hipStream_t s);
 int launch_ht_weights(PencilSoA m, uint32_t n, const int32_t* pa, const int32_t* pb, int n_pairs, int ht, float* peak,
                       float* weights, hipStream_t s);
 

@@ -123,6 +123,11 @@ struct lr_context {
     uint32_t* d_hcounts = nullptr;  // cap_chunk
     uint32_t* h_hcounts = nullptr;
     size_t cap_chunk = 0, cap_wlines = 0;
+    uint32_t* d_rec = nullptr;       // PROSAC: new-best iterations of a chunk ([0] = how many) ...
+    uint32_t* h_rec = nullptr;
+    uint8_t* d_recflags = nullptr;   // ... and a row of inlier flags for each
+    uint8_t* h_recflags = nullptr;
+    size_t cap_recflags = 0;
     std::vector<lr_context*> workers;  // extra contexts (own stream + workspace) for frames in flight in batch calls
     int batch_streams = 4;
     int estimator = 0;            // 0 = RANSAC (reference default), 1 = PROSAC, 2 = DirectEstimator, 3 = diamond space (CHT)

@@ -449,7 +449,7 @@ void ctx_destroy(lr_context* c) {
                     c->fb.blocked, c->fb.count, c->fb.flags, c->fb.state, c->fb.tier, c->fb.act_a, c->fb.act_b,
                     c->fb.ctrl, c->fb.big_list, c->fb.dirty, c->fb.slab_ring, c->fb.slab_hash, c->d_pairs, c->d_peak, c->d_weights,
                     c->d_samples, c->d_hcounts, c->comp_large, c->d_tables, c->d_orig, c->d_inl, c->d_flines, c->d_gctl,
-                    c->d_gnorm, c->d_models, c->d_refine_table, c->d_refine_edges, c->d_cht_acc, c->d_cht_idx, c->d_cht_peak};
+                    c->d_gnorm, c->d_models, c->d_refine_table, c->d_refine_edges, c->d_cht_acc, c->d_cht_idx, c->d_cht_peak, c->d_rec, c->d_recflags};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete static_cast<StagingCrew*>(c->crew);
@@ -477,6 +477,8 @@ void ctx_destroy(lr_context* c) {
     if (c->h_weights) (void)hipHostFree(c->h_weights);
     if (c->h_samples) (void)hipHostFree(c->h_samples);
     if (c->h_hcounts) (void)hipHostFree(c->h_hcounts);
+    if (c->h_recflags) (void)hipHostFree(c->h_recflags);
+    if (c->h_rec) (void)hipHostFree(c->h_rec);
     if (c->h_cht_idx) (void)hipHostFree(c->h_cht_idx);
     if (c->h_cht_peak) (void)hipHostFree(c->h_cht_peak);
     for (auto& e : c->ev)
@@ -910,6 +912,8 @@ int upload_model(lr_context* c, const PencilModel& model, const std::vector<int>
     return 0;
 }
 
+constexpr uint32_t kProsacRecCap = 16;  // new-best iterations of a chunk whose inlier flags come back with its counts
+
 int ensure_prosac_buffers(lr_context* c, size_t n_lines, size_t n_pairs, size_t chunk) {
     if (n_pairs > c->cap_pairs) {
         LR_HIP(hipStreamSynchronize(c->stream));
@@ -927,6 +931,16 @@ int ensure_prosac_buffers(lr_context* c, size_t n_lines, size_t n_pairs, size_t 
         LR_HIP(hipHostMalloc((void**)&c->h_weights, cl * sizeof(float)));
         c->cap_wlines = cl;
     }
+    if (n_lines * kProsacRecCap > c->cap_recflags) {
+        LR_HIP(hipStreamSynchronize(c->stream));
+        const size_t bytes = std::max<size_t>(n_lines, 4096) * kProsacRecCap;
+        if (dev_alloc(c->d_recflags, bytes) || dev_alloc(c->d_rec, kProsacRecCap + 1)) return 1;
+        if (c->h_recflags) (void)hipHostFree(c->h_recflags);
+        if (c->h_rec) (void)hipHostFree(c->h_rec);
+        LR_HIP(hipHostMalloc((void**)&c->h_recflags, bytes));
+        LR_HIP(hipHostMalloc((void**)&c->h_rec, (kProsacRecCap + 1) * sizeof(uint32_t)));
+        c->cap_recflags = bytes;
+    }
     if (chunk > c->cap_chunk) {
         LR_HIP(hipStreamSynchronize(c->stream));
         if (dev_alloc(c->d_samples, 2 * chunk) || dev_alloc(c->d_hcounts, chunk)) return 1;
@@ -937,6 +951,44 @@ int ensure_prosac_buffers(lr_context* c, size_t n_lines, size_t n_pairs, size_t 
         c->cap_chunk = chunk;
     }
     return 0;
+}
+
+// Stable argsort by weight, descending (reference utils.h:36-44 uses std::stable_sort with a > comparator).  The weights
+// are fourth powers (>= +0), so the order of their bit patterns is their order: three stable 11-bit counting passes over
+// the complemented bits, a fifth of std::stable_sort's time on 24 000 lines.  A NaN weight (a line through the peak
+// itself) has no place in that order: then the comparison sort decides, as before.
+void stable_order_descending(const std::vector<float>& w, std::vector<int>& order) {
+    const size_t n = w.size();
+    order.resize(n);
+    bool plain = true;
+    for (size_t i = 0; i < n; ++i) plain = plain && w[i] >= 0.0f && !std::signbit(w[i]);  // (false for NaN and -0)
+    if (!plain || n < 256) {
+        for (size_t i = 0; i < n; ++i) order[i] = (int)i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return w[a] > w[b]; });
+        return;
+    }
+    std::vector<uint32_t> key(n), key2(n);
+    std::vector<int> idx(n), idx2(n);
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t b;
+        std::memcpy(&b, &w[i], 4);
+        key[i] = ~b;
+        idx[i] = (int)i;
+    }
+    for (int pass = 0; pass < 3; ++pass) {
+        const int shift = pass * 11;
+        uint32_t cnt[2049] = {0};
+        for (size_t i = 0; i < n; ++i) cnt[((key[i] >> shift) & 2047u) + 1]++;
+        for (int b = 0; b < 2048; ++b) cnt[b + 1] += cnt[b];
+        for (size_t i = 0; i < n; ++i) {
+            const uint32_t p = cnt[(key[i] >> shift) & 2047u]++;
+            key2[p] = key[i];
+            idx2[p] = idx[i];
+        }
+        key.swap(key2);
+        idx.swap(idx2);
+    }
+    order = idx;
 }
 
 // prosac.h:31-55
@@ -1019,8 +1071,7 @@ int ctx_prosac_solve(lr_context* c, const PencilModel& model, const std::vector<
     const double t_w1 = now_ms();
     const int N = (int)indices.size();
     std::vector<int> order(N);
-    for (int i = 0; i < N; ++i) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return weights[a] > weights[b]; });  // utils.h:36-44
+    stable_order_descending(weights, order);  // utils.h:36-44 (argsort, stable, by weight descending)
     const double t_s1 = now_ms();
     std::vector<int> idx(N);
     for (int i = 0; i < N; ++i) idx[i] = indices[order[i]];
@@ -1078,7 +1129,16 @@ int ctx_prosac_solve(lr_context* c, const PencilModel& model, const std::vector<
                                 (uint32_t)cnt, c->d_hcounts, c->stream))
             return 1;
         LR_HIP(hipMemcpyAsync(c->h_hcounts, c->d_hcounts, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        // the chunk's new-best iterations (they follow from the counts and the best count so far) and the inlier flags of
+        // each come back with the counts: one wait per chunk, not one per new best
+        if (launch_prosac_records(soa, (uint32_t)N, c->d_samples, c->d_samples + chunk, c->d_hcounts, (uint32_t)cnt,
+                                  (uint32_t)std::max(I_N_best, 0), tol, c->d_rec, kProsacRecCap, c->d_recflags, c->stream))
+            return 1;
+        LR_HIP(hipMemcpyAsync(c->h_rec, c->d_rec, (kProsacRecCap + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        LR_HIP(hipMemcpyAsync(c->h_recflags, c->d_recflags, (size_t)N * kProsacRecCap, hipMemcpyDeviceToHost, c->stream));
         LR_HIP(hipStreamSynchronize(c->stream));
+        const uint32_t n_rec = std::min<uint32_t>(c->h_rec[0], kProsacRecCap);
+        uint32_t rec_pos = 0;
         const double tg2 = now_ms();
         t_gpu += tg2 - tg1;
         // The chunk was generated under the state at its start.  A new best hypothesis changes n_star and k_n_star;
@@ -1098,7 +1158,11 @@ int ctx_prosac_solve(lr_context* c, const PencilModel& model, const std::vector<
                 const int ia = idx[c->h_samples[j]], ib = idx[c->h_samples[chunk + j]];
                 const Vec3 p_t = model.fit(ia, ib);
                 int I_N = 0;
-                if (N >= 4096) {  // the inliers of the new best, line by line: on the GPU for large tables
+                while (rec_pos < n_rec && c->h_rec[1 + rec_pos] < (uint32_t)j) ++rec_pos;
+                if (rec_pos < n_rec && c->h_rec[1 + rec_pos] == (uint32_t)j) {  // its flags came with the chunk
+                    std::memcpy(isInlier.data(), c->h_recflags + (size_t)rec_pos * N, (size_t)N);
+                    for (int i = 0; i < N; ++i) I_N += isInlier[i];
+                } else if (N >= 4096) {  // (more new bests in the chunk than flag rows: one by one, as before)
                     if (launch_prosac_flags(soa, (uint32_t)N, p_t.x, p_t.y, p_t.z, tol, reinterpret_cast<uint8_t*>(c->d_weights), c->stream))  // (the weights buffer is free by now)
                         return 1;
                     LR_HIP(hipMemcpyAsync(isInlier.data(), c->d_weights, (size_t)N, hipMemcpyDeviceToHost, c->stream));
@@ -1305,7 +1369,9 @@ int ctx_estimate_line_pencils_cht(lr_context* c, std::vector<LineSegment>& lines
         LR_HIP(hipStreamSynchronize(c->stream));
         const size_t cl = std::max<size_t>((size_t)N, 4096);
         if (dev_alloc(c->d_cht_idx, cl)) return 1;
-        if (c->h_cht_idx) (void)hipHostFree(c->h_cht_idx);
+        if (c->h_recflags) (void)hipHostFree(c->h_recflags);
+    if (c->h_rec) (void)hipHostFree(c->h_rec);
+    if (c->h_cht_idx) (void)hipHostFree(c->h_cht_idx);
         c->h_cht_idx = nullptr;
         LR_HIP(hipHostMalloc((void**)&c->h_cht_idx, cl * sizeof(uint32_t)));
         c->cap_cht_idx = cl;

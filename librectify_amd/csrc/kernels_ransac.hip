@@ -382,6 +382,90 @@ __global__ __launch_bounds__(256) void prosac_flags_kernel(PencilSoA m, uint32_t
     flags[i] = inlier_exact(vx, vy, m.dx[i], m.dy[i], tol) ? 1 : 0;
 }
 
+// The iterations of a speculative chunk at which PROSAC finds a new best hypothesis (prosac.h:208-222) follow from the
+// inlier counts alone: iteration j is one iff its count exceeds every earlier valid count of the chunk and the best count
+// the chunk started with.  One workgroup lists them in order (at most `cap`; *n_rec is their true number), so that the
+// inlier flags the host needs at each of them can be produced before it looks at the chunk -- one wait per chunk
+// instead of one per new best.
+__global__ __launch_bounds__(1024) void prosac_records_kernel(const uint32_t* __restrict__ counts, uint32_t n_hyp, uint32_t best_in,
+                                                              uint32_t* __restrict__ rec /* [0] = n_rec, [1..cap] = iterations */,
+                                                              uint32_t cap) {
+    __shared__ uint32_t s_max[1024];
+    __shared__ uint32_t s_cnt[1024];
+    const uint32_t L = (n_hyp + 1023u) / 1024u;
+    const uint32_t i0 = threadIdx.x * L, i1 = min(n_hyp, i0 + L);
+    uint32_t mx = 0;
+    for (uint32_t i = i0; i < i1; ++i) {
+        const uint32_t c = counts[i];
+        if (c != 0xFFFFFFFFu) mx = max(mx, c);
+    }
+    s_max[threadIdx.x] = mx;
+    __syncthreads();
+    // best count before this thread's run (a serial pass over 1024 words per thread would do as well; this is a tree)
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t o = threadIdx.x >= (unsigned)off ? s_max[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_max[threadIdx.x] = max(s_max[threadIdx.x], o);
+        __syncthreads();
+    }
+    uint32_t run = max(best_in, threadIdx.x ? s_max[threadIdx.x - 1] : 0u);
+    uint32_t n = 0;
+    for (uint32_t i = i0; i < i1; ++i) {
+        const uint32_t c = counts[i];
+        if (c != 0xFFFFFFFFu && c > run) {
+            run = c;
+            ++n;
+        }
+    }
+    s_cnt[threadIdx.x] = n;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t o = threadIdx.x >= (unsigned)off ? s_cnt[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_cnt[threadIdx.x] += o;
+        __syncthreads();
+    }
+    uint32_t pos = s_cnt[threadIdx.x] - n;
+    run = max(best_in, threadIdx.x ? s_max[threadIdx.x - 1] : 0u);
+    for (uint32_t i = i0; i < i1; ++i) {
+        const uint32_t c = counts[i];
+        if (c != 0xFFFFFFFFu && c > run) {
+            run = c;
+            if (pos < cap) rec[1 + pos] = i;
+            ++pos;
+        }
+    }
+    if (threadIdx.x == 1023) rec[0] = s_cnt[1023];
+}
+
+// Inlier flags (canonical test, as prosac_flags_kernel) of the listed iterations' hypotheses h_a x h_b, one row of n
+// bytes per listed iteration.
+__global__ __launch_bounds__(256) void prosac_record_flags_kernel(PencilSoA m, uint32_t n, const uint32_t* __restrict__ sa,
+                                                                  const uint32_t* __restrict__ sb,
+                                                                  const uint32_t* __restrict__ rec, uint32_t cap, float tol,
+                                                                  uint8_t* __restrict__ flags) {
+    const uint32_t r = blockIdx.y;
+    if (r >= min(rec[0], cap)) return;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t j = rec[1 + r];
+    const uint32_t a = sa[j], b = sb[j];
+    const float hax = m.hx[a], hay = m.hy[a], haz = m.hz[a];
+    const float hbx = m.hx[b], hby = m.hy[b], hbz = m.hz[b];
+    const float px = hay * hbz - haz * hby;  // line_pencil.cpp:101-108
+    const float py = haz * hbx - hax * hbz;
+    const float pz = hax * hby - hay * hbx;
+    float vx, vy;
+    if (fabsf(pz) < kEps) {
+        vx = px;
+        vy = py;
+    } else {
+        vx = px / pz - m.ax[i];
+        vy = py / pz - m.ay[i];
+    }
+    flags[(size_t)r * n + i] = inlier_exact(vx, vy, m.dx[i], m.dy[i], tol) ? 1 : 0;
+}
+
 // Hough votes of get_weights on the unit hemisphere: ht x ht accumulator in LDS, 64-bit integer atomics
 // (votes in 2^-20 fixed point, so the result does not depend on arrival order), then the first maximum
 // in column-major order.  Single workgroup: 20 000 votes are nothing.
@@ -690,6 +774,15 @@ int launch_prosac_count(PencilSoA m, uint32_t n, float tol, float degeneracy_tol
         hipLaunchKernelGGL(prosac_count_kernel<2>, dim3((n_hyp + 7) / 8), dim3(256), 0, s, m, n, tol, degeneracy_tol, sa, sb,
                            n_hyp, counts);
     }
+    LR_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_prosac_records(PencilSoA m, uint32_t n, const uint32_t* sa, const uint32_t* sb, const uint32_t* counts,
+                          uint32_t n_hyp, uint32_t best_in, float tol, uint32_t* rec, uint32_t cap, uint8_t* flags, hipStream_t s) {
+    if (n_hyp == 0 || n == 0) return 0;
+    hipLaunchKernelGGL(prosac_records_kernel, dim3(1), dim3(1024), 0, s, counts, n_hyp, best_in, rec, cap);
+    hipLaunchKernelGGL(prosac_record_flags_kernel, dim3((n + 255) / 256, cap), dim3(256), 0, s, m, n, sa, sb, rec, cap, tol, flags);
     LR_HIP(hipGetLastError());
     return 0;
 }

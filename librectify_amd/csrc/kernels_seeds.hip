@@ -34,7 +34,6 @@ __global__ __launch_bounds__(256) void seed_count_scan_kernel(const uint64_t* __
                                                               uint32_t* __restrict__ tile_pass, uint32_t* __restrict__ tile_off,
                                                               uint32_t* __restrict__ n_seeds, uint32_t* __restrict__ ticket) {
     __shared__ uint32_t s_red[4];
-    __shared__ uint32_t s_scan[256];
     __shared__ uint32_t s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t m = 0;  // magnitudes are >= 0, so their bit patterns order like the floats
@@ -56,39 +55,61 @@ __global__ __launch_bounds__(256) void seed_count_scan_kernel(const uint64_t* __
         for (int off = 32; off >= 1; off >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, off);
         if (lane == 0) tile_pass[tile] = cnt;
     }
-    // the last workgroup to get here scans (every other one has written its counts before taking its ticket)
+    // The last workgroup to get here scans (every other one has written its counts before taking its ticket).  Tickets in
+    // two levels -- 32 counters for the workgroups with the same index modulo 32, and one for those 32 groups' last
+    // arrivals -- because a thousand returning atomics on ONE address are executed one after the other by the L2 (30 us
+    // for the 1242 workgroups of a 4K frame; some 70 arrivals per address take 2).
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
-        s_last = atomicAdd(ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+        const uint32_t g = blockIdx.x & 31u;
+        const uint32_t in_group = (gridDim.x - g + 31u) / 32u;  // workgroups with this index modulo 32
+        uint32_t last = 0u;
+        if (atomicAdd(&ticket[g], 1u) == in_group - 1u) {
+            ticket[g] = 0u;  // (for the next frame: nobody else touches it any more)
+            __threadfence();
+            const uint32_t groups = min(32u, gridDim.x);
+            if (atomicAdd(&ticket[32], 1u) == groups - 1u) {
+                ticket[32] = 0u;
+                last = 1u;
+            }
+        }
+        s_last = last;
     }
     __syncthreads();
     if (!s_last) return;
     __threadfence();
-    const int chunk = (n_tiles + 255) / 256;
-    const int i0 = (int)threadIdx.x * chunk, i1 = min(n_tiles, i0 + chunk);
-    uint32_t sum = 0;
-    for (int i = i0; i < i1; ++i) sum += ld_agent_u32(&tile_pass[i]);
-    s_scan[threadIdx.x] = sum;
-    __syncthreads();
-    // exclusive scan of the 256 chunk sums (Hillis-Steele in LDS: eight steps)
-    uint32_t v = sum;
-    for (int off = 1; off < 256; off <<= 1) {
-        const uint32_t o = threadIdx.x >= (unsigned)off ? s_scan[threadIdx.x - off] : 0u;
-        __syncthreads();
-        v += o;
-        s_scan[threadIdx.x] = v;
-        __syncthreads();
+    // Exclusive scan of the counts, 256 at a time, sixteen such slices loaded up front (coalesced, all in flight together:
+    // a thread summing a contiguous run of counts one dependent L2 access after the other made this tail 25 us long).
+    __shared__ uint32_t s_wave[4];
+    uint32_t running = 0;
+    for (int base = 0; base < n_tiles; base += 256 * 16) {
+        uint32_t v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = base + k * 256 + (int)threadIdx.x;
+            v[k] = i < n_tiles ? ld_agent_u32(&tile_pass[i]) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (base + k * 256 >= n_tiles) break;  // (uniform)
+            uint32_t inc = v[k];  // inclusive scan inside the wavefront
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)inc, off);
+                if (lane >= off) inc += o;
+            }
+            __syncthreads();  // s_wave of the previous slice has been read
+            if (lane == 63) s_wave[wave] = inc;
+            __syncthreads();
+            uint32_t before = running;
+            for (int w2 = 0; w2 < wave; ++w2) before += s_wave[w2];
+            const int i = base + k * 256 + (int)threadIdx.x;
+            if (i < n_tiles) tile_off[i] = before + inc - v[k];
+            running += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        }
     }
-    uint32_t run = v - sum;
-    for (int i = i0; i < i1; ++i) {
-        tile_off[i] = run;
-        run += ld_agent_u32(&tile_pass[i]);
-    }
-    if (threadIdx.x == 255) {
-        *n_seeds = v;
-        *ticket = 0u;  // for the next frame
-    }
+    if (threadIdx.x == 0) *n_seeds = running;
 }
 
 __global__ __launch_bounds__(256) void seed_write_kernel(const uint64_t* __restrict__ cand,
@@ -281,7 +302,7 @@ size_t seeds_temp_bytes(int n_tiles, size_t max_seeds) {
     return b + 256;
 }
 
-// `ticket`: one zero-initialised word of the context (the last workgroup of a launch resets it)
+// `ticket`: 33 zero-initialised words of the context (the last arrivals of a launch reset them)
 int launch_seed_select(const uint64_t* cand, const uint32_t* cand_count, const uint32_t* tile_max, int n_tiles,
                        int cand_cap, float seed_keep_ratio, float* maxmag, uint32_t* tile_pass, uint32_t* tile_off, uint64_t* keys,
                        uint32_t key_cap, uint32_t* n_seeds, uint32_t* ticket, hipStream_t s) {

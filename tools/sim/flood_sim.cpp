@@ -305,6 +305,184 @@ static int pixel_level(int scheme, const std::vector<int>& ref, long labelled) {
     return bad != 0;
 }
 
+// ---- scheme 9: ascending batches inside a round, pixel-level commits ------------------------------------------------------
+// A round takes the active seeds in `nb` batches of ascending index (geometric sizes: the first holds n >> shift0 seeds,
+// each next one `grow` times as many).  The seeds of a batch walk concurrently against the labels committed so far --
+// including what the earlier batches of this round committed -- and stamp; then every seed of the batch commits the part
+// G of its footprint that is connected to what it owns (or its seed pixel) through pixels without a lower stamp (stamps
+// of the earlier batches' still-contested seeds stay in place).  A seed whose pixel has been committed when its batch
+// starts is dead without a walk.  Contested seeds go on to the next round, where they explore from what they own.
+// seed_level = 1: a seed commits all of its footprint or nothing (no G).
+static int batched(int shift0, int grow, bool seed_level, const std::vector<int>& ref, long labelled) {
+    std::vector<uint8_t> dm = dmask;
+    std::vector<int> label((size_t)W * H, -1);
+    const int INF = 0x7fffffff;
+    std::vector<int> stamp((size_t)W * H, INF);
+    std::vector<int> active(NS);
+    for (int k = 0; k < NS; ++k) active[k] = k;
+    std::vector<std::vector<int>> own(NS);
+    long tot_px = 0, tot_steps = 0, g_px = 0;
+    int rounds = 0, crit = 0, phases = 0;
+    std::vector<int> q;
+    const int tw = (W + 7) / 8;
+    while (!active.empty() && rounds < 100) {
+        ++rounds;
+        std::vector<int> next, touched;
+        long r_px = 0, r_steps = 0;
+        int r_crit = 0, r_walk = 0, r_dead = 0, r_done = 0, r_batches = 0;
+        size_t pos = 0;
+        long bsize = std::max<long>(1024, (long)active.size() >> shift0);
+        while (pos < active.size()) {
+            const size_t end = std::min(active.size(), pos + (size_t)bsize);
+            bsize *= grow;
+            ++r_batches;
+            int longest = 0;
+            struct W1 {
+                int k;
+                std::vector<int> fpx;
+            };
+            std::vector<W1> walks;
+            for (size_t ai = pos; ai < end; ++ai) {
+                const int k = active[ai];
+                const int b = sbin[k];
+                const float t = thr[k];
+                const int s = sidx[k];
+                const bool has_own = !own[k].empty();
+                if (!has_own) {
+                    if (label[s] >= 0) {
+                        r_dead++;
+                        continue;
+                    }
+                    if (!(((dm[s] >> b) & 1) && resp(s, b) > t)) {
+                        r_dead++;
+                        continue;
+                    }
+                }
+                ++g_epoch;
+                q.clear();
+                W1 w;
+                w.k = k;
+                if (has_own) {
+                    for (int p : own[k]) {
+                        g_seen[p] = g_epoch;
+                        q.push_back(p);
+                    }
+                } else {
+                    g_seen[s] = g_epoch;
+                    q.push_back(s);
+                    w.fpx.push_back(s);
+                }
+                for (size_t head = 0; head < q.size(); ++head) {
+                    const int p = q[head];
+                    const int r = p / W, c = p % W;
+                    for (int dr = -1; dr <= 1; ++dr)
+                        for (int dc = -1; dc <= 1; ++dc) {
+                            if (!dr && !dc) continue;
+                            const int rr = r + dr, cc = c + dc;
+                            if (rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
+                            const int x = rr * W + cc;
+                            if (g_seen[x] == g_epoch) continue;
+                            if (((dm[x] >> b) & 1) && resp(x, b) > t) {
+                                g_seen[x] = g_epoch;
+                                q.push_back(x);
+                                w.fpx.push_back(x);
+                            }
+                        }
+                }
+                int tiles = 0;
+                for (int p : w.fpx) {
+                    const int ti = (p / W / 8) * tw + (p % W) / 8;
+                    if (g_tile_seen[ti] != g_epoch) {
+                        g_tile_seen[ti] = g_epoch;
+                        tiles++;
+                    }
+                }
+                r_walk++;
+                r_px += (long)w.fpx.size();
+                r_steps += tiles;
+                longest = std::max(longest, tiles);
+                walks.push_back(std::move(w));
+            }
+            // stamps of the whole batch, then the commits of the batch
+            for (auto& w : walks)
+                for (int p : w.fpx) {
+                    if (stamp[p] == INF) touched.push_back(p);
+                    stamp[p] = std::min(stamp[p], w.k);
+                }
+            for (auto& w : walks) {
+                const int k = w.k, b = sbin[k];
+                const float t = thr[k];
+                bool contested = false;
+                for (int p : w.fpx)
+                    if (stamp[p] < k) contested = true;
+                std::vector<int> G;
+                if (!contested) {
+                    G = w.fpx;
+                } else if (!seed_level) {
+                    ++g_epoch;
+                    q.clear();
+                    if (!own[k].empty()) {
+                        for (int p : own[k]) {
+                            g_seen[p] = g_epoch;
+                            q.push_back(p);
+                        }
+                    } else if (stamp[sidx[k]] >= k) {
+                        g_seen[sidx[k]] = g_epoch;
+                        q.push_back(sidx[k]);
+                        G.push_back(sidx[k]);
+                    }
+                    for (size_t head = 0; head < q.size(); ++head) {
+                        const int p = q[head];
+                        const int r = p / W, c = p % W;
+                        for (int dr = -1; dr <= 1; ++dr)
+                            for (int dc = -1; dc <= 1; ++dc) {
+                                if (!dr && !dc) continue;
+                                const int rr = r + dr, cc = c + dc;
+                                if (rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
+                                const int x = rr * W + cc;
+                                if (g_seen[x] == g_epoch) continue;
+                                if (((dm[x] >> b) & 1) && resp(x, b) > t && stamp[x] >= k) {
+                                    g_seen[x] = g_epoch;
+                                    q.push_back(x);
+                                    G.push_back(x);
+                                }
+                            }
+                    }
+                    g_px += (long)G.size();
+                }
+                for (int p : G) {
+                    label[p] = k;
+                    dm[p] = 0;
+                }
+                if (contested) {
+                    next.push_back(k);
+                    own[k].insert(own[k].end(), G.begin(), G.end());
+                } else {
+                    r_done++;
+                    own[k].clear();
+                    own[k].shrink_to_fit();
+                }
+            }
+            r_crit += longest;
+            pos = end;
+        }
+        for (int p : touched) stamp[p] = INF;
+        std::sort(next.begin(), next.end());
+        printf("round %d: active %zu in %d batches, walked %d seeds, %ld px in %ld steps, sum of the batches' longest walks %d; finished %d, dead %d\n", rounds,
+               active.size(), r_batches, r_walk, r_px, r_steps, r_crit, r_done, r_dead);
+        tot_px += r_px;
+        tot_steps += r_steps;
+        crit += r_crit;
+        phases += r_batches;
+        active.swap(next);
+    }
+    long bad = 0;
+    for (size_t i = 0; i < ref.size(); ++i) bad += ref[i] != label[i];
+    printf("batched (first n>>%d, x%d, %s commits): %d rounds, %d batch launches, %ld px walked (%.2fx labelled) + %ld px of G re-walks (%.2fx), %ld steps, critical path %d steps; label mismatches vs sequential: %ld\n",
+           shift0, grow, seed_level ? "seed-level" : "pixel-level", rounds, phases, tot_px, (double)tot_px / labelled, g_px, (double)g_px / labelled, tot_steps, crit, bad);
+    return bad != 0;
+}
+
 // scheme 0: every active seed walks every round (what kernels_flood.hip did in r02)
 // scheme 1: perfect deferral -- seeds that die in the round never walk or stamp (lower bound of the deferral family)
 // scheme 2: opportunistic deferral in dispatch batches of `conc` walks (strongest first), phases until nothing is left
@@ -333,6 +511,7 @@ int main(int argc, char** argv) {
     long labelled = 0;
     for (int v : ref) labelled += v >= 0;
     printf("%dx%d, %d seeds, %ld labelled px\n", W, H, NS, labelled);
+    if (scheme == 9 || scheme == 10) return batched(argc > 3 ? atoi(argv[3]) : 3, argc > 4 ? atoi(argv[4]) : 2, scheme == 10, ref, labelled);
     if (scheme >= 3 && scheme <= 6) {
         // 3: pixel-level, all walk; 4: + perfect deferral; 5: seed-level commits + perfect deferral (= scheme 1); 6: seed-level, all walk
         if (argc > 3) g_win_first_shift = atoi(argv[3]);
@@ -369,7 +548,54 @@ int main(int argc, char** argv) {
                 stamp[p] = std::min(stamp[p], k);
             }
         };
-        if (scheme == 0) {
+        if (scheme == 7 || scheme == 8) {
+            // seed-level commits as scheme 0, but only the seeds below a window walk.  7: static hold-back (argv[3] = pct:
+            // the weakest (100 - pct) % wait until at most 64 seeds below the line are active); 8: dynamic -- after a round
+            // the window closes at the lowest BLOCKED seed whose walk took more than argv[3] steps, while seeds below it
+            // are active
+            static long window = -1;
+            static int phase = 0;
+            const int param = argc > 3 ? atoi(argv[3]) : (scheme == 7 ? 80 : 96);
+            if (window < 0) window = scheme == 7 ? (long)NS * param / 100 : NS;
+            for (int k : active)
+                if (k < window) do_walk(k);
+            rs.longest_sum = rs.longest;
+            int lowest_long_blocked = INF;
+            for (int k : active) {
+                if (k >= window) continue;
+                if (fp[k].px.empty()) {
+                    dead.push_back(k);
+                    continue;
+                }
+                bool blocked = false;
+                for (int p : fp[k].px)
+                    if (stamp[p] < k) {
+                        blocked = true;
+                        break;
+                    }
+                if (!blocked) commit.push_back(k);
+                else if (fp[k].tiles > param && scheme == 8) lowest_long_blocked = std::min(lowest_long_blocked, k);
+            }
+            // next window
+            std::vector<uint8_t> gone2(NS, 0);
+            for (int k : commit) gone2[k] = 1;
+            for (int k : dead) gone2[k] = 1;
+            if (scheme == 7) {
+                long below = 0;
+                for (int k : active)
+                    if (k < window && !gone2[k]) below++;
+                if (phase == 0 && below <= 64) {
+                    window = NS;
+                    phase = 1;
+                }
+            } else {
+                long below = 0;
+                for (int k : active)
+                    if (k < lowest_long_blocked && !gone2[k]) below++;
+                window = (lowest_long_blocked != INF && below > 0) ? lowest_long_blocked : NS;
+                if (commit.empty() && dead.empty()) window = NS;
+            }
+        } else if (scheme == 0) {
             for (int k : active) do_walk(k);
             rs.longest_sum = rs.longest;
             for (int k : active) {
@@ -547,10 +773,11 @@ int main(int argc, char** argv) {
         crit += rs.longest_sum;
         crit_commit += rs.longest_commit;
         tot_phases += rs.phases;
-        if (commit.empty() && next.size() == active.size()) {
+        if (commit.empty() && next.size() == active.size() && scheme != 7 && scheme != 8) {
             printf("STALL\n");
             break;
         }
+        if (rounds > 100) break;
         active.swap(next);
     }
     long bad = 0;
