@@ -95,7 +95,7 @@ FilterGeom filter_geometry(int w, int h);
 size_t seeds_temp_bytes(int n_tiles, size_t max_seeds);
 int launch_seed_select(const uint64_t* cand, const uint32_t* cand_count, const uint32_t* tile_max, int n_tiles,
                        int cand_cap, float seed_keep_ratio, float* maxmag, uint32_t* tile_pass, uint32_t* tile_off, uint64_t* keys,
-                       uint32_t key_cap, uint32_t* n_seeds, uint32_t* ticket, hipStream_t s);
+                       uint32_t key_cap, uint32_t* n_seeds, hipStream_t s);
 int launch_seed_sort(uint64_t* keys_in, uint64_t* keys_out, uint32_t n, void* temp, size_t temp_bytes, hipStream_t s);
 // the seed count stays on the device (*n_seeds, clamped to cap); the launch covers `cap` seeds
 bool seed_order_is_fused(uint32_t cap);

@@ -498,7 +498,7 @@ void ctx_destroy(lr_context* c) {
 namespace {
 
 // d_counts words
-enum { kCntSeeds = 0, kCntComp = 1, kCntPx = 2, kCntLarge = 4, kCntTicket = 12 /* seed_count_scan_kernel's ticket counter: zero between launches */ };
+enum { kCntSeeds = 0, kCntComp = 1, kCntPx = 2, kCntLarge = 4 };
 
 uint32_t round_up(uint32_t v, uint32_t m) { return (v + m - 1) / m * m; }
 
@@ -607,8 +607,7 @@ int enqueue_filter(lr_context* c, const float* d_image, int w, int h, int stride
 int enqueue_seeds(lr_context* c) {
     const FilterGeom fg = filter_geometry(c->w, c->h);
     if (launch_seed_select(c->cand, c->cand_count, c->tile_max, fg.n_tiles, fg.cand_cap, c->seed_keep_ratio, c->maxmag,
-                           c->tile_pass, c->tile_off, c->keys_a, c->seed_cap, c->d_counts + kCntSeeds, c->d_counts + kCntTicket,
-                           c->stream))
+                           c->tile_pass, c->tile_off, c->keys_a, c->seed_cap, c->d_counts + kCntSeeds, c->stream))
         return 1;
     if (seed_order_is_fused(c->seed_cap)) {
         if (launch_seed_order(c->keys_a, c->d_counts + kCntSeeds, c->seed_cap, c->dx, c->dy, c->trig, kTraceTolerance,

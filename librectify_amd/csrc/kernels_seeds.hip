@@ -16,28 +16,34 @@
 namespace lramd {
 namespace {
 
-__device__ __forceinline__ uint32_t ld_agent_u32(const uint32_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Seed threshold, per-band counts and their exclusive scan in ONE launch (it used to be four: a one-workgroup max
-// reduction, the counts, and rocPRIM's scan with its own initialisation kernel -- each some 4.5 us of launch floor in a
-// chain that the flood waits for).
+// Seed threshold and per-band counts in one launch, their exclusive scan in a second (one workgroup); it used to be four
+// (a one-workgroup max reduction, the counts, rocPRIM's scan with its own initialisation kernel), each some 4.5 us of
+// launch floor in a chain that the flood waits for.
 //  - min_seed_value needs the frame's largest magnitude (line_detector.cpp:209): every workgroup reduces ALL the per-band
 //    maxima itself (20 KB from L2 for a 4K frame) instead of waiting for a kernel that does it once;
-//  - one wavefront per band counts the band's candidates above the threshold (filter.cpp:168);
-//  - the workgroup that finishes last (a ticket counter) scans the counts into offsets and writes the seed count.
-__global__ __launch_bounds__(256) void seed_count_scan_kernel(const uint64_t* __restrict__ cand,
-                                                              const uint32_t* __restrict__ cand_count,
-                                                              const uint32_t* __restrict__ tile_max, int n_tiles,
-                                                              int cand_cap, float keep_ratio, float* __restrict__ maxmag,
-                                                              uint32_t* __restrict__ tile_pass, uint32_t* __restrict__ tile_off,
-                                                              uint32_t* __restrict__ n_seeds, uint32_t* __restrict__ ticket) {
+//  - one wavefront per band counts the band's candidates above the threshold (filter.cpp:168).
+// (Folding the scan into the same launch -- the workgroup that finishes last does it -- was built and measured: the
+// agent-scope fence every workgroup needs before it takes its ticket costs more than the launch it saves: 40 us for the
+// fused kernel against 5 + 5.)
+__global__ __launch_bounds__(256) void seed_count_kernel(const uint64_t* __restrict__ cand,
+                                                         const uint32_t* __restrict__ cand_count,
+                                                         const uint32_t* __restrict__ tile_max, int n_tiles, int cand_cap,
+                                                         float keep_ratio, float* __restrict__ maxmag,
+                                                         uint32_t* __restrict__ tile_pass) {
     __shared__ uint32_t s_red[4];
-    __shared__ uint32_t s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t m = 0;  // magnitudes are >= 0, so their bit patterns order like the floats
-    for (int i = threadIdx.x; i < n_tiles; i += 256) m = max(m, tile_max[i]);
+    // (eight loads in flight at a time, not one dependent L2 round trip per band maximum)
+    for (int i0 = threadIdx.x; i0 < n_tiles; i0 += 256 * 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k * 256;
+            v[k] = i < n_tiles ? tile_max[i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m = max(m, v[k]);
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
     if (lane == 0) s_red[wave] = m;
@@ -46,49 +52,29 @@ __global__ __launch_bounds__(256) void seed_count_scan_kernel(const uint64_t* __
     if (blockIdx.x == 0 && threadIdx.x == 0) *maxmag = mx;
     const float thr = mx * keep_ratio;
     const int tile = blockIdx.x * 4 + wave;
-    if (tile < n_tiles) {
-        const uint32_t n = cand_count[tile];
-        const uint64_t* c = cand + (size_t)tile * cand_cap;
-        uint32_t cnt = 0;
-        for (uint32_t i = lane; i < n; i += 64) cnt += (__uint_as_float((uint32_t)(c[i] >> 32)) > thr) ? 1u : 0u;
+    if (tile >= n_tiles) return;
+    const uint32_t n = cand_count[tile];
+    const uint64_t* c = cand + (size_t)tile * cand_cap;
+    uint32_t cnt = 0;
+    for (uint32_t i = lane; i < n; i += 64) cnt += (__uint_as_float((uint32_t)(c[i] >> 32)) > thr) ? 1u : 0u;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, off);
-        if (lane == 0) tile_pass[tile] = cnt;
-    }
-    // The last workgroup to get here scans (every other one has written its counts before taking its ticket).  Tickets in
-    // two levels -- 32 counters for the workgroups with the same index modulo 32, and one for those 32 groups' last
-    // arrivals -- because a thousand returning atomics on ONE address are executed one after the other by the L2 (30 us
-    // for the 1242 workgroups of a 4K frame; some 70 arrivals per address take 2).
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const uint32_t g = blockIdx.x & 31u;
-        const uint32_t in_group = (gridDim.x - g + 31u) / 32u;  // workgroups with this index modulo 32
-        uint32_t last = 0u;
-        if (atomicAdd(&ticket[g], 1u) == in_group - 1u) {
-            ticket[g] = 0u;  // (for the next frame: nobody else touches it any more)
-            __threadfence();
-            const uint32_t groups = min(32u, gridDim.x);
-            if (atomicAdd(&ticket[32], 1u) == groups - 1u) {
-                ticket[32] = 0u;
-                last = 1u;
-            }
-        }
-        s_last = last;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    // Exclusive scan of the counts, 256 at a time, sixteen such slices loaded up front (coalesced, all in flight together:
-    // a thread summing a contiguous run of counts one dependent L2 access after the other made this tail 25 us long).
+    for (int off = 32; off >= 1; off >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, off);
+    if (lane == 0) tile_pass[tile] = cnt;
+}
+
+// Exclusive scan of the band counts by one workgroup, 256 at a time, sixteen such slices loaded up front (coalesced, all
+// in flight together); writes the seed count.
+__global__ __launch_bounds__(256) void seed_scan_kernel(const uint32_t* __restrict__ tile_pass, int n_tiles,
+                                                        uint32_t* __restrict__ tile_off, uint32_t* __restrict__ n_seeds) {
     __shared__ uint32_t s_wave[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t running = 0;
     for (int base = 0; base < n_tiles; base += 256 * 16) {
         uint32_t v[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int i = base + k * 256 + (int)threadIdx.x;
-            v[k] = i < n_tiles ? ld_agent_u32(&tile_pass[i]) : 0u;
+            v[k] = i < n_tiles ? tile_pass[i] : 0u;
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
@@ -302,13 +288,13 @@ size_t seeds_temp_bytes(int n_tiles, size_t max_seeds) {
     return b + 256;
 }
 
-// `ticket`: 33 zero-initialised words of the context (the last arrivals of a launch reset them)
 int launch_seed_select(const uint64_t* cand, const uint32_t* cand_count, const uint32_t* tile_max, int n_tiles,
                        int cand_cap, float seed_keep_ratio, float* maxmag, uint32_t* tile_pass, uint32_t* tile_off, uint64_t* keys,
-                       uint32_t key_cap, uint32_t* n_seeds, uint32_t* ticket, hipStream_t s) {
+                       uint32_t key_cap, uint32_t* n_seeds, hipStream_t s) {
     const int blocks = (n_tiles + 3) / 4;
-    hipLaunchKernelGGL(seed_count_scan_kernel, dim3(blocks), dim3(256), 0, s, cand, cand_count, tile_max, n_tiles, cand_cap,
-                       seed_keep_ratio, maxmag, tile_pass, tile_off, n_seeds, ticket);
+    hipLaunchKernelGGL(seed_count_kernel, dim3(blocks), dim3(256), 0, s, cand, cand_count, tile_max, n_tiles, cand_cap,
+                       seed_keep_ratio, maxmag, tile_pass);
+    hipLaunchKernelGGL(seed_scan_kernel, dim3(1), dim3(256), 0, s, tile_pass, n_tiles, tile_off, n_seeds);
     hipLaunchKernelGGL(seed_write_kernel, dim3(blocks), dim3(256), 0, s, cand, cand_count, n_tiles, cand_cap, maxmag,
                        seed_keep_ratio, tile_pass, tile_off, keys, key_cap);
     if (!seed_order_is_fused(key_cap))
