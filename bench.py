@@ -57,7 +57,8 @@ sys.path.insert(0, ROOT)
 W4K, H4K = 3840, 2160
 ALGO_BYTES_PER_PX = 18.0  # 4 read + 12 (dx,dy,mag) + 1 (bin) + 1 (peak candidate)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_FILE = os.path.join("profiles", "r02_pmc_filter_traffic.txt")
+PMC_FILE = os.path.join("profiles", "r03_pmc_filter_traffic.txt")
+ROCPROF_LEG = os.path.join("profiles", "r03_kernel_stats_roofline_leg.csv")  # rocprofv3 --kernel-trace --stats of `bench.py --roofline-only`
 
 
 def make_frames(n, w, h, seed0, bases=4, out=None):
@@ -83,6 +84,19 @@ def pmc_traffic(w, h):
     for line in open(path):
         if line.startswith("traffic_bytes_per_launch"):
             return float(line.split()[1])
+    return None
+
+
+def rocprof_filter_ms(w, h):
+    """Average duration of the filter kernel in the committed rocprofv3 summary of the roofline leg (4K only)."""
+    path = os.path.join(ROOT, ROCPROF_LEG)
+    if (w, h) != (W4K, H4K) or not os.path.exists(path):
+        return None
+    import csv
+
+    for row in csv.DictReader(open(path)):
+        if "filter_lanes_kernel" in row["Name"]:
+            return float(row["AverageNs"]) * 1e-6
     return None
 
 
@@ -632,6 +646,10 @@ def main(argv=None):
                 "achieved_moved_bytes": round(traffic / (kdur_ms * 1e-3) / 1e9, 2) if traffic else None,
                 "frac_moved_bytes": round(traffic / (kdur_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                 "kernel_ms": round(kdur_ms, 5),
+                "rocprof": (lambda k: None if k is None else {
+                    "source": ROCPROF_LEG, "kernel_ms": round(k, 5),
+                    "frac": round(ALGO_BYTES_PER_PX * rw * rh / (k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "frac_moved_bytes": round(traffic / (k * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None})(rocprof_filter_ms(rw, rh)),
                 "kernel_ms_in_pipeline": round(float(np.mean(filt_ms)), 5) if filt_ms else None,
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_PX * rw * rh,
                 "frame": "%dx%d" % (rw, rh),

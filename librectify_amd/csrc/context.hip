@@ -262,21 +262,34 @@ struct StagingCrew {
         std::atomic<int>* ready = nullptr;    // ... and then ready[k] = 1 (-1 if the band failed)
     } jobs[2];
 
+    // A band is staged by ALL the threads together, piece by piece (kPieces row runs per band, claimed in order through
+    // `next`), and sent by whichever thread finishes its last piece: the first transfer starts after one band's worth of
+    // copying spread over the crew instead of after every thread has copied a whole band of its own (which is when all of
+    // them are ready at once: the link used to idle for the first 0.4 ms of a 4K frame and then find eight bands waiting).
+    static constexpr int kPieces = 8;
+    static constexpr int kMaxBands = 256;
+    std::atomic<int> pieces_left[2][kMaxBands];
+
     void work(uint32_t gen) {
         const Job j = jobs[gen & 1u];
         const size_t row_bytes = (size_t)j.w * sizeof(float);
+        const int rows_per_piece = (j.rows_per_band + kPieces - 1) / kPieces;
         for (;;) {
             uint64_t x = next.load(std::memory_order_acquire);
-            if ((uint32_t)(x >> 32) != gen || (int)(uint32_t)x >= j.n_bands) return;
+            if ((uint32_t)(x >> 32) != gen || (int)(uint32_t)x >= j.n_bands * kPieces) return;
             if (!next.compare_exchange_weak(x, x + 1, std::memory_order_acq_rel)) continue;
-            const int k = (int)(uint32_t)x;
-            const int r0 = k * j.rows_per_band, r1 = std::min(j.h, r0 + j.rows_per_band);
-            if (j.stride == j.w) {
-                std::memcpy(j.stage + (size_t)r0 * j.w, j.src + (size_t)r0 * j.stride, (size_t)(r1 - r0) * row_bytes);
-            } else {
-                for (int r = r0; r < r1; ++r) std::memcpy(j.stage + (size_t)r * j.w, j.src + (size_t)r * j.stride, row_bytes);
+            const int k = (int)(uint32_t)x / kPieces, piece = (int)(uint32_t)x % kPieces;
+            const int b0 = k * j.rows_per_band, b1 = std::min(j.h, b0 + j.rows_per_band);
+            const int r0 = std::min(b1, b0 + piece * rows_per_piece), r1 = std::min(b1, r0 + rows_per_piece);
+            if (r1 > r0) {
+                if (j.stride == j.w) {
+                    std::memcpy(j.stage + (size_t)r0 * j.w, j.src + (size_t)r0 * j.stride, (size_t)(r1 - r0) * row_bytes);
+                } else {
+                    for (int r = r0; r < r1; ++r) std::memcpy(j.stage + (size_t)r * j.w, j.src + (size_t)r * j.stride, row_bytes);
+                }
             }
-            bool ok = hipMemcpyAsync(j.dst + (size_t)r0 * j.w, j.stage + (size_t)r0 * j.w, (size_t)(r1 - r0) * row_bytes,
+            if (pieces_left[gen & 1u][k].fetch_sub(1, std::memory_order_acq_rel) != 1) continue;  // not the band's last piece
+            bool ok = hipMemcpyAsync(j.dst + (size_t)b0 * j.w, j.stage + (size_t)b0 * j.w, (size_t)(b1 - b0) * row_bytes,
                                      hipMemcpyHostToDevice, j.up) == hipSuccess;
             if (ok && j.band_ev) ok = hipEventRecord(j.band_ev[k], j.up) == hipSuccess;
             if (!ok) {
@@ -333,6 +346,11 @@ struct StagingCrew {
         j.ready = ready_;
         j.rows_per_band = (int)std::max<size_t>(1, band_bytes / ((size_t)w_ * sizeof(float)));
         j.n_bands = (h_ + j.rows_per_band - 1) / j.rows_per_band;
+        if (j.n_bands > kMaxBands) {  // (a frame of more than 1 GiB: fewer, larger bands)
+            j.rows_per_band = (h_ + kMaxBands - 1) / kMaxBands;
+            j.n_bands = (h_ + j.rows_per_band - 1) / j.rows_per_band;
+        }
+        for (int k = 0; k < j.n_bands; ++k) pieces_left[g & 1u][k].store(kPieces, std::memory_order_relaxed);
         failed.store(0, std::memory_order_relaxed);  // (per frame: every band of the previous one has been accounted for)
         bands_left.store(j.n_bands, std::memory_order_relaxed);
         next.store((uint64_t)g << 32, std::memory_order_release);
@@ -1632,6 +1650,7 @@ int ctx_find_groups_device(lr_context* c, const float* d_image, int w, int h, in
 // What cannot overlap: everything after the filter needs the frame's largest magnitude, i.e. the whole frame.
 int ctx_find_groups_host(lr_context* c, const float* buffer, int w, int h, int stride, float min_length, bool refine,
                          int num_threads, std::vector<LineSegment>& out) {
+    const double t_call = now_ms();
     LR_HIP(hipSetDevice(c->device));
     if (w < 5 || h < 5 || buffer == nullptr) {
         set_error("image smaller than the 5x5 filter");
@@ -1678,7 +1697,8 @@ int ctx_find_groups_host(lr_context* c, const float* buffer, int w, int h, int s
     // 3.01 ms per call with 4 MB bands, 3.49 with 1 MB, 4.07 with 512 KB (profiles/r03_single_call_sweep.txt).
     static const size_t band_bytes = std::getenv("LIBRECTIFY_UPLOAD_BAND_KB") ? (size_t)std::max(64, std::atoi(std::getenv("LIBRECTIFY_UPLOAD_BAND_KB"))) << 10 : (size_t)4 << 20;
     static const int filter_every = std::getenv("LIBRECTIFY_FILTER_EVERY") ? std::max(1, std::atoi(std::getenv("LIBRECTIFY_FILTER_EVERY"))) : 1;
-    const int rpb = (int)std::max<size_t>(1, band_bytes / row_bytes);
+    int rpb = (int)std::max<size_t>(1, band_bytes / row_bytes);
+    if ((h + rpb - 1) / rpb > StagingCrew::kMaxBands) rpb = (h + StagingCrew::kMaxBands - 1) / StagingCrew::kMaxBands;  // (as StagingCrew::begin)
     const int n_bands = (h + rpb - 1) / rpb;
     while ((int)c->band_ev.size() < n_bands) {
         hipEvent_t e = nullptr;
@@ -1705,7 +1725,7 @@ int ctx_find_groups_host(lr_context* c, const float* buffer, int w, int h, int s
         return 0;
     };
     if (c->timing_on) LR_HIP(hipEventRecord(c->ev[0], c->stream));
-    const int T = stage ? std::min(staging_threads(num_threads), n_bands) : 1;
+    const int T = stage ? staging_threads(num_threads) : 1;  // (the threads share every band: StagingCrew::work)
     if (T <= 1) {
         // the calling thread alone (the reference's serial mode, or a page-locked source that needs no staging)
         for (int k = 0; k < n_bands; ++k) {
@@ -1755,7 +1775,14 @@ int ctx_find_groups_host(lr_context* c, const float* buffer, int w, int h, int s
     }
     if (c->timing_on) LR_HIP(hipEventRecord(c->ev[1], c->stream));
     LR_HIP(hipEventRecord(c->ev_up[slot], up));
-    return run_frame(c, dst, w, h, w, min_length, refine, out, true);
+    static const bool call_debug = std::getenv("LIBRECTIFY_CALL_DEBUG") != nullptr;
+    const double t_up = now_ms();
+    const int rc = run_frame(c, dst, w, h, w, min_length, refine, out, true);
+    if (call_debug)
+        std::fprintf(stderr, "host frame: bands staged, sent and filter launched in %.3f ms; rest of the frame enqueued in %.3f ms; waited %.3f ms; "
+                     "results out in %.3f ms; whole call %.3f ms\n", t_up - t_call, c->host_ms[0], c->host_ms[2],
+                     now_ms() - t_up - c->host_ms[0] - c->host_ms[2], now_ms() - t_call);
+    return rc;
 }
 
 // Batch of independent frames: the stages of one frame are latency-bound (flood rounds,

@@ -62,40 +62,51 @@ __global__ __launch_bounds__(256) void seed_count_kernel(const uint64_t* __restr
     if (lane == 0) tile_pass[tile] = cnt;
 }
 
-// Exclusive scan of the band counts by one workgroup, 256 at a time, sixteen such slices loaded up front (coalesced, all
-// in flight together); writes the seed count.
-__global__ __launch_bounds__(256) void seed_scan_kernel(const uint32_t* __restrict__ tile_pass, int n_tiles,
-                                                        uint32_t* __restrict__ tile_off, uint32_t* __restrict__ n_seeds) {
-    __shared__ uint32_t s_wave[4];
+// Exclusive scan of the band counts by one workgroup of 1024 threads: every thread takes a contiguous run of the counts
+// (loaded eight at a time, all in flight together), the runs' sums are scanned across the workgroup, and every thread
+// writes its run's offsets; also writes the seed count.  Two barriers in all.
+__global__ __launch_bounds__(1024) void seed_scan_kernel(const uint32_t* __restrict__ tile_pass, int n_tiles,
+                                                         uint32_t* __restrict__ tile_off, uint32_t* __restrict__ n_seeds) {
+    __shared__ uint32_t s_wave[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t running = 0;
-    for (int base = 0; base < n_tiles; base += 256 * 16) {
-        uint32_t v[16];
+    const int K = (n_tiles + 1023) / 1024;
+    const int i0 = (int)threadIdx.x * K, i1 = min(n_tiles, i0 + K);
+    uint32_t sum = 0;
+    for (int b0 = i0; b0 < i1; b0 += 8) {
+        uint32_t v[8];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int i = base + k * 256 + (int)threadIdx.x;
-            v[k] = i < n_tiles ? tile_pass[i] : 0u;
-        }
+        for (int k = 0; k < 8; ++k) v[k] = b0 + k < i1 ? tile_pass[b0 + k] : 0u;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            if (base + k * 256 >= n_tiles) break;  // (uniform)
-            uint32_t inc = v[k];  // inclusive scan inside the wavefront
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t o = (uint32_t)__shfl_up((int)inc, off);
-                if (lane >= off) inc += o;
-            }
-            __syncthreads();  // s_wave of the previous slice has been read
-            if (lane == 63) s_wave[wave] = inc;
-            __syncthreads();
-            uint32_t before = running;
-            for (int w2 = 0; w2 < wave; ++w2) before += s_wave[w2];
-            const int i = base + k * 256 + (int)threadIdx.x;
-            if (i < n_tiles) tile_off[i] = before + inc - v[k];
-            running += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-        }
+        for (int k = 0; k < 8; ++k) sum += v[k];
     }
-    if (threadIdx.x == 0) *n_seeds = running;
+    uint32_t inc = sum;  // inclusive scan of the runs' sums inside the wavefront ...
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0, total = 0;  // ... and across the sixteen wavefronts
+#pragma unroll
+    for (int w2 = 0; w2 < 16; ++w2) {
+        const uint32_t t = s_wave[w2];
+        before += w2 < wave ? t : 0u;
+        total += t;
+    }
+    uint32_t run = before + inc - sum;
+    for (int b0 = i0; b0 < i1; b0 += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = b0 + k < i1 ? tile_pass[b0 + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (b0 + k < i1) {
+                tile_off[b0 + k] = run;
+                run += v[k];
+            }
+    }
+    if (threadIdx.x == 0) *n_seeds = total;
 }
 
 __global__ __launch_bounds__(256) void seed_write_kernel(const uint64_t* __restrict__ cand,
@@ -294,7 +305,7 @@ int launch_seed_select(const uint64_t* cand, const uint32_t* cand_count, const u
     const int blocks = (n_tiles + 3) / 4;
     hipLaunchKernelGGL(seed_count_kernel, dim3(blocks), dim3(256), 0, s, cand, cand_count, tile_max, n_tiles, cand_cap,
                        seed_keep_ratio, maxmag, tile_pass);
-    hipLaunchKernelGGL(seed_scan_kernel, dim3(1), dim3(256), 0, s, tile_pass, n_tiles, tile_off, n_seeds);
+    hipLaunchKernelGGL(seed_scan_kernel, dim3(1), dim3(1024), 0, s, tile_pass, n_tiles, tile_off, n_seeds);
     hipLaunchKernelGGL(seed_write_kernel, dim3(blocks), dim3(256), 0, s, cand, cand_count, n_tiles, cand_cap, maxmag,
                        seed_keep_ratio, tile_pass, tile_off, keys, key_cap);
     if (!seed_order_is_fused(key_cap))

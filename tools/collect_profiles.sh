@@ -1,6 +1,6 @@
 #!/bin/bash
 # On the GPU box: the measurements that go into profiles/ for a round.  usage: tools/collect_profiles.sh r02
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out/profiles_$R
 export TMPDIR=/tmp
 mkdir -p $O
@@ -14,4 +14,11 @@ find $O/p3 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/${R}_kernel
 bash tools/pmc_traffic.sh > $O/${R}_pmc_filter_traffic.txt 2>&1
 bash tools/pmc_explore.sh > $O/${R}_pmc_flood_explore.txt 2>&1
 rm -rf gpurun_out/pmc_* gpurun_out/cal_f gpurun_out/flt_* /tmp/pmcx_*
+
+python3 tools/flood_debug.py bench > /dev/null 2> $O/${R}_flood_rounds_bench_frame.txt
+python3 tools/run8k.py > $O/${R}_config5_8k.txt 2>&1
+bash tools/single_frame_trace.sh $O/sft 1 2 3 4 > $O/${R}_single_frame_timeline.txt 2>&1; cp $O/sft/run.txt $O/${R}_single_frame.txt; cp $O/sft/kernel_stats.csv $O/${R}_kernel_stats_single_frames.csv; rm -rf $O/sft
+python3 tools/single_call_sweep.py 8 > $O/${R}_single_call.txt 2>&1
+python3 tools/bench_ransac.py > $O/${R}_ransac_cht_rates.txt 2>&1
+
 ls -la $O
