@@ -36,6 +36,10 @@ typedef struct lr_context lr_context;
  * one context per host thread (the drop-in functions do exactly that). */
 int lr_context_create(int device, lr_context** out);
 void lr_context_destroy(lr_context* ctx);
+/* The drop-in functions keep one context per calling host thread (device workspace of about 130 bytes per pixel of the
+ * largest frame seen, 288 MB of flood overflow slabs, page-locked staging, staging threads) until the thread exits;
+ * a thread that is done with the library for a while can give it back at once.  The next call makes a new one. */
+void lr_release_thread_context(void);
 const char* lr_last_error(void);
 int lr_synchronize(lr_context* ctx);
 /* RANSAC sample stream seed (the reference seeds from std::random_device, estimator.h:35;

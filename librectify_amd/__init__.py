@@ -70,7 +70,7 @@ EXPORTS = [
     "lr_stage_counters", "lr_filter_kernel_ms", "lr_ransac_best", "lr_estimate_line_pencils",
     "lr_find_line_segment_groups_batch_host", "lr_find_line_segment_groups_batch_host_ptrs", "lr_host_alloc", "lr_host_free",
     "lr_set_seed_capacity", "lr_set_flood_blind_rounds", "lr_set_flood_staged", "lr_set_batch_streams", "lr_device_malloc", "lr_device_free", "lr_memcpy_h2d", "lr_cht_vanishing_point", "lr_refine_lines", "lr_set_estimator", "lr_ht_weights", "lr_prosac_solve", "lr_estimate_line_pencils_prosac", "lr_direct_solve", "lr_estimate_line_pencils_direct",
-    "lr_estimate_line_pencils_cht", "lr_set_stage_timing",
+    "lr_estimate_line_pencils_cht", "lr_set_stage_timing", "lr_release_thread_context",
 ]
 
 _lib = None
@@ -144,6 +144,8 @@ def lib():
         L.lr_set_flood_blind_rounds.restype = None
         L.lr_cht_vanishing_point.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Point), C.c_void_p]
         L.lr_refine_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        L.lr_release_thread_context.argtypes = []
+        L.lr_release_thread_context.restype = None
         L.lr_set_stage_timing.argtypes = [C.c_void_p, C.c_int]
         L.lr_set_stage_timing.restype = None
         L.lr_set_estimator.argtypes = [C.c_void_p, C.c_int, C.c_int]
@@ -446,6 +448,11 @@ class Context:
 
 
 # ---- the reference's six functions, by name --------------------------------------------------
+
+def release_thread_context():
+    """frees the calling thread's drop-in context (the next drop-in call makes a new one)"""
+    lib().lr_release_thread_context()
+
 
 def find_line_segment_groups(buffer, min_length, refine=False, num_threads=-1):
     """reference find_line_segment_groups (src/librectify.h:111-116) on a 2-D float32 array.

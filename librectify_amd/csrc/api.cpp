@@ -18,8 +18,13 @@ struct CtxDeleter {
 
 // The reference API is stateless and re-entrant: each host thread lazily gets
 // its own context on the device named by LIBRECTIFY_DEVICE (default 0).
-lr_context* thread_context() {
+std::unique_ptr<lr_context, CtxDeleter>& thread_context_slot() {
     thread_local std::unique_ptr<lr_context, CtxDeleter> ctx;
+    return ctx;
+}
+
+lr_context* thread_context() {
+    std::unique_ptr<lr_context, CtxDeleter>& ctx = thread_context_slot();
     if (!ctx) {
         const char* env = std::getenv("LIBRECTIFY_DEVICE");
         lr_context* c = nullptr;
@@ -108,6 +113,7 @@ void assign_to_group(const LineSegment* lines_array, int n_lines, LineSegment* n
 // ---- extensions -----------------------------------------------------------------------------
 
 int lr_context_create(int device, lr_context** out) { return ctx_create(device, out); }
+void lr_release_thread_context(void) { thread_context_slot().reset(); }
 void lr_context_destroy(lr_context* ctx) { ctx_destroy(ctx); }
 const char* lr_last_error(void) { return get_error().c_str(); }
 int lr_synchronize(lr_context* ctx) {

@@ -672,7 +672,9 @@ int finish_flood(lr_context* c, bool* extra) {
     c->flood_big_hint = c->flood_tiers[0] > 0 || c->flood_tiers[1] > 0;
     c->flood_hold_hint = c->flood_tiers[3] != 0;
     // blind rounds of the next frame: what this one needed plus two, decaying slowly
-    c->flood_rounds_hint = std::max(std::max(c->flood_rounds + 2, 6), c->flood_rounds_hint - 1);
+    static const int blind_extra = std::getenv("LIBRECTIFY_BLIND_EXTRA") ? std::atoi(std::getenv("LIBRECTIFY_BLIND_EXTRA")) : 2;  // (experiment knob)
+    static const int blind_min = std::getenv("LIBRECTIFY_BLIND_MIN") ? std::atoi(std::getenv("LIBRECTIFY_BLIND_MIN")) : 6;
+    c->flood_rounds_hint = std::max(std::max(c->flood_rounds + blind_extra, blind_min), c->flood_rounds_hint - 1);
     return 0;
 }
 

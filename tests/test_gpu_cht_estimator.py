@@ -158,3 +158,21 @@ def test_config_5_8k_frame_segments_through_the_cht_accumulator_parity_unpinned(
     np.testing.assert_array_equal(got_c, ref_c)
     _assert_models_close(got_m, ref_m)
     assert votes > 100 * len(filt)
+
+
+def test_cht_accumulator_is_linear_in_the_lines_at_full_size(L, ctx):
+    """Size-independent property (no oracle run): votes are integers, so the accumulator of a set of lines is the sum of
+    the accumulators of its parts -- on 20 000 segments, over several workgroups and any split.  (All three calls see the
+    same normalisation: the bounding box is pinned by two corner segments present in every part.)"""
+    from librectify_amd import synth
+
+    segs = synth.random_segments(20000, 7)
+    box = O.lines_from_rows(np.array([[0, 0, 1, 1, 1, 0, -1], [999, 999, 1000, 1000, 1, 0, -1]], np.float64))
+    _, acc_box = ctx.cht_vanishing_point(box, 128)
+    _, acc_all = ctx.cht_vanishing_point(np.concatenate([box, segs]), 128)
+    total = np.zeros_like(acc_all)
+    for a, b in [(0, 7000), (7000, 7001), (7001, 20000)]:
+        _, acc = ctx.cht_vanishing_point(np.concatenate([box, segs[a:b]]), 128)
+        total += acc - acc_box
+    np.testing.assert_array_equal(total + acc_box, acc_all)
+    assert acc_all.sum() > 0

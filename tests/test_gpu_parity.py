@@ -282,6 +282,18 @@ def test_seed_order_with_a_capacity_that_cuts_the_last_sort_block(L, ctx):
         c2.close()
 
 
+def test_drop_in_thread_context_can_be_released_and_comes_back(L):
+    """lr_release_thread_context: the calling thread's drop-in context (workspace, slabs, staging threads) is freed at once;
+    the next call through the reference's entry makes a new one and gives the same records."""
+    img = FRAMES["640x480"]
+    ref, _ = O.find_line_segment_groups(img, 6.4, seed=0)
+    for nt in (8, -1):
+        _assert_lines_equal(L.find_line_segment_groups(img, 6.4, num_threads=nt), ref)
+        L.release_thread_context()
+        L.release_thread_context()  # (nothing to release: fine)
+    _assert_lines_equal(L.find_line_segment_groups(img, 6.4), ref)
+
+
 def test_grouping_of_the_reference_golden_lines_on_the_gpu(L, ctx):
     """Pin 4 through the C ABI: the device peeling (kernels_groups.hip) on the reference's own 848 golden lines gives
     the oracle's group ids bit for bit, i.e. the reference's three pencils (tests/test_oracle_pins.py::test_pin4_*)."""
