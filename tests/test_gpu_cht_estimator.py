@@ -167,7 +167,8 @@ def test_cht_accumulator_is_linear_in_the_lines_at_full_size(L, ctx):
     from librectify_amd import synth
 
     segs = synth.random_segments(20000, 7)
-    box = O.lines_from_rows(np.array([[0, 0, 1, 1, 1, 0, -1], [999, 999, 1000, 1000, 1, 0, -1]], np.float64))
+    box = O.lines_from_rows(np.array([[-300, -300, -299, -299, 1, 0, -1], [1299, 1299, 1300, 1300, 1, 0, -1]], np.float64))
+    assert min(segs["x1"].min(), segs["x2"].min(), segs["y1"].min(), segs["y2"].min()) > -299 and max(segs["x1"].max(), segs["x2"].max(), segs["y1"].max(), segs["y2"].max()) < 1299
     _, acc_box = ctx.cht_vanishing_point(box, 128)
     _, acc_all = ctx.cht_vanishing_point(np.concatenate([box, segs]), 128)
     total = np.zeros_like(acc_all)
