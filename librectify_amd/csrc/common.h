@@ -135,6 +135,9 @@ struct FloodBuffers {
     // (100 - pct) % of the seeds wait until all others are resolved (0 = never).  Measured at 4K with pct = 80: a
     // natural image 8.6 -> ~5 ms, the long-edge stress frame 11 -> ~6 ms, frames without such walks untouched.
     int win_hold_pct = 80;
+    // Partial commits (kernels_flood.hip: flood_partial_commit_kernel): blocked seeds commit at once the part of their
+    // footprint that no lower seed can reach.  LIBRECTIFY_FLOOD_PARTIAL=0 switches them off (comparison).
+    bool partial_commits = true;
     bool second_tier = true;  // test hook: without it every walk that outgrows the first tier goes to a slab
     // The second-tier kernel asks for 41 KB of LDS per workgroup: launched every round for nothing it waits behind
     // other frames' walks (44 us per launch with 16 frames in flight).  So a flood starts WITH it only if the

@@ -581,6 +581,8 @@ FloodBuffers flood_buffers_for(lr_context* c) {
         fbuf.n_slabs = 0;      // the weakest seeds are held back, and must still hand over to the ordered tail
         fbuf.big_cap_override = 1;
     }
+    static const bool partial_off = std::getenv("LIBRECTIFY_FLOOD_PARTIAL") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_PARTIAL")) == 0;
+    fbuf.partial_commits = !partial_off;
     if (c->flood_staged) fbuf.win_first_shift = 3;
     fbuf.blind_rounds = c->flood_rounds_hint;
     return fbuf;

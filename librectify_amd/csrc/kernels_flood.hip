@@ -184,6 +184,7 @@ struct FloodArgs {
     uint32_t win_shift;                              // staged start (see kCtrlWindow): growth of the window per round
     uint32_t from_end;                               // explore the active list from its end (see flood_explore_kernel)
     uint32_t big_cap;                                // seeds per round the second tier takes (0: tier switched off)
+    uint32_t g_cap;                                  // partial-commit walks stop after this many tile steps
 };
 // All words but kCtrlGen are set up by flood_init_seeds_kernel every frame; kCtrlGen lives on for the lifetime of
 // the slab memory (hash entries are tagged with it, so a generation must never be reused while old entries are
@@ -241,6 +242,7 @@ struct WalkState {
     uint32_t head, tail, cnt, ntiles;
     bool blocked;
     uint32_t steps;  // frontier records popped (diagnostics)
+    uint32_t fresh;  // partial-commit walk: pixels it turned from stamps into labels
 };
 
 // The walk works on 8x8 pixel tiles, one tile per step, one pixel per lane: the acceptance test of the
@@ -573,6 +575,7 @@ struct TileFetch {
     size_t q;
     float dx, dy, rdx, rdy;
     uint32_t dm, rdm;
+    uint32_t lab, rlab;  // label words of the lane's pixel / ring pixel (own-aware walks and the partial-commit walk only)
     bool known;
     uint64_t inside, rinside;  // lane masks: the lane's pixel of the tile / of the ring lies in the frame
 };
@@ -593,10 +596,12 @@ struct LaneGeom {
     uint32_t off, roff;
 };
 
-template <class Store>
+// kMode 0: exploration (direction mask and gradients; the label words too if the seed already owns pixels, `own`);
+// kMode 1: the partial-commit walk, which looks at nothing but the label words.
+template <int kMode, class Store>
 __device__ __forceinline__ TileFetch fetch_tile(const FloodArgs& A, const Store& S, uint32_t i, int lr, int lc,
                                                 int rx, int ry, bool ring_lane, const Forward& fw,
-                                                const LaneGeom& G) {
+                                                const LaneGeom& G, bool own) {
     TileFetch f;
     if (fw.valid) {
         f.tile = fw.tile;
@@ -617,17 +622,29 @@ __device__ __forceinline__ TileFetch fetch_tile(const FloodArgs& A, const Store&
     // walks share a CU -- and the loads are on their way before the table is looked at.
     // (no label load: the commit pass clears the direction mask of every pixel it commits, so "not claimed by an
     // earlier flood" is part of the mask test)
-    f.dm = ld8(A.dmask, q);
-    f.dx = ldf(A.dx, q);
-    f.dy = ldf(A.dy, q);
+    f.dm = 0u;
+    f.dx = f.dy = 0.f;
+    f.lab = kLabelFree;
+    if constexpr (kMode == 0) {
+        f.dm = ld8(A.dmask, q);
+        f.dx = ldf(A.dx, q);
+        f.dy = ldf(A.dy, q);
+    }
+    if (kMode == 1 || own) f.lab = ld32(A.label, q);  // (wave-uniform condition)
     const int rr = ty * 8 + ry, rc = tx * 8 + rx;
     // (one unsigned comparison per coordinate: a negative one reads as a huge number; lanes 36..63 have no ring pixel)
     f.rinside = __builtin_amdgcn_uicmp((uint32_t)rr, (uint32_t)A.h, 36) & __builtin_amdgcn_uicmp((uint32_t)rc, (uint32_t)A.w, 36) &
                 0xFFFFFFFFFull;
     const uint32_t rq = lane_of(f.rinside) ? base + G.roff : 0u;
-    f.rdm = ld8(A.dmask, rq);
-    f.rdx = ldf(A.dx, rq);
-    f.rdy = ldf(A.dy, rq);
+    f.rdm = 0u;
+    f.rdx = f.rdy = 0.f;
+    f.rlab = kLabelFree;
+    if constexpr (kMode == 0) {
+        f.rdm = ld8(A.dmask, rq);
+        f.rdx = ldf(A.dx, rq);
+        f.rdy = ldf(A.dy, rq);
+    }
+    if (kMode == 1 || own) f.rlab = ld32(A.label, rq);
     if (fw.valid) {
         f.slot = fw.slot;
         f.known = fw.known;
@@ -664,9 +681,13 @@ __device__ unsigned long long g_walk_timing[8];
 #define LR_TICK(i)
 #endif
 
-template <class Store>
+// kMode 0 explores (acceptance = direction mask and response; a seed that already owns pixels -- `own`, see
+// flood_partial_commit_kernel -- also passes through the pixels labelled with its own index).  kMode 1 is the
+// partial-commit walk: it accepts the pixels that carry this seed's stamp or its label, nothing else, and turns the
+// stamps it reaches into labels; `dmask_rw` is the direction mask it clears there.
+template <class Store, int kMode = 0>
 __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, float cs, Store& S, Pending& P,
-                    WalkState& st, int lane) {
+                    WalkState& st, int lane, bool own = false, uint8_t* dmask_rw = nullptr) {
     const uint32_t mine = kMarkBit | k;
     const int lr = lane >> 3, lc = lane & 7;
     int rx, ry;
@@ -685,7 +706,7 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
     G.off = (uint32_t)(lr * A.w + lc);
     G.roff = (uint32_t)(ry * A.w + rx);
     asm volatile("" : "+v"(G.off), "+v"(G.roff));
-    TileFetch cur = fetch_tile(A, S, st.head, lr, lc, rx, ry, ring_lane, fw, G);
+    TileFetch cur = fetch_tile<kMode>(A, S, st.head, lr, lc, rx, ry, ring_lane, fw, G, own);
 #ifdef LR_WALK_TIMING
     uint64_t tacc[5] = {0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
     uint32_t nknown = 0;
@@ -698,8 +719,18 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
 #endif
         const uint32_t tile = cur.tile;
         // acceptable pixels of the tile, and of the 36-pixel ring around it (lane order, see ring_xy)
-        const uint64_t Am = cur.inside & m_ne(cur.dm & bin_bit, 0u) & m_gt_f(directional(cur.dx, cur.dy, sn, cs), thr);
-        const uint64_t Rg = cur.rinside & m_ne(cur.rdm & bin_bit, 0u) & m_gt_f(directional(cur.rdx, cur.rdy, sn, cs), thr);
+        uint64_t Am, Rg;
+        if constexpr (kMode == 0) {
+            Am = cur.inside & m_ne(cur.dm & bin_bit, 0u) & m_gt_f(directional(cur.dx, cur.dy, sn, cs), thr);
+            Rg = cur.rinside & m_ne(cur.rdm & bin_bit, 0u) & m_gt_f(directional(cur.rdx, cur.rdy, sn, cs), thr);
+            if (own) {  // (wave-uniform) pixels this seed has committed already are its own ground
+                Am |= cur.inside & m_eq(cur.lab, k);
+                Rg |= cur.rinside & m_eq(cur.rlab, k);
+            }
+        } else {
+            Am = cur.inside & (m_eq(cur.lab, mine) | m_eq(cur.lab, k));
+            Rg = cur.rinside & (m_eq(cur.rlab, mine) | m_eq(cur.rlab, k));
+        }
         LR_TICK(0)
         uint64_t R = cur.entry & Am;
         uint64_t New = 0ull;
@@ -724,11 +755,21 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
             }
         }
         st.cnt += (uint32_t)__popcll(New);
+        if constexpr (kMode == 1) {
+            // stamps of this seed reached from its seed pixel through its own stamps and labels only: no lower active seed
+            // can reach them (it would have stamped them), so they belong to this seed's flood whatever happens elsewhere
+            const uint64_t fresh = New & m_eq(cur.lab, mine);
+            if (lane_of(fresh)) {
+                A.label[cur.q] = k;
+                dmask_rw[cur.q] = 0;
+            }
+            st.fresh += (uint32_t)__popcll(fresh);
+        }
         LR_TICK(2)
         fw.valid = false;
         const bool was_empty = st.head == st.tail;  // then the first record appended now is the next one popped
         if (New != 0ull) {
-            if constexpr (!Store::kDeferStamps) {
+            if constexpr (!Store::kDeferStamps && kMode == 0) {
                 uint32_t old = kLabelFree;
                 if (lane_of(New)) {
                     old = atomicMin(&A.label[cur.q], mine);
@@ -759,7 +800,8 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
         if (st.head == st.tail) return 0;
         if ((st.tail - st.head) + 8u > S.ring_cap() || st.ntiles + 2u > S.hash_limit()) return 1;
         if (st.steps > kMaxSteps) return 1;  // never reached by a terminating walk; treated like exhausted storage
-        cur = fetch_tile(A, S, st.head, lr, lc, rx, ry, ring_lane, fw, G);
+        if (kMode == 1 && st.steps >= A.g_cap) return 1;  // partial-commit walk: any connected part is as safe as the whole
+        cur = fetch_tile<kMode>(A, S, st.head, lr, lc, rx, ry, ring_lane, fw, G, own);
         LR_TICK(4)
     }
 }
@@ -815,12 +857,15 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
     const uint32_t seed_label = A.label[s];
     const uint32_t seed_mask = A.dmask[s];
     const float seed_dx = A.dx[s], seed_dy = A.dy[s];
-    if (seed_label < kMarkBit) return;  // claimed by an earlier flood: dead (the survivors pass takes it off the list)
-    if (!(((seed_mask >> b) & 1) && directional(seed_dx, seed_dy, sn, cs) > thr)) {
+    // A seed whose pixel carries its OWN index has committed a part of its flood in an earlier round (partial commit,
+    // flood_partial_commit_kernel) and explores on from there: its walk passes through the pixels labelled with its index.
+    const bool own = seed_label == k;
+    if (seed_label < kMarkBit && !own) return;  // claimed by an earlier flood: dead (the survivors pass takes it off the list)
+    if (!own && !(((seed_mask >> b) & 1) && directional(seed_dx, seed_dy, sn, cs) > thr)) {
         if (lane == 0) A.flags[k] = kFlagSelfFail;  // flood() accepts nothing, not even the seed
         return;
     }
-    WalkState st{0u, 1u, 0u, 0u, false, 0u};
+    WalkState st{0u, 1u, 0u, 0u, false, 0u, 0u};
     int rc = 1;
     // a walk that outgrew the first tier in an earlier round does not try it again (footprints only shrink, but
     // rarely below 190 tiles from above 1500 px)
@@ -830,7 +875,7 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
         P.pt[lane] = 0u;
         const int sr = s / A.w, sc = s - sr * A.w;
         L.put(0u, ((uint32_t)(sr >> 3) << 16) | (uint32_t)(sc >> 3), 1ull << ((sr & 7) * 8 + (sc & 7)));
-        rc = walk(A, k, b, thr, sn, cs, L, P, st, lane);
+        rc = walk(A, k, b, thr, sn, cs, L, P, st, lane, own);
     }
     if (kFirstTier && rc != 0 && A.big_cap != 0u) {
         // outgrew the first tier: start again in the second (nothing is stamped yet, so nothing to undo)
@@ -850,7 +895,7 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
             P.pt[lane] = 0u;
             const int sr = s / A.w, sc = s - sr * A.w;
             L.put(0u, ((uint32_t)(sr >> 3) << 16) | (uint32_t)(sc >> 3), 1ull << ((sr & 7) * 8 + (sc & 7)));
-            rc = walk(A, k, b, thr, sn, cs, L, P, st, lane);
+            rc = walk(A, k, b, thr, sn, cs, L, P, st, lane, own);
         }
         // second tier full this round: carry on in a slab from the state reached
     }
@@ -882,7 +927,7 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
                     G.update(slot, key - 1u, ((uint64_t)L.hv1[i] << 32) | L.hv0[i]);
                 }
             }
-            rc = walk(A, k, b, thr, sn, cs, G, P, st, lane);
+            rc = walk(A, k, b, thr, sn, cs, G, P, st, lane, own);
         }
         if (rc != 0 && lane == 0) {
             A.flags[k] = kFlagIncomplete;
@@ -996,6 +1041,43 @@ __global__ __launch_bounds__(64) void flood_explore_big_kernel(FloodArgs A, BinT
     LdsStoreBig L{ring, ring + kRingBig, ring + 2 * kRingBig, hash, hash + kHashBig, hash + 2 * kHashBig, ord};
     Pending P{pend, pend + kPend};
     explore_seed<LdsStoreBig, false>(A, trig, k, L, P, big_list, lane);
+}
+
+// Partial commits (round 3).  A seed that is blocked -- a lower active seed reaches some pixel of its footprint -- still
+// owns, for certain, the part of the footprint that is connected to its seed pixel through pixels that carry ITS stamp
+// (the lowest stamp wins a pixel, so no lower active seed reaches those) or its label from an earlier round: nothing a
+// lower seed does can take them away, and the ordered flood (filter.cpp:110-153) gives them to this seed.  After the
+// round's explorations one wavefront per blocked seed walks that part (the same tile walk, acceptance = "my stamp or my
+// label"), turns its stamps into labels and clears their direction mask, so that
+//   - seeds whose pixel lies in it are dead now, not after the round in which this seed finally comes out unblocked,
+//   - the seed's later explorations start from what it owns and meet fewer foreign stamps.
+// Only for seeds below the round's barrier (all lower seeds have stamped completely) whose exploration finished.  A
+// walk that outgrows the first storage tier simply stops: any connected part is as safe as the whole.
+__global__ __launch_bounds__(64) void flood_partial_commit_kernel(FloodArgs A, const uint32_t* __restrict__ act,
+                                                                  uint8_t* __restrict__ dmask_rw) {
+    __shared__ uint32_t s_ring[3][kRingT];
+    __shared__ uint32_t s_hash[3][kHashT];
+    __shared__ uint32_t s_pend[2][kPend];
+    __shared__ uint8_t s_ord[kHashT];
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_act = uni(A.ctrl[kCtrlNAct]), window = uni(A.ctrl[kCtrlWindow]), barrier = uni(A.ctrl[kCtrlBarrier]);
+    LdsStore L{s_ring[0], s_ring[1], s_ring[2], s_hash[0], s_hash[1], s_hash[2], s_ord};
+    Pending P{s_pend[0], s_pend[1]};
+    for (uint32_t ai = uni(blockIdx.x); ai < n_act; ai += gridDim.x) {
+        const uint32_t k = uni(act[ai]);
+        if (k >= window || k >= barrier) continue;
+        const uint32_t fl = uni(A.flags[k]);
+        if (uni(A.count[k]) == 0u || uni(A.blocked[k]) == 0u || (fl & (kFlagIncomplete | kFlagSelfFail))) continue;
+        const int s = (int)uni((uint32_t)A.seed_idx[k]);
+        const uint32_t seed_label = uni(A.label[s]);
+        if (seed_label != (kMarkBit | k) && seed_label != k) continue;  // its own pixel is contested (or taken)
+        for (int i = lane; i < LdsStore::kHashN; i += 64) L.hk[i] = 0u;
+        P.pt[lane] = 0u;
+        const int sr = s / A.w, sc = s - sr * A.w;
+        L.put(0u, ((uint32_t)(sr >> 3) << 16) | (uint32_t)(sc >> 3), 1ull << ((sr & 7) * 8 + (sc & 7)));
+        WalkState st{0u, 1u, 0u, 0u, false, 0u, 0u};
+        (void)walk<LdsStore, 1>(A, k, 0, 0.f, 0.f, 0.f, L, P, st, lane, false, dmask_rw);
+    }
 }
 
 // Does seed k commit in this round?  Its walk finished (count > 0, not incomplete), no lower active seed reaches its
@@ -1126,7 +1208,8 @@ __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, const
                 seed_size[k] = (int32_t)A.count[k];
                 done = true;
             } else if (state[k] == 0) {
-                if (A.label[A.seed_idx[k]] < kMarkBit) {  // its pixel now belongs to a committed flood: skipped forever
+                const uint32_t own_label = A.label[A.seed_idx[k]];
+                if (own_label < kMarkBit && own_label != k) {  // its pixel now belongs to another seed's flood: skipped forever
                     state[k] = 2;
                     seed_size[k] = 0;
                 } else {
@@ -1234,7 +1317,11 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
 }
 
 // Ordered tail: the reference's loop over an (ascending) list of remaining seeds, starting from
-// the labels committed so far.  Same walk as flood_ordered_kernel.
+// the labels committed so far.  Same walk as flood_ordered_kernel.  A seed that has committed a part of its flood in the
+// rounds (its pixel carries its own index) goes on from there: the walk passes through its own pixels, which it tags on
+// the way (bit 30 of the label: seed indices stay below 2^29) so that each is visited once, and removes the tags at the
+// end; the size it reports covers the whole flood.
+constexpr uint32_t kTailTag = 0x40000000u;
 __global__ __launch_bounds__(64) void flood_ordered_tail_kernel(const float* __restrict__ dx, const float* __restrict__ dy,
                                                                 const uint8_t* __restrict__ dmask, int w,
                                                                 const int32_t* __restrict__ seed_idx,
@@ -1252,13 +1339,16 @@ __global__ __launch_bounds__(64) void flood_ordered_tail_kernel(const float* __r
         const uint32_t k = act[ai];
         const int sidx = seed_idx[k];
         int size = 0;
-        if (ld_agent(&label[sidx]) == kLabelFree) {
+        const uint32_t seed_label = ld_agent(&label[sidx]);
+        const bool own = seed_label == k;
+        if (seed_label == kLabelFree || own) {
             const int b = seed_bin[k];
             const float thr = seed_thr[k];
             const float s = trig.st[b], c = trig.ct[b];
-            if (((dmask[sidx] >> b) & 1) && (directional(dx[sidx], dy[sidx], s, c) > thr)) {
+            if (own || (((dmask[sidx] >> b) & 1) && (directional(dx[sidx], dy[sidx], s, c) > thr))) {
+                const uint32_t tagged = k | kTailTag;
                 if (lane == 0) {
-                    atomicExch(&label[sidx], k);
+                    atomicExch(&label[sidx], tagged);
                     __hip_atomic_store(&queue[0], sidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 int head = 0, tail = 1;
@@ -1270,8 +1360,12 @@ __global__ __launch_bounds__(64) void flood_ordered_tail_kernel(const float* __r
                     if (si < nsrc) {
                         const int p = __hip_atomic_load(&queue[head + si], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         q = p + noff;
-                        if (((dmask[q] >> b) & 1) && directional(dx[q], dy[q], s, c) > thr)
-                            claim = atomicCAS(&label[q], kLabelFree, k) == kLabelFree;
+                        const uint32_t lq = ld_agent(&label[q]);
+                        if (lq == k) {  // a pixel it committed in the rounds, not yet visited
+                            claim = atomicCAS(&label[q], k, tagged) == k;
+                        } else if (lq == kLabelFree && ((dmask[q] >> b) & 1) && directional(dx[q], dy[q], s, c) > thr) {
+                            claim = atomicCAS(&label[q], kLabelFree, tagged) == kLabelFree;
+                        }
                     }
                     const uint64_t m = __ballot(claim);
                     if (claim)
@@ -1281,6 +1375,12 @@ __global__ __launch_bounds__(64) void flood_ordered_tail_kernel(const float* __r
                     head += nsrc;
                 }
                 size = tail;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                for (int i = lane; i < tail; i += 64) {
+                    const int p = __hip_atomic_load(&queue[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&label[p], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             }
         }
         if (lane == 0) seed_size[k] = size;
@@ -1431,6 +1531,8 @@ FloodArgs flood_args(const FloodBuffers& B, const FloodFrame& F, bool use_big) {
     A.win_shift = 2u;
     const uint32_t big_cap = B.big_cap_override ? B.big_cap_override : kBigCap;
     A.big_cap = use_big ? big_cap : 0u;
+    static const int g_cap_env = std::getenv("LIBRECTIFY_FLOOD_PARTIAL_STEPS") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_PARTIAL_STEPS")) : 16;
+    A.g_cap = g_cap_env > 0 ? (uint32_t)g_cap_env : kMaxSteps;
     return A;
 }
 
@@ -1472,6 +1574,10 @@ void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& 
         (void)hipEventDestroy(dbg0);
         (void)hipEventDestroy(dbg1);
     }
+    static const int g_rounds_env = std::getenv("LIBRECTIFY_FLOOD_PARTIAL_ROUNDS") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_PARTIAL_ROUNDS")) : 1000;
+    if (B.partial_commits && index < g_rounds_env)
+        hipLaunchKernelGGL(flood_partial_commit_kernel, dim3(grid), dim3(64), 0, s, A, act,
+                           const_cast<uint8_t*>(F.dmask));
     hipLaunchKernelGGL(flood_commit_pixels_kernel, dim3(pix_blocks), dim3(256), 0, s, A, F.label, npix,
                        const_cast<uint8_t*>(F.dmask));
     hipLaunchKernelGGL(flood_survivors_kernel, dim3(seed_blocks), dim3(256), 0, s, A, act, B.state, F.seed_size, act_next);
