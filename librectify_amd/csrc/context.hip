@@ -258,14 +258,16 @@ struct StagingCrew {
         const float* src = nullptr;
         int w = 0, h = 0, stride = 0, rows_per_band = 1, n_bands = 0;
         hipStream_t up = nullptr;
+        int pieces = 1;                       // row runs a band is copied in (by different threads)
         hipEvent_t* band_ev = nullptr;        // optional: recorded after each band's transfer is enqueued ...
         std::atomic<int>* ready = nullptr;    // ... and then ready[k] = 1 (-1 if the band failed)
     } jobs[2];
 
-    // A band is staged by ALL the threads together, piece by piece (kPieces row runs per band, claimed in order through
-    // `next`), and sent by whichever thread finishes its last piece: the first transfer starts after one band's worth of
-    // copying spread over the crew instead of after every thread has copied a whole band of its own (which is when all of
-    // them are ready at once: the link used to idle for the first 0.4 ms of a 4K frame and then find eight bands waiting).
+    // A single frame's bands are staged by ALL the threads together, piece by piece (`pieces` row runs per band, claimed in
+    // order through `next`), and sent by whichever thread finishes a band's last piece: the first transfer starts after one
+    // band's worth of copying spread over the crew instead of after every thread has copied a whole band of its own (which
+    // is when all of them are ready at once).  A batch's uploader keeps whole bands per thread (pieces = 1): there the
+    // link is busy with the previous frame anyway, and fewer hand-overs are worth more than an early start.
     static constexpr int kPieces = 8;
     static constexpr int kMaxBands = 256;
     std::atomic<int> pieces_left[2][kMaxBands];
@@ -273,12 +275,13 @@ struct StagingCrew {
     void work(uint32_t gen) {
         const Job j = jobs[gen & 1u];
         const size_t row_bytes = (size_t)j.w * sizeof(float);
-        const int rows_per_piece = (j.rows_per_band + kPieces - 1) / kPieces;
+        const int kP = j.pieces;
+        const int rows_per_piece = (j.rows_per_band + kP - 1) / kP;
         for (;;) {
             uint64_t x = next.load(std::memory_order_acquire);
-            if ((uint32_t)(x >> 32) != gen || (int)(uint32_t)x >= j.n_bands * kPieces) return;
+            if ((uint32_t)(x >> 32) != gen || (int)(uint32_t)x >= j.n_bands * kP) return;
             if (!next.compare_exchange_weak(x, x + 1, std::memory_order_acq_rel)) continue;
-            const int k = (int)(uint32_t)x / kPieces, piece = (int)(uint32_t)x % kPieces;
+            const int k = (int)(uint32_t)x / kP, piece = (int)(uint32_t)x % kP;
             const int b0 = k * j.rows_per_band, b1 = std::min(j.h, b0 + j.rows_per_band);
             const int r0 = std::min(b1, b0 + piece * rows_per_piece), r1 = std::min(b1, r0 + rows_per_piece);
             if (r1 > r0) {
@@ -350,7 +353,8 @@ struct StagingCrew {
             j.rows_per_band = (h_ + kMaxBands - 1) / kMaxBands;
             j.n_bands = (h_ + j.rows_per_band - 1) / j.rows_per_band;
         }
-        for (int k = 0; k < j.n_bands; ++k) pieces_left[g & 1u][k].store(kPieces, std::memory_order_relaxed);
+        j.pieces = band_ev_ ? kPieces : 1;  // (band events = the single-frame path)
+        for (int k = 0; k < j.n_bands; ++k) pieces_left[g & 1u][k].store(j.pieces, std::memory_order_relaxed);
         failed.store(0, std::memory_order_relaxed);  // (per frame: every band of the previous one has been accounted for)
         bands_left.store(j.n_bands, std::memory_order_relaxed);
         next.store((uint64_t)g << 32, std::memory_order_release);
