@@ -22,7 +22,7 @@ constexpr uint32_t kNoComp = 0xFFFFFFFFu;
 // Rank and pixel offset of every kept flood, in seed order: a two-level scan.  Workgroup b owns seeds
 // [b * kOffChunk, (b + 1) * kOffChunk), eight consecutive seeds per thread.  First kernel: per-chunk totals.
 // Second kernel: every workgroup adds up the totals of the chunks before it and scans its own chunk.
-constexpr uint32_t kSortLds = 4096;  // longest pixel list sorted in LDS
+constexpr uint32_t kSortLds = 1024;  // longest pixel list sorted by a 256-thread workgroup (4 KB of LDS); longer ones take 1024 threads
 constexpr int kOffPer = 8;
 constexpr uint32_t kOffChunk = 256 * kOffPer;
 
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void component_offsets_kernel(const int32_t* _
                 comp_seed[rank] = k;
                 comp_off[rank] = off_px;
                 // lists of more than 64 pixels are sorted by a workgroup each (component_sort_large_kernel): in LDS up to
-                // 4096 pixels (list filled from the front), through global memory beyond (filled from the back)
+                // 1024 pixels (list filled from the front), through global memory beyond (filled from the back)
                 if (sz[j] > (int)kSortLds) large_list[large_cap - 1u - atomicAdd(n_large + 1, 1u)] = rank;
                 else if (sz[j] > 64) large_list[atomicAdd(n_large, 1u)] = rank;
                 rank += 1u;
@@ -233,8 +233,10 @@ __global__ __launch_bounds__(256) void component_sort_small_kernel(const uint32_
 }
 
 // Longer lists: one workgroup each, bitonic network on the list padded to a power of two.  Three classes, told apart
-// when the offsets are computed (component_offsets_kernel): up to 4096 pixels in 16 KB of LDS by 256 threads (many
-// workgroups; entries at the front of large_list); up to 16384 pixels in 64 KB of LDS by 1024 threads; beyond that in
+// when the offsets are computed (component_offsets_kernel): up to 1024 pixels in 4 KB of LDS by 256 threads (many
+// workgroups; entries at the front of large_list); up to 16384 pixels in 64 KB of LDS by 1024 threads (a 4096-pixel list
+// took the 256-thread kernel 40 us -- every pass of the network eight trips through its loop -- and was what a 4K frame's
+// sort stage waited for); beyond that in
 // place in global memory by a single workgroup (a flood of more than 16384 pixels: rare, and slow here -- every pass
 // is a round trip to L2).  The last two share the entries at the back of large_list.
 template <int kThreads, class Keys>
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(1024) void component_sort_big_kernel(const uint32_t
         const uint32_t off = comp_off[comp];
         const uint32_t n = comp_off[comp + 1] - off;
         if ((n > kSortLdsBig) != kGlobal) continue;  // the other launch's
-        uint32_t P = 8192;
+        uint32_t P = 2048;
         while (P < n) P <<= 1;
         if (!kGlobal) {
             for (uint32_t i = threadIdx.x; i < P; i += 1024) s_key[i] = i < n ? px_in[off + i] : 0xFFFFFFFFu;
@@ -430,8 +432,8 @@ int launch_component_sort(const uint32_t* px_in, uint32_t* px_out, const uint32_
     if (comp_cap == 0) return 0;
     hipLaunchKernelGGL(component_sort_small_kernel, dim3((comp_cap + 3) / 4), dim3(256), 0, s, px_in, px_out, comp_off,
                        d_n_comp);
-    hipLaunchKernelGGL(component_sort_large_kernel, dim3(1024), dim3(256), 0, s, px_in, px_out, comp_off, large_list, n_large);
-    hipLaunchKernelGGL(component_sort_big_kernel<false>, dim3(32), dim3(1024), 0, s, px_in, px_out, comp_off, large_list,
+    hipLaunchKernelGGL(component_sort_large_kernel, dim3(4096), dim3(256), 0, s, px_in, px_out, comp_off, large_list, n_large);
+    hipLaunchKernelGGL(component_sort_big_kernel<false>, dim3(128), dim3(1024), 0, s, px_in, px_out, comp_off, large_list,
                        large_cap, n_large, scratch);
     hipLaunchKernelGGL(component_sort_big_kernel<true>, dim3(1), dim3(1024), 0, s, px_in, px_out, comp_off, large_list,
                        large_cap, n_large, scratch);
