@@ -115,6 +115,9 @@ void lr_set_seed_capacity(lr_context* ctx, uint32_t cap);
  * round (same result; it was the batch lanes' setting in round 1). */
 void lr_set_flood_staged(lr_context* ctx, int on);
 void lr_set_flood_blind_rounds(lr_context* ctx, int rounds);
+/* Comparison hook: the flood's partial commits (a blocked seed commits at once the part of its footprint that no lower
+ * seed can reach; on by default, LIBRECTIFY_FLOOD_PARTIAL=0 also switches them off).  Same labels either way. */
+void lr_set_flood_partial_commits(lr_context* ctx, int on);
 
 /* ---- stage API (tests, bench) --------------------------------------------------------- */
 /* Stage 1: fused 5x5 derivative filter + magnitude + direction bin + dilated-bin mask +

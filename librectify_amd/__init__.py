@@ -70,7 +70,7 @@ EXPORTS = [
     "lr_stage_counters", "lr_filter_kernel_ms", "lr_ransac_best", "lr_estimate_line_pencils",
     "lr_find_line_segment_groups_batch_host", "lr_find_line_segment_groups_batch_host_ptrs", "lr_host_alloc", "lr_host_free",
     "lr_set_seed_capacity", "lr_set_flood_blind_rounds", "lr_set_flood_staged", "lr_set_batch_streams", "lr_device_malloc", "lr_device_free", "lr_memcpy_h2d", "lr_cht_vanishing_point", "lr_refine_lines", "lr_set_estimator", "lr_ht_weights", "lr_prosac_solve", "lr_estimate_line_pencils_prosac", "lr_direct_solve", "lr_estimate_line_pencils_direct",
-    "lr_estimate_line_pencils_cht", "lr_set_stage_timing", "lr_release_thread_context",
+    "lr_estimate_line_pencils_cht", "lr_set_stage_timing", "lr_release_thread_context", "lr_set_flood_partial_commits",
 ]
 
 _lib = None
@@ -144,6 +144,8 @@ def lib():
         L.lr_set_flood_blind_rounds.restype = None
         L.lr_cht_vanishing_point.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Point), C.c_void_p]
         L.lr_refine_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        L.lr_set_flood_partial_commits.argtypes = [C.c_void_p, C.c_int]
+        L.lr_set_flood_partial_commits.restype = None
         L.lr_release_thread_context.argtypes = []
         L.lr_release_thread_context.restype = None
         L.lr_set_stage_timing.argtypes = [C.c_void_p, C.c_int]
@@ -390,6 +392,9 @@ class Context:
         n = C.c_int(0)
         _check(lib().lr_refine_lines(self._h, _ptr(lines), len(lines), _ptr(out), C.byref(n)))
         return out[: n.value].copy()
+
+    def set_flood_partial_commits(self, on=True):
+        lib().lr_set_flood_partial_commits(self._h, int(bool(on)))
 
     def set_stage_timing(self, on=True):
         """stage timers of the frame calls (off by default: each event record idles the GPU for a few microseconds)"""

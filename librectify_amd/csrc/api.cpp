@@ -214,6 +214,7 @@ void lr_set_batch_streams(lr_context* ctx, int n) { ctx->batch_streams = n < 1 ?
 void lr_set_seed_capacity(lr_context* ctx, uint32_t cap) { ctx->seed_cap_once = cap; }
 void lr_set_flood_staged(lr_context* ctx, int on) { ctx->flood_staged = on != 0; }
 void lr_set_flood_blind_rounds(lr_context* ctx, int rounds) { ctx->flood_rounds_hint = rounds; }
+void lr_set_flood_partial_commits(lr_context* ctx, int on) { ctx->flood_partial = on != 0; }
 
 int lr_stage_filter(lr_context* ctx, const float* d_image, int width, int height, int stride) {
     return ctx_stage_filter(ctx, d_image, width, height, stride);

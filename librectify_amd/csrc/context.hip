@@ -586,7 +586,7 @@ FloodBuffers flood_buffers_for(lr_context* c) {
         fbuf.big_cap_override = 1;
     }
     static const bool partial_off = std::getenv("LIBRECTIFY_FLOOD_PARTIAL") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_PARTIAL")) == 0;
-    fbuf.partial_commits = !partial_off;
+    fbuf.partial_commits = !partial_off && c->flood_partial;
     if (c->flood_staged) fbuf.win_first_shift = 3;
     fbuf.blind_rounds = c->flood_rounds_hint;
     return fbuf;
@@ -1853,7 +1853,8 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
         l->ransac_seed = c->ransac_seed;
         l->ransac_iters = c->ransac_iters;
         l->flood_mode = c->flood_mode;
-        l->flood_staged = c->flood_staged;  // (off unless lr_set_flood_staged: +6 % in round 1, -3 % now)
+        l->flood_staged = c->flood_staged;
+        l->flood_partial = c->flood_partial;  // (off unless lr_set_flood_staged: +6 % in round 1, -3 % now)
         l->estimator = c->estimator;
         l->prosac_T_N = c->prosac_T_N;
         l->cht_d = c->cht_d;

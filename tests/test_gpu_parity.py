@@ -282,6 +282,37 @@ def test_seed_order_with_a_capacity_that_cuts_the_last_sort_block(L, ctx):
         c2.close()
 
 
+def test_partial_commits_change_the_work_not_the_labels(L, ctx):
+    """The flood's partial commits (a blocked seed commits at once the part of its footprint connected to its seed pixel
+    through its own stamps: no lower seed can reach it) against the same flood without them: identical label images and
+    records (both equal the oracle's), fewer pixels walked, no more rounds.  Also through the exhausted-storage hooks,
+    where seeds that own pixels reach the ordered tail."""
+    from librectify_amd import synth
+
+    img = synth.frame(1280, 960, 31)
+    ref = O.find_line_segment_groups(img, 12.8, seed=0)[0]
+    ref_label = O.find_line_segments(img)["label"]
+    ctx.set_seed(0)
+    stats = {}
+    try:
+        for on in (False, True):
+            ctx.set_flood_partial_commits(on)
+            for mode in (1, 2, 3, 5):
+                ctx.set_flood_mode(mode)
+                ctx.stage_filter_host(img)
+                ctx.stage_seeds()
+                ctx.stage_flood()
+                np.testing.assert_array_equal(ctx.download(L.BUF_LABEL), ref_label)
+                _assert_lines_equal(ctx.find_line_segment_groups(img, 12.8), ref)
+                if mode == 1:
+                    stats[on] = ctx.stage_counters()
+    finally:
+        ctx.set_flood_partial_commits(True)
+        ctx.set_flood_mode(1)
+    assert stats[True]["walked_px"] < stats[False]["walked_px"]
+    assert stats[True]["flood_rounds"] <= stats[False]["flood_rounds"]
+
+
 def test_drop_in_thread_context_can_be_released_and_comes_back(L):
     """lr_release_thread_context: the calling thread's drop-in context (workspace, slabs, staging threads) is freed at once;
     the next call through the reference's entry makes a new one and gives the same records."""
