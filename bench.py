@@ -228,29 +228,39 @@ def cpu_list(text):
     return out
 
 
-def rank_cpus(local_rank, world, pci_bus_id=None, available=None):
-    """Host cores for this rank's lanes and staging threads: the cores of its GPU's NUMA node (sysfs), split evenly
-    among the ranks whose GPUs share the node; without that information, the rank's contiguous share of the cores this
-    process may run on.  Returns (cores, how)."""
+def numa_node_of(pci_bus_id):
+    """NUMA node of a PCI device (sysfs), -1 if unknown."""
+    try:
+        return int(open("/sys/bus/pci/devices/%s/numa_node" % pci_bus_id.lower()).read())
+    except (OSError, ValueError, AttributeError):
+        return -1
+
+
+def rank_cpus(local_rank, world, pci_bus_ids=None, available=None, nodes=None):
+    """Host cores for this rank's lanes and staging threads: the cores of its GPU's NUMA node (sysfs), split evenly among
+    the ranks whose GPUs sit on the same node (by their order among those GPUs, whatever the numbering of the devices);
+    without that information, the rank's contiguous share of the cores this process may run on.
+    pci_bus_ids: the bus id of every rank's device, by local rank (nodes: their NUMA nodes, for tests).  Returns
+    (cores, how)."""
     avail = sorted(available if available is not None else os.sched_getaffinity(0))
     if world <= 1 or not avail:
         return avail, "all"
     share = max(1, len(avail) // world)
     fallback = avail[local_rank * share : (local_rank + 1) * share] or avail
-    if pci_bus_id:
+    if nodes is None and pci_bus_ids:
+        nodes = [numa_node_of(b) for b in pci_bus_ids]
+    if nodes and len(nodes) > local_rank and nodes[local_rank] >= 0:
+        node = nodes[local_rank]
         try:
-            node = int(open("/sys/bus/pci/devices/%s/numa_node" % pci_bus_id.lower()).read())
-            if node >= 0:
-                cpus = [c for c in cpu_list(open("/sys/devices/system/node/node%d/cpulist" % node).read()) if c in set(avail)]
-                n_nodes = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()])
-                per_node = max(1, world // max(1, n_nodes))  # ranks that share this node
-                k = local_rank % per_node
-                sh = max(1, len(cpus) // per_node)
-                mine = cpus[k * sh : (k + 1) * sh]
-                if mine:
-                    return mine, "numa node %d" % node
+            cpus = [c for c in cpu_list(open("/sys/devices/system/node/node%d/cpulist" % node).read()) if c in set(avail)]
         except (OSError, ValueError):
-            pass
+            cpus = []
+        peers = [r for r in range(min(world, len(nodes))) if nodes[r] == node]
+        k = peers.index(local_rank)
+        sh = max(1, len(cpus) // len(peers))
+        mine = cpus[k * sh : (k + 1) * sh]
+        if mine:
+            return mine, "numa node %d (%d rank(s) on it)" % (node, len(peers))
     return fallback, "contiguous share"
 
 
@@ -413,12 +423,15 @@ def main(argv=None):
     n_gpus = world if world > 1 else 1
     # host side of a rank: its lanes, its uploader and its staging threads stay on the cores of its GPU's NUMA node, and
     # no rank asks for more staging threads than its share of the cores (threads inherit the affinity set here)
-    try:
-        bus = torch.cuda.get_device_properties(local_rank).pci_bus_id
-        bus_id = "%04x:%02x:%02x.0" % (torch.cuda.get_device_properties(local_rank).pci_domain_id, bus, torch.cuda.get_device_properties(local_rank).pci_device_id)
-    except Exception:
-        bus_id = None
-    cpus, cpus_how = rank_cpus(local_rank, world, bus_id)
+    bus_ids = []
+    single = os.environ.get("LR_BENCH_SINGLE_DEVICE") == "1"
+    for r in range(world):
+        try:
+            pr = torch.cuda.get_device_properties(0 if single else r)
+            bus_ids.append("%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id))
+        except Exception:
+            bus_ids.append(None)
+    cpus, cpus_how = rank_cpus(int(os.environ.get("LOCAL_RANK", "0")), world, bus_ids)
     if world > 1 and cpus:
         try:
             os.sched_setaffinity(0, cpus)

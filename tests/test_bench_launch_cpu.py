@@ -49,3 +49,29 @@ def test_rank_cpus_splits_the_cores_evenly():
     assert sorted(seen) == avail
     assert bench.rank_cpus(0, 1, None, avail)[0] == avail
     assert bench.cpu_list("0-3,8,10-11") == [0, 1, 2, 3, 8, 10, 11]
+
+
+def test_rank_cpus_follows_the_numa_node_of_each_gpu():
+    """Ranks whose GPUs sit on the same NUMA node split that node's cores by their order among those GPUs, whatever the
+    device numbering (here: interleaved).  Uses this machine's node 0 if sysfs has one."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    if not os.path.exists("/sys/devices/system/node/node0/cpulist"):
+        import pytest
+
+        pytest.skip("no NUMA information in sysfs")
+    node0 = bench.cpu_list(open("/sys/devices/system/node/node0/cpulist").read())
+    avail = sorted(os.sched_getaffinity(0))
+    usable = [c for c in node0 if c in set(avail)]
+    if len(usable) < 4:
+        import pytest
+
+        pytest.skip("too few cores on node 0")
+    nodes = [0, 7, 0, 7, 0, 7, 0, 7]  # GPUs 0, 2, 4, 6 on node 0; the others on a node this machine may not have
+    seen = []
+    for r in (0, 2, 4, 6):
+        cpus, how = bench.rank_cpus(r, 8, None, avail, nodes=nodes)
+        assert how.startswith("numa node 0") and len(cpus) == len(usable) // 4
+        seen += cpus
+    assert len(set(seen)) == len(seen) and set(seen) <= set(usable)
