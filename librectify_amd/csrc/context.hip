@@ -650,9 +650,9 @@ int enqueue_seeds(lr_context* c) {
 // the flood's rounds, blindly (parallel modes) or the single-wave ordered kernel (mode 0)
 int enqueue_flood(lr_context* c) {
     const size_t npix = (size_t)c->w * c->h;
-    if (launch_label_init(c->label, npix, c->stream)) return 1;
     c->flood_rounds = 1;
     if (c->flood_mode == 0) {
+        if (launch_label_init(c->label, npix, c->stream)) return 1;  // (the parallel rounds' set-up kernel does it itself)
         if (launch_flood_ordered(c->dx, c->dy, c->dmask, c->w, c->h, c->seed_idx, c->seed_bin, c->seed_thr,
                                  c->d_counts + kCntSeeds, c->seed_cap, c->trig, c->label, c->seed_size, c->queue, c->stream))
             return 1;

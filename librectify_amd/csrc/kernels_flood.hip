@@ -1274,7 +1274,10 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
                                                                uint32_t* __restrict__ count, uint32_t* __restrict__ flags,
                                                                int32_t* __restrict__ seed_size, uint32_t* __restrict__ ctrl,
                                                                uint8_t* __restrict__ dirty, uint32_t n_runs,
-                                                               int win_first_shift, int hold_pct, uint32_t hold_from_start) {
+                                                               int win_first_shift, int hold_pct, uint32_t hold_from_start,
+                                                               uint32_t* __restrict__ label, size_t npix) {
+    // (the label image is set to "free" here as well: one launch less in front of the first round)
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) label[i] = kLabelFree;
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     const uint32_t n_seeds = min(*n_ptr, cap);
     if (k == 0u) {
@@ -1591,7 +1594,7 @@ void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& 
 int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, uint32_t* h_ctrl, hipStream_t s) {
     P->enqueued = 0;
     P->use_big = B.second_tier && B.second_tier_from_start;
-    if (F.seed_cap == 0) return 0;
+    if (F.seed_cap == 0) return launch_label_init(F.label, (size_t)F.w * F.h, s);
     // staged start (FloodBuffers::win_*); LIBRECTIFY_FLOOD_WINDOW="<first shift>,<growth shift>" overrides
     static const char* win_env = std::getenv("LIBRECTIFY_FLOOD_WINDOW");
     int win_first_shift = B.win_first_shift, win_growth = B.win_growth;
@@ -1620,10 +1623,14 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
             done_mask.fetch_or(bit, std::memory_order_release);
         }
     }
-    hipLaunchKernelGGL(flood_init_seeds_kernel, dim3((F.seed_cap + 255) / 256), dim3(256), 0, s, F.d_n_seeds, F.seed_cap,
-                       B.act_a, B.state, B.tier, B.blocked, B.count, B.flags, F.seed_size, B.ctrl, B.dirty,
-                       (uint32_t)(((size_t)F.w * F.h + 255) >> 8), win_first_shift, hold_pct,
-                       hold_start ? 1u : 0u);
+    {
+        const size_t npix = (size_t)F.w * F.h;
+        const uint32_t seed_blocks = (F.seed_cap + 255) / 256;
+        const uint32_t blocks = std::max<uint32_t>(seed_blocks, (uint32_t)std::min<size_t>((npix + 255) / 256, 4096));
+        hipLaunchKernelGGL(flood_init_seeds_kernel, dim3(blocks), dim3(256), 0, s, F.d_n_seeds, F.seed_cap, B.act_a, B.state,
+                           B.tier, B.blocked, B.count, B.flags, F.seed_size, B.ctrl, B.dirty,
+                           (uint32_t)((npix + 255) >> 8), win_first_shift, hold_pct, hold_start ? 1u : 0u, F.label, npix);
+    }
     FloodArgs A = flood_args(B, F, P->use_big);
     A.win_shift = (uint32_t)win_growth;
     // rounds enqueued blindly: two more than the context's previous frame needed (a round past the end costs five
