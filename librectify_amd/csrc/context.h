@@ -118,16 +118,18 @@ struct lr_context {
     float* d_peak = nullptr;      // 3 floats
     float* d_weights = nullptr;   // cap_lines
     float* h_weights = nullptr;
-    uint32_t* d_samples = nullptr;  // 2 x cap_chunk
+    uint32_t* d_samples = nullptr;  // 2 buffers x 2 x cap_chunk
     uint32_t* h_samples = nullptr;
-    uint32_t* d_hcounts = nullptr;  // cap_chunk
+    uint32_t* d_hcounts = nullptr;  // 2 x cap_chunk
     uint32_t* h_hcounts = nullptr;
     size_t cap_chunk = 0, cap_wlines = 0;
     uint32_t* d_rec = nullptr;       // PROSAC: new-best iterations of a chunk ([0] = how many) ...
     uint32_t* h_rec = nullptr;
     uint8_t* d_recflags = nullptr;   // ... and a row of inlier flags for each
     uint8_t* h_recflags = nullptr;
-    size_t cap_recflags = 0;
+    size_t cap_recflags = 0;         // (per chunk buffer; there are two of each)
+    hipEvent_t prosac_ev[2] = {nullptr, nullptr};  // end of a chunk's work on the stream
+    std::vector<int> prosac_imin;    // prosac.h's Imin(2, n) by n (constants of prosac.h:62-66 only)
     std::vector<lr_context*> workers;  // extra contexts (own stream + workspace) for frames in flight in batch calls
     int batch_streams = 4;
     int estimator = 0;            // 0 = RANSAC (reference default), 1 = PROSAC, 2 = DirectEstimator, 3 = diamond space (CHT)

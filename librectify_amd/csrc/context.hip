@@ -501,6 +501,8 @@ void ctx_destroy(lr_context* c) {
     if (c->h_hcounts) (void)hipHostFree(c->h_hcounts);
     if (c->h_recflags) (void)hipHostFree(c->h_recflags);
     if (c->h_rec) (void)hipHostFree(c->h_rec);
+    for (auto& e : c->prosac_ev)
+        if (e) (void)hipEventDestroy(e);
     if (c->h_cht_idx) (void)hipHostFree(c->h_cht_idx);
     if (c->h_cht_peak) (void)hipHostFree(c->h_cht_peak);
     for (auto& e : c->ev)
@@ -937,7 +939,7 @@ int upload_model(lr_context* c, const PencilModel& model, const std::vector<int>
     return 0;
 }
 
-constexpr uint32_t kProsacRecCap = 16;  // new-best iterations of a chunk whose inlier flags come back with its counts
+constexpr uint32_t kProsacRecCap = 32;  // new-best iterations of a chunk whose inlier flags come back with its counts
 
 int ensure_prosac_buffers(lr_context* c, size_t n_lines, size_t n_pairs, size_t chunk) {
     if (n_pairs > c->cap_pairs) {
@@ -956,25 +958,32 @@ int ensure_prosac_buffers(lr_context* c, size_t n_lines, size_t n_pairs, size_t 
         LR_HIP(hipHostMalloc((void**)&c->h_weights, cl * sizeof(float)));
         c->cap_wlines = cl;
     }
+    // (two of everything a chunk of hypotheses uses: the next chunk is on the GPU while the host goes through the last one)
     if (n_lines * kProsacRecCap > c->cap_recflags) {
         LR_HIP(hipStreamSynchronize(c->stream));
         const size_t bytes = std::max<size_t>(n_lines, 4096) * kProsacRecCap;
-        if (dev_alloc(c->d_recflags, bytes) || dev_alloc(c->d_rec, kProsacRecCap + 1)) return 1;
+        if (dev_alloc(c->d_recflags, 2 * bytes) || dev_alloc(c->d_rec, 2 * (kProsacRecCap + 1))) return 1;
         if (c->h_recflags) (void)hipHostFree(c->h_recflags);
         if (c->h_rec) (void)hipHostFree(c->h_rec);
-        LR_HIP(hipHostMalloc((void**)&c->h_recflags, bytes));
-        LR_HIP(hipHostMalloc((void**)&c->h_rec, (kProsacRecCap + 1) * sizeof(uint32_t)));
+        c->h_recflags = nullptr;
+        c->h_rec = nullptr;
+        LR_HIP(hipHostMalloc((void**)&c->h_recflags, 2 * bytes));
+        LR_HIP(hipHostMalloc((void**)&c->h_rec, 2 * (kProsacRecCap + 1) * sizeof(uint32_t)));
         c->cap_recflags = bytes;
     }
     if (chunk > c->cap_chunk) {
         LR_HIP(hipStreamSynchronize(c->stream));
-        if (dev_alloc(c->d_samples, 2 * chunk) || dev_alloc(c->d_hcounts, chunk)) return 1;
+        if (dev_alloc(c->d_samples, 4 * chunk) || dev_alloc(c->d_hcounts, 2 * chunk)) return 1;
         if (c->h_samples) (void)hipHostFree(c->h_samples);
         if (c->h_hcounts) (void)hipHostFree(c->h_hcounts);
-        LR_HIP(hipHostMalloc((void**)&c->h_samples, 2 * chunk * sizeof(uint32_t)));
-        LR_HIP(hipHostMalloc((void**)&c->h_hcounts, chunk * sizeof(uint32_t)));
+        c->h_samples = nullptr;
+        c->h_hcounts = nullptr;
+        LR_HIP(hipHostMalloc((void**)&c->h_samples, 4 * chunk * sizeof(uint32_t)));
+        LR_HIP(hipHostMalloc((void**)&c->h_hcounts, 2 * chunk * sizeof(uint32_t)));
         c->cap_chunk = chunk;
     }
+    for (auto& e : c->prosac_ev)
+        if (!e) LR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return 0;
 }
 
@@ -1089,8 +1098,8 @@ int ctx_ht_weights(lr_context* c, const PencilModel& model, const std::vector<in
 int ctx_prosac_solve(lr_context* c, const PencilModel& model, const std::vector<int>& indices, float tol, int T_N_in,
                      uint64_t seed, uint32_t round, Vec3* h_out, ProsacTrace* trace) {
     static const bool pdebug = std::getenv("LIBRECTIFY_PROSAC_DEBUG") != nullptr;
-    double t_w = now_ms(), t_events = 0, t_gen = 0, t_gpu = 0;
-    int n_events = 0, n_chunks = 0;
+    double t_w = now_ms(), t_events = 0, t_gen = 0, t_gpu = 0, t_flags = 0, t_len = 0;
+    int n_events = 0, n_chunks = 0, n_single = 0;
     std::vector<float> weights;
     if (ctx_ht_weights(c, model, indices, weights)) return 1;
     const double t_w1 = now_ms();
@@ -1119,6 +1128,7 @@ int ctx_prosac_solve(lr_context* c, const PencilModel& model, const std::vector<
     for (int i = 0; i < m; i++) g.T_n *= (double)(g.n - i) / (N - i);
     Vec3 p_best{0, 0, 0};
     std::vector<uint8_t> best_inl(N, 0), isInlier(N);
+    std::vector<int> pre;
     PencilSoA soa;
     if (N >= 2 && upload_model(c, model, idx, &soa)) return 1;
     // sample of iteration s.t from the growth state (prosac.h:170-190)
@@ -1130,69 +1140,120 @@ int ctx_prosac_solve(lr_context* c, const PencilModel& model, const std::vector<
             sb = (uint32_t)(s.n - 1);  // prosac.h:186 writes n (one past U_n); n-1 is meant
         }
     };
-    size_t chunk = 1024;
-    while (N >= 2 && ((I_N_best < I_N_min) || g.t <= k_n_star) && g.t < T_N) {
-        // speculative chunk under "no new best": growth and loop condition then depend on nothing else
-        if (ensure_prosac_buffers(c, (size_t)N, 1, chunk)) return 1;
-        const double tg0 = now_ms();
-        ++n_chunks;
-        Growth s = g;
+    // Chunks of upcoming iterations, two in flight: while the host goes through the counts of one, the GPU works on the
+    // next, which was generated as if the first held no new best.  Nothing of a chunk is used without the check below
+    // (iteration by iteration: does the true state still draw this sample?), so a chunk generated under a wrong guess
+    // costs GPU time and never a result.
+    constexpr size_t kChunkMax = 1u << 16;
+    struct Chunk {
         size_t cnt = 0;
-        while (cnt < chunk && ((I_N_best < I_N_min) || s.t <= k_n_star) && s.t < T_N) {
+        int buf = 0;
+        Growth start{0, 0, 0, 0.0}, end{0, 0, 0, 0.0};  // growth state before its first / behind its last sample
+        int n_star = 0;                                  // ... and the n_star it was drawn with
+        bool live = false;
+    };
+    if (N >= 2 && ensure_prosac_buffers(c, (size_t)N, 1, kChunkMax)) return 1;
+    const size_t rf_bytes = c->cap_recflags;
+    auto running = [&](const Growth& s) { return ((I_N_best < I_N_min) || s.t <= k_n_star) && s.t < T_N; };
+    size_t chunk = 2048;
+    auto start_chunk = [&](const Growth& from, int buf, Chunk& ch) -> int {
+        const double tg0 = now_ms();
+        uint32_t* hs = c->h_samples + (size_t)buf * 2 * kChunkMax;
+        uint32_t* ds = c->d_samples + (size_t)buf * 2 * kChunkMax;
+        Growth s = from;
+        // the second sample of the pairs follows the first ones directly: the length is not known before the loop ends,
+        // so they are written at the far end first (cheap: one pass over 4 bytes per iteration)
+        size_t cnt = 0;
+        while (cnt < chunk && running(s)) {
             s.advance(n_star, m);
             uint32_t sa, sb;
             sample_of(s, sa, sb);
-            c->h_samples[cnt] = sa;
-            c->h_samples[chunk + cnt] = sb;
+            hs[cnt] = sa;
+            hs[kChunkMax + cnt] = sb;
             ++cnt;
         }
+        ch.cnt = cnt;
+        ch.buf = buf;
+        ch.start = from;
+        ch.end = s;
+        ch.n_star = n_star;
+        ch.live = cnt > 0;
+        t_gen += now_ms() - tg0;
+        if (!ch.live) return 0;
+        ++n_chunks;
+        if (cnt < kChunkMax) std::memmove(hs + cnt, hs + kChunkMax, cnt * sizeof(uint32_t));
+        uint32_t* dcnt = c->d_hcounts + (size_t)buf * kChunkMax;
+        uint32_t* drec = c->d_rec + (size_t)buf * (kProsacRecCap + 1);
+        uint8_t* dflags = c->d_recflags + (size_t)buf * rf_bytes;
+        LR_HIP(hipMemcpyAsync(ds, hs, 2 * cnt * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        if (launch_prosac_count(soa, (uint32_t)N, tol, model.degeneracy_tol, ds, ds + cnt, (uint32_t)cnt, dcnt, c->stream)) return 1;
+        LR_HIP(hipMemcpyAsync(c->h_hcounts + (size_t)buf * kChunkMax, dcnt, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        // the chunk's new-best iterations (they follow from the counts and the best count known when it is enqueued: a
+        // best found in the chunk before it can only strike some of them off) and the inlier flags of each come back
+        // with the counts: one wait per chunk, not one per new best
+        if (launch_prosac_records(soa, (uint32_t)N, ds, ds + cnt, dcnt, (uint32_t)cnt, (uint32_t)std::max(I_N_best, 0), tol, drec,
+                                  kProsacRecCap, dflags, c->stream))
+            return 1;
+        LR_HIP(hipMemcpyAsync(c->h_rec + (size_t)buf * (kProsacRecCap + 1), drec, (kProsacRecCap + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        LR_HIP(hipMemcpyAsync(c->h_recflags + (size_t)buf * rf_bytes, dflags, (size_t)N * kProsacRecCap, hipMemcpyDeviceToHost, c->stream));
+        LR_HIP(hipEventRecord(c->prosac_ev[buf], c->stream));
+        chunk = std::min<size_t>(chunk * 4, kChunkMax);
+        return 0;
+    };
+    Chunk cur, nxt;
+    while (N >= 2 && running(g)) {
+        if (!cur.live) {
+            if (start_chunk(g, 0, cur)) return 1;
+            if (!cur.live) break;
+        }
+        if (!nxt.live && start_chunk(cur.end, cur.buf ^ 1, nxt)) return 1;
         const double tg1 = now_ms();
-        t_gen += tg1 - tg0;
-        LR_HIP(hipMemcpyAsync(c->d_samples, c->h_samples, cnt * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-        LR_HIP(hipMemcpyAsync(c->d_samples + chunk, c->h_samples + chunk, cnt * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-        if (launch_prosac_count(soa, (uint32_t)N, tol, model.degeneracy_tol, c->d_samples, c->d_samples + chunk,
-                                (uint32_t)cnt, c->d_hcounts, c->stream))
-            return 1;
-        LR_HIP(hipMemcpyAsync(c->h_hcounts, c->d_hcounts, cnt * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        // the chunk's new-best iterations (they follow from the counts and the best count so far) and the inlier flags of
-        // each come back with the counts: one wait per chunk, not one per new best
-        if (launch_prosac_records(soa, (uint32_t)N, c->d_samples, c->d_samples + chunk, c->d_hcounts, (uint32_t)cnt,
-                                  (uint32_t)std::max(I_N_best, 0), tol, c->d_rec, kProsacRecCap, c->d_recflags, c->stream))
-            return 1;
-        LR_HIP(hipMemcpyAsync(c->h_rec, c->d_rec, (kProsacRecCap + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-        LR_HIP(hipMemcpyAsync(c->h_recflags, c->d_recflags, (size_t)N * kProsacRecCap, hipMemcpyDeviceToHost, c->stream));
-        LR_HIP(hipStreamSynchronize(c->stream));
-        const uint32_t n_rec = std::min<uint32_t>(c->h_rec[0], kProsacRecCap);
-        uint32_t rec_pos = 0;
+        LR_HIP(hipEventSynchronize(c->prosac_ev[cur.buf]));
         const double tg2 = now_ms();
         t_gpu += tg2 - tg1;
-        // The chunk was generated under the state at its start.  A new best hypothesis changes n_star and k_n_star;
-        // what follows it in the chunk is still the sequential algorithm's as long as the loop would go on and would
-        // draw the same sample: checked iteration by iteration, and the chunk is cut where that stops being true.
-        for (size_t j = 0; j < cnt; ++j) {
-            if (!(((I_N_best < I_N_min) || g.t <= k_n_star) && g.t < T_N)) break;
+        const uint32_t* hs = c->h_samples + (size_t)cur.buf * 2 * kChunkMax;
+        const uint32_t* hsb = hs + cur.cnt;
+        const uint32_t* hcnt = c->h_hcounts + (size_t)cur.buf * kChunkMax;
+        const uint32_t* hrec = c->h_rec + (size_t)cur.buf * (kProsacRecCap + 1);
+        const uint8_t* hflags = c->h_recflags + (size_t)cur.buf * rf_bytes;
+        const uint32_t n_rec = std::min<uint32_t>(hrec[0], kProsacRecCap);
+        uint32_t rec_pos = 0;
+        // The chunk was generated under the state at its start (or an earlier one).  A new best hypothesis changes n_star
+        // and k_n_star; what follows it in the chunk is still the sequential algorithm's as long as the loop would go on
+        // and would draw the same sample: checked iteration by iteration, and the chunk is cut where that stops being true.
+        // (Drawn from this very state with this n_star, the samples ARE the sequence: nothing to compare until a new best
+        // changes n_star.)
+        bool same = cur.n_star == n_star && cur.start.t == g.t && cur.start.n == g.n && cur.start.T_n_prime == g.T_n_prime &&
+                    cur.start.T_n == g.T_n;
+        size_t j = 0;
+        for (; j < cur.cnt; ++j) {
+            if (!running(g)) break;
             Growth gn = g;
             gn.advance(n_star, m);
-            uint32_t ea, eb;
-            sample_of(gn, ea, eb);
-            if (ea != c->h_samples[j] || eb != c->h_samples[chunk + j]) break;
+            if (!same) {
+                uint32_t ea, eb;
+                sample_of(gn, ea, eb);
+                if (ea != hs[j] || eb != hsb[j]) break;
+            }
             g = gn;
-            const uint32_t I = c->h_hcounts[j];
+            const uint32_t I = hcnt[j];
             if (I == 0xFFFFFFFFu) continue;  // degenerate sample
             if ((int)I > I_N_best) {
-                const int ia = idx[c->h_samples[j]], ib = idx[c->h_samples[chunk + j]];
+                const int ia = idx[hs[j]], ib = idx[hsb[j]];
                 const Vec3 p_t = model.fit(ia, ib);
                 int I_N = 0;
-                while (rec_pos < n_rec && c->h_rec[1 + rec_pos] < (uint32_t)j) ++rec_pos;
-                if (rec_pos < n_rec && c->h_rec[1 + rec_pos] == (uint32_t)j) {  // its flags came with the chunk
-                    std::memcpy(isInlier.data(), c->h_recflags + (size_t)rec_pos * N, (size_t)N);
+                const double te0 = pdebug ? now_ms() : 0.;
+                while (rec_pos < n_rec && hrec[1 + rec_pos] < (uint32_t)j) ++rec_pos;
+                if (rec_pos < n_rec && hrec[1 + rec_pos] == (uint32_t)j) {  // its flags came with the chunk
+                    std::memcpy(isInlier.data(), hflags + (size_t)rec_pos * N, (size_t)N);
                     for (int i = 0; i < N; ++i) I_N += isInlier[i];
-                } else if (N >= 4096) {  // (more new bests in the chunk than flag rows: one by one, as before)
+                } else if (N >= 4096) {  // (more new bests in the chunk than flag rows: one by one)
                     if (launch_prosac_flags(soa, (uint32_t)N, p_t.x, p_t.y, p_t.z, tol, reinterpret_cast<uint8_t*>(c->d_weights), c->stream))  // (the weights buffer is free by now)
                         return 1;
                     LR_HIP(hipMemcpyAsync(isInlier.data(), c->d_weights, (size_t)N, hipMemcpyDeviceToHost, c->stream));
                     LR_HIP(hipStreamSynchronize(c->stream));
                     for (int i = 0; i < N; ++i) I_N += isInlier[i];
+                    ++n_single;
                 } else {
                     for (int i = 0; i < N; ++i) {
                         isInlier[i] = model.error(p_t, idx[i]) < tol;
@@ -1203,20 +1264,65 @@ int ctx_prosac_solve(lr_context* c, const PencilModel& model, const std::vector<
                 p_best = p_t;
                 best_inl = isInlier;
                 best_iter = g.t;
+                const double te1 = pdebug ? now_ms() : 0.;
+                t_flags += te1 - te0;
                 int n_best = N, I_n_best = I_N;
                 double epsilon_n_best = (double)I_n_best / n_best;
-                int n_test, I_n_test;
-                for (n_test = N, I_n_test = I_N; n_test > m; n_test--) {
-                    if ((I_n_test * n_best > I_n_best * n_test) &&
-                        (I_n_test > epsilon_n_best * n_test + std::sqrt(n_test * epsilon_n_best * (1. - epsilon_n_best) * 2.706))) {
-                        if (I_n_test < Imin(m, n_test)) break;
-                        n_best = n_test;
-                        I_n_best = I_n_test;
-                        epsilon_n_best = (double)I_n_best / n_best;
+                // prosac.h:236-262, the search for the best termination length, as written -- but lengths that could pass
+                // its two conditions (more inliers per line among the first n_test than among the first n_best, and
+                // more than chance explains) are looked for 64 at a time on the prefix counts (a loop without exits,
+                // which the compiler vectorises): few lengths do, and the scalar loop took a square root for most of
+                // the N of them, for every new best
+                // (Imin depends on the length alone, not on the lines: two roots per length once per context, not per new best)
+                std::vector<int>& imin_tab = c->prosac_imin;
+                for (int n = (int)imin_tab.size(); n <= N; ++n) imin_tab.push_back(n > m ? Imin(m, n) : 0);
+                pre.resize((size_t)N + 1);
+                pre[0] = 0;
+                for (int i = 0; i < N; ++i) pre[(size_t)i + 1] = pre[(size_t)i] + isInlier[i];
+                int n_test = N;
+                bool stop = false;
+                while (n_test > m && !stop) {
+                    const int lo = std::max(m + 1, n_test - 63);
+                    // (the second condition without its root, in single precision with room for every rounding -- the sum
+                    // I - eps n is off by less than 4e-7 n + 0.02 for any line count the interface allows: lengths whose
+                    // upper bound of (I - eps n)^2 is clearly below the variance term cannot pass; the expression as
+                    // written decides in the scalar loop.  Four lengths per SSE instruction.)
+                    const float e_b = (float)epsilon_n_best;
+                    const float q_b = (float)(epsilon_n_best * (1. - epsilon_n_best) * 2.706 * (1. - 1e-3));
+                    int any = 0;
+                    for (int n = lo; n <= n_test; ++n) {
+                        const float dn = (float)n, dd = ((float)pre[(size_t)n] - e_b * dn) + (4e-7f * dn + 0.02f);
+                        any |= (dd > 0.f) & (dd * dd >= dn * q_b);
                     }
-                    I_n_test -= isInlier[n_test - 1];
+                    if (!any) {
+                        n_test = lo - 1;
+                        continue;
+                    }
+                    for (; n_test >= lo; n_test--) {
+                        const int I_n_test = pre[(size_t)n_test];
+                        if (!(I_n_test * n_best > I_n_best * n_test)) continue;
+                        // I > eps n + sqrt(v): decided on (I - eps n)^2 against v where that is clear of every rounding,
+                        // by the expression as written otherwise (the root is what this loop's time went into)
+                        const double en = epsilon_n_best * n_test, v = n_test * epsilon_n_best * (1. - epsilon_n_best) * 2.706;
+                        const double dd = (double)I_n_test - en;
+                        bool second;
+                        if (!(dd > 0.) || dd * dd < v * (1. - 1e-9)) second = false;
+                        else if (dd * dd > v * (1. + 1e-9)) second = true;
+                        else second = I_n_test > en + std::sqrt(v);
+                        if (second) {
+                            if (I_n_test < imin_tab[(size_t)n_test]) {
+                                stop = true;
+                                break;
+                            }
+                            n_best = n_test;
+                            I_n_best = I_n_test;
+                            epsilon_n_best = (double)I_n_best / n_best;
+                        }
+                    }
                 }
+                if (pdebug) t_len += now_ms() - te1;
                 if (I_n_best * n_star > I_n_star * n_best) {
+                    same = same && n_best == n_star;
                     n_star = n_best;
                     I_n_star = I_n_best;
                     k_n_star = niter_ransac(1. - eta, 1. - I_n_star / (double)n_star, m, T_N);
@@ -1225,11 +1331,19 @@ int ctx_prosac_solve(lr_context* c, const PencilModel& model, const std::vector<
             }
         }
         t_events += now_ms() - tg2;
-        chunk = std::min<size_t>(chunk * 4, 1u << 16);
+        if (j == cur.cnt && nxt.live) {
+            cur = nxt;  // its first iteration is the one after this chunk's last: still in step
+            nxt.live = false;
+        } else {
+            // cut (or over): what is in flight continues a sequence that was not drawn; its buffers are free once it is done
+            if (nxt.live) LR_HIP(hipEventSynchronize(c->prosac_ev[nxt.buf]));
+            cur.live = nxt.live = false;
+        }
     }
+    if (cur.live || nxt.live) LR_HIP(hipStreamSynchronize(c->stream));
     if (pdebug)
-        std::fprintf(stderr, "prosac round %u: N %d, weights %.2f ms, sort %.2f, chunks %d (generate %.2f, gpu+sync %.2f, scan+events %.2f; %d events), total %.2f ms\n",
-                     round, N, t_w1 - t_w, t_s1 - t_w1, n_chunks, t_gen, t_gpu, t_events, n_events, now_ms() - t_w);
+        std::fprintf(stderr, "prosac round %u: N %d, weights %.2f ms, sort %.2f, chunks %d (generate %.2f, gpu+sync %.2f, scan+events %.2f of which flags %.2f, lengths %.2f; %d events, %d with a wait of their own), total %.2f ms\n",
+                     round, N, t_w1 - t_w, t_s1 - t_w1, n_chunks, t_gen, t_gpu, t_events, t_flags, t_len, n_events, n_single, now_ms() - t_w);
     if (trace) {
         trace->iterations = g.t;
         trace->n_star = n_star;
@@ -1394,9 +1508,7 @@ int ctx_estimate_line_pencils_cht(lr_context* c, std::vector<LineSegment>& lines
         LR_HIP(hipStreamSynchronize(c->stream));
         const size_t cl = std::max<size_t>((size_t)N, 4096);
         if (dev_alloc(c->d_cht_idx, cl)) return 1;
-        if (c->h_recflags) (void)hipHostFree(c->h_recflags);
-    if (c->h_rec) (void)hipHostFree(c->h_rec);
-    if (c->h_cht_idx) (void)hipHostFree(c->h_cht_idx);
+        if (c->h_cht_idx) (void)hipHostFree(c->h_cht_idx);
         c->h_cht_idx = nullptr;
         LR_HIP(hipHostMalloc((void**)&c->h_cht_idx, cl * sizeof(uint32_t)));
         c->cap_cht_idx = cl;

@@ -177,3 +177,22 @@ def test_cht_accumulator_is_linear_in_the_lines_at_full_size(L, ctx):
         total += acc - acc_box
     np.testing.assert_array_equal(total + acc_box, acc_all)
     assert acc_all.sum() > 0
+
+
+def test_estimators_take_turns_on_one_context(L):
+    """PROSAC, then the diamond-space estimator on more lines than the context has seen (its index buffers grow), then
+    PROSAC again on the same context, which is then destroyed: each estimator's page-locked buffers are its own (round 3:
+    growing the accumulator's index buffer released two of PROSAC's by mistake).  Every result against the oracle."""
+    from librectify_amd import synth
+
+    c = L.Context(0)
+    small, large = synth.random_segments(1500, 5), synth.random_segments(9000, 6)
+    want = O.estimate_line_pencils_prosac(small, T_N=3000, seed=9)
+    np.testing.assert_array_equal(c.estimate_line_pencils_prosac(small, T_N=3000, seed=9)["group_id"], want["group_id"])
+    got, _, cells, _ = c.estimate_line_pencils_cht(large, d=64)
+    ref = O.estimate_line_pencils_cht(large, d=64)
+    np.testing.assert_array_equal(got["group_id"], ref[0]["group_id"])
+    np.testing.assert_array_equal(c.estimate_line_pencils_prosac(small, T_N=3000, seed=9)["group_id"], want["group_id"])
+    want2 = O.estimate_line_pencils_prosac(large, T_N=5000, seed=3)
+    np.testing.assert_array_equal(c.estimate_line_pencils_prosac(large, T_N=5000, seed=3)["group_id"], want2["group_id"])
+    c.close()

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <unordered_set>
 #include <vector>
 
@@ -41,7 +42,9 @@ static inline float resp(int q, int b) { return std::fabs(fmaf(dx[q], st[b], dy[
 struct Walk {
     std::vector<int> px;
     int tiles = 0;
+    int par[4] = {0, 0, 0, 0};  // steps of the walk's critical path with 1, 2, 4, 8 wavefronts on its frontier (g_par)
 };
+static bool g_par = false;
 
 static std::vector<int> g_seen;  // epoch marks
 static int g_epoch = 0;
@@ -80,6 +83,42 @@ static void footprint(int k, const std::vector<uint8_t>& dm, Walk& out) {
                 }
             }
     }
+    if (!g_par) return;
+    // tile graph of the footprint, breadth-first from the seed's tile: a level's tiles are independent steps
+    std::unordered_map<int, int> id;
+    std::vector<std::vector<int>> adj;
+    auto tile_of = [&](int p) { return (p / W / 8) * tw + (p % W) / 8; };
+    for (int p : out.px) {
+        const int ti = tile_of(p);
+        if (id.emplace(ti, (int)adj.size()).second) adj.emplace_back();
+    }
+    for (int p : out.px) {
+        const int a = id[tile_of(p)];
+        const int r = p / W, c = p % W;
+        for (int dr = -1; dr <= 1; ++dr)
+            for (int dc = -1; dc <= 1; ++dc) {
+                const int rr = r + dr, cc = c + dc;
+                if (rr < 0 || rr >= H || cc < 0 || cc >= W) continue;
+                const int q = rr * W + cc;
+                if (g_seen[q] != g_epoch) continue;
+                const int bq = id[tile_of(q)];
+                if (bq != a && std::find(adj[a].begin(), adj[a].end(), bq) == adj[a].end()) adj[a].push_back(bq);
+            }
+    }
+    std::vector<int> lvl(adj.size(), -1), cur{id[tile_of(s)]}, nxt;
+    lvl[cur[0]] = 0;
+    for (int w = 0; w < 4; ++w) out.par[w] = 0;
+    while (!cur.empty()) {
+        for (int w = 0; w < 4; ++w) out.par[w] += ((int)cur.size() + (1 << w) - 1) >> w;
+        nxt.clear();
+        for (int a : cur)
+            for (int bq : adj[a])
+                if (lvl[bq] < 0) {
+                    lvl[bq] = 1;
+                    nxt.push_back(bq);
+                }
+        cur.swap(nxt);
+    }
 }
 
 // sequential reference
@@ -102,10 +141,15 @@ static std::vector<int> sequential(std::vector<int>& sizes) {
 
 struct RoundStat {
     long walked_px = 0, steps = 0;
+    int par[4] = {0, 0, 0, 0};
+    long same_steps = 0;
+    int same_walks = 0, longest_changed = 0;
     int longest = 0, longest_commit = 0, n_walk = 0, n_commit = 0, n_dead = 0, n_active = 0, phases = 1, longest_sum = 0;
 };
 
 static void print_round(int r, const RoundStat& s) {
+    if (g_par) printf("round %d: %d walks (%ld steps) have the footprint of the round before; longest walk among the others %d\n", r, s.same_walks, s.same_steps, s.longest_changed);
+    if (g_par) printf("round %d: longest walk on 1 / 2 / 4 / 8 wavefronts: %d / %d / %d / %d steps\n", r, s.par[0], s.par[1], s.par[2], s.par[3]);
     printf("round %d: active %d, walked %d seeds, %ld px in %ld steps, longest walk %d (committing: %d), sum of per-phase longest %d, phases %d; commit %d, dead %d\n", r,
            s.n_active, s.n_walk, s.walked_px, s.steps, s.longest, s.longest_commit, s.longest_sum, s.phases, s.n_commit, s.n_dead);
 }
@@ -490,6 +534,7 @@ static int batched(int shift0, int grow, bool seed_level, const std::vector<int>
 int main(int argc, char** argv) {
     const std::string dir = argv[1];
     const int scheme = argc > 2 ? atoi(argv[2]) : 0;
+    g_par = std::getenv("SIM_PAR") != nullptr;
     const int conc = argc > 3 ? atoi(argv[3]) : 5120;
     const int max_phases = argc > 4 ? atoi(argv[4]) : 100;
     FILE* m = fopen((dir + "/meta.txt").c_str(), "r");
@@ -537,12 +582,21 @@ int main(int argc, char** argv) {
         std::vector<uint8_t> walked(NS, 0);
         std::vector<int> touched;  // pixels stamped this round
         auto do_walk = [&](int k) {
+            const size_t prev_size = fp[k].px.size();
             footprint(k, dm, fp[k]);
+            // (a footprint only shrinks from round to round: equal size = the same pixels = a walk a replay of the saved list could replace)
+            if (rounds > 1 && fp[k].px.size() == prev_size && prev_size > 0) {
+                rs.same_walks++;
+                rs.same_steps += fp[k].tiles;
+            } else {
+                rs.longest_changed = std::max(rs.longest_changed, fp[k].tiles);
+            }
             walked[k] = 1;
             rs.n_walk++;
             rs.walked_px += (long)fp[k].px.size();
             rs.steps += fp[k].tiles;
             rs.longest = std::max(rs.longest, fp[k].tiles);
+            for (int w = 0; w < 4; ++w) rs.par[w] = std::max(rs.par[w], fp[k].par[w]);
             for (int p : fp[k].px) {
                 if (stamp[p] == INF) touched.push_back(p);
                 stamp[p] = std::min(stamp[p], k);
