@@ -50,7 +50,8 @@ void lr_set_ransac_iterations(lr_context* ctx, int n_iter);
 /* Flood implementation: 0 = ordered single-wave (simple, slow), 1 = parallel rounds (default);
  * 2 / 3 / 4 = test hooks: parallel rounds without the second LDS storage tier and with no / two / all overflow
  * slabs (exhausted-storage and slab paths; lr_stage_counters tells which storage a frame used); 5 = second tier with
- * room for one seed per round and no slab (a stall while the weakest seeds are held back).
+ * room for one seed per round and no slab (a stall while the weakest seeds are held back); 6 / 7 = the second tier's team of
+ * wavefronts runs out of storage after 200 tiles and hands the walk to a slab / has no slab to hand it to.
  * All modes give identical results. */
 void lr_set_flood_mode(lr_context* ctx, int mode);
 int lr_device_count(void);

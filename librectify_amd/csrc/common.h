@@ -149,6 +149,7 @@ struct FloodBuffers {
     bool hold_from_start = false;
     int blind_rounds = 10;  // rounds flood_enqueue enqueues without looking at the control block
     uint32_t big_cap_override = 0;  // test hook: seeds per round the second tier takes (0 = the default, 8192)
+    uint32_t team_tile_cap = 0;     // test hook: tiles after which the second tier's team hands a walk to a slab (0 = its table)
 };
 // What a frame hands to the flood.  The seed count stays on the device (*d_n_seeds, clamped to seed_cap, the
 // capacity the seed sort ran with): launches are sized by seed_cap.

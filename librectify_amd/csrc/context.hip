@@ -577,7 +577,7 @@ int ensure_result_block(lr_context* c, size_t lines) {
 FloodBuffers flood_buffers_for(lr_context* c) {
     FloodBuffers fbuf = c->fb;
     // test hooks: 2 and 3 exercise the slab and exhausted-storage paths (no second LDS tier, no / two slabs),
-    // 4 the slab path with the full pool, 5 a stall during the hold-back
+    // 4 the slab path with the full pool, 5 a stall during the hold-back, 6 / 7 the second tier's team running out of storage
     if (c->flood_mode >= 2 && c->flood_mode <= 4) fbuf.second_tier = false;
     fbuf.second_tier_from_start = c->flood_big_hint;
     fbuf.hold_from_start = c->flood_hold_hint;
@@ -586,6 +586,11 @@ FloodBuffers flood_buffers_for(lr_context* c) {
     if (c->flood_mode == 5) {  // second tier with room for one seed per round and no slab: the rounds stall while
         fbuf.n_slabs = 0;      // the weakest seeds are held back, and must still hand over to the ordered tail
         fbuf.big_cap_override = 1;
+    }
+    if (c->flood_mode == 6) fbuf.team_tile_cap = 200;  // the second tier's team runs out early: it stamps what it has and one
+    if (c->flood_mode == 7) {                           // wavefront carries on in a slab (6), or there is none: incomplete
+        fbuf.team_tile_cap = 200;                       // walk, barrier, ordered tail (7)
+        fbuf.n_slabs = 0;
     }
     static const bool partial_off = std::getenv("LIBRECTIFY_FLOOD_PARTIAL") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_PARTIAL")) == 0;
     fbuf.partial_commits = !partial_off && c->flood_partial;

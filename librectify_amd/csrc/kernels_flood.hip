@@ -185,6 +185,9 @@ struct FloodArgs {
     uint32_t from_end;                               // explore the active list from its end (see flood_explore_kernel)
     uint32_t big_cap;                                // seeds per round the second tier takes (0: tier switched off)
     uint32_t g_cap;                                  // partial-commit walks stop after this many tile steps
+    uint32_t t1_tiles;                               // first tier hands a walk to the second at this many tiles (when there is one)
+    uint32_t team_tiles;                             // test hook: the team's table counts as full at this many tiles
+    uint32_t t1_wide_tiles, t1_wide_front;           // ... or at this many tiles when its frontier holds this many records
 };
 // All words but kCtrlGen are set up by flood_init_seeds_kernel every frame; kCtrlGen lives on for the lifetime of
 // the slab memory (hash entries are tagged with it, so a generation must never be reused while old entries are
@@ -687,7 +690,8 @@ __device__ unsigned long long g_walk_timing[8];
 // stamps it reaches into labels; `dmask_rw` is the direction mask it clears there.
 template <class Store, int kMode = 0>
 __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, float cs, Store& S, Pending& P,
-                    WalkState& st, int lane, bool own = false, uint8_t* dmask_rw = nullptr) {
+                    WalkState& st, int lane, bool own = false, uint8_t* dmask_rw = nullptr, uint32_t tile_cap = 0xFFFFFFFFu,
+                    uint32_t wide_tiles = 0xFFFFFFFFu, uint32_t wide_front = 0xFFFFFFFFu) {
     const uint32_t mine = kMarkBit | k;
     const int lr = lane >> 3, lc = lane & 7;
     int rx, ry;
@@ -697,7 +701,8 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
     uint64_t nbr = tile_neighbours(lane);
     asm volatile("" : "+v"(nbr));  // a per-lane constant: keep it in registers
     if (st.head == st.tail) return 0;
-    if ((st.tail - st.head) + 8u > S.ring_cap() || st.ntiles + 2u > S.hash_limit()) return 1;
+    const uint32_t tile_limit = min(S.hash_limit(), tile_cap);
+    if ((st.tail - st.head) + 8u > S.ring_cap() || st.ntiles + 2u > tile_limit) return 1;
     const PushLane pc = push_lane(lane);
     const uint32_t bin_bit = 1u << b;
     Forward fw;
@@ -798,7 +803,10 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
         }
 #endif
         if (st.head == st.tail) return 0;
-        if ((st.tail - st.head) + 8u > S.ring_cap() || st.ntiles + 2u > S.hash_limit()) return 1;
+        if ((st.tail - st.head) + 8u > S.ring_cap() || st.ntiles + 2u > tile_limit) return 1;
+        // a walk with a wide frontier (a region, not a line) is handed to the second tier early: its team of wavefronts
+        // takes a frontier eight records at a time
+        if (st.ntiles >= wide_tiles && (st.tail - st.head) >= wide_front) return 1;
         if (st.steps > kMaxSteps) return 1;  // never reached by a terminating walk; treated like exhausted storage
         if (kMode == 1 && st.steps >= A.g_cap) return 1;  // partial-commit walk: any connected part is as safe as the whole
         cur = fetch_tile<kMode>(A, S, st.head, lr, lc, rx, ry, ring_lane, fw, G, own);
@@ -811,11 +819,12 @@ __device__ int walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, 
 // seed is blocked); a higher stamp replaced means that seed is blocked.
 template <class Lds>
 __device__ __forceinline__ void stamp_footprint(const FloodArgs& A, uint32_t k, const Lds& S, WalkState& st,
-                                                int lane) {
+                                                int lane, uint32_t first = 0u, uint32_t stride = 8u) {
     const uint32_t mine = kMarkBit | k;
     const int lr = lane >> 3, lc = lane & 7;
     bool foreign = false;
-    for (uint32_t i0 = 0; i0 < st.ntiles; i0 += 8) {
+    // (a team of wavefronts shares the tiles: each takes eight at `first`, `first + stride`, ...)
+    for (uint32_t i0 = first; i0 < st.ntiles; i0 += stride) {
         uint32_t old[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -875,7 +884,11 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
         P.pt[lane] = 0u;
         const int sr = s / A.w, sc = s - sr * A.w;
         L.put(0u, ((uint32_t)(sr >> 3) << 16) | (uint32_t)(sc >> 3), 1ull << ((sr & 7) * 8 + (sc & 7)));
-        rc = walk(A, k, b, thr, sn, cs, L, P, st, lane, own);
+        // (with a second tier behind it, the first hands a walk over at A.t1_tiles tiles, before its table is full: the
+        // second tier's team of wavefronts is the faster walker from there on)
+        const bool hand_over = kFirstTier && A.big_cap != 0u;
+        rc = walk(A, k, b, thr, sn, cs, L, P, st, lane, own, nullptr, hand_over ? A.t1_tiles : 0xFFFFFFFFu,
+                  hand_over ? A.t1_wide_tiles : 0xFFFFFFFFu, hand_over ? A.t1_wide_front : 0xFFFFFFFFu);
     }
     if (kFirstTier && rc != 0 && A.big_cap != 0u) {
         // outgrew the first tier: start again in the second (nothing is stamped yet, so nothing to undo)
@@ -1041,6 +1054,329 @@ __global__ __launch_bounds__(64) void flood_explore_big_kernel(FloodArgs A, BinT
     LdsStoreBig L{ring, ring + kRingBig, ring + 2 * kRingBig, hash, hash + kHashBig, hash + 2 * kHashBig, ord};
     Pending P{pend, pend + kPend};
     explore_seed<LdsStoreBig, false>(A, trig, k, L, P, big_list, lane);
+}
+
+// ---- Second tier, cooperative: a TEAM of wavefronts walks one footprint -------------------------------------------------
+// The walks that reach the second tier are the long ones (hundreds of tiles: the weak seeds of smooth regions and long
+// edges), few per frame, and one wavefront takes them a tile at a time: on a natural 4K image the second-tier kernel was
+// half of the flood (1.75 of 3.1 ms) for 52 walks.  Their frontiers are wide -- a footprint of 800 tiles is some 100
+// tile-levels deep (tools/sim/flood_sim.cpp, SIM_PAR) -- so here the frontier is processed a LEVEL at a time by the
+// eight wavefronts of a workgroup: records [begin, end) of the ring are this level, wavefront w takes records
+// begin + w, begin + w + 8, ..., the records it pushes are appended behind `end` through an LDS counter and form the
+// next level.  Two barriers per level.  The footprint (the fixed point) does not depend on the order of the steps:
+//   - tile table: find-or-insert by compare-and-swap on the key; the walked set V of a tile only grows, by atomic OR;
+//   - a step pushes neighbour records only for the pixels IT was the first to add to V (the OR returns the old bits): two
+//     wavefronts that enter a tile at once share its new pixels between them instead of both walking on from all;
+//   - a stale V read by a neighbour's filter only costs a record that finds nothing new.
+// Stamps, pixel count and the blocked mark are taken from the table when the walk is over, by all wavefronts.  If ring or
+// table run out, the part walked so far is stamped and the first wavefront carries on alone in a global slab, as before.
+#ifndef LR_TEAM_WAVES
+#define LR_TEAM_WAVES 8
+#endif
+constexpr int kTeamWaves = LR_TEAM_WAVES;
+constexpr int kRingTeam = 2048;
+constexpr uint32_t kTeamGrid = 512;  // workgroups; each strides over the round's second-tier list
+constexpr uint32_t kVoidTile = 0xFFFFFFFFu;
+
+struct TeamShared {
+    uint32_t tail, end, ntiles, blocked, overflow, cnt, steps, pad;
+};
+__device__ __forceinline__ uint32_t lds_now(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+struct TeamStore {
+    static constexpr int kHashShift = 32 - __builtin_ctz((unsigned)kHashBig);
+    uint32_t* rt;
+    uint32_t* rlo;
+    uint32_t* rhi;
+    uint32_t* hk;
+    uint32_t* hv0;
+    uint32_t* hv1;
+    uint16_t* ord;
+    TeamShared* sh;
+    __device__ uint32_t hash_limit() const { return kHashBig * 3 / 4; }
+    __device__ void get(uint32_t i, uint32_t& tile, uint64_t& m) const {
+        const uint32_t j = i & (kRingTeam - 1);
+        tile = uni(rt[j]);
+        m = uni64(rlo[j], rhi[j]);
+    }
+    // find or insert (wave-uniform; the atomics are lane 0's): true if the tile was known
+    __device__ bool lookup(uint32_t tile, uint32_t& slot, uint64_t& V) const {
+        const uint32_t key = tile + 1u;
+        const bool first_lane = (threadIdx.x & 63u) == 0u;
+        uint32_t hs = (key * 2654435761u) >> kHashShift;
+        for (int probe = 0; probe < kHashBig; ++probe) {
+            uint32_t cur = uni(lds_now(&hk[hs]));
+            if (cur == 0u) {
+                uint32_t old = 0u;
+                if (first_lane) old = atomicCAS(&hk[hs], 0u, key);
+                old = uni(old);
+                if (old == 0u) {
+                    uint32_t idx = 0u;
+                    if (first_lane) idx = atomicAdd(&sh->ntiles, 1u);
+                    idx = uni(idx);
+                    if (first_lane) ord[idx] = (uint16_t)hs;
+                    slot = hs;
+                    V = 0ull;
+                    return false;
+                }
+                cur = old;
+            }
+            if (cur == key) {
+                slot = hs;
+                V = uni64(lds_now(&hv0[hs]), lds_now(&hv1[hs]));
+                return true;
+            }
+            hs = (hs + 1) & (kHashBig - 1);
+        }
+        slot = hs;  // (never: the table is kept below hash_limit)
+        V = 0ull;
+        return true;
+    }
+    __device__ void value(uint32_t slot, uint64_t& V) const { V = uni64(lds_now(&hv0[slot]), lds_now(&hv1[slot])); }
+};
+
+// neighbour records of a step, one direction per lane 0..7 (as push8; no merging with pending records of the same tile:
+// duplicates of a level are taken by different wavefronts at the same time)
+__device__ __forceinline__ void team_push8(TeamStore& S, uint32_t tile, uint64_t H, int lane, const PushLane& c) {
+    const uint32_t nt = tile + c.off;
+    const uint32_t key = nt + 1u;
+    const uint64_t src = (H >> c.shamt) & (uint64_t)c.msk;
+    uint64_t E = (c.spread ? spread_col(src) : src) << c.sh;
+    uint32_t ts = (key * 2654435761u) >> TeamStore::kHashShift;
+    uint32_t hk0 = S.hk[ts];
+    uint32_t v0 = S.hv0[ts], v1 = S.hv1[ts];
+    const uint64_t m_want = m_ne64(E, 0ull) & 0xFFull;
+    uint64_t m_found = m_eq(hk0, key);
+    uint64_t m_search = m_want & ~m_found & m_ne(hk0, 0u);
+    for (int probe = 1; probe < kHashBig && m_search != 0ull; ++probe) {  // collisions
+        if (lane_of(m_search)) {
+            ts = (ts + 1) & (kHashBig - 1);
+            hk0 = S.hk[ts];
+        }
+        const uint64_t hit = m_search & m_eq(hk0, key);
+        if (lane_of(hit)) {
+            v0 = S.hv0[ts];
+            v1 = S.hv1[ts];
+        }
+        m_found |= hit;
+        m_search &= ~hit & m_ne(hk0, 0u);
+    }
+    if (lane_of(m_found)) E &= ~(((uint64_t)v1 << 32) | v0);  // entries the neighbour has walked add nothing
+    const uint64_t mf = m_want & m_ne64(E, 0ull);
+    if (mf != 0ull) {
+        uint32_t base = 0u;
+        if (lane == 0) base = atomicAdd(&S.sh->tail, (uint32_t)__popcll(mf));
+        base = uni(base);
+        if (lane_of(mf)) {
+            const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mf >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mf, 0u));
+            const uint32_t j = pos & (kRingTeam - 1);
+            S.rt[j] = nt;
+            S.rlo[j] = (uint32_t)E;
+            S.rhi[j] = (uint32_t)(E >> 32);
+        }
+    }
+}
+
+// returns 0 when the footprint is complete; 1 when ring or table ran out: *begin_out is then the first ring index that
+// may hold an unprocessed record (processed ones read kVoidTile)
+__device__ int team_walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, float cs, TeamStore& S, int lane,
+                         int wave, bool own, uint32_t* begin_out, uint32_t* steps_out) {
+    TeamShared* sh = S.sh;
+    const int lr = lane >> 3, lc = lane & 7;
+    int rx, ry;
+    ring_xy(lane, rx, ry);
+    const bool ring_lane = lane < 36;
+    const uint64_t adj = ring_adjacency(lane);
+    uint64_t nbr = tile_neighbours(lane);
+    asm volatile("" : "+v"(nbr));
+    const PushLane pc = push_lane(lane);
+    const uint32_t bin_bit = 1u << b;
+    Forward fw;
+    fw.valid = false;
+    LaneGeom G;
+    G.off = (uint32_t)(lr * A.w + lc);
+    G.roff = (uint32_t)(ry * A.w + rx);
+    asm volatile("" : "+v"(G.off), "+v"(G.roff));
+    uint32_t gb = 0u, ge = 1u, steps = 0u, levels = 0u;
+    int rc = 0;
+    for (;;) {
+        for (uint32_t i = gb + (uint32_t)wave; i < ge; i += kTeamWaves) {
+            // room for what the steps in flight may add: eight records and one tile each
+            if ((uni(lds_now(&sh->tail)) - gb) + 8u * kTeamWaves > (uint32_t)kRingTeam ||
+                uni(lds_now(&sh->ntiles)) + kTeamWaves + 1u > min(S.hash_limit(), A.team_tiles)) {
+                if (lane == 0) sh->overflow = 1u;
+                break;
+            }
+            if (uni(lds_now(&sh->overflow)) != 0u) break;
+            const TileFetch cur = fetch_tile<0>(A, S, i, lr, lc, rx, ry, ring_lane, fw, G, own);
+            ++steps;
+            const uint32_t tile = cur.tile;
+            uint64_t Am = cur.inside & m_ne(cur.dm & bin_bit, 0u) & m_gt_f(directional(cur.dx, cur.dy, sn, cs), thr);
+            uint64_t Rg = cur.rinside & m_ne(cur.rdm & bin_bit, 0u) & m_gt_f(directional(cur.rdx, cur.rdy, sn, cs), thr);
+            if (own) {
+                Am |= cur.inside & m_eq(cur.lab, k);
+                Rg |= cur.rinside & m_eq(cur.rlab, k);
+            }
+            uint64_t R = cur.entry & Am;
+            if (R != 0ull) {
+                const uint64_t reach = lane_of(Am) ? nbr : 0ull;
+                for (;;) {
+                    const uint64_t R1 = m_ne64(R & reach, 0ull);
+                    R = m_ne64(R1 & reach, 0ull);
+                    if (R == R1) break;
+                }
+                const uint64_t New = R & ~cur.V;
+                if (New != 0ull) {
+                    uint32_t o0 = 0u, o1 = 0u;
+                    if (lane == 0) {
+                        if ((uint32_t)New) o0 = atomicOr(&S.hv0[cur.slot], (uint32_t)New);
+                        if ((uint32_t)(New >> 32)) o1 = atomicOr(&S.hv1[cur.slot], (uint32_t)(New >> 32));
+                    }
+                    const uint64_t first_here = New & ~uni64(o0, o1);  // the pixels this step was the first to walk
+                    if (first_here != 0ull) {
+                        const uint64_t H = Rg & m_ne64(first_here & adj, 0ull);
+                        if (H != 0ull) team_push8(S, tile, H, lane, pc);
+                    }
+                }
+            }
+            if (lane == 0) S.rt[i & (kRingTeam - 1)] = kVoidTile;  // processed
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) sh->end = sh->tail;
+        __syncthreads();
+        const uint32_t ne = sh->end;
+        if (sh->overflow != 0u || ++levels > kMaxSteps) {
+            rc = 1;
+            break;
+        }
+        if (ne == ge) break;
+        gb = ge;
+        ge = ne;
+    }
+    *begin_out = gb;
+    *steps_out = steps;
+    return rc;
+}
+
+constexpr size_t kTeamLdsBytes = (size_t)(3 * kRingTeam + 3 * kHashBig + 2 * kPend) * 4 + (size_t)kHashBig * 2 + sizeof(TeamShared);
+__global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(FloodArgs A, BinTrig trig,
+                                                                             uint32_t* __restrict__ big_list) {
+    extern __shared__ uint32_t s_team[];
+    const int lane = threadIdx.x & 63, wave = (int)uni(threadIdx.x >> 6);
+    const uint32_t n_big_raw = uni(A.ctrl[kCtrlNBig]);
+    const uint32_t n_big = n_big_raw < A.big_cap ? n_big_raw : A.big_cap;
+    uint32_t* ring = s_team;
+    uint32_t* hash = ring + 3 * kRingTeam;
+    uint32_t* pend = hash + 3 * kHashBig;
+    uint16_t* ord = reinterpret_cast<uint16_t*>(pend + 2 * kPend);
+    TeamShared* sh = reinterpret_cast<TeamShared*>(reinterpret_cast<char*>(ord) + (size_t)kHashBig * 2);
+    TeamStore S{ring, ring + kRingTeam, ring + 2 * kRingTeam, hash, hash + kHashBig, hash + 2 * kHashBig, ord, sh};
+    for (uint32_t ai = uni(blockIdx.x); ai < n_big; ai += gridDim.x) {
+        const uint32_t k = uni(big_list[ai]);
+        const int s = (int)uni((uint32_t)A.seed_idx[k]);
+        const int b = (int)uni((uint32_t)A.seed_bin[k]);
+        const float thr = __uint_as_float(uni(__float_as_uint(A.seed_thr[k])));
+        const float sn = trig.st[b], cs = trig.ct[b];
+        // (the checks of explore_seed again: the first tier passed them in this round, on the same labels)
+        const uint32_t seed_label = uni(A.label[s]);
+        const bool own = seed_label == k;
+        if (seed_label < kMarkBit && !own) continue;
+        if (!own && !(((uni((uint32_t)A.dmask[s]) >> b) & 1u) &&
+                      directional(__uint_as_float(uni(__float_as_uint(A.dx[s]))), __uint_as_float(uni(__float_as_uint(A.dy[s]))), sn, cs) > thr)) {
+            if (threadIdx.x == 0) A.flags[k] = kFlagSelfFail;
+            continue;
+        }
+        __syncthreads();  // the previous seed's table is no longer read
+        for (int i = (int)threadIdx.x; i < kHashBig; i += 64 * kTeamWaves) {
+            S.hk[i] = 0u;
+            S.hv0[i] = 0u;
+            S.hv1[i] = 0u;
+        }
+        if (threadIdx.x == 0) {
+            const int sr = s / A.w, sc = s - sr * A.w;
+            const uint64_t m = 1ull << ((sr & 7) * 8 + (sc & 7));
+            S.rt[0] = ((uint32_t)(sr >> 3) << 16) | (uint32_t)(sc >> 3);
+            S.rlo[0] = (uint32_t)m;
+            S.rhi[0] = (uint32_t)(m >> 32);
+            sh->tail = 1u;
+            sh->end = 1u;
+            sh->ntiles = 0u;
+            sh->blocked = 0u;
+            sh->overflow = 0u;
+            sh->cnt = 0u;
+            sh->steps = 0u;
+        }
+        __syncthreads();
+        uint32_t begin = 0u, my_steps = 0u;
+        int rc = team_walk(A, k, b, thr, sn, cs, S, lane, wave, own, &begin, &my_steps);
+        // (team_walk ends behind a barrier: every wavefront sees the final table)
+        WalkState st{0u, 0u, 0u, sh->ntiles, false, 0u, 0u};
+        stamp_footprint(A, k, S, st, lane, (uint32_t)wave * 8u, 8u * kTeamWaves);
+        uint32_t px = 0u;
+        for (int i = (int)threadIdx.x; i < kHashBig; i += 64 * kTeamWaves) px += (uint32_t)__popc(S.hv0[i]) + (uint32_t)__popc(S.hv1[i]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) px += (uint32_t)__shfl_xor((int)px, off);
+        if (lane == 0) {
+            atomicAdd(&sh->cnt, px);
+            atomicAdd(&sh->steps, my_steps);
+            if (st.blocked) atomicOr(&sh->blocked, 1u);
+        }
+        __syncthreads();
+        if (wave != 0) continue;  // (the first wavefront finishes the seed; the others wait at the next seed's barrier or leave)
+        st.cnt = sh->cnt;
+        st.steps = sh->steps;
+        st.blocked = sh->blocked != 0u;
+        if (rc != 0) {
+            // storage exhausted: what has been walked is stamped; this wavefront carries on alone in a global slab from
+            // the records that are still unprocessed (as explore_seed does for the single-wavefront tiers)
+            uint32_t slab = 0;
+            if (lane == 0) slab = atomicAdd(&A.ctrl[kCtrlSlabs], 1u);
+            slab = (uint32_t)__shfl((int)slab, 0);
+            if (slab < A.n_slabs) {
+                uint32_t gen = 0;
+                if (lane == 0) atomicAdd(&A.ctrl[kCtrlSlabTotal], 1u);
+                if (lane == 0) gen = atomicAdd(&A.ctrl[kCtrlGen], 1u) + 1u;
+                gen = (uint32_t)__shfl((int)gen, 0);
+                SlabStore G{A.slab_ring + (size_t)slab * A.slab_ring_cap, A.slab_hash + (size_t)slab * A.slab_hash_cap * 2,
+                            A.slab_ring_cap, A.slab_hash_cap, gen};
+                Pending P{pend, pend + kPend};
+                P.pt[lane] = 0u;
+                const uint32_t tail = sh->tail;
+                uint32_t n = 0u;
+                for (uint32_t i = begin; i != tail; ++i) {
+                    uint32_t t;
+                    uint64_t m;
+                    S.get(i, t, m);
+                    if (t == kVoidTile) continue;
+                    G.put(n, t, m);
+                    ++n;
+                }
+                for (int i = 0; i < kHashBig; ++i) {
+                    const uint32_t key = S.hk[i];
+                    if (key) {
+                        uint32_t slot;
+                        uint64_t v0;
+                        (void)G.lookup(key - 1u, slot, v0);
+                        G.update(slot, key - 1u, ((uint64_t)S.hv1[i] << 32) | S.hv0[i]);
+                    }
+                }
+                st.head = 0u;
+                st.tail = n;
+                rc = walk(A, k, b, thr, sn, cs, G, P, st, lane, own);
+            }
+            if (rc != 0 && lane == 0) {
+                A.flags[k] = kFlagIncomplete;
+                atomicMin(&A.ctrl[kCtrlBarrier], k);
+            }
+        }
+        if (lane == 0) {
+            A.count[k] = st.cnt;
+            if (st.blocked) A.blocked[k] = 1u;
+            A.flags[k] |= st.steps << 8;
+        }
+    }
 }
 
 // Partial commits (round 3).  A seed that is blocked -- a lower active seed reaches some pixel of its footprint -- still
@@ -1534,6 +1870,13 @@ FloodArgs flood_args(const FloodBuffers& B, const FloodFrame& F, bool use_big) {
     A.win_shift = 2u;
     const uint32_t big_cap = B.big_cap_override ? B.big_cap_override : kBigCap;
     A.big_cap = use_big ? big_cap : 0u;
+    static const int t1_env = std::getenv("LIBRECTIFY_FLOOD_T1_TILES") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_T1_TILES")) : 0;
+    A.team_tiles = B.team_tile_cap ? B.team_tile_cap : 0xFFFFFFFFu;
+    A.t1_tiles = t1_env > 8 ? (uint32_t)t1_env : 0xFFFFFFFFu;
+    static const int t1w_env = std::getenv("LIBRECTIFY_FLOOD_T1_WIDE_TILES") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_T1_WIDE_TILES")) : 0;
+    static const int t1f_env = std::getenv("LIBRECTIFY_FLOOD_T1_WIDE_FRONT") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_T1_WIDE_FRONT")) : 6;
+    A.t1_wide_tiles = t1w_env > 0 ? (uint32_t)t1w_env : 0xFFFFFFFFu;
+    A.t1_wide_front = (uint32_t)std::max(t1f_env, 1);
     static const int g_cap_env = std::getenv("LIBRECTIFY_FLOOD_PARTIAL_STEPS") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_PARTIAL_STEPS")) : 16;
     A.g_cap = g_cap_env > 0 ? (uint32_t)g_cap_env : kMaxSteps;
     return A;
@@ -1562,7 +1905,11 @@ void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& 
     hipLaunchKernelGGL(flood_explore_kernel, dim3(grid), dim3(64), 0, s, A, F.trig, act, B.big_list);
     if (grid < F.seed_cap)  // entries past the guess, if any
         hipLaunchKernelGGL(flood_explore_rest_kernel, dim3(1024), dim3(64), 0, s, A, F.trig, act, B.big_list, grid);
-    if (use_big)
+    static const bool team = !(std::getenv("LIBRECTIFY_FLOOD_TEAM") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_TEAM")) == 0);
+    if (use_big && team)
+        hipLaunchKernelGGL(flood_explore_team_kernel, dim3(std::min<uint32_t>(F.seed_cap, kTeamGrid)), dim3(64 * kTeamWaves),
+                           kTeamLdsBytes, s, A, F.trig, B.big_list);
+    else if (use_big)
         hipLaunchKernelGGL(flood_explore_big_kernel, dim3(std::min<uint32_t>(F.seed_cap, kBigCap)), dim3(64), kBigLdsBytes, s,
                            A, F.trig, B.big_list);
     if (g_flood_debug) (void)hipEventRecord(dbg1, s);
@@ -1616,7 +1963,9 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
         const uint64_t bit = 1ull << (dev & 63);
         if (!(done_mask.load(std::memory_order_acquire) & bit)) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(flood_explore_big_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigLdsBytes) != hipSuccess) {
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigLdsBytes) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(flood_explore_team_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTeamLdsBytes) != hipSuccess) {
                 set_error("flood: cannot reserve the second-tier LDS");
                 return 1;
             }

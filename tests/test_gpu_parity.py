@@ -664,11 +664,13 @@ def _long_bars(W, H, seed, K=14):
 def test_every_storage_tier_of_the_flood_is_exact_on_long_edges(L, ctx):
     """2560x480 with edges of 1500-2400 px against the oracle: default (walks restart in the second LDS tier), mode 4
     (no second tier: they carry on in global slabs, and when the pool runs out the ordered tail finishes), mode 3 (two
-    slabs), mode 2 (no slab at all).  The counters prove that each path was really taken."""
+    slabs), mode 2 (no slab at all), modes 6 and 7 (the second tier's team of wavefronts runs out of storage in the middle
+    of a level: one wavefront carries on in a slab from the unprocessed records / no slab: incomplete walk, barrier,
+    ordered tail).  The counters prove that each path was really taken."""
     img = _long_bars(2560, 480, 5)
     ref = O.find_line_segments(img)
     used = {}
-    for mode in (1, 4, 3, 2, 5):
+    for mode in (1, 4, 3, 2, 5, 6, 7):
         ctx.set_flood_mode(mode)
         ctx.stage_filter_host(img)
         ctx.stage_seeds()
@@ -682,6 +684,8 @@ def test_every_storage_tier_of_the_flood_is_exact_on_long_edges(L, ctx):
     assert used[3]["ordered_tail_seeds"] > 0
     assert used[2]["slabs"] == 0 and used[2]["ordered_tail_seeds"] > 0
     assert used[5]["second_tier_seeds"] > 0 and used[5]["slabs"] == 0 and used[5]["ordered_tail_seeds"] > 0
+    assert used[6]["second_tier_seeds"] > 0 and used[6]["slabs"] > 0  # (the pool may run out as well: then the tail finishes)
+    assert used[7]["second_tier_seeds"] > 0 and used[7]["slabs"] == 0 and used[7]["ordered_tail_seeds"] > 0
 
 
 def test_component_sort_classes_up_to_a_flood_of_20000_pixels(L, ctx):

@@ -20,6 +20,10 @@ def main():
         img = synth.frame(w, h, seed)
     elif kind == "tiled":
         img = synth.frame(w, h, seed, bars=int(sys.argv[6]), tile=512)
+    elif kind == "doc":  # the natural 4K frame of tools/run_doc4k.py
+        import scipy.ndimage as ndi
+        g = np.load(os.path.join(ROOT, "tests", "golden", "doc_image_gray.npy")).astype(np.float32) / np.float32(256.0)
+        img = np.ascontiguousarray(ndi.zoom(g, (h / g.shape[0], w / g.shape[1]), order=3).astype(np.float32)[:h, :w])
     else:
         raise SystemExit("kind?")
     f = O.filter_stage(img, num_threads=8)

@@ -23,7 +23,7 @@ for i in range(n):
     ref = O.find_line_segments(img)
     ml = max(w, h) / 100.0
     full, _ = O.find_line_segment_groups(img, ml, seed=0)
-    ctx.set_flood_mode(int(rng.choice([1, 1, 1, 2, 3, 5])))
+    ctx.set_flood_mode(int(rng.choice([1, 1, 1, 2, 3, 5, 6, 7])))
     ctx.stage_filter_host(img); ctx.stage_seeds(); ctx.stage_flood()
     lab = ctx.download(L.BUF_LABEL)
     ok = np.array_equal(lab, ref["label"])

@@ -34,7 +34,7 @@ for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
     W, H = 2600, 1500
     img = long_frame(W, H, 100 + i, 14)
     ref = O.find_line_segments(img, num_threads=8)
-    for mode in (1, 2, 3, 5):
+    for mode in (1, 2, 3, 5, 6, 7):
         for part in (1, 0):
             ctx.set_flood_partial_commits(part)
             ctx.set_flood_mode(mode)
