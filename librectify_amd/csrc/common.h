@@ -112,6 +112,7 @@ int launch_flood_ordered(const float* dx, const float* dy, const uint8_t* dmask,
                          BinTrig trig, uint32_t* label, int32_t* seed_size, int32_t* queue, hipStream_t s);
 
 // parallel-round flood (mode 1): per-seed round state, active lists and overflow slabs
+constexpr size_t kFloodHandWords = 1024;  // per hand-over: header, up to 192 table entries, up to 128 frontier records
 struct FloodBuffers {
     uint32_t* blocked = nullptr;
     uint32_t* count = nullptr;
@@ -123,6 +124,7 @@ struct FloodBuffers {
     uint32_t* ctrl = nullptr;       // kFloodCtrlWords words
     uint8_t* dirty = nullptr;       // one mark per 256 pixels of the label image: stamped in the current round
     uint32_t* big_list = nullptr;   // 8192 seeds: this round's hand-over to the second storage tier
+    uint32_t* handover = nullptr;   // ... and the state each of their walks had reached (kFloodHandWords words per list entry)
     void* slab_ring = nullptr;  // n_slabs x slab_ring_cap 16-byte records
     void* slab_hash = nullptr;  // n_slabs x slab_hash_cap 16-byte records
     uint32_t n_slabs = 0, slab_ring_cap = 0, slab_hash_cap = 0;

@@ -159,6 +159,9 @@ constexpr uint32_t kMarkBit = 0x80000000u;
 #endif
 constexpr int kRingT = LR_RING_T, kHashT = LR_HASH_T;
 constexpr int kRingBig = 1024, kHashBig = 2048;
+constexpr uint32_t kHandTiles = kHashT * 3 / 4, kHandRecs = kRingT;  // what a first-tier walk can hold when it is handed over
+constexpr uint32_t kHandTable = 4, kHandRing = kHandTable + 3 * kHandTiles;
+static_assert(kHandRing + 3 * kHandRecs <= kFloodHandWords, "hand-over record");
 constexpr uint32_t kBigCap = 8192;  // seeds per round that can move to the second tier (FloodBuffers::big_list)
 constexpr uint32_t kFlagIncomplete = 1u, kFlagSelfFail = 2u;
 constexpr uint32_t kMaxSteps = 1u << 22;  // safety net of the walk loop: more records than an 8K frame has tile visits
@@ -186,7 +189,9 @@ struct FloodArgs {
     uint32_t big_cap;                                // seeds per round the second tier takes (0: tier switched off)
     uint32_t g_cap;                                  // partial-commit walks stop after this many tile steps
     uint32_t t1_tiles;                               // first tier hands a walk to the second at this many tiles (when there is one)
+    uint32_t* handover;                              // state of the walks handed to the second tier (FloodBuffers::handover)
     uint32_t team_tiles;                             // test hook: the team's table counts as full at this many tiles
+    uint32_t t1_regional, t1_regional_min;           // ... at t1_regional tiles once the frame has sent t1_regional_min walks there
     uint32_t t1_wide_tiles, t1_wide_front;           // ... or at this many tiles when its frontier holds this many records
 };
 // All words but kCtrlGen are set up by flood_init_seeds_kernel every frame; kCtrlGen lives on for the lifetime of
@@ -220,6 +225,7 @@ enum {
     kCtrlWinHold = 17,  // the window stops here while the weakest seeds are held back
     kCtrlWalked = 18,   // [18..19] 64-bit: pixels walked by all explorations of the frame (diagnostics: re-walk factor)
     kCtrlSteps = 20,    // [20..21] 64-bit: tile steps of all explorations
+    kCtrlBigSeen = 22,  // kCtrlBigTotal as it stood when the current round began
     kCtrlWords = 32,
 };
 static_assert(kCtrlWords == kFloodCtrlWords, "control block size");
@@ -857,7 +863,7 @@ __device__ __forceinline__ void stamp_footprint(const FloodArgs& A, uint32_t k, 
 // second tier (big_list) instead of going on in a slab.
 template <class Lds, bool kFirstTier>
 __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& trig, uint32_t k, Lds& L, Pending& P,
-                                             uint32_t* __restrict__ big_list, int lane) {
+                                             uint32_t* __restrict__ big_list, int lane, uint32_t t1_tiles = 0xFFFFFFFFu) {
     const int s = (int)uni((uint32_t)A.seed_idx[k]);
     const int b = (int)uni((uint32_t)A.seed_bin[k]);
     const float thr = __uint_as_float(uni(__float_as_uint(A.seed_thr[k])));
@@ -887,7 +893,7 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
         // (with a second tier behind it, the first hands a walk over at A.t1_tiles tiles, before its table is full: the
         // second tier's team of wavefronts is the faster walker from there on)
         const bool hand_over = kFirstTier && A.big_cap != 0u;
-        rc = walk(A, k, b, thr, sn, cs, L, P, st, lane, own, nullptr, hand_over ? A.t1_tiles : 0xFFFFFFFFu,
+        rc = walk(A, k, b, thr, sn, cs, L, P, st, lane, own, nullptr, hand_over ? t1_tiles : 0xFFFFFFFFu,
                   hand_over ? A.t1_wide_tiles : 0xFFFFFFFFu, hand_over ? A.t1_wide_front : 0xFFFFFFFFu);
     }
     if (kFirstTier && rc != 0 && A.big_cap != 0u) {
@@ -900,6 +906,27 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
                 big_list[pos] = k;
                 A.tier[k] = 1;
                 atomicAdd(&A.ctrl[kCtrlBigTotal], 1u);
+            }
+            // The second tier goes on from where this walk stands (nothing is stamped yet): the walked sets of its tiles
+            // and the frontier records travel with the list entry.  A seed that skipped this tier has nothing to hand over.
+            uint32_t* hb = A.handover + (size_t)pos * kFloodHandWords;
+            const uint32_t nt = skip_first ? 0u : st.ntiles, nr = skip_first ? 0u : st.tail - st.head;
+            if (lane == 0) {
+                hb[0] = nt;
+                hb[1] = nr;
+                hb[2] = st.steps;
+            }
+            for (uint32_t i = (uint32_t)lane; i < nt; i += 64u) {
+                const uint32_t slot = L.ord[i];
+                hb[kHandTable + 3u * i] = L.hk[slot];
+                hb[kHandTable + 3u * i + 1u] = L.hv0[slot];
+                hb[kHandTable + 3u * i + 2u] = L.hv1[slot];
+            }
+            for (uint32_t i = (uint32_t)lane; i < nr; i += 64u) {
+                const uint32_t j = (st.head + i) & (uint32_t)(Lds::kRingN - 1);
+                hb[kHandRing + 3u * i] = L.rt[j];
+                hb[kHandRing + 3u * i + 1u] = L.rlo[j];
+                hb[kHandRing + 3u * i + 2u] = L.rhi[j];
             }
             return;
         }
@@ -1004,6 +1031,11 @@ __device__ __forceinline__ void explore_body(const FloodArgs& A, const BinTrig& 
 #endif
     const int lane = threadIdx.x & 63;
     const uint32_t n_act = uni(A.ctrl[kCtrlNAct]), window = uni(A.ctrl[kCtrlWindow]);
+    // A frame that has sent many walks to the second tier (a natural image: regions, not lines) hands its walks over
+    // earlier from the next round on: their frontiers are wide, which is what the second tier's team is fast on, while
+    // the first tier's rounds last as long as its longest walk.  Frames of thin edges keep the whole first tier: a thin
+    // walk gains nothing from a team, and the tiers' kernels run one after the other.
+    const uint32_t t1_tiles = uni(A.ctrl[kCtrlBigSeen]) >= A.t1_regional_min ? min(A.t1_tiles, A.t1_regional) : A.t1_tiles;
     LdsStore L{s_ring[0], s_ring[1], s_ring[2], s_hash[0], s_hash[1], s_hash[2], s_ord};
     Pending P{s_pend[0], s_pend[1]};
     // The list is walked from its end: the first round's list is in seed order, strongest first, and the longest
@@ -1014,12 +1046,12 @@ __device__ __forceinline__ void explore_body(const FloodArgs& A, const BinTrig& 
         if (ai >= n_act) return;
         const uint32_t k = uni(act[A.from_end ? n_act - 1u - ai : ai]);
         if (k >= window) return;  // not yet in the staged window (stays active)
-        explore_seed<LdsStore, true>(A, trig, k, L, P, big_list, lane);
+        explore_seed<LdsStore, true>(A, trig, k, L, P, big_list, lane, t1_tiles);
     } else {
         for (uint32_t ai = first + uni(blockIdx.x); ai < n_act; ai += gridDim.x) {
             const uint32_t k = uni(act[A.from_end ? n_act - 1u - ai : ai]);
             if (k >= window) continue;
-            explore_seed<LdsStore, true>(A, trig, k, L, P, big_list, lane);
+            explore_seed<LdsStore, true>(A, trig, k, L, P, big_list, lane, t1_tiles);
         }
     }
 }
@@ -1182,7 +1214,7 @@ __device__ __forceinline__ void team_push8(TeamStore& S, uint32_t tile, uint64_t
 // returns 0 when the footprint is complete; 1 when ring or table ran out: *begin_out is then the first ring index that
 // may hold an unprocessed record (processed ones read kVoidTile)
 __device__ int team_walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, float cs, TeamStore& S, int lane,
-                         int wave, bool own, uint32_t* begin_out, uint32_t* steps_out) {
+                         int wave, bool own, uint32_t first_level, uint32_t* begin_out, uint32_t* steps_out) {
     TeamShared* sh = S.sh;
     const int lr = lane >> 3, lc = lane & 7;
     int rx, ry;
@@ -1199,7 +1231,7 @@ __device__ int team_walk(const FloodArgs& A, uint32_t k, int b, float thr, float
     G.off = (uint32_t)(lr * A.w + lc);
     G.roff = (uint32_t)(ry * A.w + rx);
     asm volatile("" : "+v"(G.off), "+v"(G.roff));
-    uint32_t gb = 0u, ge = 1u, steps = 0u, levels = 0u;
+    uint32_t gb = 0u, ge = first_level, steps = 0u, levels = 0u;  // the first level: the seed's record, or the frontier handed over
     int rc = 0;
     for (;;) {
         for (uint32_t i = gb + (uint32_t)wave; i < ge; i += kTeamWaves) {
@@ -1294,23 +1326,45 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
             S.hv0[i] = 0u;
             S.hv1[i] = 0u;
         }
+        // what the first tier handed over with this entry (A.big_cap entries at most, so ai is its position in the list)
+        const uint32_t* hb = A.handover + (size_t)ai * kFloodHandWords;
+        const uint32_t h_tiles = min(uni(hb[0]), kHandTiles), h_recs = min(uni(hb[1]), kHandRecs);
+        const uint32_t first_level = h_recs ? h_recs : 1u;
+        __syncthreads();  // (table cleared)
+        if (h_recs) {
+            for (uint32_t t = threadIdx.x; t < h_tiles; t += 64u * kTeamWaves) {
+                const uint32_t key = hb[kHandTable + 3u * t];
+                uint32_t hs = (key * 2654435761u) >> TeamStore::kHashShift;
+                while (atomicCAS(&S.hk[hs], 0u, key) != 0u) hs = (hs + 1u) & (uint32_t)(kHashBig - 1);  // (the tiles are distinct)
+                S.hv0[hs] = hb[kHandTable + 3u * t + 1u];
+                S.hv1[hs] = hb[kHandTable + 3u * t + 2u];
+                S.ord[t] = (uint16_t)hs;
+            }
+            for (uint32_t t = threadIdx.x; t < h_recs; t += 64u * kTeamWaves) {
+                S.rt[t] = hb[kHandRing + 3u * t];
+                S.rlo[t] = hb[kHandRing + 3u * t + 1u];
+                S.rhi[t] = hb[kHandRing + 3u * t + 2u];
+            }
+        }
         if (threadIdx.x == 0) {
-            const int sr = s / A.w, sc = s - sr * A.w;
-            const uint64_t m = 1ull << ((sr & 7) * 8 + (sc & 7));
-            S.rt[0] = ((uint32_t)(sr >> 3) << 16) | (uint32_t)(sc >> 3);
-            S.rlo[0] = (uint32_t)m;
-            S.rhi[0] = (uint32_t)(m >> 32);
-            sh->tail = 1u;
-            sh->end = 1u;
-            sh->ntiles = 0u;
+            if (!h_recs) {
+                const int sr = s / A.w, sc = s - sr * A.w;
+                const uint64_t m = 1ull << ((sr & 7) * 8 + (sc & 7));
+                S.rt[0] = ((uint32_t)(sr >> 3) << 16) | (uint32_t)(sc >> 3);
+                S.rlo[0] = (uint32_t)m;
+                S.rhi[0] = (uint32_t)(m >> 32);
+            }
+            sh->tail = first_level;
+            sh->end = first_level;
+            sh->ntiles = h_recs ? h_tiles : 0u;
             sh->blocked = 0u;
             sh->overflow = 0u;
             sh->cnt = 0u;
-            sh->steps = 0u;
+            sh->steps = h_recs ? hb[2] : 0u;
         }
         __syncthreads();
         uint32_t begin = 0u, my_steps = 0u;
-        int rc = team_walk(A, k, b, thr, sn, cs, S, lane, wave, own, &begin, &my_steps);
+        int rc = team_walk(A, k, b, thr, sn, cs, S, lane, wave, own, first_level, &begin, &my_steps);
         // (team_walk ends behind a barrier: every wavefront sees the final table)
         WalkState st{0u, 0u, 0u, sh->ntiles, false, 0u, 0u};
         stamp_footprint(A, k, S, st, lane, (uint32_t)wave * 8u, 8u * kTeamWaves);
@@ -1508,6 +1562,7 @@ __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift) {
     ctrl[kCtrlBarrier] = 0xFFFFFFFFu;
     ctrl[kCtrlSlabs] = 0u;
     ctrl[kCtrlNBig] = 0u;
+    ctrl[kCtrlBigSeen] = ld_agent(&ctrl[kCtrlBigTotal]);
 }
 
 // (Commit pass and survivors pass in ONE launch -- blocked marks in two alternating buffers, counts and flags written
@@ -1631,6 +1686,7 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
         ctrl[kCtrlBelow] = 0u;
         ctrl[kCtrlNBig] = 0u;
         ctrl[kCtrlBigTotal] = 0u;
+        ctrl[kCtrlBigSeen] = 0u;
         ctrl[kCtrlSlabTotal] = 0u;
         ctrl[kCtrlBarrier] = 0xFFFFFFFFu;
         ctrl[kCtrlSlabs] = 0u;
@@ -1872,7 +1928,12 @@ FloodArgs flood_args(const FloodBuffers& B, const FloodFrame& F, bool use_big) {
     A.big_cap = use_big ? big_cap : 0u;
     static const int t1_env = std::getenv("LIBRECTIFY_FLOOD_T1_TILES") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_T1_TILES")) : 0;
     A.team_tiles = B.team_tile_cap ? B.team_tile_cap : 0xFFFFFFFFu;
+    A.handover = B.handover;
     A.t1_tiles = t1_env > 8 ? (uint32_t)t1_env : 0xFFFFFFFFu;
+    static const int t1r_env = std::getenv("LIBRECTIFY_FLOOD_T1_REGIONAL") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_T1_REGIONAL")) : 48;
+    static const int t1m_env = std::getenv("LIBRECTIFY_FLOOD_T1_REGIONAL_MIN") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_T1_REGIONAL_MIN")) : 16;
+    A.t1_regional = t1r_env > 8 ? (uint32_t)t1r_env : 0xFFFFFFFFu;
+    A.t1_regional_min = (uint32_t)std::max(t1m_env, 1);
     static const int t1w_env = std::getenv("LIBRECTIFY_FLOOD_T1_WIDE_TILES") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_T1_WIDE_TILES")) : 0;
     static const int t1f_env = std::getenv("LIBRECTIFY_FLOOD_T1_WIDE_FRONT") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_T1_WIDE_FRONT")) : 6;
     A.t1_wide_tiles = t1w_env > 0 ? (uint32_t)t1w_env : 0xFFFFFFFFu;
@@ -2004,7 +2065,8 @@ int flood_finish(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, u
     A.win_shift = (uint32_t)P->win_growth;
     while (h_ctrl[kCtrlNAct] != 0u) {
         *extra = true;
-        if (g_flood_debug)
+        static const bool call_debug = std::getenv("LIBRECTIFY_CALL_DEBUG") != nullptr;
+        if (g_flood_debug || call_debug)
             std::fprintf(stderr, "flood after %d rounds enqueued: %u done, active %u, remain %u, stall %u\n", P->enqueued,
                          h_ctrl[kCtrlRounds], h_ctrl[kCtrlNAct], h_ctrl[kCtrlNRemain], h_ctrl[kCtrlStall]);
         if (!P->use_big && B.second_tier && h_ctrl[kCtrlSlabTotal] > 0u) {  // long walks after all: second tier from now on
