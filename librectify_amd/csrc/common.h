@@ -141,10 +141,9 @@ struct FloodBuffers {
     // footprint that no lower seed can reach.  LIBRECTIFY_FLOOD_PARTIAL=0 switches them off (comparison).
     bool partial_commits = true;
     bool second_tier = true;  // test hook: without it every walk that outgrows the first tier goes to a slab
-    // The second-tier kernel asks for 41 KB of LDS per workgroup: launched every round for nothing it waits behind
-    // other frames' walks (44 us per launch with 16 frames in flight).  So a flood starts WITH it only if the
-    // context's previous frame needed it (or there was none), and turns it on at the next look at the control block
-    // once a walk has had to go to a slab.
+    // Whether a flood starts with the second tier or only turns it on once a walk has had to go to a slab.  Since round 3
+    // the context always asks for it from the start (context.hip, finish_flood: a frame of regions after a frame of lines
+    // otherwise runs its long walks in slabs, 6.4 instead of 1.7 ms of flood at 4K; an empty launch costs a round 5 us).
     bool second_tier_from_start = true;
     // Likewise the hold-back: if the context's previous frame engaged it, this frame starts with it (a round of very
     // long walks saved); otherwise it engages after the first full round that shows such walks.

@@ -683,8 +683,21 @@ int finish_flood(lr_context* c, bool* extra) {
     if (flood_finish(flood_buffers_for(c), flood_frame_for(c), &c->flood_prog, c->h_counts + 16, &c->flood_rounds,
                      c->flood_tiers, extra, c->stream))
         return 1;
-    c->flood_big_hint = c->flood_tiers[0] > 0 || c->flood_tiers[1] > 0;
-    c->flood_hold_hint = c->flood_tiers[3] != 0;
+    static const int hints_env = std::getenv("LIBRECTIFY_FLOOD_HINTS") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_HINTS")) : 1;  // (experiment knob)
+    if (hints_env == 0) {  // as in round 2
+        c->flood_big_hint = c->flood_tiers[0] > 0 || c->flood_tiers[1] > 0;
+        c->flood_hold_hint = c->flood_tiers[3] != 0;
+    } else {
+        // The second tier is always there: a frame of regions that follows a frame of lines on this context used to run its
+        // first batch of rounds without it, every long walk in a global slab (6.4 instead of 1.5 ms of flood on the natural
+        // 4K frame), and an empty launch of its kernel costs a round 5 us.  The hold-back starts with the frame only after a
+        // frame of REGIONS (many walks beyond the first tier's table): engaged from the start on a frame of lines it costs
+        // three rounds (1.55 instead of 1.10 ms), and the old rule -- "the last frame engaged it" -- kept itself alive from
+        // frame to frame once a single frame had.
+        c->flood_big_hint = true;
+        c->flood_hold_hint = c->flood_tiers[3] != 0 && c->flood_tiers[8] >= 16;
+    }
+
     // blind rounds of the next frame: what this one needed plus two, decaying slowly
     static const int blind_extra = std::getenv("LIBRECTIFY_BLIND_EXTRA") ? std::atoi(std::getenv("LIBRECTIFY_BLIND_EXTRA")) : 2;  // (experiment knob)
     static const int blind_min = std::getenv("LIBRECTIFY_BLIND_MIN") ? std::atoi(std::getenv("LIBRECTIFY_BLIND_MIN")) : 6;

@@ -225,7 +225,8 @@ enum {
     kCtrlWinHold = 17,  // the window stops here while the weakest seeds are held back
     kCtrlWalked = 18,   // [18..19] 64-bit: pixels walked by all explorations of the frame (diagnostics: re-walk factor)
     kCtrlSteps = 20,    // [20..21] 64-bit: tile steps of all explorations
-    kCtrlBigSeen = 22,  // kCtrlBigTotal as it stood when the current round began
+    kCtrlBigSeen = 22,  // kCtrlBigLong as it stood when the current round began
+    kCtrlBigLong = 23,  // walks of the frame that really outgrew the first tier (more tiles than its table holds)
     kCtrlWords = 32,
 };
 static_assert(kCtrlWords == kFloodCtrlWords, "control block size");
@@ -1429,6 +1430,9 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
             A.count[k] = st.cnt;
             if (st.blocked) A.blocked[k] = 1u;
             A.flags[k] |= st.steps << 8;
+            // (what makes a frame "regional", explore_body: walks the first tier could not have held, however early they
+            // were handed over)
+            if (st.ntiles > kHandTiles) atomicAdd(&A.ctrl[kCtrlBigLong], 1u);
         }
     }
 }
@@ -1562,7 +1566,7 @@ __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift) {
     ctrl[kCtrlBarrier] = 0xFFFFFFFFu;
     ctrl[kCtrlSlabs] = 0u;
     ctrl[kCtrlNBig] = 0u;
-    ctrl[kCtrlBigSeen] = ld_agent(&ctrl[kCtrlBigTotal]);
+    ctrl[kCtrlBigSeen] = ld_agent(&ctrl[kCtrlBigLong]);
 }
 
 // (Commit pass and survivors pass in ONE launch -- blocked marks in two alternating buffers, counts and flags written
@@ -1686,6 +1690,7 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
         ctrl[kCtrlBelow] = 0u;
         ctrl[kCtrlNBig] = 0u;
         ctrl[kCtrlBigTotal] = 0u;
+        ctrl[kCtrlBigLong] = 0u;
         ctrl[kCtrlBigSeen] = 0u;
         ctrl[kCtrlSlabTotal] = 0u;
         ctrl[kCtrlBarrier] = 0xFFFFFFFFu;
@@ -2110,6 +2115,7 @@ int flood_finish(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, u
         tiers_out[5] = h_ctrl[kCtrlWalked + 1];
         tiers_out[6] = h_ctrl[kCtrlSteps];
         tiers_out[7] = h_ctrl[kCtrlSteps + 1];
+        tiers_out[8] = h_ctrl[kCtrlBigLong];
     }
     return 0;
 }
