@@ -308,6 +308,36 @@ def single_frame_rates(L, ctx, frames, min_length):
     return out
 
 
+def natural_frame_rates(L, ctx):
+    """A NATURAL image at 4K next to the synthetic bench frames: the reference's own doc image (tests/golden/
+    doc_image_gray.npy, the luma of doc/image.jpg) upsampled to 3840x2160 with a cubic spline.  Its floods are regions,
+    not lines (walks of hundreds of tiles: second storage tier, hold-back of the weakest seeds), which is what the
+    library's users feed it.  One frame at a time through the frame call, from a pageable buffer."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "doc_image_gray.npy")
+    try:
+        import scipy.ndimage as ndi
+        g = np.load(path).astype(np.float32) / np.float32(256.0)
+    except Exception as e:  # (scipy or the fixture missing: not a failure of the bench)
+        return {"skipped": repr(e)}
+    w, h = W4K, H4K
+    img = np.ascontiguousarray(ndi.zoom(g, (h / g.shape[0], w / g.shape[1]), order=3).astype(np.float32)[:h, :w])
+    ctx.set_stage_timing(True)
+    wall, flood = [], []
+    for rep in range(5):
+        t0 = time.perf_counter()
+        lines = ctx.find_line_segment_groups(img, float(max(w, h)) / 100.0)
+        dt = time.perf_counter() - t0
+        if rep > 1:
+            wall.append(dt)
+            flood.append(float(ctx.stage_times()[L.T_FLOOD]))
+    c = ctx.stage_counters()
+    ctx.set_stage_timing(False)
+    return {"frame": "doc image upsampled to %dx%d (cubic spline)" % (w, h), "wall_ms": round(float(np.mean(wall)) * 1e3, 4),
+            "Mpix_per_s": round(w * h / float(np.mean(wall)) / 1e6, 2), "flood_ms": round(float(np.mean(flood)), 4),
+            "lines": int(len(lines)), "seeds": c["seeds"], "components": c["components"], "flood_rounds": c["flood_rounds"],
+            "second_tier_walks": c["second_tier_seeds"], "walked_per_labelled": round(c.get("walked_px", 0) / max(1, c["labelled_px"]), 3)}
+
+
 def flood_rates(L, ctx, frames):
     """The ordered flood (filter.cpp:110-153, line_detector.cpp:92-122) of the bench frames, one frame at a time through
     the frame call: device ms of the flood stage, labelled component pixels per second, and how many pixels the rounds
@@ -690,6 +720,7 @@ def main(argv=None):
             if args.config == "frames4k" and wl.B:
                 res["single_frame"] = single_frame_rates(L, ctx, wl.pageable[: min(4, wl.B)], wl.min_length)
                 res["flood"] = flood_rates(L, ctx, wl.pageable[: min(4, wl.B)])
+                res["natural_frame"] = natural_frame_rates(L, ctx)
             res["roofline_8k"] = roofline_8k(L, ctx, torch, dev, wl.pageable[0] if wl.B and (wl.w, wl.h) == (W4K, H4K) else None)
         if not args.no_cpu_baseline and n_gpus == 1 and wl.B:
             res["cpu_baseline"] = cpu_baseline(wl.pageable[:2], w, h, wl.min_length)

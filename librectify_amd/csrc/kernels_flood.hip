@@ -1107,8 +1107,14 @@ __global__ __launch_bounds__(64) void flood_explore_big_kernel(FloodArgs A, BinT
 #define LR_TEAM_WAVES 8
 #endif
 constexpr int kTeamWaves = LR_TEAM_WAVES;
-constexpr int kRingTeam = 2048;
-constexpr uint32_t kTeamGrid = 512;  // workgroups; each strides over the round's second-tier list
+#ifndef LR_TEAM_RING
+#define LR_TEAM_RING 1024
+#endif
+constexpr int kRingTeam = LR_TEAM_RING;
+#ifndef LR_TEAM_GRID
+#define LR_TEAM_GRID 128
+#endif
+constexpr uint32_t kTeamGrid = LR_TEAM_GRID;  // workgroups; each strides over the round's second-tier list
 constexpr uint32_t kVoidTile = 0xFFFFFFFFu;
 
 struct TeamShared {

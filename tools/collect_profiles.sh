@@ -20,5 +20,7 @@ python3 tools/run8k.py > $O/${R}_config5_8k.txt 2>&1
 bash tools/single_frame_trace.sh $O/sft 1 2 3 4 > $O/${R}_single_frame_timeline.txt 2>&1; cp $O/sft/run.txt $O/${R}_single_frame.txt; cp $O/sft/kernel_stats.csv $O/${R}_kernel_stats_single_frames.csv; rm -rf $O/sft
 python3 tools/single_call_sweep.py 8 > $O/${R}_single_call.txt 2>&1
 python3 tools/bench_ransac.py > $O/${R}_ransac_cht_rates.txt 2>&1
+bash tools/trace_doc4k.sh $O/doc > $O/${R}_natural_frame_timeline.txt 2>&1; rm -rf $O/doc
+python3 tools/run_mixed.py > $O/${R}_mixed_frames.txt 2>&1
 
 ls -la $O
