@@ -191,7 +191,7 @@ struct FloodArgs {
     uint32_t t1_tiles;                               // first tier hands a walk to the second at this many tiles (when there is one)
     uint32_t* handover;                              // state of the walks handed to the second tier (FloodBuffers::handover)
     uint32_t team_tiles;                             // test hook: the team's table counts as full at this many tiles
-    uint32_t t1_regional, t1_regional_min;           // ... at t1_regional tiles once the frame has sent t1_regional_min walks there
+    uint32_t t1_regional, t1_regional_min;           // ... at t1_regional tiles once the frame has had t1_regional_min WIDE walks there (flood_advance)
     uint32_t t1_wide_tiles, t1_wide_front;           // ... or at this many tiles when its frontier holds this many records
 };
 // All words but kCtrlGen are set up by flood_init_seeds_kernel every frame; kCtrlGen lives on for the lifetime of
@@ -225,8 +225,9 @@ enum {
     kCtrlWinHold = 17,  // the window stops here while the weakest seeds are held back
     kCtrlWalked = 18,   // [18..19] 64-bit: pixels walked by all explorations of the frame (diagnostics: re-walk factor)
     kCtrlSteps = 20,    // [20..21] 64-bit: tile steps of all explorations
-    kCtrlBigSeen = 22,  // kCtrlBigLong as it stood when the current round began
+    kCtrlBigSeen = 22,  // the verdict "frame of regions" on kCtrlBigLong / kCtrlBigWide as they stood when the current round began
     kCtrlBigLong = 23,  // walks of the frame that really outgrew the first tier (more tiles than its table holds)
+    kCtrlBigWide = 24,  // ... and took eight tiles and more to a level of their footprint (regions, not lines)
     kCtrlWords = 32,
 };
 static_assert(kCtrlWords == kFloodCtrlWords, "control block size");
@@ -1032,11 +1033,11 @@ __device__ __forceinline__ void explore_body(const FloodArgs& A, const BinTrig& 
 #endif
     const int lane = threadIdx.x & 63;
     const uint32_t n_act = uni(A.ctrl[kCtrlNAct]), window = uni(A.ctrl[kCtrlWindow]);
-    // A frame that has sent many walks to the second tier (a natural image: regions, not lines) hands its walks over
-    // earlier from the next round on: their frontiers are wide, which is what the second tier's team is fast on, while
-    // the first tier's rounds last as long as its longest walk.  Frames of thin edges keep the whole first tier: a thin
-    // walk gains nothing from a team, and the tiers' kernels run one after the other.
-    const uint32_t t1_tiles = uni(A.ctrl[kCtrlBigSeen]) >= A.t1_regional_min ? min(A.t1_tiles, A.t1_regional) : A.t1_tiles;
+    // A frame whose long walks are WIDE (a natural image: regions, not lines; the verdict is flood_advance's, on what the
+    // second tier's teams have counted) hands its walks over earlier from the next round on: wide frontiers are what a
+    // team is fast on, while the first tier's rounds last as long as its longest walk.  Frames of lines and of long bars
+    // keep the whole first tier: a thin walk gains nothing from a team, and the tiers' kernels run one after the other.
+    const uint32_t t1_tiles = uni(A.ctrl[kCtrlBigSeen]) != 0u ? min(A.t1_tiles, A.t1_regional) : A.t1_tiles;
     LdsStore L{s_ring[0], s_ring[1], s_ring[2], s_hash[0], s_hash[1], s_hash[2], s_ord};
     Pending P{s_pend[0], s_pend[1]};
     // The list is walked from its end: the first round's list is in seed order, strongest first, and the longest
@@ -1221,7 +1222,8 @@ __device__ __forceinline__ void team_push8(TeamStore& S, uint32_t tile, uint64_t
 // returns 0 when the footprint is complete; 1 when ring or table ran out: *begin_out is then the first ring index that
 // may hold an unprocessed record (processed ones read kVoidTile)
 __device__ int team_walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, float cs, TeamStore& S, int lane,
-                         int wave, bool own, uint32_t first_level, uint32_t* begin_out, uint32_t* steps_out) {
+                         int wave, bool own, uint32_t first_level, uint32_t* begin_out, uint32_t* steps_out,
+                         uint32_t* levels_out) {
     TeamShared* sh = S.sh;
     const int lr = lane >> 3, lc = lane & 7;
     int rx, ry;
@@ -1296,9 +1298,18 @@ __device__ int team_walk(const FloodArgs& A, uint32_t k, int b, float thr, float
     }
     *begin_out = gb;
     *steps_out = steps;
+    *levels_out = levels;
     return rc;
 }
 
+// (The same walk WITHOUT levels -- the ring as a queue: a wavefront claims the record at the head by compare-and-swap, waits
+// for its slot to be written, walks the tile, appends, comes back; head and the number of record holders in one word, so
+// that "queue empty and nobody holds a record" is one read -- was built, is exact, and is slower: natural 4K frame 1.67 ms
+// of flood against 1.51, and walks handed over at 160 tiles still cost the synthetic frames 0.1-0.6 ms
+// (profiles/r03_flood_team_queue_variant.txt): a claimed step is 3-4 us -- poll, claim, slot, lookup, two atomic ORs, append,
+// all LDS round trips in a chain -- against 1.4 us for a step of the single-wavefront walk, which keeps that chain in
+// registers.  A first version counted the wavefronts "trying to claim" in a counter of its own: three and more idle
+// wavefronts then kept each other waiting for ever, each finding another in the middle of its attempt.  Not in the tree.)
 constexpr size_t kTeamLdsBytes = (size_t)(3 * kRingTeam + 3 * kHashBig + 2 * kPend) * 4 + (size_t)kHashBig * 2 + sizeof(TeamShared);
 __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(FloodArgs A, BinTrig trig,
                                                                              uint32_t* __restrict__ big_list) {
@@ -1370,8 +1381,9 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
             sh->steps = h_recs ? hb[2] : 0u;
         }
         __syncthreads();
-        uint32_t begin = 0u, my_steps = 0u;
-        int rc = team_walk(A, k, b, thr, sn, cs, S, lane, wave, own, first_level, &begin, &my_steps);
+        uint32_t begin = 0u, my_steps = 0u, levels = 0u;
+        const uint32_t steps_before = h_recs ? uni(hb[2]) : 0u;
+        int rc = team_walk(A, k, b, thr, sn, cs, S, lane, wave, own, first_level, &begin, &my_steps, &levels);
         // (team_walk ends behind a barrier: every wavefront sees the final table)
         WalkState st{0u, 0u, 0u, sh->ntiles, false, 0u, 0u};
         stamp_footprint(A, k, S, st, lane, (uint32_t)wave * 8u, 8u * kTeamWaves);
@@ -1436,9 +1448,14 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
             A.count[k] = st.cnt;
             if (st.blocked) A.blocked[k] = 1u;
             A.flags[k] |= st.steps << 8;
-            // (what makes a frame "regional", explore_body: walks the first tier could not have held, however early they
-            // were handed over)
-            if (st.ntiles > kHandTiles) atomicAdd(&A.ctrl[kCtrlBigLong], 1u);
+            // What makes a frame "regional" (explore_body): walks the first tier could not have held, however early they were
+            // handed over (kCtrlBigLong), a good part of which ran eight tiles and more to a level (kCtrlBigWide).  The natural
+            // 4K frame: 13 of 40 (7 of 33 when its weakest seeds are held back from the start); a frame of long bars, as many
+            // tiles a walk but few to a level: 9 of 290 (0 of 72); the synthetic bench frames: none.
+            if (st.ntiles > kHandTiles) {
+                atomicAdd(&A.ctrl[kCtrlBigLong], 1u);
+                if (sh->steps - steps_before >= 8u * levels) atomicAdd(&A.ctrl[kCtrlBigWide], 1u);
+            }
         }
     }
 }
@@ -1527,7 +1544,7 @@ __global__ __launch_bounds__(256) void flood_commit_pixels_kernel(FloodArgs A, u
 
 // End of a round (one thread: the last workgroup of the survivors pass): the next list becomes the current one.  A round without progress (possible only
 // when storage ran out on the lowest active seed) stops the rounds and leaves the rest to the ordered tail.
-__device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift) {
+__device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift, uint32_t regional_min) {
     const uint32_t n_act = ld_agent(&ctrl[kCtrlNAct]);
     if (n_act == 0u) return;
     const uint32_t n_seeds = ld_agent(&ctrl[kCtrlNSeeds]), win_hold = ld_agent(&ctrl[kCtrlWinHold]);
@@ -1572,7 +1589,10 @@ __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift) {
     ctrl[kCtrlBarrier] = 0xFFFFFFFFu;
     ctrl[kCtrlSlabs] = 0u;
     ctrl[kCtrlNBig] = 0u;
-    ctrl[kCtrlBigSeen] = ld_agent(&ctrl[kCtrlBigLong]);
+    {
+        const uint32_t n_long = ld_agent(&ctrl[kCtrlBigLong]), n_wide = ld_agent(&ctrl[kCtrlBigWide]);
+        ctrl[kCtrlBigSeen] = (n_wide >= regional_min && n_wide * 8u >= n_long) ? 1u : 0u;
+    }
 }
 
 // (Commit pass and survivors pass in ONE launch -- blocked marks in two alternating buffers, counts and flags written
@@ -1664,7 +1684,7 @@ __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, const
         if (atomicAdd(&A.ctrl[kCtrlDone], 1u) == gridDim.x - 1u) {
             __threadfence();
             A.ctrl[kCtrlDone] = 0u;
-            flood_advance(A.ctrl, A.win_shift);
+            flood_advance(A.ctrl, A.win_shift, A.t1_regional_min);
         }
     }
 }
@@ -1697,6 +1717,7 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
         ctrl[kCtrlNBig] = 0u;
         ctrl[kCtrlBigTotal] = 0u;
         ctrl[kCtrlBigLong] = 0u;
+        ctrl[kCtrlBigWide] = 0u;
         ctrl[kCtrlBigSeen] = 0u;
         ctrl[kCtrlSlabTotal] = 0u;
         ctrl[kCtrlBarrier] = 0xFFFFFFFFu;
@@ -1942,7 +1963,7 @@ FloodArgs flood_args(const FloodBuffers& B, const FloodFrame& F, bool use_big) {
     A.handover = B.handover;
     A.t1_tiles = t1_env > 8 ? (uint32_t)t1_env : 0xFFFFFFFFu;
     static const int t1r_env = std::getenv("LIBRECTIFY_FLOOD_T1_REGIONAL") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_T1_REGIONAL")) : 48;
-    static const int t1m_env = std::getenv("LIBRECTIFY_FLOOD_T1_REGIONAL_MIN") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_T1_REGIONAL_MIN")) : 16;
+    static const int t1m_env = std::getenv("LIBRECTIFY_FLOOD_T1_REGIONAL_MIN") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_T1_REGIONAL_MIN")) : 4;
     A.t1_regional = t1r_env > 8 ? (uint32_t)t1r_env : 0xFFFFFFFFu;
     A.t1_regional_min = (uint32_t)std::max(t1m_env, 1);
     static const int t1w_env = std::getenv("LIBRECTIFY_FLOOD_T1_WIDE_TILES") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_T1_WIDE_TILES")) : 0;
@@ -2122,6 +2143,7 @@ int flood_finish(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, u
         tiers_out[6] = h_ctrl[kCtrlSteps];
         tiers_out[7] = h_ctrl[kCtrlSteps + 1];
         tiers_out[8] = h_ctrl[kCtrlBigLong];
+        tiers_out[9] = h_ctrl[kCtrlBigWide];
     }
     return 0;
 }

@@ -12,7 +12,7 @@ B = 32
 frames = np.stack([base + rng.normal(0, 0.002, base.shape).astype(np.float32) for _ in range(4)] * (B // 4))
 ctx = L.Context(0)
 ctx.set_seed(0)
-ctx.set_batch_streams(16)
+ctx.set_batch_streams(int(sys.argv[1]) if len(sys.argv) > 1 else 6)
 d = ctx.device_upload(frames)
 for rep in range(4):
     t = time.time()

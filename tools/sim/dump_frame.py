@@ -20,6 +20,21 @@ def main():
         img = synth.frame(w, h, seed)
     elif kind == "tiled":
         img = synth.frame(w, h, seed, bars=int(sys.argv[6]), tile=512)
+    elif kind == "long":  # the long-edge stress frame of tools/run_long.py
+        rng = np.random.RandomState(seed)
+        img = np.full((h, w), 0.5, np.float64)
+        yy, xx = np.mgrid[0:h, 0:w]
+        for _ in range(60):
+            c = np.array([rng.uniform(0.3, 0.7) * w, rng.uniform(0.1, 0.9) * h])
+            ang = rng.uniform(-0.25, 0.25) + (np.pi / 2 if rng.rand() < 0.3 else 0.0)
+            d = np.array([np.cos(ang), np.sin(ang)]); nrm = np.array([-d[1], d[0]])
+            length = rng.uniform(0.5, 0.95) * (w if abs(d[0]) > 0.7 else h)
+            half_w = rng.uniform(3.0, 12.0)
+            contrast = rng.uniform(0.1, 0.4) * (1 if rng.rand() < 0.5 else -1)
+            px, py = xx - c[0], yy - c[1]
+            m = (np.abs(px * d[0] + py * d[1]) <= length / 2) & (np.abs(px * nrm[0] + py * nrm[1]) <= half_w)
+            img[m] += contrast
+        img = (synth._gauss_blur(np.clip(img, 0, 1), 1.0) + rng.normal(0, 0.005, size=img.shape)).astype(np.float32)
     elif kind == "doc":  # the natural 4K frame of tools/run_doc4k.py
         import scipy.ndimage as ndi
         g = np.load(os.path.join(ROOT, "tests", "golden", "doc_image_gray.npy")).astype(np.float32) / np.float32(256.0)

@@ -43,6 +43,7 @@ struct Walk {
     std::vector<int> px;
     int tiles = 0;
     int par[4] = {0, 0, 0, 0};  // steps of the walk's critical path with 1, 2, 4, 8 wavefronts on its frontier (g_par)
+    int levels = 0;             // tile levels of the footprint, breadth-first from the seed's tile
 };
 static bool g_par = false;
 
@@ -108,7 +109,9 @@ static void footprint(int k, const std::vector<uint8_t>& dm, Walk& out) {
     std::vector<int> lvl(adj.size(), -1), cur{id[tile_of(s)]}, nxt;
     lvl[cur[0]] = 0;
     for (int w = 0; w < 4; ++w) out.par[w] = 0;
+    out.levels = 0;
     while (!cur.empty()) {
+        out.levels++;
         for (int w = 0; w < 4; ++w) out.par[w] += ((int)cur.size() + (1 << w) - 1) >> w;
         nxt.clear();
         for (int a : cur)
@@ -143,12 +146,18 @@ struct RoundStat {
     long walked_px = 0, steps = 0;
     int par[4] = {0, 0, 0, 0};
     long same_steps = 0;
+    int width_hist[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int same_walks = 0, longest_changed = 0;
     int longest = 0, longest_commit = 0, n_walk = 0, n_commit = 0, n_dead = 0, n_active = 0, phases = 1, longest_sum = 0;
 };
 
 static void print_round(int r, const RoundStat& s) {
     if (g_par) printf("round %d: %d walks (%ld steps) have the footprint of the round before; longest walk among the others %d\n", r, s.same_walks, s.same_steps, s.longest_changed);
+    if (g_par) {
+        printf("round %d: walks of more than 190 tiles by tiles per level (1, 2, ... 9+):", r);
+        for (int i = 1; i < 10; ++i) printf(" %d", s.width_hist[i]);
+        printf("\n");
+    }
     if (g_par) printf("round %d: longest walk on 1 / 2 / 4 / 8 wavefronts: %d / %d / %d / %d steps\n", r, s.par[0], s.par[1], s.par[2], s.par[3]);
     printf("round %d: active %d, walked %d seeds, %ld px in %ld steps, longest walk %d (committing: %d), sum of per-phase longest %d, phases %d; commit %d, dead %d\n", r,
            s.n_active, s.n_walk, s.walked_px, s.steps, s.longest, s.longest_commit, s.longest_sum, s.phases, s.n_commit, s.n_dead);
@@ -597,6 +606,10 @@ int main(int argc, char** argv) {
             rs.steps += fp[k].tiles;
             rs.longest = std::max(rs.longest, fp[k].tiles);
             for (int w = 0; w < 4; ++w) rs.par[w] = std::max(rs.par[w], fp[k].par[w]);
+            if (g_par && fp[k].tiles > 190) {  // tiles per level of the walks beyond the first storage tier
+                const int r = std::min(9, fp[k].tiles / std::max(1, fp[k].levels));
+                rs.width_hist[r]++;
+            }
             for (int p : fp[k].px) {
                 if (stamp[p] == INF) touched.push_back(p);
                 stamp[p] = std::min(stamp[p], k);
