@@ -605,6 +605,14 @@ def main(argv=None):
                 ctx.host_free(wl.pinned)
                 wl.pinned = None
             torch.cuda.empty_cache()
+            if world == 1 and args.frames < 256:
+                # The same workload in calls of 256 frames: every batch call has a ramp (the first frames' uploads) and a
+                # tail (the last frames on ever fewer lanes) of about one frame's latency, 6 ms of a 56 ms call of 64 frames.
+                w3 = Workload(wl.w, wl.h, 256, 1 + 100 * rank, 4, 8192, False)
+                w3.step("pageable")
+                e = timed(lambda: w3.step("pageable"), 2)
+                extra["pageable_256_per_call"] = round(256 * wl.w * wl.h * 2 / e / 1e6, 3)
+                del w3
             w2, nt2 = make_batch1080()
             w2.step("pageable", nt2)
             e = timed(lambda: w2.step("pageable", nt2), 2)
@@ -675,6 +683,7 @@ def main(argv=None):
                 "host_pageable": extra.get("pageable"),
                 "host_pinned": extra.get("pinned"),
                 "device_resident": extra.get("device"),
+                "host_pageable_256_frames_per_call": extra.get("pageable_256_per_call"),
             },
             "config4_batch1080": extra.get("config4_batch1080"),
             "roofline": {

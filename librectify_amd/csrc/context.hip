@@ -325,14 +325,15 @@ struct StagingCrew {
             });
     }
     // stages one frame (rows as in upload_rows) and enqueues its transfers; returns when every band is enqueued
-    int run(float* dst_, float* stage_, const float* buffer, int w_, int h_, int stride_, hipStream_t up_) {
-        const uint32_t g = begin(dst_, stage_, buffer, w_, h_, stride_, up_, nullptr, nullptr);
+    int run(float* dst_, float* stage_, const float* buffer, int w_, int h_, int stride_, hipStream_t up_,
+            size_t band_bytes = (size_t)4 << 20, int pieces_ = 1) {
+        const uint32_t g = begin(dst_, stage_, buffer, w_, h_, stride_, up_, nullptr, nullptr, band_bytes, pieces_);
         work(g);
         return finish();
     }
     // the two halves of run(): publish the job (the helpers start on it), and wait for its last band
     uint32_t begin(float* dst_, float* stage_, const float* buffer, int w_, int h_, int stride_, hipStream_t up_,
-                   hipEvent_t* band_ev_, std::atomic<int>* ready_, size_t band_bytes = (size_t)4 << 20) {
+                   hipEvent_t* band_ev_, std::atomic<int>* ready_, size_t band_bytes = (size_t)4 << 20, int pieces_ = 0) {
         if (stride_ < 0) {
             buffer = buffer + (std::ptrdiff_t)(h_ - 1) * stride_;
             stride_ = -stride_;
@@ -354,7 +355,7 @@ struct StagingCrew {
             j.rows_per_band = (h_ + kMaxBands - 1) / kMaxBands;
             j.n_bands = (h_ + j.rows_per_band - 1) / j.rows_per_band;
         }
-        j.pieces = band_ev_ ? kPieces : 1;  // (band events = the single-frame path)
+        j.pieces = pieces_ > 0 ? std::min(pieces_, kPieces) : (band_ev_ ? kPieces : 1);  // (band events = the single-frame path)
         for (int k = 0; k < j.n_bands; ++k) pieces_left[g & 1u][k].store(j.pieces, std::memory_order_relaxed);
         failed.store(0, std::memory_order_relaxed);  // (per frame: every band of the previous one has been accounted for)
         bands_left.store(j.n_bands, std::memory_order_relaxed);
@@ -2037,6 +2038,7 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
     for (auto& a : enq) a.store(0, std::memory_order_relaxed);
     for (auto& a : slot_busy) a.store(0, std::memory_order_relaxed);
     static const bool lane_debug = std::getenv("LIBRECTIFY_LANE_DEBUG") != nullptr;
+    static const size_t batch_band = std::getenv("LIBRECTIFY_BATCH_BAND_KB") ? (size_t)std::max(64, std::atoi(std::getenv("LIBRECTIFY_BATCH_BAND_KB"))) << 10 : (size_t)4 << 20;
     std::atomic<int> abort_all{0};
     std::string up_err;
     auto nap = [](int& spins) {  // a wait that is usually short: yield first, then sleep
@@ -2065,7 +2067,7 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
             const double t_u0 = now_ms();
             hipEvent_t e_dbg = nullptr;
             if (lane_debug && hipEventCreate(&e_dbg) == hipSuccess) (void)hipEventRecord(e_dbg, c->copy_stream);
-            const int up_rc = stage ? crew.run(c->ring_img[(size_t)slot], stage, h_frames[i], w, h, stride, c->copy_stream)
+            const int up_rc = stage ? crew.run(c->ring_img[(size_t)slot], stage, h_frames[i], w, h, stride, c->copy_stream, batch_band, batch_band > ((size_t)4 << 20) ? StagingCrew::kPieces : 1)
                                     : upload_rows(c, c->ring_img[(size_t)slot], nullptr, h_frames[i], w, h, stride, 1, c->copy_stream);
             if (up_rc || hipEventRecord(c->ring_ev[(size_t)slot], c->copy_stream) != hipSuccess) {
                 up_err = get_error().empty() ? "upload failed" : get_error();
