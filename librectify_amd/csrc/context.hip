@@ -12,10 +12,54 @@
 #include <cstring>
 #include <random>
 #include <thread>
+#if defined(__SSE2__)
+#include <immintrin.h>
+#endif
 
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
 #endif
+
+
+// Copy into a page-locked staging buffer with non-temporal stores (SSE2, part of every x86-64): a plain memcpy reads the
+// destination's lines before it overwrites them, and the staging buffers are read next by the DMA engine, not by a core.
+// Less host-memory traffic beside the transfers, which read the same memory.
+static inline void stage_copy(void* dst, const void* src, size_t n) {
+#if defined(__SSE2__)
+    static const bool plain = std::getenv("LIBRECTIFY_STAGE_PLAIN") != nullptr;  // (comparison knob)
+    char* d = static_cast<char*>(dst);
+    const char* s_ = static_cast<const char*>(src);
+    if (plain || n < 4096) {
+        std::memcpy(d, s_, n);
+        return;
+    }
+    const size_t head = (16u - (reinterpret_cast<uintptr_t>(d) & 15u)) & 15u;
+    if (head) {
+        std::memcpy(d, s_, head);
+        d += head;
+        s_ += head;
+        n -= head;
+    }
+    size_t blocks = n / 64;
+    while (blocks--) {
+        const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s_));
+        const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s_ + 16));
+        const __m128i c2 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s_ + 32));
+        const __m128i e = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s_ + 48));
+        _mm_stream_si128(reinterpret_cast<__m128i*>(d), a);
+        _mm_stream_si128(reinterpret_cast<__m128i*>(d + 16), b);
+        _mm_stream_si128(reinterpret_cast<__m128i*>(d + 32), c2);
+        _mm_stream_si128(reinterpret_cast<__m128i*>(d + 48), e);
+        s_ += 64;
+        d += 64;
+    }
+    n &= 63;
+    if (n) std::memcpy(d, s_, n);
+    _mm_sfence();
+#else
+    std::memcpy(dst, src, n);
+#endif
+}
 
 namespace lramd {
 
@@ -287,9 +331,9 @@ struct StagingCrew {
             const int r0 = std::min(b1, b0 + piece * rows_per_piece), r1 = std::min(b1, r0 + rows_per_piece);
             if (r1 > r0) {
                 if (j.stride == j.w) {
-                    std::memcpy(j.stage + (size_t)r0 * j.w, j.src + (size_t)r0 * j.stride, (size_t)(r1 - r0) * row_bytes);
+                    stage_copy(j.stage + (size_t)r0 * j.w, j.src + (size_t)r0 * j.stride, (size_t)(r1 - r0) * row_bytes);
                 } else {
-                    for (int r = r0; r < r1; ++r) std::memcpy(j.stage + (size_t)r * j.w, j.src + (size_t)r * j.stride, row_bytes);
+                    for (int r = r0; r < r1; ++r) stage_copy(j.stage + (size_t)r * j.w, j.src + (size_t)r * j.stride, row_bytes);
                 }
             }
             if (pieces_left[gen & 1u][k].fetch_sub(1, std::memory_order_acq_rel) != 1) continue;  // not the band's last piece
