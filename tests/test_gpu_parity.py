@@ -688,6 +688,39 @@ def test_every_storage_tier_of_the_flood_is_exact_on_long_edges(L, ctx):
     assert used[7]["second_tier_seeds"] > 0 and used[7]["slabs"] == 0 and used[7]["ordered_tail_seeds"] > 0
 
 
+def _regions(W, H, seed):
+    """Soft blobs and ramps: floods that are regions (wide frontiers), the kind the second tier's team counts as wide."""
+    from librectify_amd import synth
+
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    img = np.full((H, W), 0.4, np.float64)
+    for _ in range(10):
+        cx, cy, r = rng.uniform(0, W), rng.uniform(0, H), rng.uniform(40, 160)
+        img += rng.uniform(0.1, 0.3) * np.exp(-(((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * r * r)))
+    img += 0.15 * xx / W
+    img = synth._gauss_blur(np.clip(img, 0, 1), 2.0) + rng.normal(0, 0.003, size=img.shape)
+    return img.astype(np.float32)
+
+
+def test_what_a_context_carries_from_frame_to_frame_never_changes_a_result(L):
+    """Frames of lines, of long bars and of regions in turn on ONE fresh context: second tier, hold-back from the start and
+    the early hand-over on frames of regions are decided from the previous frame and from the frame's own rounds; every
+    frame must equal the oracle whatever came before it (round 3: the rules changed; the results may not)."""
+    c = L.Context(0)
+    c.set_seed(0)
+    frames = [FRAMES["640x480"], _long_bars(1600, 400, 9), _regions(960, 540, 3), FRAMES["320x240"], _regions(960, 540, 4),
+              _long_bars(1600, 400, 10), _regions(960, 540, 3)]
+    order = [0, 1, 2, 3, 2, 2, 0, 4, 1, 5, 6, 0]
+    refs = {}
+    for i in order:
+        if i not in refs:
+            refs[i] = O.find_line_segment_groups(frames[i], max(frames[i].shape) / 100.0, seed=0)[0]
+        got = c.find_line_segment_groups(frames[i], max(frames[i].shape) / 100.0)
+        _assert_lines_equal(got, refs[i])
+    c.close()
+
+
 def test_component_sort_classes_up_to_a_flood_of_20000_pixels(L, ctx):
     """The per-component pixel sort has four size classes (<= 64 px in a wavefront, <= 4096 and <= 16384 in LDS, beyond
     that in global memory).  A 3200x200 frame with a soft horizontal step (a 6-px wide, 3200-px long flood) and bars of
