@@ -730,8 +730,8 @@ int finish_flood(lr_context* c, bool* extra) {
         return 1;
     static const bool call_debug = std::getenv("LIBRECTIFY_CALL_DEBUG") != nullptr;
     if (call_debug)
-        std::fprintf(stderr, "flood: %d rounds, %u walks in the second tier, %u of them long, %u wide, hold-back phase %u (started with it: %d)\n",
-                     c->flood_rounds, c->flood_tiers[0], c->flood_tiers[8], c->flood_tiers[9], c->flood_tiers[3], (int)c->flood_hold_hint);
+        std::fprintf(stderr, "flood: %d rounds, %u walks in the second tier, %u of them long, hold-back phase %u (started with it: %d)\n",
+                     c->flood_rounds, c->flood_tiers[0], c->flood_tiers[8], c->flood_tiers[3], (int)c->flood_hold_hint);
     static const int hints_env = std::getenv("LIBRECTIFY_FLOOD_HINTS") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_HINTS")) : 1;  // (experiment knob)
     if (hints_env == 0) {  // as in round 2
         c->flood_big_hint = c->flood_tiers[0] > 0 || c->flood_tiers[1] > 0;
@@ -745,9 +745,9 @@ int finish_flood(lr_context* c, bool* extra) {
         // frame to frame once a single frame had.
         c->flood_big_hint = true;
         c->flood_hold_hint = c->flood_tiers[3] != 0 && c->flood_tiers[8] >= 16;
-        // (The verdict "frame of regions" -- early hand-over to the second tier, flood_advance -- is NOT carried over: started
-        // with it, the natural 4K frame sends 735 walks to the second tier instead of 55-119 and its flood takes 1.88 instead
-        // of 1.75 ms, and a frame of lines that follows pays 0.7 ms for the wrong guess.)
+        // (The verdict "many long walks" -- early hand-over to the second tier, flood_advance -- is NOT carried over: started
+        // with it, the natural 4K frame sends 735 walks to the second tier in round one and its flood takes 1.88 ms instead
+        // of 1.5, and a frame of lines that follows pays 0.7 ms for the wrong guess.)
     }
     static const int hold_hint_env = std::getenv("LIBRECTIFY_FLOOD_HOLD_HINT") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_HOLD_HINT")) : -1;  // (experiment knob)
     if (hold_hint_env >= 0) c->flood_hold_hint = hold_hint_env != 0;

@@ -191,7 +191,7 @@ struct FloodArgs {
     uint32_t t1_tiles;                               // first tier hands a walk to the second at this many tiles (when there is one)
     uint32_t* handover;                              // state of the walks handed to the second tier (FloodBuffers::handover)
     uint32_t team_tiles;                             // test hook: the team's table counts as full at this many tiles
-    uint32_t t1_regional, t1_regional_min;           // ... at t1_regional tiles once the frame has had t1_regional_min WIDE walks there (flood_advance)
+    uint32_t t1_regional, t1_regional_min;           // ... at t1_regional tiles once the frame has had t1_regional_min walks beyond the first tier's table
     uint32_t t1_wide_tiles, t1_wide_front;           // ... or at this many tiles when its frontier holds this many records
 };
 // All words but kCtrlGen are set up by flood_init_seeds_kernel every frame; kCtrlGen lives on for the lifetime of
@@ -225,9 +225,8 @@ enum {
     kCtrlWinHold = 17,  // the window stops here while the weakest seeds are held back
     kCtrlWalked = 18,   // [18..19] 64-bit: pixels walked by all explorations of the frame (diagnostics: re-walk factor)
     kCtrlSteps = 20,    // [20..21] 64-bit: tile steps of all explorations
-    kCtrlBigSeen = 22,  // the verdict "frame of regions" on kCtrlBigLong / kCtrlBigWide as they stood when the current round began
+    kCtrlBigSeen = 22,  // 1: the frame had many long walks (kCtrlBigLong) when the current round began -- early hand-over
     kCtrlBigLong = 23,  // walks of the frame that really outgrew the first tier (more tiles than its table holds)
-    kCtrlBigWide = 24,  // ... and took eight tiles and more to a level of their footprint (regions, not lines)
     kCtrlWords = 32,
 };
 static_assert(kCtrlWords == kFloodCtrlWords, "control block size");
@@ -1033,10 +1032,12 @@ __device__ __forceinline__ void explore_body(const FloodArgs& A, const BinTrig& 
 #endif
     const int lane = threadIdx.x & 63;
     const uint32_t n_act = uni(A.ctrl[kCtrlNAct]), window = uni(A.ctrl[kCtrlWindow]);
-    // A frame whose long walks are WIDE (a natural image: regions, not lines; the verdict is flood_advance's, on what the
-    // second tier's teams have counted) hands its walks over earlier from the next round on: wide frontiers are what a
-    // team is fast on, while the first tier's rounds last as long as its longest walk.  Frames of lines and of long bars
-    // keep the whole first tier: a thin walk gains nothing from a team, and the tiers' kernels run one after the other.
+    // A frame with many LONG walks (sixteen beyond what the first tier's table holds: natural images, frames of long bars)
+    // hands its walks over earlier from the next round on -- at 32 tiles instead of 190: the first tier's rounds last as
+    // long as its longest walk, and the second tier has 512 teams to take the walks side by side (with 128 teams the long
+    // bars' thousands of thin walks queued up behind each other and the same rule cost that frame 0.5 ms; with 512 it
+    // gains 0.3).  The synthetic bench frames never get there (0-7 long walks), and handing THEIR walks over early costs
+    // them 0.3-0.9 ms: the tiers' kernels run one after the other, and a thin walk gains nothing from a team.
     const uint32_t t1_tiles = uni(A.ctrl[kCtrlBigSeen]) != 0u ? min(A.t1_tiles, A.t1_regional) : A.t1_tiles;
     LdsStore L{s_ring[0], s_ring[1], s_ring[2], s_hash[0], s_hash[1], s_hash[2], s_ord};
     Pending P{s_pend[0], s_pend[1]};
@@ -1113,7 +1114,7 @@ constexpr int kTeamWaves = LR_TEAM_WAVES;
 #endif
 constexpr int kRingTeam = LR_TEAM_RING;
 #ifndef LR_TEAM_GRID
-#define LR_TEAM_GRID 128
+#define LR_TEAM_GRID 512
 #endif
 constexpr uint32_t kTeamGrid = LR_TEAM_GRID;  // workgroups; each strides over the round's second-tier list
 constexpr uint32_t kVoidTile = 0xFFFFFFFFu;
@@ -1222,8 +1223,7 @@ __device__ __forceinline__ void team_push8(TeamStore& S, uint32_t tile, uint64_t
 // returns 0 when the footprint is complete; 1 when ring or table ran out: *begin_out is then the first ring index that
 // may hold an unprocessed record (processed ones read kVoidTile)
 __device__ int team_walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, float cs, TeamStore& S, int lane,
-                         int wave, bool own, uint32_t first_level, uint32_t* begin_out, uint32_t* steps_out,
-                         uint32_t* levels_out) {
+                         int wave, bool own, uint32_t first_level, uint32_t* begin_out, uint32_t* steps_out) {
     TeamShared* sh = S.sh;
     const int lr = lane >> 3, lc = lane & 7;
     int rx, ry;
@@ -1298,7 +1298,6 @@ __device__ int team_walk(const FloodArgs& A, uint32_t k, int b, float thr, float
     }
     *begin_out = gb;
     *steps_out = steps;
-    *levels_out = levels;
     return rc;
 }
 
@@ -1381,9 +1380,8 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
             sh->steps = h_recs ? hb[2] : 0u;
         }
         __syncthreads();
-        uint32_t begin = 0u, my_steps = 0u, levels = 0u;
-        const uint32_t steps_before = h_recs ? uni(hb[2]) : 0u;
-        int rc = team_walk(A, k, b, thr, sn, cs, S, lane, wave, own, first_level, &begin, &my_steps, &levels);
+        uint32_t begin = 0u, my_steps = 0u;
+        int rc = team_walk(A, k, b, thr, sn, cs, S, lane, wave, own, first_level, &begin, &my_steps);
         // (team_walk ends behind a barrier: every wavefront sees the final table)
         WalkState st{0u, 0u, 0u, sh->ntiles, false, 0u, 0u};
         stamp_footprint(A, k, S, st, lane, (uint32_t)wave * 8u, 8u * kTeamWaves);
@@ -1448,14 +1446,9 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
             A.count[k] = st.cnt;
             if (st.blocked) A.blocked[k] = 1u;
             A.flags[k] |= st.steps << 8;
-            // What makes a frame "regional" (explore_body): walks the first tier could not have held, however early they were
-            // handed over (kCtrlBigLong), a good part of which ran eight tiles and more to a level (kCtrlBigWide).  The natural
-            // 4K frame: 13 of 40 (7 of 33 when its weakest seeds are held back from the start); a frame of long bars, as many
-            // tiles a walk but few to a level: 9 of 290 (0 of 72); the synthetic bench frames: none.
-            if (st.ntiles > kHandTiles) {
-                atomicAdd(&A.ctrl[kCtrlBigLong], 1u);
-                if (sh->steps - steps_before >= 8u * levels) atomicAdd(&A.ctrl[kCtrlBigWide], 1u);
-            }
+            // (what makes a frame "regional", explore_body: walks the first tier could not have held, however early they
+            // were handed over)
+            if (st.ntiles > kHandTiles) atomicAdd(&A.ctrl[kCtrlBigLong], 1u);
         }
     }
 }
@@ -1589,10 +1582,7 @@ __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift, u
     ctrl[kCtrlBarrier] = 0xFFFFFFFFu;
     ctrl[kCtrlSlabs] = 0u;
     ctrl[kCtrlNBig] = 0u;
-    {
-        const uint32_t n_long = ld_agent(&ctrl[kCtrlBigLong]), n_wide = ld_agent(&ctrl[kCtrlBigWide]);
-        ctrl[kCtrlBigSeen] = (n_wide >= regional_min && n_wide * 8u >= n_long) ? 1u : 0u;
-    }
+    ctrl[kCtrlBigSeen] = ld_agent(&ctrl[kCtrlBigLong]) >= regional_min ? 1u : 0u;
 }
 
 // (Commit pass and survivors pass in ONE launch -- blocked marks in two alternating buffers, counts and flags written
@@ -1717,7 +1707,6 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
         ctrl[kCtrlNBig] = 0u;
         ctrl[kCtrlBigTotal] = 0u;
         ctrl[kCtrlBigLong] = 0u;
-        ctrl[kCtrlBigWide] = 0u;
         ctrl[kCtrlBigSeen] = 0u;
         ctrl[kCtrlSlabTotal] = 0u;
         ctrl[kCtrlBarrier] = 0xFFFFFFFFu;
@@ -1962,8 +1951,8 @@ FloodArgs flood_args(const FloodBuffers& B, const FloodFrame& F, bool use_big) {
     A.team_tiles = B.team_tile_cap ? B.team_tile_cap : 0xFFFFFFFFu;
     A.handover = B.handover;
     A.t1_tiles = t1_env > 8 ? (uint32_t)t1_env : 0xFFFFFFFFu;
-    static const int t1r_env = std::getenv("LIBRECTIFY_FLOOD_T1_REGIONAL") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_T1_REGIONAL")) : 48;
-    static const int t1m_env = std::getenv("LIBRECTIFY_FLOOD_T1_REGIONAL_MIN") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_T1_REGIONAL_MIN")) : 4;
+    static const int t1r_env = std::getenv("LIBRECTIFY_FLOOD_T1_REGIONAL") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_T1_REGIONAL")) : 32;
+    static const int t1m_env = std::getenv("LIBRECTIFY_FLOOD_T1_REGIONAL_MIN") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_T1_REGIONAL_MIN")) : 16;
     A.t1_regional = t1r_env > 8 ? (uint32_t)t1r_env : 0xFFFFFFFFu;
     A.t1_regional_min = (uint32_t)std::max(t1m_env, 1);
     static const int t1w_env = std::getenv("LIBRECTIFY_FLOOD_T1_WIDE_TILES") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_T1_WIDE_TILES")) : 0;
@@ -2143,7 +2132,6 @@ int flood_finish(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, u
         tiers_out[6] = h_ctrl[kCtrlSteps];
         tiers_out[7] = h_ctrl[kCtrlSteps + 1];
         tiers_out[8] = h_ctrl[kCtrlBigLong];
-        tiers_out[9] = h_ctrl[kCtrlBigWide];
     }
     return 0;
 }
