@@ -133,7 +133,7 @@ struct FloodBuffers {
     // strong seed takes die unwalked) at the price of one or two more rounds: better throughput with many frames
     // in flight, worse latency for a single frame.
     int win_first_shift = 0, win_growth = 2;
-    // Hold-back: on frames whose first full round shows walks beyond the first storage tier, the weakest
+    // Hold-back: on frames whose first full round shows walks beyond the first storage tier (four or more), the weakest
     // (100 - pct) % of the seeds wait until all others are resolved (0 = never).  Measured at 4K with pct = 80: a
     // natural image 8.6 -> ~5 ms, the long-edge stress frame 11 -> ~6 ms, frames without such walks untouched.
     int win_hold_pct = 80;

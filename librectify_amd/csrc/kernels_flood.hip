@@ -191,6 +191,7 @@ struct FloodArgs {
     uint32_t t1_tiles;                               // first tier hands a walk to the second at this many tiles (when there is one)
     uint32_t* handover;                              // state of the walks handed to the second tier (FloodBuffers::handover)
     uint32_t team_tiles;                             // test hook: the team's table counts as full at this many tiles
+    uint32_t hold_min_big;                           // walks in the second tier after which the hold-back engages
     uint32_t t1_regional, t1_regional_min;           // ... at t1_regional tiles once the frame has had t1_regional_min walks beyond the first tier's table
     uint32_t t1_wide_tiles, t1_wide_front;           // ... or at this many tiles when its frontier holds this many records
 };
@@ -1537,7 +1538,7 @@ __global__ __launch_bounds__(256) void flood_commit_pixels_kernel(FloodArgs A, u
 
 // End of a round (one thread: the last workgroup of the survivors pass): the next list becomes the current one.  A round without progress (possible only
 // when storage ran out on the lowest active seed) stops the rounds and leaves the rest to the ordered tail.
-__device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift, uint32_t regional_min) {
+__device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift, uint32_t regional_min, uint32_t hold_min_big) {
     const uint32_t n_act = ld_agent(&ctrl[kCtrlNAct]);
     if (n_act == 0u) return;
     const uint32_t n_seeds = ld_agent(&ctrl[kCtrlNSeeds]), win_hold = ld_agent(&ctrl[kCtrlWinHold]);
@@ -1553,7 +1554,7 @@ __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift, u
     unsigned long long grown = (unsigned long long)window << win_shift;
     if (grown > n_seeds) grown = n_seeds;
     const uint32_t phase = ld_agent(&ctrl[kCtrlPhase]);
-    if (phase == 0u && window >= n_seeds && win_hold < n_seeds && ld_agent(&ctrl[kCtrlBigTotal]) > 0u && n_next > 0u) {
+    if (phase == 0u && window >= n_seeds && win_hold < n_seeds && ld_agent(&ctrl[kCtrlBigTotal]) >= hold_min_big && n_next > 0u) {
         grown = win_hold;
         ctrl[kCtrlPhase] = 1u;
     } else if (phase == 1u) {
@@ -1674,7 +1675,7 @@ __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, const
         if (atomicAdd(&A.ctrl[kCtrlDone], 1u) == gridDim.x - 1u) {
             __threadfence();
             A.ctrl[kCtrlDone] = 0u;
-            flood_advance(A.ctrl, A.win_shift, A.t1_regional_min);
+            flood_advance(A.ctrl, A.win_shift, A.t1_regional_min, A.hold_min_big);
         }
     }
 }
@@ -1955,6 +1956,8 @@ FloodArgs flood_args(const FloodBuffers& B, const FloodFrame& F, bool use_big) {
     static const int t1m_env = std::getenv("LIBRECTIFY_FLOOD_T1_REGIONAL_MIN") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_T1_REGIONAL_MIN")) : 16;
     A.t1_regional = t1r_env > 8 ? (uint32_t)t1r_env : 0xFFFFFFFFu;
     A.t1_regional_min = (uint32_t)std::max(t1m_env, 1);
+    static const int holdmin_env = std::getenv("LIBRECTIFY_FLOOD_HOLD_MIN") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_HOLD_MIN")) : 4;
+    A.hold_min_big = (uint32_t)std::max(holdmin_env, 1);
     static const int t1w_env = std::getenv("LIBRECTIFY_FLOOD_T1_WIDE_TILES") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_T1_WIDE_TILES")) : 0;
     static const int t1f_env = std::getenv("LIBRECTIFY_FLOOD_T1_WIDE_FRONT") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_T1_WIDE_FRONT")) : 6;
     A.t1_wide_tiles = t1w_env > 0 ? (uint32_t)t1w_env : 0xFFFFFFFFu;
