@@ -31,7 +31,7 @@ def long_frame(W, H, seed, K):
 ctx = L.Context(0)
 bad = 0
 for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
-    W, H = 2600, 1500
+    W, H = (2600, 1500) if i % 2 == 0 else (2597, 1503)  # (every other frame ragged in both directions: walks along the right and bottom borders)
     img = long_frame(W, H, 100 + i, 14)
     ref = O.find_line_segments(img, num_threads=8)
     for mode in (1, 2, 3, 5, 6, 7):
