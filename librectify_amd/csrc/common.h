@@ -197,7 +197,7 @@ int launch_component_scatter(const uint32_t* label, size_t npix, const uint32_t*
 int launch_component_sort(const uint32_t* px_in, uint32_t* px_out, const uint32_t* comp_off, const uint32_t* d_n_comp,
                           uint32_t comp_cap, const uint32_t* large_list, uint32_t large_cap, const uint32_t* n_large,
                           uint32_t* scratch, hipStream_t s);
-int launch_fit(const uint32_t* px_sorted, const uint32_t* comp_off, const uint32_t* comp_seed, const uint32_t* d_n_comp,
+int launch_fit(const uint32_t* px_sorted, const uint32_t* px_unsorted, const uint32_t* comp_off, const uint32_t* comp_seed, const uint32_t* d_n_comp,
                uint32_t comp_cap, const int32_t* seed_bin, const float* dx, const float* dy, int w, BinTrig trig,
                float* scratch_w, LineSegment* out, hipStream_t s);
 

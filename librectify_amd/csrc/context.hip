@@ -773,7 +773,7 @@ int enqueue_fit(lr_context* c) {
                               (uint32_t)(c->cap_pix / 64 + 16), c->d_counts + kCntLarge, reinterpret_cast<uint32_t*>(c->keys_b),
                               c->stream))
         return 1;
-    if (launch_fit(c->px_b, c->comp_off, c->comp_seed, c->d_counts + kCntComp, comp_cap, c->seed_bin, c->dx, c->dy, c->w,
+    if (launch_fit(c->px_b, c->px_a, c->comp_off, c->comp_seed, c->d_counts + kCntComp, comp_cap, c->seed_bin, c->dx, c->dy, c->w,
                    c->trig, c->scratch_w, c->d_lines, c->stream))
         return 1;
     if (c->timing_on) LR_HIP(hipEventRecord(c->ev[4], c->stream));

@@ -213,25 +213,9 @@ __device__ inline void major_axis_2x2(float a_, float b_, float c_, float& d_r, 
 
 // fit_line_parameters (geometry.cpp:20-61) for one component per wavefront.
 // ---- per-component sort of the pixel lists ---------------------------------------------------------------
-// Lists of up to 64 pixels (nearly all of them: the mean flood has some 25 pixels): one wavefront, one pixel per
-// lane, rank = number of smaller keys (keys are distinct), found with 64 scalar broadcasts.
-__global__ __launch_bounds__(256) void component_sort_small_kernel(const uint32_t* __restrict__ px_in,
-                                                                   uint32_t* __restrict__ px_out,
-                                                                   const uint32_t* __restrict__ comp_off,
-                                                                   const uint32_t* __restrict__ n_comp_ptr) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t comp = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (comp >= *n_comp_ptr) return;
-    const uint32_t off = comp_off[comp];
-    const uint32_t n = comp_off[comp + 1] - off;
-    if (n > 64u) return;
-    const uint32_t key = (uint32_t)lane < n ? px_in[off + lane] : 0xFFFFFFFFu;
-    uint32_t rank = 0;
-#pragma unroll
-    for (int j = 0; j < 64; ++j) rank += ((uint32_t)__builtin_amdgcn_readlane((int)key, j) < key) ? 1u : 0u;
-    if ((uint32_t)lane < n) px_out[off + rank] = key;
-}
-
+// Lists of up to 64 pixels (nearly all of them: the mean flood has some 25 pixels) are not sorted by a kernel of their
+// own any more: fit_kernel takes them unsorted, one pixel per lane, ranks them (rank = number of smaller keys: the keys are
+// distinct; 64 scalar broadcasts) and permutes them into order across the wavefront, all in registers.
 // Longer lists: one workgroup each, bitonic network on the list padded to a power of two.  Three classes, told apart
 // when the offsets are computed (component_offsets_kernel): up to 1024 pixels in 4 KB of LDS by 256 threads (many
 // workgroups; entries at the front of large_list); up to 16384 pixels in 64 KB of LDS by 1024 threads (a 4096-pixel list
@@ -313,7 +297,8 @@ __global__ __launch_bounds__(1024) void component_sort_big_kernel(const uint32_t
     }
 }
 
-__global__ __launch_bounds__(256) void fit_kernel(const uint32_t* __restrict__ px, const uint32_t* __restrict__ comp_off,
+__global__ __launch_bounds__(256) void fit_kernel(const uint32_t* __restrict__ px, const uint32_t* __restrict__ px_unsorted,
+                                                  const uint32_t* __restrict__ comp_off,
                                                   const uint32_t* __restrict__ comp_seed, const uint32_t* __restrict__ n_comp_ptr,
                                                   const int32_t* __restrict__ seed_bin, const float* __restrict__ dx,
                                                   const float* __restrict__ dy, int w, BinTrig trig,
@@ -326,6 +311,73 @@ __global__ __launch_bounds__(256) void fit_kernel(const uint32_t* __restrict__ p
     const int b = seed_bin[comp_seed[comp]];
     const float s = trig.st[b], c = trig.ct[b];
     const uint32_t uw = (uint32_t)w;
+
+    if (n <= 64u) {
+        // A component of up to 64 pixels is one pixel per lane: everything after the first (dependent) loads stays in
+        // registers -- the general form below reads the pixel list and the weights back from memory in each of its four
+        // passes, a round trip each.  Same operations in the same order (the lane-strided sums have one term each: 0 + x),
+        // so the same bits.  Most components are this small (4K bench frame: 19 000 of 20 500; natural frame: 46 000 of 47 400).
+        const bool has = (uint32_t)lane < n;
+        // the list in ascending pixel order (the order of the reference's component lists, which the sums follow): lane
+        // `rank` gets this lane's key
+        const uint32_t key = has ? px_unsorted[off + lane] : 0xFFFFFFFFu;
+        uint32_t rank = 0;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) rank += ((uint32_t)__builtin_amdgcn_readlane((int)key, j) < key) ? 1u : 0u;
+        // (the padding keys are equal and all rank n: they collide on lane n or beyond, which no sum reads)
+        const uint32_t p_sorted = (uint32_t)__builtin_amdgcn_ds_permute((int)(min(rank, 63u) << 2), (int)key);
+        const uint32_t p = has ? p_sorted : 0u;
+        float wv = 0.f;
+        if (has) wv = directional(dx[p], dy[p], s, c);
+        float acc = 0.f;
+        if (has) acc = acc + wv;
+        const float S = wave_tree(acc);
+        const float r = (float)(p / uw), cq = (float)(p % uw);
+        const float wn = wv / S;
+        float ar = 0.f, ac = 0.f;
+        if (has) {
+            ar = ar + wn * r;
+            ac = ac + wn * cq;
+        }
+        const float a_r = wave_tree(ar), a_c = wave_tree(ac);
+        const float cr = r - a_r, cc = cq - a_c;
+        float crr = 0.f, crc = 0.f, ccc = 0.f;
+        if (has) {
+            const float t = cr * wn, u = cc * wn;
+            crr = crr + t * cr;
+            crc = crc + t * cc;
+            ccc = ccc + u * cc;
+        }
+        const float cov_rr = wave_tree(crr), cov_rc = wave_tree(crc), cov_cc = wave_tree(ccc);
+        float d_r, d_c;
+        major_axis_2x2(cov_rr, cov_rc, cov_cc, d_r, d_c);
+        const float n_r = -d_c, n_c = d_r;
+        float t0 = INFINITY, t1 = -INFINITY, es = 0.f;
+        if (has) {
+            const float t = cr * d_r + cc * d_c;
+            t0 = fminf(t0, t);
+            t1 = fmaxf(t1, t);
+            es = es + fabsf(cr * n_r + cc * n_c);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            t0 = fminf(t0, __shfl_xor(t0, o));
+            t1 = fmaxf(t1, __shfl_xor(t1, o));
+        }
+        const float esum = wave_tree(es);
+        if (lane == 0) {
+            LineSegment l;
+            l.x1 = a_c + d_c * t0;
+            l.y1 = a_r + d_r * t0;
+            l.x2 = a_c + d_c * t1;
+            l.y2 = a_r + d_r * t1;
+            l.weight = S / (float)n;
+            l.err = esum / (float)n;
+            l.group_id = -1;
+            out[comp] = l;
+        }
+        return;
+    }
 
     float acc = 0.f;
     for (uint32_t i = lane; i < n; i += 64) {
@@ -430,8 +482,7 @@ int launch_component_sort(const uint32_t* px_in, uint32_t* px_out, const uint32_
                           uint32_t comp_cap, const uint32_t* large_list, uint32_t large_cap, const uint32_t* n_large,
                           uint32_t* scratch, hipStream_t s) {
     if (comp_cap == 0) return 0;
-    hipLaunchKernelGGL(component_sort_small_kernel, dim3((comp_cap + 3) / 4), dim3(256), 0, s, px_in, px_out, comp_off,
-                       d_n_comp);
+    (void)d_n_comp;  // (lists of up to 64 pixels: fit_kernel)
     hipLaunchKernelGGL(component_sort_large_kernel, dim3(4096), dim3(256), 0, s, px_in, px_out, comp_off, large_list, n_large);
     hipLaunchKernelGGL(component_sort_big_kernel<false>, dim3(128), dim3(1024), 0, s, px_in, px_out, comp_off, large_list,
                        large_cap, n_large, scratch);
@@ -441,11 +492,11 @@ int launch_component_sort(const uint32_t* px_in, uint32_t* px_out, const uint32_
     return 0;
 }
 
-int launch_fit(const uint32_t* px_sorted, const uint32_t* comp_off, const uint32_t* comp_seed, const uint32_t* d_n_comp,
+int launch_fit(const uint32_t* px_sorted, const uint32_t* px_unsorted, const uint32_t* comp_off, const uint32_t* comp_seed, const uint32_t* d_n_comp,
                uint32_t comp_cap, const int32_t* seed_bin, const float* dx, const float* dy, int w, BinTrig trig,
                float* scratch_w, LineSegment* out, hipStream_t s) {
     if (comp_cap == 0) return 0;
-    hipLaunchKernelGGL(fit_kernel, dim3((comp_cap + 3) / 4), dim3(256), 0, s, px_sorted, comp_off, comp_seed, d_n_comp,
+    hipLaunchKernelGGL(fit_kernel, dim3((comp_cap + 3) / 4), dim3(256), 0, s, px_sorted, px_unsorted, comp_off, comp_seed, d_n_comp,
                        seed_bin, dx, dy, w, trig, scratch_w, out);
     LR_HIP(hipGetLastError());
     return 0;
