@@ -186,3 +186,79 @@ def compute_rectification_transform(lines, width, height, cfg, margins=None):
     if v2h[2] != 0:
         v2h[:2] += centre[:2]
     return np.stack([t[0], t[1], t[3], t[2], v1h, v2h])
+
+
+# ---- refine: postprocess_lines_segments (line_detector.cpp:253-444), second source ----------------------------------
+# Written from the reference's text in matrix form, float64.  Returns the merged segments as rows
+# (x1, y1, x2, y2, weight, err) and, for the test, how close the nearest pair came to one of the three gates.
+def _fit_line_parameters(X, w):
+    """geometry.cpp:20-61: weighted principal axis of the points X (rows (row, col)), end points = extreme projections"""
+    wn = w / w.sum()
+    a = (X * wn[:, None]).sum(axis=0)
+    Cn = X - a
+    cov = Cn.T @ (wn[:, None] * Cn)
+    ev, evec = np.linalg.eigh(cov)  # ascending: column 1 is the major axis, column 0 the normal
+    d, n = evec[:, 1], evec[:, 0]
+    t = Cn @ d
+    c0, c1 = a + d * t.min(), a + d * t.max()
+    return np.array([c0[1], c0[0], c1[1], c1[0], w.mean(), np.abs(Cn @ n).mean()])
+
+
+def refine(lines, cos_gate=0.99, max_offset=0.02, lo=-0.5, hi=1.5):
+    P1, P2 = _endpoints(lines)
+    n_lines = len(P1)
+    dv = P2 - P1
+    ln = np.linalg.norm(dv, axis=1)
+    d = dv / ln[:, None]
+    nrm = np.stack([-d[:, 1], d[:, 0]], axis=1)
+    weight = np.asarray(lines["weight"], np.float64)
+    closest = np.inf  # smallest distance of a DECISIVE test quantity from its gate: one whose other two gates are open
+    succ = [[] for _ in range(n_lines)]
+    for i in range(n_lines - 1):
+        js = np.arange(i + 1, n_lines)
+        cosv = np.abs(d[js] @ d[i])
+        for j, cv in zip(js[cosv >= cos_gate - 1e-3], cosv[cosv >= cos_gate - 1e-3]):
+            if ln[i] < ln[j]:  # the shorter one's end points in the longer one's frame, in units of its length
+                Wm = (np.stack([P1[i], P2[i]]) - P1[j]) @ np.stack([d[j], nrm[j]], axis=1) / ln[j]
+            else:
+                Wm = (np.stack([P1[j], P2[j]]) - P1[i]) @ np.stack([d[i], nrm[i]], axis=1) / ln[i]
+            off = np.abs(Wm[:, 1]).max()
+            x = Wm[:, 0]
+            g_cos, g_off, g_ovl = cv >= cos_gate, off < max_offset, bool((x > lo).any() and (x < hi).any())
+            if g_off and g_ovl:
+                closest = min(closest, abs(cv - cos_gate))
+            if g_cos and g_ovl:
+                closest = min(closest, abs(off - max_offset))
+            if g_cos and g_off:
+                # (the overlap gate is "any end point above lo and any below hi": it flips where the larger crosses lo or
+                # the smaller crosses hi)
+                closest = min(closest, abs(x.max() - lo), abs(x.min() - hi))
+            if g_cos and g_off and g_ovl:
+                succ[i].append(int(j))
+    # graph_components / dfs (line_detector.cpp:282-329): a breadth-first walk that only follows edges to HIGHER indices
+    comp = -np.ones(n_lines, np.int64)
+    visited = np.zeros(n_lines, bool)
+    for v in range(n_lines):
+        if visited[v]:
+            continue
+        queue = [v]
+        while queue:
+            u = queue.pop(0)
+            visited[u] = True
+            comp[u] = v
+            queue.extend(j for j in succ[u] if not visited[j])
+    out = []
+    for lbl in sorted(set(comp.tolist())):
+        idx = np.nonzero(comp == lbl)[0]
+        if len(idx) == 1:
+            k = idx[0]
+            out.append([P1[k][0], P1[k][1], P2[k][0], P2[k][1], weight[k], float(lines["err"][k])])
+            continue
+        wts = ln[idx] * weight[idx]  # merge_lines (line_detector.cpp:253-274)
+        X = np.empty((2 * len(idx), 2))
+        X[0::2] = P1[idx][:, ::-1]
+        X[1::2] = P2[idx][:, ::-1]
+        m = _fit_line_parameters(X, np.repeat(wts, 2))
+        m[4] = wts.sum() / ln[idx].sum()
+        out.append(m.tolist())
+    return np.array(out), float(closest)

@@ -123,3 +123,43 @@ def test_fit_optimal_and_single_point_entries_against_the_second_source(L):
     t = N.compute_image_transform(W, H, v1, v2)
     R = np.stack([t[0], t[1], t[3], t[2]])
     np.testing.assert_allclose(T[:4, :2], R[:, :2], rtol=1e-4, atol=1e-2)
+
+
+def _match_segments(got, ref, tol_px):
+    """got: LINE_DTYPE rows (the oracle's refine, float32); ref: rows (x1, y1, x2, y2, weight, err) of numpy_ref.refine.
+    Every row of one has its twin in the other: end points as an unordered pair within tol_px, weight and error close."""
+    assert len(got) == len(ref), (len(got), len(ref))
+    g = np.stack([got["x1"], got["y1"], got["x2"], got["y2"]], 1).astype(np.float64)
+    used = np.zeros(len(ref), bool)
+    for k in range(len(g)):
+        d1 = np.abs(ref[:, :4] - g[k]).max(axis=1)
+        d2 = np.abs(ref[:, [2, 3, 0, 1]] - g[k]).max(axis=1)
+        d = np.minimum(d1, d2)
+        d[used] = np.inf
+        j = int(np.argmin(d))
+        assert d[j] < tol_px, (k, got[k], ref[j], d[j])
+        used[j] = True
+        assert abs(float(got["weight"][k]) - ref[j, 4]) <= 1e-4 * max(1.0, abs(ref[j, 4])), (k, got[k], ref[j])
+        assert abs(float(got["err"][k]) - ref[j, 5]) <= 2e-3, (k, got[k], ref[j])
+
+
+def test_refine_against_the_second_source():
+    """postprocess_lines_segments (`refine = true` at the boundary; line_detector.cpp:253-444): the oracle's restatement --
+    which the product equals bit for bit on the GPU tests -- against numpy_ref.refine, written from the reference's text
+    in float64 matrix form: the pair gates (direction, normal offset, overlap), the reference's one-way walk over the
+    pair graph, the weighted merge.  Detections of three synthetic frames and the 848 golden rows; a sample whose
+    nearest pair lies within 1e-5 of a gate would be undecidable between float32 and float64 and is reported, not hidden."""
+    from librectify_amd import synth
+
+    samples = [O.find_line_segments(synth.frame(640, 480, 5), want_label=False)["lines"],
+               O.find_line_segments(synth.frame(960, 540, 8, bars=60), want_label=False)["lines"],
+               O.find_line_segments(synth.frame(320, 240, 13, bars=24), want_label=False)["lines"],
+               _golden()]
+    merged_anywhere = 0
+    for lines in samples:
+        ref, closest = N.refine(lines)
+        got = O.refine_lines(lines)
+        assert closest > 1e-5, "a pair within %.1e of a gate: pick another sample" % closest
+        merged_anywhere += len(lines) - len(ref)
+        _match_segments(got, ref, 5e-3)
+    assert merged_anywhere > 20  # (the samples do merge segments: the test is not vacuous)
