@@ -1177,35 +1177,131 @@ struct TeamStore {
         return true;
     }
     __device__ void value(uint32_t slot, uint64_t& V) const { V = uni64(lds_now(&hv0[slot]), lds_now(&hv1[slot])); }
+    // what team_walk / team_push8 need besides (the same names on the store in global memory below)
+    __device__ uint32_t ring_cap() const { return (uint32_t)kRingTeam; }
+    __device__ uint32_t hash_mask() const { return (uint32_t)(kHashBig - 1); }
+    __device__ uint32_t hash_of(uint32_t key) const { return (key * 2654435761u) >> kHashShift; }
+    __device__ uint32_t peek_key(uint32_t slot) const { return hk[slot]; }                              // (per lane)
+    __device__ uint64_t peek_walked(uint32_t slot) const { return ((uint64_t)hv1[slot] << 32) | hv0[slot]; }  // (per lane)
+    __device__ uint64_t add_walked(uint32_t slot, uint64_t New) const {  // one lane; returns the bits that were there
+        uint32_t o0 = 0u, o1 = 0u;
+        if ((uint32_t)New) o0 = atomicOr(&hv0[slot], (uint32_t)New);
+        if ((uint32_t)(New >> 32)) o1 = atomicOr(&hv1[slot], (uint32_t)(New >> 32));
+        return ((uint64_t)o1 << 32) | o0;
+    }
+    __device__ void write_record(uint32_t pos, uint32_t tile, uint64_t E) const {  // (per lane)
+        const uint32_t j = pos & (uint32_t)(kRingTeam - 1);
+        rt[j] = tile;
+        rlo[j] = (uint32_t)E;
+        rhi[j] = (uint32_t)(E >> 32);
+    }
+    __device__ void mark_processed(uint32_t i) const { rt[i & (uint32_t)(kRingTeam - 1)] = kVoidTile; }
+};
+
+// The same store in GLOBAL memory (one overflow slab of FloodBuffers: 16 Ki ring records, a table of 64 Ki tiles), for a
+// team whose walk has outgrown its LDS: frames without strong edges, where a single flood covers a smooth ramp of
+// hundreds of thousands of pixels.  (One wavefront used to carry such a walk on alone, a tile at a time through global
+// memory: 72 ms for a 2051x1153 frame of soft blobs.)  Only this workgroup touches the slab, its waves share one L1, and
+// every access is an agent-scope atomic as in SlabStore; the counters stay in LDS.  The table is CLEARED by the team
+// before use (1 MB of stores) instead of being tagged with a generation: find-or-insert is then a compare-and-swap on
+// the key word alone, the walked set of a fresh entry is zero, and later users of the slab (generation-tagged) see
+// nothing valid in it.  Entry layout as SlabStore's: uint4 (generation, key, walked lo, walked hi) at hash[2 * slot];
+// the unused second uint4 of entry i holds the slot of the i-th tile inserted (what the stamping walks).
+struct TeamGlobalStore {
+    uint4* ring;
+    uint4* hash;
+    uint32_t rcap, hcap;
+    TeamShared* sh;
+    __device__ static uint32_t* w(uint4* p, int k) { return reinterpret_cast<uint32_t*>(p) + k; }
+    __device__ static uint32_t ldw(uint4* p, int k) { return __hip_atomic_load(w(p, k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ static void stw(uint4* p, int k, uint32_t v) { __hip_atomic_store(w(p, k), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ uint32_t hash_limit() const { return hcap / 4 * 3; }
+    __device__ uint32_t ring_cap() const { return rcap; }
+    __device__ uint32_t hash_mask() const { return hcap - 1u; }
+    __device__ uint32_t hash_of(uint32_t key) const { return (key * 2654435761u) & (hcap - 1u); }
+    __device__ void get(uint32_t i, uint32_t& tile, uint64_t& m) const {
+        uint4* r = &ring[i & (rcap - 1u)];
+        tile = uni(ldw(r, 0));
+        m = uni64(ldw(r, 2), ldw(r, 3));
+    }
+    __device__ bool lookup(uint32_t tile, uint32_t& slot, uint64_t& V) const {
+        const uint32_t key = tile + 1u;
+        const bool first_lane = (threadIdx.x & 63u) == 0u;
+        uint32_t hs = hash_of(key);
+        for (uint32_t probe = 0; probe < hcap; ++probe) {
+            uint4* e = &hash[2u * hs];
+            uint32_t cur = uni(ldw(e, 1));
+            if (cur == 0u) {
+                uint32_t old = 0u;
+                if (first_lane) old = atomicCAS(w(e, 1), 0u, key);
+                old = uni(old);
+                if (old == 0u) {
+                    uint32_t idx = 0u;
+                    if (first_lane) idx = atomicAdd(&sh->ntiles, 1u);
+                    idx = uni(idx);
+                    if (first_lane) stw(&hash[2u * idx + 1u], 0, hs);
+                    slot = hs;
+                    V = 0ull;
+                    return false;
+                }
+                cur = old;
+            }
+            if (cur == key) {
+                slot = hs;
+                V = uni64(ldw(e, 2), ldw(e, 3));
+                return true;
+            }
+            hs = (hs + 1u) & (hcap - 1u);
+        }
+        slot = hs;
+        V = 0ull;
+        return true;
+    }
+    __device__ void value(uint32_t slot, uint64_t& V) const { V = uni64(ldw(&hash[2u * slot], 2), ldw(&hash[2u * slot], 3)); }
+    __device__ uint32_t peek_key(uint32_t slot) const { return ldw(&hash[2u * slot], 1); }
+    __device__ uint64_t peek_walked(uint32_t slot) const { return ((uint64_t)ldw(&hash[2u * slot], 3) << 32) | ldw(&hash[2u * slot], 2); }
+    __device__ uint64_t add_walked(uint32_t slot, uint64_t New) const {
+        uint32_t o0 = 0u, o1 = 0u;
+        if ((uint32_t)New) o0 = atomicOr(w(&hash[2u * slot], 2), (uint32_t)New);
+        if ((uint32_t)(New >> 32)) o1 = atomicOr(w(&hash[2u * slot], 3), (uint32_t)(New >> 32));
+        return ((uint64_t)o1 << 32) | o0;
+    }
+    __device__ void write_record(uint32_t pos, uint32_t tile, uint64_t E) const {
+        uint4* r = &ring[pos & (rcap - 1u)];
+        stw(r, 0, tile);
+        stw(r, 2, (uint32_t)E);
+        stw(r, 3, (uint32_t)(E >> 32));
+    }
+    __device__ void mark_processed(uint32_t i) const { stw(&ring[i & (rcap - 1u)], 0, kVoidTile); }
+    __device__ uint32_t ord_slot(uint32_t idx) const { return ldw(&hash[2u * idx + 1u], 0); }
 };
 
 // neighbour records of a step, one direction per lane 0..7 (as push8; no merging with pending records of the same tile:
 // duplicates of a level are taken by different wavefronts at the same time)
-__device__ __forceinline__ void team_push8(TeamStore& S, uint32_t tile, uint64_t H, int lane, const PushLane& c) {
+template <class Store>
+__device__ __forceinline__ void team_push8(Store& S, uint32_t tile, uint64_t H, int lane, const PushLane& c) {
     const uint32_t nt = tile + c.off;
     const uint32_t key = nt + 1u;
     const uint64_t src = (H >> c.shamt) & (uint64_t)c.msk;
     uint64_t E = (c.spread ? spread_col(src) : src) << c.sh;
-    uint32_t ts = (key * 2654435761u) >> TeamStore::kHashShift;
-    uint32_t hk0 = S.hk[ts];
-    uint32_t v0 = S.hv0[ts], v1 = S.hv1[ts];
+    uint32_t ts = S.hash_of(key);
     const uint64_t m_want = m_ne64(E, 0ull) & 0xFFull;
-    uint64_t m_found = m_eq(hk0, key);
+    uint32_t hk0 = 0u;
+    uint64_t Vn = 0ull;
+    if (lane_of(m_want)) hk0 = S.peek_key(ts);
+    uint64_t m_found = m_want & m_eq(hk0, key);
     uint64_t m_search = m_want & ~m_found & m_ne(hk0, 0u);
-    for (int probe = 1; probe < kHashBig && m_search != 0ull; ++probe) {  // collisions
+    for (uint32_t probe = 1; probe <= S.hash_mask() && m_search != 0ull; ++probe) {  // collisions
         if (lane_of(m_search)) {
-            ts = (ts + 1) & (kHashBig - 1);
-            hk0 = S.hk[ts];
+            ts = (ts + 1u) & S.hash_mask();
+            hk0 = S.peek_key(ts);
         }
         const uint64_t hit = m_search & m_eq(hk0, key);
-        if (lane_of(hit)) {
-            v0 = S.hv0[ts];
-            v1 = S.hv1[ts];
-        }
         m_found |= hit;
         m_search &= ~hit & m_ne(hk0, 0u);
     }
-    if (lane_of(m_found)) E &= ~(((uint64_t)v1 << 32) | v0);  // entries the neighbour has walked add nothing
+    if (lane_of(m_found)) Vn = S.peek_walked(ts);
+    E &= ~Vn;  // entries the neighbour has walked add nothing
     const uint64_t mf = m_want & m_ne64(E, 0ull);
     if (mf != 0ull) {
         uint32_t base = 0u;
@@ -1213,18 +1309,16 @@ __device__ __forceinline__ void team_push8(TeamStore& S, uint32_t tile, uint64_t
         base = uni(base);
         if (lane_of(mf)) {
             const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mf >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mf, 0u));
-            const uint32_t j = pos & (kRingTeam - 1);
-            S.rt[j] = nt;
-            S.rlo[j] = (uint32_t)E;
-            S.rhi[j] = (uint32_t)(E >> 32);
+            S.write_record(pos, nt, E);
         }
     }
 }
 
 // returns 0 when the footprint is complete; 1 when ring or table ran out: *begin_out is then the first ring index that
 // may hold an unprocessed record (processed ones read kVoidTile)
-__device__ int team_walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, float cs, TeamStore& S, int lane,
-                         int wave, bool own, uint32_t first_level, uint32_t* begin_out, uint32_t* steps_out) {
+template <class Store>
+__device__ int team_walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, float cs, Store& S, int lane,
+                         int wave, bool own, uint32_t first_level, uint32_t tile_cap, uint32_t* begin_out, uint32_t* steps_out) {
     TeamShared* sh = S.sh;
     const int lr = lane >> 3, lc = lane & 7;
     int rx, ry;
@@ -1246,8 +1340,8 @@ __device__ int team_walk(const FloodArgs& A, uint32_t k, int b, float thr, float
     for (;;) {
         for (uint32_t i = gb + (uint32_t)wave; i < ge; i += kTeamWaves) {
             // room for what the steps in flight may add: eight records and one tile each
-            if ((uni(lds_now(&sh->tail)) - gb) + 8u * kTeamWaves > (uint32_t)kRingTeam ||
-                uni(lds_now(&sh->ntiles)) + kTeamWaves + 1u > min(S.hash_limit(), A.team_tiles)) {
+            if ((uni(lds_now(&sh->tail)) - gb) + 8u * kTeamWaves > S.ring_cap() ||
+                uni(lds_now(&sh->ntiles)) + kTeamWaves + 1u > min(S.hash_limit(), tile_cap)) {
                 if (lane == 0) sh->overflow = 1u;
                 break;
             }
@@ -1271,19 +1365,16 @@ __device__ int team_walk(const FloodArgs& A, uint32_t k, int b, float thr, float
                 }
                 const uint64_t New = R & ~cur.V;
                 if (New != 0ull) {
-                    uint32_t o0 = 0u, o1 = 0u;
-                    if (lane == 0) {
-                        if ((uint32_t)New) o0 = atomicOr(&S.hv0[cur.slot], (uint32_t)New);
-                        if ((uint32_t)(New >> 32)) o1 = atomicOr(&S.hv1[cur.slot], (uint32_t)(New >> 32));
-                    }
-                    const uint64_t first_here = New & ~uni64(o0, o1);  // the pixels this step was the first to walk
+                    uint64_t was = 0ull;
+                    if (lane == 0) was = S.add_walked(cur.slot, New);
+                    const uint64_t first_here = New & ~uni64(was);  // the pixels this step was the first to walk
                     if (first_here != 0ull) {
                         const uint64_t H = Rg & m_ne64(first_here & adj, 0ull);
                         if (H != 0ull) team_push8(S, tile, H, lane, pc);
                     }
                 }
             }
-            if (lane == 0) S.rt[i & (kRingTeam - 1)] = kVoidTile;  // processed
+            if (lane == 0) S.mark_processed(i);
         }
         __syncthreads();
         if (threadIdx.x == 0) sh->end = sh->tail;
@@ -1382,12 +1473,84 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
         }
         __syncthreads();
         uint32_t begin = 0u, my_steps = 0u;
-        int rc = team_walk(A, k, b, thr, sn, cs, S, lane, wave, own, first_level, &begin, &my_steps);
+        int rc = team_walk(A, k, b, thr, sn, cs, S, lane, wave, own, first_level, A.team_tiles, &begin, &my_steps);
         // (team_walk ends behind a barrier: every wavefront sees the final table)
-        WalkState st{0u, 0u, 0u, sh->ntiles, false, 0u, 0u};
-        stamp_footprint(A, k, S, st, lane, (uint32_t)wave * 8u, 8u * kTeamWaves);
+        WalkState st{0u, 0u, 0u, 0u, false, 0u, 0u};
         uint32_t px = 0u;
-        for (int i = (int)threadIdx.x; i < kHashBig; i += 64 * kTeamWaves) px += (uint32_t)__popc(S.hv0[i]) + (uint32_t)__popc(S.hv1[i]);
+        bool in_slab = false;
+        if (rc != 0) {
+            // LDS exhausted.  The whole team moves into a global slab and goes on there (TeamGlobalStore), from the records
+            // that are still unprocessed; nothing has been stamped yet, the table travels.
+            if (threadIdx.x == 0) {
+                const uint32_t slab = atomicAdd(&A.ctrl[kCtrlSlabs], 1u);
+                if (slab < A.n_slabs) atomicAdd(&A.ctrl[kCtrlSlabTotal], 1u);
+                sh->pad = slab;
+            }
+            __syncthreads();
+            const uint32_t slab = sh->pad;
+            if (slab < A.n_slabs) {
+                in_slab = true;
+                TeamGlobalStore G{A.slab_ring + (size_t)slab * A.slab_ring_cap, A.slab_hash + (size_t)slab * A.slab_hash_cap * 2,
+                                  A.slab_ring_cap, A.slab_hash_cap, sh};
+                for (uint32_t i = threadIdx.x; i < 2u * A.slab_hash_cap; i += 64u * kTeamWaves) G.hash[i] = make_uint4(0u, 0u, 0u, 0u);
+                const uint32_t n_tiles = sh->ntiles, tail = sh->tail;
+                __syncthreads();  // (the cleared table is in L2; sh->cnt below is used as the compaction counter)
+                for (uint32_t t = threadIdx.x; t < n_tiles; t += 64u * kTeamWaves) {
+                    const uint32_t slot = S.ord[t], key = S.hk[slot];
+                    uint32_t hs = G.hash_of(key);
+                    while (atomicCAS(TeamGlobalStore::w(&G.hash[2u * hs], 1), 0u, key) != 0u) hs = (hs + 1u) & G.hash_mask();
+                    TeamGlobalStore::stw(&G.hash[2u * hs], 2, S.hv0[slot]);
+                    TeamGlobalStore::stw(&G.hash[2u * hs], 3, S.hv1[slot]);
+                    TeamGlobalStore::stw(&G.hash[2u * t + 1u], 0, hs);
+                }
+                for (uint32_t i = begin + threadIdx.x; (int32_t)(tail - i) > 0; i += 64u * kTeamWaves) {
+                    const uint32_t j = i & (uint32_t)(kRingTeam - 1);
+                    const uint32_t t = S.rt[j];
+                    if (t == kVoidTile) continue;
+                    G.write_record(atomicAdd(&sh->cnt, 1u), t, ((uint64_t)S.rhi[j] << 32) | S.rlo[j]);
+                }
+                __syncthreads();
+                const uint32_t first = sh->cnt;
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    sh->tail = first;
+                    sh->end = first;
+                    sh->overflow = 0u;
+                    sh->cnt = 0u;
+                }
+                __syncthreads();
+                uint32_t more_steps = 0u;
+                rc = first ? team_walk(A, k, b, thr, sn, cs, G, lane, wave, own, first, 0xFFFFFFFFu, &begin, &more_steps) : 0;
+                my_steps += more_steps;
+                // stamps and pixel count from the slab's table, the tiles shared out as in stamp_footprint
+                const uint32_t mine = kMarkBit | k, nt = sh->ntiles;
+                const int lr = lane >> 3, lc = lane & 7;
+                bool foreign = false;
+                for (uint32_t i = (uint32_t)wave; i < nt; i += kTeamWaves) {
+                    const uint32_t slot = uni(G.ord_slot(i));
+                    const uint32_t tile = uni(G.peek_key(slot)) - 1u;
+                    const uint64_t V = uni64(G.peek_walked(slot));
+                    if (lane == 0) px += (uint32_t)__popcll(V);
+                    if ((V >> lane) & 1ull) {
+                        const size_t q = (size_t)((tile >> 16) * 8 + lr) * A.w + ((tile & 0xFFFFu) * 8 + lc);
+                        const uint32_t old = atomicMin(&A.label[q], mine);
+                        A.dirty[q >> 8] = 1;
+                        if (old > mine) {
+                            if (old != kLabelFree) A.blocked[old & ~kMarkBit] = 1u;
+                        } else if (old < mine && old >= kMarkBit) {
+                            foreign = true;
+                        }
+                    }
+                }
+                if (__ballot(foreign)) st.blocked = true;
+                st.ntiles = nt;
+            }
+        }
+        if (!in_slab) {
+            st.ntiles = sh->ntiles;
+            stamp_footprint(A, k, S, st, lane, (uint32_t)wave * 8u, 8u * kTeamWaves);
+            for (int i = (int)threadIdx.x; i < kHashBig; i += 64 * kTeamWaves) px += (uint32_t)__popc(S.hv0[i]) + (uint32_t)__popc(S.hv1[i]);
+        }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) px += (uint32_t)__shfl_xor((int)px, off);
         if (lane == 0) {
@@ -1400,48 +1563,9 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
         st.cnt = sh->cnt;
         st.steps = sh->steps;
         st.blocked = sh->blocked != 0u;
-        if (rc != 0) {
-            // storage exhausted: what has been walked is stamped; this wavefront carries on alone in a global slab from
-            // the records that are still unprocessed (as explore_seed does for the single-wavefront tiers)
-            uint32_t slab = 0;
-            if (lane == 0) slab = atomicAdd(&A.ctrl[kCtrlSlabs], 1u);
-            slab = (uint32_t)__shfl((int)slab, 0);
-            if (slab < A.n_slabs) {
-                uint32_t gen = 0;
-                if (lane == 0) atomicAdd(&A.ctrl[kCtrlSlabTotal], 1u);
-                if (lane == 0) gen = atomicAdd(&A.ctrl[kCtrlGen], 1u) + 1u;
-                gen = (uint32_t)__shfl((int)gen, 0);
-                SlabStore G{A.slab_ring + (size_t)slab * A.slab_ring_cap, A.slab_hash + (size_t)slab * A.slab_hash_cap * 2,
-                            A.slab_ring_cap, A.slab_hash_cap, gen};
-                Pending P{pend, pend + kPend};
-                P.pt[lane] = 0u;
-                const uint32_t tail = sh->tail;
-                uint32_t n = 0u;
-                for (uint32_t i = begin; i != tail; ++i) {
-                    uint32_t t;
-                    uint64_t m;
-                    S.get(i, t, m);
-                    if (t == kVoidTile) continue;
-                    G.put(n, t, m);
-                    ++n;
-                }
-                for (int i = 0; i < kHashBig; ++i) {
-                    const uint32_t key = S.hk[i];
-                    if (key) {
-                        uint32_t slot;
-                        uint64_t v0;
-                        (void)G.lookup(key - 1u, slot, v0);
-                        G.update(slot, key - 1u, ((uint64_t)S.hv1[i] << 32) | S.hv0[i]);
-                    }
-                }
-                st.head = 0u;
-                st.tail = n;
-                rc = walk(A, k, b, thr, sn, cs, G, P, st, lane, own);
-            }
-            if (rc != 0 && lane == 0) {
-                A.flags[k] = kFlagIncomplete;
-                atomicMin(&A.ctrl[kCtrlBarrier], k);
-            }
+        if (rc != 0 && lane == 0) {  // no slab to go to, or the slab ran out as well: the ordered tail will finish this seed
+            A.flags[k] = kFlagIncomplete;
+            atomicMin(&A.ctrl[kCtrlBarrier], k);
         }
         if (lane == 0) {
             A.count[k] = st.cnt;
