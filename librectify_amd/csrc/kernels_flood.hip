@@ -1105,7 +1105,7 @@ __global__ __launch_bounds__(64) void flood_explore_big_kernel(FloodArgs A, BinT
 //     wavefronts that enter a tile at once share its new pixels between them instead of both walking on from all;
 //   - a stale V read by a neighbour's filter only costs a record that finds nothing new.
 // Stamps, pixel count and the blocked mark are taken from the table when the walk is over, by all wavefronts.  If ring or
-// table run out, the part walked so far is stamped and the first wavefront carries on alone in a global slab, as before.
+// table run out, the team moves into a global slab -- table, unprocessed records and all -- and goes on there (TeamGlobalStore).
 #ifndef LR_TEAM_WAVES
 #define LR_TEAM_WAVES 8
 #endif
