@@ -186,6 +186,8 @@ struct FloodArgs {
     uint32_t n_slabs, slab_ring_cap, slab_hash_cap;  // caps are powers of two
     uint32_t win_shift;                              // staged start (see kCtrlWindow): growth of the window per round
     uint32_t from_end;                               // explore the active list from its end (see flood_explore_kernel)
+    uint32_t no_rest;                                // this round has no `rest` launch: entries past the grid are not walked
+    uint32_t next_reach;                             // list entries the NEXT round's exploration reaches (0xFFFFFFFF: all)
     uint32_t big_cap;                                // seeds per round the second tier takes (0: tier switched off)
     uint32_t g_cap;                                  // partial-commit walks stop after this many tile steps
     uint32_t t1_tiles;                               // first tier hands a walk to the second at this many tiles (when there is one)
@@ -227,6 +229,7 @@ enum {
     kCtrlWalked = 18,   // [18..19] 64-bit: pixels walked by all explorations of the frame (diagnostics: re-walk factor)
     kCtrlSteps = 20,    // [20..21] 64-bit: tile steps of all explorations
     kCtrlBigSeen = 22,  // 1: the frame had many long walks (kCtrlBigLong) when the current round began -- early hand-over
+    kCtrlBarrierNext = 24,  // lowest seed of the next round's list that its exploration launch will not reach (no `rest` launch)
     kCtrlBigLong = 23,  // walks of the frame that really outgrew the first tier (more tiles than its table holds)
     kCtrlWords = 32,
 };
@@ -1048,7 +1051,10 @@ __device__ __forceinline__ void explore_body(const FloodArgs& A, const BinTrig& 
     if (!kRest) {
         const uint32_t ai = uni(blockIdx.x);
         if (ai >= n_act) return;
-        const uint32_t k = uni(act[A.from_end ? n_act - 1u - ai : ai]);
+        // (a round without a `rest` launch whose list is longer than its grid walks the FIRST entries: the survivors pass
+        // that wrote the list has put a barrier at the lowest seed behind them -- enqueue_round)
+        const bool fwd = A.no_rest != 0u && n_act > gridDim.x;
+        const uint32_t k = uni(act[(A.from_end && !fwd) ? n_act - 1u - ai : ai]);
         if (k >= window) return;  // not yet in the staged window (stays active)
         explore_seed<LdsStore, true>(A, trig, k, L, P, big_list, lane, t1_tiles);
     } else {
@@ -1704,7 +1710,8 @@ __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift, u
     ctrl[kCtrlNAct] = progress ? n_next : 0u;
     ctrl[kCtrlNNext] = 0u;
     ctrl[kCtrlNCommit] = 0u;
-    ctrl[kCtrlBarrier] = 0xFFFFFFFFu;
+    ctrl[kCtrlBarrier] = ld_agent(&ctrl[kCtrlBarrierNext]);  // (0xFFFFFFFF unless the next round cannot reach its whole list)
+    ctrl[kCtrlBarrierNext] = 0xFFFFFFFFu;
     ctrl[kCtrlSlabs] = 0u;
     ctrl[kCtrlNBig] = 0u;
     ctrl[kCtrlBigSeen] = ld_agent(&ctrl[kCtrlBigLong]) >= regional_min ? 1u : 0u;
@@ -1787,7 +1794,9 @@ __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, const
         if (a) {
             uint32_t base = s_base;
             for (int w2 = 0; w2 < wave; ++w2) base += s_cnt[w2][0];
-            act_next[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = k;
+            const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            act_next[pos] = k;
+            if (pos >= A.next_reach) atomicMin(&A.ctrl[kCtrlBarrierNext], k);  // (never, in practice: see enqueue_round)
         }
         __syncthreads();  // s_cnt and s_base are rewritten by the next pass of the loop
     }
@@ -1835,6 +1844,7 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
         ctrl[kCtrlBigSeen] = 0u;
         ctrl[kCtrlSlabTotal] = 0u;
         ctrl[kCtrlBarrier] = 0xFFFFFFFFu;
+        ctrl[kCtrlBarrierNext] = 0xFFFFFFFFu;
         ctrl[kCtrlSlabs] = 0u;
         ctrl[kCtrlNAct] = n_seeds;
         ctrl[kCtrlNCommit] = 0u;
@@ -2069,6 +2079,8 @@ FloodArgs flood_args(const FloodBuffers& B, const FloodFrame& F, bool use_big) {
     A.slab_hash_cap = B.slab_hash_cap;
     static const int order_env = std::getenv("LIBRECTIFY_FLOOD_ORDER") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_ORDER")) : -1;
     A.from_end = order_env >= 0 ? (uint32_t)order_env : 1u;
+    A.no_rest = 0u;
+    A.next_reach = 0xFFFFFFFFu;
     A.win_shift = 2u;
     const uint32_t big_cap = B.big_cap_override ? B.big_cap_override : kBigCap;
     A.big_cap = use_big ? big_cap : 0u;
@@ -2094,7 +2106,7 @@ FloodArgs flood_args(const FloodBuffers& B, const FloodFrame& F, bool use_big) {
 const bool g_flood_debug = std::getenv("LIBRECTIFY_FLOOD_DEBUG") != nullptr;
 
 // one round: explore (main launch, the entries past its grid, second LDS tier), commit pass, survivors pass
-void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& A, bool use_big, int index, hipStream_t s) {
+void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& A0, bool use_big, int index, hipStream_t s) {
     uint32_t* lists[2] = {B.act_a, B.act_b};
     uint32_t* act = lists[index & 1];
     uint32_t* act_next = lists[(index + 1) & 1];
@@ -2109,10 +2121,25 @@ void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& 
     }
     // grid: see flood_explore_kernel.  A staged start keeps the list long for a round more.
     // (not below a quarter: while the weakest fifth of the seeds is held back, the list stays that long)
-    const int shift = std::min(std::max(index - (B.win_first_shift > 0 ? 1 : 0), 0), 2);
-    const uint32_t grid = std::max<uint32_t>(std::min<uint32_t>(F.seed_cap, 2048u), F.seed_cap >> shift);
+    // From the fourth round on the lists are a tenth of the grid (a quarter of the capacity) and the `rest` launch -- the
+    // entries past the guess -- was one empty launch per round, blind rounds included.  It is gone there; should such a list
+    // ever be longer than its grid, the round walks its first entries and the survivors pass that wrote the list has set
+    // the round's barrier at the lowest seed behind them (next_reach): nothing above an unwalked seed commits, exact as
+    // with a walk that ran out of storage.  (Test hook LIBRECTIFY_FLOOD_TEST_GRID: a tiny grid for those rounds.)
+    static const int test_grid = std::getenv("LIBRECTIFY_FLOOD_TEST_GRID") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_TEST_GRID")) : 0;
+    auto grid_of = [&](int idx) {
+        const int shift = std::min(std::max(idx - (B.win_first_shift > 0 ? 1 : 0), 0), 2);
+        uint32_t g = std::max<uint32_t>(std::min<uint32_t>(F.seed_cap, 2048u), F.seed_cap >> shift);
+        if (test_grid > 0 && idx >= 3) g = std::min<uint32_t>(g, (uint32_t)test_grid);
+        return g;
+    };
+    auto has_rest = [&](int idx) { return idx < 3 && grid_of(idx) < F.seed_cap; };
+    const uint32_t grid = grid_of(index);
+    FloodArgs A = A0;
+    A.no_rest = (grid < F.seed_cap && !has_rest(index)) ? 1u : 0u;
+    A.next_reach = (grid_of(index + 1) < F.seed_cap && !has_rest(index + 1)) ? grid_of(index + 1) : 0xFFFFFFFFu;
     hipLaunchKernelGGL(flood_explore_kernel, dim3(grid), dim3(64), 0, s, A, F.trig, act, B.big_list);
-    if (grid < F.seed_cap)  // entries past the guess, if any
+    if (has_rest(index))  // entries past the guess, if any
         hipLaunchKernelGGL(flood_explore_rest_kernel, dim3(1024), dim3(64), 0, s, A, F.trig, act, B.big_list, grid);
     static const bool team = !(std::getenv("LIBRECTIFY_FLOOD_TEAM") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_TEAM")) == 0);
     if (use_big && team)

@@ -721,6 +721,36 @@ def test_what_a_context_carries_from_frame_to_frame_never_changes_a_result(L):
     c.close()
 
 
+def test_a_round_whose_list_outgrows_its_grid_is_exact(L):
+    """From the fourth round on the exploration has no `rest` launch behind it: a list longer than the grid is walked in its
+    first entries only, and the survivors pass before it has put the round's barrier at the lowest seed behind them.
+    LIBRECTIFY_FLOOD_TEST_GRID=4 makes every such round outgrow its grid (the flood then stalls and the ordered tail
+    finishes it: slow, and exact).  The knob is read once per process: one child process, three frames against the oracle."""
+    import subprocess
+    import sys
+
+    code = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np
+import oracle_lib as O
+import librectify_amd as L
+from librectify_amd import synth
+ctx = L.Context(0); ctx.set_seed(0)
+tails = 0
+for img in (synth.frame(3840, 2160, 1), synth.frame(1920, 1080, 9), synth.frame(960, 540, 4, bars=40)):
+    ref, _ = O.find_line_segment_groups(img, max(img.shape) / 100.0, seed=0)
+    got = ctx.find_line_segment_groups(img, max(img.shape) / 100.0)
+    assert got.tobytes() == ref.tobytes(), "mismatch"
+    tails += ctx.stage_counters()["ordered_tail_seeds"]
+assert tails > 0, "the knob did not bite"
+print("ok", tails)
+""" % (ROOT, ROOT)
+    env = dict(os.environ, LIBRECTIFY_FLOOD_TEST_GRID="4")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().startswith("ok"), (r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_component_sort_classes_up_to_a_flood_of_20000_pixels(L, ctx):
     """The per-component pixel sort has four size classes (<= 64 px in a wavefront, <= 4096 and <= 16384 in LDS, beyond
     that in global memory).  A 3200x200 frame with a soft horizontal step (a 6-px wide, 3200-px long flood) and bars of
