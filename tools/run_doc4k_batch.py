@@ -1,4 +1,5 @@
-"""Batch throughput on the natural 4K frame of tools/run_doc4k.py (16 frames in flight, device-resident)."""
+"""Batch throughput on the natural 4K frame of tools/run_doc4k.py: frames resident in HBM, then the same frames from
+pageable host memory (upload inside the call).  usage: tools/run_doc4k_batch.py [lanes]"""
 import os, sys; sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np, time
 import scipy.ndimage as ndi
@@ -20,3 +21,8 @@ for rep in range(4):
     dt = time.time() - t
     print("%d frames: %.1f ms, %.0f Mpix/s, mean segments %.0f" % (B, dt * 1e3, B * W * H / dt / 1e6, float(np.mean(n))), flush=True)
 ctx.device_free(d)
+for rep in range(4):
+    t = time.time()
+    out, n, tf = ctx.find_line_segment_groups_batch_host(frames, max(W, H) / 100.0, num_threads=12, capacity=4096)
+    dt = time.time() - t
+    print("%d frames from pageable host memory: %.1f ms, %.0f Mpix/s, mean segments %.0f" % (B, dt * 1e3, B * W * H / dt / 1e6, float(np.mean(n))), flush=True)
