@@ -37,7 +37,7 @@ typedef struct lr_context lr_context;
 int lr_context_create(int device, lr_context** out);
 void lr_context_destroy(lr_context* ctx);
 /* The drop-in functions keep one context per calling host thread (device workspace of about 130 bytes per pixel of the
- * largest frame seen, 288 MB of flood overflow slabs, page-locked staging, staging threads) until the thread exits;
+ * largest frame seen, 288 MB of flood overflow slabs, 32 MB of hand-over records, page-locked staging, staging threads) until the thread exits;
  * a thread that is done with the library for a while can give it back at once.  The next call makes a new one. */
 void lr_release_thread_context(void);
 const char* lr_last_error(void);
