@@ -749,8 +749,6 @@ int finish_flood(lr_context* c, bool* extra) {
         // with it, the natural 4K frame sends 735 walks to the second tier in round one and its flood takes 1.88 ms instead
         // of 1.5, and a frame of lines that follows pays 0.7 ms for the wrong guess.)
     }
-    static const int hold_hint_env = std::getenv("LIBRECTIFY_FLOOD_HOLD_HINT") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_HOLD_HINT")) : -1;  // (experiment knob)
-    if (hold_hint_env >= 0) c->flood_hold_hint = hold_hint_env != 0;
 
     // blind rounds of the next frame: what this one needed plus two, decaying slowly
     static const int blind_extra = std::getenv("LIBRECTIFY_BLIND_EXTRA") ? std::atoi(std::getenv("LIBRECTIFY_BLIND_EXTRA")) : 2;  // (experiment knob)
