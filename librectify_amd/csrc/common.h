@@ -81,7 +81,8 @@ void set_error(const std::string& msg);
 // kernels_filter.hip
 int launch_filter(const float* img, int w, int h, int stride, const FilterConsts& fc, float* dx, float* dy,
                   uint8_t* dmask, uint64_t* cand, uint32_t* cand_count, uint32_t* tile_max, hipStream_t s);
-int filter_band_rows();  // image rows per band of the filter kernel (a band reads four rows above and 33 below its first)
+int filter_band_rows();  // image rows per band of the filter kernel
+int filter_band_last_row(int by);  // last image row band row `by` reads (its first is filter_band_rows() * by - 4)
 int launch_filter_rows(const float* img, int w, int h, int stride, const FilterConsts& fc, float* dx, float* dy,
                        uint8_t* dmask, uint64_t* cand, uint32_t* cand_count, uint32_t* tile_max, int by_begin, int by_end,
                        hipStream_t s);

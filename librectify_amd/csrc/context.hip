@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <mutex>
 #include <cmath>
 #include <cstdio>
@@ -292,7 +293,8 @@ struct StagingCrew {
     lr_context* c = nullptr;
     std::vector<std::thread> th;
     std::atomic<uint32_t> job{0};
-    std::atomic<uint64_t> next{0};  // job number << 32 | next band
+    std::atomic<uint64_t> next{0};   // job number << 32 | next piece
+    std::atomic<uint64_t> total{0};  // job number << 32 | pieces of that job
     std::atomic<int> bands_left{0}, failed{0};
     std::atomic<bool> quit{false};
     // Two job descriptors, used alternately (job number & 1): the one a late helper may still be reading is not the one
@@ -317,15 +319,21 @@ struct StagingCrew {
     static constexpr int kMaxBands = 256;
     std::atomic<int> pieces_left[2][kMaxBands];
 
-    void work(uint32_t gen) {
-        const Job j = jobs[gen & 1u];
-        const size_t row_bytes = (size_t)j.w * sizeof(float);
-        const int kP = j.pieces;
-        const int rows_per_piece = (j.rows_per_band + kP - 1) / kP;
+    // One piece of job `gen`, if there is one left: true if a piece was claimed (and copied).  The descriptor is read only
+    // AFTER the claim: a claimed piece keeps bands_left above zero, the uploader is then still inside finish() of this very
+    // job, and nobody writes either descriptor (begin() of the next job comes after that finish(); the job after it, which
+    // reuses this slot, after the next one's).  A helper that is late for a job finds another job's number in `next` /
+    // `total` and leaves without having looked at anything else.
+    bool work_one(uint32_t gen) {
         for (;;) {
             uint64_t x = next.load(std::memory_order_acquire);
-            if ((uint32_t)(x >> 32) != gen || (int)(uint32_t)x >= j.n_bands * kP) return;
+            const uint64_t t = total.load(std::memory_order_acquire);
+            if ((uint32_t)(x >> 32) != gen || (uint32_t)(t >> 32) != gen || (uint32_t)x >= (uint32_t)t) return false;
             if (!next.compare_exchange_weak(x, x + 1, std::memory_order_acq_rel)) continue;
+            const Job& j = jobs[gen & 1u];
+            const size_t row_bytes = (size_t)j.w * sizeof(float);
+            const int kP = j.pieces;
+            const int rows_per_piece = (j.rows_per_band + kP - 1) / kP;
             const int k = (int)(uint32_t)x / kP, piece = (int)(uint32_t)x % kP;
             const int b0 = k * j.rows_per_band, b1 = std::min(j.h, b0 + j.rows_per_band);
             const int r0 = std::min(b1, b0 + piece * rows_per_piece), r1 = std::min(b1, r0 + rows_per_piece);
@@ -336,7 +344,7 @@ struct StagingCrew {
                     for (int r = r0; r < r1; ++r) stage_copy(j.stage + (size_t)r * j.w, j.src + (size_t)r * j.stride, row_bytes);
                 }
             }
-            if (pieces_left[gen & 1u][k].fetch_sub(1, std::memory_order_acq_rel) != 1) continue;  // not the band's last piece
+            if (pieces_left[gen & 1u][k].fetch_sub(1, std::memory_order_acq_rel) != 1) return true;  // not the band's last piece
             bool ok = hipMemcpyAsync(j.dst + (size_t)b0 * j.w, j.stage + (size_t)b0 * j.w, (size_t)(b1 - b0) * row_bytes,
                                      hipMemcpyHostToDevice, j.up) == hipSuccess;
             if (ok && j.band_ev) ok = hipEventRecord(j.band_ev[k], j.up) == hipSuccess;
@@ -345,21 +353,45 @@ struct StagingCrew {
                 failed.store(1);
             }
             if (j.ready) j.ready[k].store(ok ? 1 : -1, std::memory_order_release);
-            bands_left.fetch_sub(1, std::memory_order_acq_rel);
+            bands_left.fetch_sub(1, std::memory_order_acq_rel);  // (last: the descriptor is not touched after this)
+            return true;
         }
     }
+    void work(uint32_t gen) {
+        while (work_one(gen)) {
+        }
+    }
+    // Helpers between jobs: a short spin (frames of a batch follow each other within microseconds), then they BLOCK on a
+    // condition variable -- a library behind librectify.h must not keep eight threads polling in a process that is doing
+    // nothing (round 3 did: 20 us naps for ever).  begin() wakes them only if somebody sleeps.
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<int> sleepers{0};
+    std::atomic<int> live{0};  // helpers that have a device and are taking jobs (the caller stages alone if none is)
     void start(lr_context* ctx, int helpers) {
         c = ctx;
+        live.store(helpers, std::memory_order_relaxed);
         for (int t = 0; t < helpers; ++t)
             th.emplace_back([this]() {
-                if (hipSetDevice(c->device) != hipSuccess) return;  // a helper less: the uploader stages every band itself if need be
+                if (hipSetDevice(c->device) != hipSuccess) {  // a helper less; whoever waits for bands works on them itself
+                    (void)hipGetLastError();
+                    live.fetch_sub(1, std::memory_order_acq_rel);
+                    return;
+                }
                 uint32_t last = 0;
                 int spins = 0;
                 while (!quit.load(std::memory_order_acquire)) {
-                    const uint32_t g = job.load(std::memory_order_acquire);
+                    const uint32_t g = job.load(std::memory_order_seq_cst);
                     if (g == last) {
-                        if (++spins < 256) std::this_thread::yield();
-                        else std::this_thread::sleep_for(std::chrono::microseconds(20));
+                        if (++spins < 512) {
+                            std::this_thread::yield();
+                            continue;
+                        }
+                        std::unique_lock<std::mutex> lk(mu);
+                        sleepers.fetch_add(1, std::memory_order_seq_cst);
+                        cv.wait(lk, [&]() { return quit.load(std::memory_order_acquire) || job.load(std::memory_order_seq_cst) != last; });
+                        sleepers.fetch_sub(1, std::memory_order_seq_cst);
+                        spins = 0;
                         continue;
                     }
                     spins = 0;
@@ -367,6 +399,12 @@ struct StagingCrew {
                     work(g);
                 }
             });
+    }
+    void wake() {
+        if (sleepers.load(std::memory_order_seq_cst) > 0) {
+            { std::lock_guard<std::mutex> lk(mu); }
+            cv.notify_all();
+        }
     }
     // stages one frame (rows as in upload_rows) and enqueues its transfers; returns when every band is enqueued
     int run(float* dst_, float* stage_, const float* buffer, int w_, int h_, int stride_, hipStream_t up_,
@@ -403,20 +441,25 @@ struct StagingCrew {
         for (int k = 0; k < j.n_bands; ++k) pieces_left[g & 1u][k].store(j.pieces, std::memory_order_relaxed);
         failed.store(0, std::memory_order_relaxed);  // (per frame: every band of the previous one has been accounted for)
         bands_left.store(j.n_bands, std::memory_order_relaxed);
+        total.store(((uint64_t)g << 32) | (uint32_t)(j.n_bands * j.pieces), std::memory_order_release);
         next.store((uint64_t)g << 32, std::memory_order_release);
-        job.store(g, std::memory_order_release);
+        job.store(g, std::memory_order_seq_cst);
+        wake();
         return g;
     }
     int finish() {
         int spins = 0;
         while (bands_left.load(std::memory_order_acquire) > 0) {
+            if (live.load(std::memory_order_acquire) == 0 && work_one(job.load(std::memory_order_relaxed))) continue;
             if (++spins < 256) std::this_thread::yield();
             else std::this_thread::sleep_for(std::chrono::microseconds(10));
         }
         return failed.load() ? 1 : 0;
     }
     ~StagingCrew() {
-        quit.store(true, std::memory_order_release);
+        quit.store(true, std::memory_order_seq_cst);
+        { std::lock_guard<std::mutex> lk(mu); }
+        cv.notify_all();
         for (auto& t : th) t.join();
     }
 };
@@ -477,23 +520,44 @@ int ctx_create(int device, lr_context** out) {
         set_error("hipStreamCreate failed");
         return 1;
     }
-    for (auto& e : c->ev) (void)hipEventCreate(&e);
-    (void)hipEventCreateWithFlags(&c->ev_wait, hipEventBlockingSync | hipEventDisableTiming);
+    // Every allocation is checked: a create that ran out of memory must fail here, cleanly, and not hand out a context
+    // whose first kernel faults on a null buffer (six lanes and their pools hold several GB -- exactly when it can happen).
+    // LIBRECTIFY_TEST_CREATE_FAIL=n (test hook) makes the n-th allocation of a create report hipErrorOutOfMemory.
     {
+        static const int fail_at = std::getenv("LIBRECTIFY_TEST_CREATE_FAIL") ? std::atoi(std::getenv("LIBRECTIFY_TEST_CREATE_FAIL")) : 0;
+        int n_alloc = 0;
+        hipError_t bad = hipSuccess;
+        const char* what = "";
+        auto check = [&](hipError_t e, const char* name) {
+            if (++n_alloc == fail_at) e = hipErrorOutOfMemory;
+            if (e != hipSuccess && bad == hipSuccess) {
+                bad = e;
+                what = name;
+            }
+        };
+        for (auto& e : c->ev) check(hipEventCreate(&e), "hipEventCreate");
+        check(hipEventCreateWithFlags(&c->ev_wait, hipEventBlockingSync | hipEventDisableTiming), "hipEventCreate");
         static const bool lane_debug = std::getenv("LIBRECTIFY_LANE_DEBUG") != nullptr;  // (its timeline times the uploads)
-        for (auto& e : c->ev_up) (void)hipEventCreateWithFlags(&e, lane_debug ? hipEventDefault : hipEventDisableTiming);
+        for (auto& e : c->ev_up) check(hipEventCreateWithFlags(&e, lane_debug ? hipEventDefault : hipEventDisableTiming), "hipEventCreate");
+        check(hipMalloc((void**)&c->maxmag, sizeof(float)), "hipMalloc(maxmag)");
+        check(hipMalloc((void**)&c->d_counts, 64 * sizeof(uint32_t)), "hipMalloc(counts)");
+        check(hipMalloc((void**)&c->d_gctl, kGcWords * sizeof(uint32_t)), "hipMalloc(peeling control block)");
+        check(hipMalloc((void**)&c->d_gnorm, 4 * sizeof(float)), "hipMalloc(normalisation)");
+        check(hipMalloc((void**)&c->d_models, 64 * sizeof(float)), "hipMalloc(models)");
+        check(hipMalloc((void**)&c->d_best_score, sizeof(float)), "hipMalloc(best score)");
+        check(hipMalloc((void**)&c->d_best_iter, sizeof(int32_t)), "hipMalloc(best iteration)");
+        check(hipHostMalloc((void**)&c->h_counts, 64 * sizeof(uint32_t)), "hipHostMalloc(counts)");
+        check(hipHostMalloc((void**)&c->h_best, 2 * sizeof(float)), "hipHostMalloc(best)");
+        if (bad == hipSuccess) check(hipMemset(c->d_models, 0, 64 * sizeof(float)), "hipMemset(models)");
+        if (bad == hipSuccess) check(hipMemset(c->d_counts, 0, 64 * sizeof(uint32_t)), "hipMemset(counts)");
+        if (bad != hipSuccess) {
+            (void)hipGetLastError();
+            const std::string msg = std::string("lr_context_create: ") + what + " failed: " + hipGetErrorString(bad);
+            ctx_destroy(c);  // (frees whatever was made; null members are skipped)
+            set_error(msg);
+            return 1;
+        }
     }
-    (void)hipMalloc((void**)&c->maxmag, sizeof(float));
-    (void)hipMalloc((void**)&c->d_counts, 64 * sizeof(uint32_t));
-    (void)hipMalloc((void**)&c->d_gctl, kGcWords * sizeof(uint32_t));
-    (void)hipMalloc((void**)&c->d_gnorm, 4 * sizeof(float));
-    (void)hipMalloc((void**)&c->d_models, 64 * sizeof(float));
-    (void)hipMemset(c->d_models, 0, 64 * sizeof(float));
-    (void)hipMemset(c->d_counts, 0, 64 * sizeof(uint32_t));
-    (void)hipMalloc((void**)&c->d_best_score, sizeof(float));
-    (void)hipMalloc((void**)&c->d_best_iter, sizeof(int32_t));
-    (void)hipHostMalloc((void**)&c->h_counts, 64 * sizeof(uint32_t));
-    (void)hipHostMalloc((void**)&c->h_best, 2 * sizeof(float));
     init_constants(c);
     const char* env = std::getenv("LIBRECTIFY_SEED");
     c->ransac_seed = env ? std::strtoull(env, nullptr, 0) : 0ull;
@@ -633,8 +697,8 @@ FloodBuffers flood_buffers_for(lr_context* c) {
         fbuf.n_slabs = 0;      // the weakest seeds are held back, and must still hand over to the ordered tail
         fbuf.big_cap_override = 1;
     }
-    if (c->flood_mode == 6) fbuf.team_tile_cap = 200;  // the second tier's team runs out early: it stamps what it has and one
-    if (c->flood_mode == 7) {                           // wavefront carries on in a slab (6), or there is none: incomplete
+    if (c->flood_mode == 6) fbuf.team_tile_cap = 200;  // the second tier's team runs out early: the whole team moves into a
+    if (c->flood_mode == 7) {                           // global slab and goes on there (6), or there is none: incomplete
         fbuf.team_tile_cap = 200;                       // walk, barrier, ordered tail (7)
         fbuf.n_slabs = 0;
     }
@@ -1875,6 +1939,19 @@ int ctx_find_groups_host(lr_context* c, const float* buffer, int w, int h, int s
         stage = c->h_stage[slot];
     }
     if (prepare_frame(c, w, h)) return 1;
+    // Whatever way this call ends, nothing of it may still be on the link or the GPU when it returns with an error: the
+    // next call would fill the staging buffer under a transfer that still reads it (ev_up is only recorded on success).
+    struct DrainOnError {
+        lr_context* c;
+        hipStream_t up;
+        bool ok = false;
+        ~DrainOnError() {
+            if (ok) return;
+            (void)hipStreamSynchronize(up);
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipGetLastError();
+        }
+    } drain{c, up};
     const float* src = buffer;
     int sstride = stride;
     if (sstride < 0) {  // image.cpp:14-18: the same rows, addressed from the other end (no flip)
@@ -1907,7 +1984,7 @@ int ctx_find_groups_host(lr_context* c, const float* buffer, int w, int h, int s
         if ((k + 1) % filter_every != 0 && k != n_bands - 1) return 0;
         const int last_row = std::min(h, (k + 1) * rpb) - 1;  // last image row on the device once bands 0..k are
         int by_end = by_next;
-        while (by_end < band_rows && std::min(h - 1, fb * by_end + 33) <= last_row) ++by_end;
+        while (by_end < band_rows && std::min(h - 1, filter_band_last_row(by_end)) <= last_row) ++by_end;
         if (k == n_bands - 1) by_end = band_rows;
         if (launch_filter_rows(dst, w, h, w, c->fconsts, c->dx, c->dy, c->dmask, c->cand, c->cand_count, c->tile_max, by_next,
                                by_end, c->stream))
@@ -1949,16 +2026,20 @@ int ctx_find_groups_host(lr_context* c, const float* buffer, int w, int h, int s
         StagingCrew* cr = static_cast<StagingCrew*>(c->crew);
         std::vector<std::atomic<int>> ready((size_t)n_bands);
         for (auto& a : ready) a.store(0, std::memory_order_relaxed);
-        (void)cr->begin(dst, stage, src, w, h, sstride, up, c->band_ev.data(), ready.data(), band_bytes);
+        const uint32_t g = cr->begin(dst, stage, src, w, h, sstride, up, c->band_ev.data(), ready.data(), band_bytes);
         int rc = 0;
         for (int k = 0; k < n_bands && rc == 0; ++k) {
             int spins = 0, r;
             while ((r = ready[(size_t)k].load(std::memory_order_acquire)) == 0) {
+                // No helper alive (none got a device), or the helpers are starved of cores: this thread stages pieces itself
+                // instead of waiting for ever for somebody else to.
+                if ((cr->live.load(std::memory_order_acquire) == 0 || spins > 4096) && cr->work_one(g)) continue;
                 if (++spins < 2048) std::this_thread::yield();
                 else std::this_thread::sleep_for(std::chrono::microseconds(5));
             }
             if (r < 0 || filter_after_band(k)) rc = 1;
         }
+        if (rc) cr->work(g);  // (the bands still unclaimed must be accounted for before finish() can return)
         if (cr->finish() || rc) {  // (every band accounted for before `ready` goes out of scope)
             if (get_error().empty()) set_error("upload: staging copy failed");
             return 1;
@@ -1969,6 +2050,7 @@ int ctx_find_groups_host(lr_context* c, const float* buffer, int w, int h, int s
     static const bool call_debug = std::getenv("LIBRECTIFY_CALL_DEBUG") != nullptr;
     const double t_up = now_ms();
     const int rc = run_frame(c, dst, w, h, w, min_length, refine, out, true);
+    drain.ok = rc == 0;
     if (call_debug)
         std::fprintf(stderr, "host frame: bands staged, sent and filter launched in %.3f ms; rest of the frame enqueued in %.3f ms; waited %.3f ms; "
                      "results out in %.3f ms; whole call %.3f ms\n", t_up - t_call, c->host_ms[0], c->host_ms[2],

@@ -260,6 +260,8 @@ static int filter_taps(const FilterConsts& fc, FilterTaps& ft) {
 }
 
 int filter_band_rows() { return kBandRows; }
+// a band walks kBandSteps image rows from kBandRows * by - 4 on (lane_step: row y0 - 4 + t, t < kBandSteps)
+int filter_band_last_row(int by) { return kBandRows * by - 4 + kBandSteps - 1; }
 
 // The bands whose image rows lie in [row_begin, row_end) -- band row `by` reads the image rows 30 by - 4 .. 30 by + 33 --
 // i.e. the band rows [by_begin, by_end).  A frame that is still arriving over the link is filtered in a few such

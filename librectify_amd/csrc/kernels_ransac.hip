@@ -101,23 +101,11 @@ __device__ __forceinline__ EstConst est_const(float tol) {
     const float a = (1.0f - tol) + kErrBand, b = (1.0f - tol) - kErrBand;
     return EstConst{a * a, b * b};
 }
-__device__ __forceinline__ void inlier_estimate(const float cx, const float cy, const float nsub, float ax, float ay, float dx,
-                                                float dy, const EstConst& K, uint64_t& m_in, uint64_t& m_unsure) {
-    const float vx = __builtin_fmaf(nsub, ax, cx), vy = __builtin_fmaf(nsub, ay, cy);
-    const float nn = __builtin_fmaf(vx, vx, vy * vy);
-    const float dot = __builtin_fmaf(vx, dx, vy * dy);
-    const float dd = dot * dot;
-    // thresholds with a floor of kTiny on either side: for |v|^2 below it neither comparison can hold (dot^2 <= |v|^2),
-    // so such a line is unsure without a comparison of its own; for any |v|^2 the floor only makes a decision less sure
-    const float t_in = __builtin_fmaf(nn, K.k_in, kTiny), t_out = __builtin_fmaf(nn, K.k_out, -kTiny);
-    // lane masks straight from the comparisons (v_cmp writes an SGPR pair); they are combined on the scalar unit
-    m_in = __builtin_amdgcn_fcmpf(dd, t_in, 2 /* > (ordered) */);
-    const uint64_t m_out = __builtin_amdgcn_fcmpf(dd, t_out, 4 /* < (ordered) */);
-    m_unsure = ~(m_in | m_out);
-}
-
-// The same for TWO hypotheses at once in packed fp32 (v_pk_fma_f32 / v_pk_mul_f32: both halves are the IEEE operations
-// of the scalar form, so the masks are the same bits): nine packed instructions instead of eighteen.
+// Evaluated for TWO hypotheses at once in packed fp32 (v_pk_fma_f32 / v_pk_mul_f32: both halves are IEEE operations, the
+// masks are what a scalar evaluation would give): nine packed instructions instead of eighteen.  Thresholds carry a floor
+// of kTiny on either side: for |v|^2 below it neither comparison can hold (dot^2 <= |v|^2), so such a line is unsure without
+// a comparison of its own.  The lane masks come straight from the comparisons (v_cmp writes an SGPR pair) and are combined
+// on the scalar unit.
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void inlier_estimate2(const f2 cx, const f2 cy, const f2 nsub, float ax, float ay, float dx, float dy,
                                                  const EstConst& K, uint64_t& m_in0, uint64_t& m_un0, uint64_t& m_in1,
@@ -197,7 +185,6 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(PencilSoA m, uint32_t
             const float ax = s_tab[buf][0][t], ay = s_tab[buf][1][t], dx = s_tab[buf][2][t], dy = s_tab[buf][3][t];
             const float len = s_tab[buf][4][t];
             uint64_t any_unsure = 0ull, mu[kH];
-#ifndef LR_SCORE_SCALAR
             static_assert(kH % 2 == 0, "hypotheses are scored in pairs");
 #pragma unroll
             for (int j = 0; j < kH; j += 2) {
@@ -209,16 +196,6 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(PencilSoA m, uint32_t
                 acc[j + 1] = acc[j + 1] + (__builtin_amdgcn_inverse_ballot_w64(mi1 & ~mu[j + 1]) ? len : 0.0f);
                 any_unsure |= mu[j] | mu[j + 1];
             }
-#else
-#pragma unroll
-            for (int j = 0; j < kH; ++j) {
-                uint64_t mi;
-                inlier_estimate(cx[j], cy[j], nsub[j], ax, ay, dx, dy, K, mi, mu[j]);
-                // (an unsure line adds nothing here; the canonical test below adds it if it is an inlier)
-                acc[j] = acc[j] + (__builtin_amdgcn_inverse_ballot_w64(mi & ~mu[j]) ? len : 0.0f);
-                any_unsure |= mu[j];
-            }
-#endif
             if (__builtin_expect(any_unsure != 0ull, 0)) {  // wave-uniform, rare
 #pragma unroll
                 for (int j = 0; j < kH; ++j)
@@ -328,7 +305,6 @@ __global__ __launch_bounds__(256) void prosac_count_kernel(PencilSoA m, uint32_t
         for (uint32_t t = lane; t < cn; t += 64) {
             const float ax = s_tab[buf][0][t], ay = s_tab[buf][1][t], dx = s_tab[buf][2][t], dy = s_tab[buf][3][t];
             uint64_t any_unsure = 0ull, mu[kH];
-#ifndef LR_SCORE_SCALAR
 #pragma unroll
             for (int j = 0; j < kH; j += 2) {
                 uint64_t mi0, mi1;
@@ -338,15 +314,6 @@ __global__ __launch_bounds__(256) void prosac_count_kernel(PencilSoA m, uint32_t
                 cnt[j + 1] += __builtin_amdgcn_inverse_ballot_w64(mi1 & ~mu[j + 1]) ? 1u : 0u;
                 any_unsure |= mu[j] | mu[j + 1];
             }
-#else
-#pragma unroll
-            for (int j = 0; j < kH; ++j) {
-                uint64_t mi;
-                inlier_estimate(cx[j], cy[j], nsub[j], ax, ay, dx, dy, K, mi, mu[j]);
-                cnt[j] += __builtin_amdgcn_inverse_ballot_w64(mi & ~mu[j]) ? 1u : 0u;
-                any_unsure |= mu[j];
-            }
-#endif
             if (__builtin_expect(any_unsure != 0ull, 0)) {  // wave-uniform, rare
 #pragma unroll
                 for (int j = 0; j < kH; ++j)

@@ -1462,9 +1462,10 @@ LineSegment merge_lines(const std::vector<LineSegment>& lines) {  // :254-274
 // The four constants of the pair test (line_detector.cpp:369,382,385): today's values are the defaults; the sweep of
 // tools/sweep_refine_pins.py varies them to look for the older set the doc/ artefacts were made with.
 struct RefineParams {
-    float cos_gate = 0.99f;   // |d_i . d_j| below this: not parallel enough           (:369, a double literal there)
-    float max_offset = 0.02f; // normal offset of both endpoints, in units of the longer segment's length (:382)
-    float lo = -0.5f, hi = 1.5f;  // overlap window along the longer segment (:385)
+    // (doubles, as the reference's literals: a float value is compared after promotion, and 0.02f < 0.02)
+    double cos_gate = 0.99;    // |d_i . d_j| below this: not parallel enough           (:369)
+    double max_offset = 0.02;  // normal offset of both endpoints, in units of the longer segment's length (:382)
+    double lo = -0.5, hi = 1.5;  // overlap window along the longer segment (:385)
 };
 std::vector<LineSegment> postprocess_lines_segments(const std::vector<LineSegment>& lines, const ThreadContext& ctx,
                                                     const RefineParams& P = RefineParams()) {  // :332-444
@@ -1484,7 +1485,7 @@ std::vector<LineSegment> postprocess_lines_segments(const std::vector<LineSegmen
         const auto& li = lines[i];
         for (int j = i + 1; j < n; ++j) {
             const auto& lj = lines[j];
-            if (std::fabs(d[i].x * d[j].x + d[i].y * d[j].y) < (double)P.cos_gate) continue;
+            if (std::fabs(d[i].x * d[j].x + d[i].y * d[j].y) < P.cos_gate) continue;
             float w00, w01, w10, w11;  // W(row, col): rows = the two endpoints, col0 = along, col1 = normal
             if (l[i] < l[j]) {
                 float ax = li.x1 - lj.x1, ay = li.y1 - lj.y1, bx = li.x2 - lj.x1, by = li.y2 - lj.y1;
@@ -1499,9 +1500,9 @@ std::vector<LineSegment> postprocess_lines_segments(const std::vector<LineSegmen
                 w10 = (bx * d[i].x + by * d[i].y) / l[i];
                 w11 = (bx * nn[i].x + by * nn[i].y) / l[i];
             }
-            if (std::max(std::fabs(w01), std::fabs(w11)) < (double)P.max_offset) {
-                bool any_gt = (w00 > (double)P.lo) || (w10 > (double)P.lo);
-                bool any_lt = (w00 < (double)P.hi) || (w10 < (double)P.hi);
+            if (std::max(std::fabs(w01), std::fabs(w11)) < P.max_offset) {
+                bool any_gt = (w00 > P.lo) || (w10 > P.lo);
+                bool any_lt = (w00 < P.hi) || (w10 < P.hi);
                 if (any_gt && any_lt) adj[i].push_back(j);
             }
         }
@@ -1625,7 +1626,7 @@ int orc_filter_lines(const LineSegment* in, int n, float min_length, LineSegment
 }
 
 // refine with other constants than today's (experiment / pin sweep only)
-int orc_refine_lines_params(const LineSegment* in, int n, float cos_gate, float max_offset, float lo, float hi, LineSegment* out) {
+int orc_refine_lines_params(const LineSegment* in, int n, double cos_gate, double max_offset, double lo, double hi, LineSegment* out) {
     RefineParams P;
     P.cos_gate = cos_gate;
     P.max_offset = max_offset;

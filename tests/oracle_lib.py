@@ -184,7 +184,7 @@ def refine_lines_params(lines, cos_gate=0.99, max_offset=0.02, lo=-0.5, hi=1.5):
     """postprocess_lines_segments with other constants than today's (pin sweep, tests/test_oracle_pins.py)"""
     lines = as_lines(lines)
     out = np.zeros(len(lines), LINE_DTYPE)
-    n = lib().orc_refine_lines_params(_p(lines), C.c_int(len(lines)), C.c_float(cos_gate), C.c_float(max_offset), C.c_float(lo), C.c_float(hi), _p(out))
+    n = lib().orc_refine_lines_params(_p(lines), C.c_int(len(lines)), C.c_double(cos_gate), C.c_double(max_offset), C.c_double(lo), C.c_double(hi), _p(out))
     return out[:n].copy()
 
 

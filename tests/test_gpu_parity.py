@@ -665,7 +665,7 @@ def test_every_storage_tier_of_the_flood_is_exact_on_long_edges(L, ctx):
     """2560x480 with edges of 1500-2400 px against the oracle: default (walks restart in the second LDS tier), mode 4
     (no second tier: they carry on in global slabs, and when the pool runs out the ordered tail finishes), mode 3 (two
     slabs), mode 2 (no slab at all), modes 6 and 7 (the second tier's team of wavefronts runs out of storage in the middle
-    of a level: one wavefront carries on in a slab from the unprocessed records / no slab: incomplete walk, barrier,
+    of a level: the team moves into a global slab with the unprocessed records / no slab: incomplete walk, barrier,
     ordered tail).  The counters prove that each path was really taken."""
     img = _long_bars(2560, 480, 5)
     ref = O.find_line_segments(img)
