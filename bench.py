@@ -236,23 +236,32 @@ def numa_node_of(pci_bus_id):
         return -1
 
 
-def rank_cpus(local_rank, world, pci_bus_ids=None, available=None, nodes=None):
+def rank_cpus(local_rank, world, pci_bus_ids=None, available=None, nodes=None, numa="gpu"):
     """Host cores for this rank's lanes and staging threads: the cores of its GPU's NUMA node (sysfs), split evenly among
     the ranks whose GPUs sit on the same node (by their order among those GPUs, whatever the numbering of the devices);
-    without that information, the rank's contiguous share of the cores this process may run on.
+    without that information, the rank's contiguous share of the cores this process may run on (all of them for a single
+    rank).  numa = "other": the cores of the NEXT node instead (experiment: staging copies and the DMA that reads the
+    staging buffers on different memory controllers); "none": no binding.
     pci_bus_ids: the bus id of every rank's device, by local rank (nodes: their NUMA nodes, for tests).  Returns
     (cores, how)."""
     avail = sorted(available if available is not None else os.sched_getaffinity(0))
-    if world <= 1 or not avail:
+    if not avail or numa == "none":
         return avail, "all"
-    share = max(1, len(avail) // world)
-    fallback = avail[local_rank * share : (local_rank + 1) * share] or avail
+    share = max(1, len(avail) // max(world, 1))
+    fallback = (avail[local_rank * share : (local_rank + 1) * share] or avail) if world > 1 else avail
     if nodes is None and pci_bus_ids:
         nodes = [numa_node_of(b) for b in pci_bus_ids]
     if nodes and len(nodes) > local_rank and nodes[local_rank] >= 0:
         node = nodes[local_rank]
+        use = node
+        if numa == "other":
+            try:
+                n_nodes = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()])
+            except OSError:
+                n_nodes = 1
+            use = (node + max(1, n_nodes // 2)) % max(1, n_nodes)
         try:
-            cpus = [c for c in cpu_list(open("/sys/devices/system/node/node%d/cpulist" % node).read()) if c in set(avail)]
+            cpus = [c for c in cpu_list(open("/sys/devices/system/node/node%d/cpulist" % use).read()) if c in set(avail)]
         except (OSError, ValueError):
             cpus = []
         peers = [r for r in range(min(world, len(nodes))) if nodes[r] == node]
@@ -260,8 +269,8 @@ def rank_cpus(local_rank, world, pci_bus_ids=None, available=None, nodes=None):
         sh = max(1, len(cpus) // len(peers))
         mine = cpus[k * sh : (k + 1) * sh]
         if mine:
-            return mine, "numa node %d (%d rank(s) on it)" % (node, len(peers))
-    return fallback, "contiguous share"
+            return mine, "numa node %d%s (%d rank(s) on it)" % (use, "" if use == node else " (the GPU sits on node %d)" % node, len(peers))
+    return fallback, ("contiguous share" if world > 1 else "all")
 
 
 def cht_rates(ctx):
@@ -336,6 +345,33 @@ def natural_frame_rates(L, ctx):
             "Mpix_per_s": round(w * h / float(np.mean(wall)) / 1e6, 2), "flood_ms": round(float(np.mean(flood)), 4),
             "lines": int(len(lines)), "seeds": c["seeds"], "components": c["components"], "flood_rounds": c["flood_rounds"],
             "second_tier_walks": c["second_tier_seeds"], "walked_per_labelled": round(c.get("walked_px", 0) / max(1, c["labelled_px"]), 3)}
+
+
+def worst_case_rates(L, ctx):
+    """Frames the ordered flood likes least, one at a time through the frame call from a pageable buffer (the latency of a
+    call depends on the content: INTEGRATION.md "Content-dependent latency"): a 4K frame WITHOUT strong edges (soft blobs
+    on a ramp: single floods of hundreds of thousands of pixels) and a 4K frame of sixty bars 2000-3600 px long."""
+    from librectify_amd import synth
+
+    w, h = W4K, H4K
+    out = {}
+    ctx.set_stage_timing(True)
+    for name, img in (("edgeless_4k", synth.region_frame(w, h, 504)), ("long_bars_4k", synth.long_bar_frame(w, h, 3))):
+        wall, flood = [], []
+        for rep in range(4):
+            t0 = time.perf_counter()
+            lines = ctx.find_line_segment_groups(img, float(max(w, h)) / 100.0)
+            dt = time.perf_counter() - t0
+            if rep > 0:
+                wall.append(dt)
+                flood.append(float(ctx.stage_times()[L.T_FLOOD]))
+        c = ctx.stage_counters()
+        out[name] = {"wall_ms": round(float(np.mean(wall)) * 1e3, 3), "max_ms": round(float(np.max(wall)) * 1e3, 3), "flood_ms": round(float(np.mean(flood)), 3),
+                     "lines": int(len(lines)), "seeds": c["seeds"], "flood_rounds": c["flood_rounds"], "second_tier_walks": c["second_tier_seeds"],
+                     "slabs": c["slabs"], "ordered_tail_seeds": c["ordered_tail_seeds"]}
+    ctx.set_stage_timing(False)
+    out["note"] = "the four synthetic bench frames take `single_frame`.pageable.wall_ms; these take 1.5-4x as long on the same call"
+    return out
 
 
 def flood_rates(L, ctx, frames):
@@ -415,10 +451,16 @@ def main(argv=None):
     ap.add_argument("--staging-threads", type=int, default=12, help="host threads that stage pageable frames (num_threads of the batch call); "
                     "capped at this rank's share of the host cores")
     ap.add_argument("--dry-run-spawn", action="store_true", help="with --gpus N > 1 and no WORLD_SIZE: print the launch command instead of running it")
+    ap.add_argument("--rehearse-collective", action="store_true",
+                    help="with --gpus 1 and no WORLD_SIZE: run the ONE rank under torch.distributed.run all the same (started as a child before "
+                         "anything here touches the GPU), so that the process group (RCCL) and the gather of the results run on the one GPU of a box")
+    ap.add_argument("--numa", choices=["gpu", "other", "none"], default="gpu",
+                    help="host cores of a rank (its lanes, uploader, staging threads; its frames are first touched there): the cores of "
+                         "its GPU's NUMA node, of another node (experiment: copies and DMA on different memory controllers), or no binding")
     args = ap.parse_args(argv)
 
     env_world = os.environ.get("WORLD_SIZE")
-    if env_world is None and args.gpus > 1:
+    if env_world is None and (args.gpus > 1 or args.rehearse_collective):
         return launch_ranks(args, argv)
     if env_world is not None and int(env_world) != args.gpus:
         print("bench.py: --gpus %d but WORLD_SIZE=%s: refusing to run a different number of ranks than asked for" % (args.gpus, env_world), file=sys.stderr)
@@ -443,7 +485,10 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)  # before the process group: RCCL binds each rank to its current device
     dev = torch.device("cuda", local_rank)
     cdev = dev if backend == "nccl" else torch.device("cpu")  # where the collectives' tensors live
-    if world > 1:
+    # A process group exists whenever a launcher started this rank (WORLD_SIZE set, even to 1: `--rehearse-collective`);
+    # the gather of the results runs exactly then.  A plain `python bench.py` (the driver's N = 1 run) has neither.
+    pg = env_world is not None
+    if pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
@@ -452,7 +497,9 @@ def main(argv=None):
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
     n_gpus = world if world > 1 else 1
     # host side of a rank: its lanes, its uploader and its staging threads stay on the cores of its GPU's NUMA node, and
-    # no rank asks for more staging threads than its share of the cores (threads inherit the affinity set here)
+    # no rank asks for more staging threads than its share of the cores (threads inherit the affinity set here; the frames
+    # made below are first touched under it).  Since round 4 also for a single rank: on a two-socket host the staging
+    # copies otherwise run wherever the scheduler puts them.
     bus_ids = []
     single = os.environ.get("LR_BENCH_SINGLE_DEVICE") == "1"
     for r in range(world):
@@ -461,19 +508,20 @@ def main(argv=None):
             bus_ids.append("%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id))
         except Exception:
             bus_ids.append(None)
-    cpus, cpus_how = rank_cpus(int(os.environ.get("LOCAL_RANK", "0")), world, bus_ids)
-    if world > 1 and cpus:
+    cpus, cpus_how = rank_cpus(int(os.environ.get("LOCAL_RANK", "0")), world, bus_ids, numa=args.numa)
+    if cpus and cpus_how != "all":
         try:
             os.sched_setaffinity(0, cpus)
         except OSError:
             cpus_how += " (not applied)"
     args.staging_threads = max(1, min(args.staging_threads, len(cpus) if cpus else args.staging_threads))
     ranks_seen = world
-    if world > 1:  # did the collective backend see every rank?
+    if pg:  # did the collective backend see every rank?
         t = torch.ones(1, dtype=torch.int32, device=cdev)
         got = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(got, t)
         ranks_seen = int(sum(int(x.item()) for x in got))
+    gather_calls = [0]
 
     ctx = L.Context(local_rank)
     ctx.set_seed(0)
@@ -484,7 +532,7 @@ def main(argv=None):
     cfg = L.RectificationConfig()
 
     def fence():
-        if world > 1:
+        if pg:
             dist.barrier()
         ctx.synchronize()
         torch.cuda.synchronize()
@@ -497,7 +545,7 @@ def main(argv=None):
             fn()
         fence()
         el = time.perf_counter() - t0
-        if world > 1:
+        if pg:
             t = torch.tensor([el], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
@@ -539,7 +587,8 @@ def main(argv=None):
                 self.n_lines[: self.B] = n
                 for b in range(self.B):
                     self.tforms[b] = tf[b].as_array()
-            if world > 1:  # the path's one exchange step: gather the per-frame results over RCCL
+            if pg:  # the path's one exchange step: gather the per-frame results over the process group (RCCL on GPUs)
+                gather_calls[0] += 1
                 D.gather_results([self.out[b][: self.n_lines[b]] for b in range(self.B)], self.tforms[: self.B], n_total if n_total is not None else self.B * world, device=cdev)
 
     def make_batch1080():
@@ -676,7 +725,21 @@ def main(argv=None):
                 "staging_threads": args.staging_threads,
                 "ransac_iterations": 10000,
                 "segments_per_frame": segs,
-                "parallelism": "frames sharded over %d GPU(s), no data-path collective, RCCL all_gather of the results" % n_gpus,
+                "parallelism": {
+                    "sharding": "frames in contiguous blocks over %d rank(s), one process per GPU, no data-path collective" % n_gpus,
+                    "process_group": bool(pg),
+                    "backend": (("nccl (RCCL)" if backend == "nccl" else backend) if pg else None),
+                    "collective_tensors_on": (str(cdev) if pg else None),
+                    "gather_ran": bool(pg and gather_calls[0] > 0),
+                    "gather": ("all_reduce(max count) + 2 x all_gather of the per-frame results, inside the timed region, %d calls in this run" % gather_calls[0]) if pg
+                              else "none: a single rank started without a launcher has no process group and nothing to gather",
+                },
+            },
+            "h2d": None if kind == "device" or args.steps == 0 else {
+                "GBps_per_rank": round(wl.B * w * h * 4.0 * args.steps / el / 1e9, 3),
+                "note": "frame bytes this rank sent up the link per second of the timed region (the link also carries nothing else of size: results are ~30 KB a frame); "
+                        "PCIe Gen5 x16: 63 GB/s rated, 52.7 GB/s measured for back-to-back copies from page-locked memory",
+                "host_memory": kind,
             },
             "other_rates_Mpix_per_s": {
                 "note": "same workload, 3 steps each, outside the timed region: frames in the other kind of host memory, and frames already resident in HBM (no H2D: NOT the metric)",
@@ -730,13 +793,14 @@ def main(argv=None):
                 res["single_frame"] = single_frame_rates(L, ctx, wl.pageable[: min(4, wl.B)], wl.min_length)
                 res["flood"] = flood_rates(L, ctx, wl.pageable[: min(4, wl.B)])
                 res["natural_frame"] = natural_frame_rates(L, ctx)
+                res["worst_case"] = worst_case_rates(L, ctx)
             res["roofline_8k"] = roofline_8k(L, ctx, torch, dev, wl.pageable[0] if wl.B and (wl.w, wl.h) == (W4K, H4K) else None)
         if not args.no_cpu_baseline and n_gpus == 1 and wl.B:
             res["cpu_baseline"] = cpu_baseline(wl.pageable[:2], w, h, wl.min_length)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))
-    if world > 1:
+    if pg:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -71,6 +71,7 @@ void set_error(const std::string& msg);
     do {                                                                                                 \
         hipError_t _e = (expr);                                                                          \
         if (_e != hipSuccess) {                                                                          \
+            (void)hipGetLastError(); /* reported here: must not resurface behind a later launch */       \
             ::lramd::set_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + ":" + \
                                std::to_string(__LINE__) + ")");                                          \
             return 1;                                                                                    \

@@ -117,3 +117,44 @@ def random_segments(n, seed, frac_on_pencils=0.6, size=1000.0):
         p1, p2 = c - d * L / 2, c + d * L / 2
         out[i] = (p1[0], p1[1], p2[0], p2[1], rng.uniform(0.05, 0.5), rng.uniform(0.1, 0.8), -1)
     return out
+
+
+def region_frame(W, H, seed):
+    """A frame WITHOUT strong edges (soft blobs on a ramp, blurred): single floods cover smooth regions of hundreds of
+    thousands of pixels -- the content the ordered flood likes least (tools/soak_regions.py, bench.py `worst_case`)."""
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    img = np.full((H, W), 0.4, np.float64)
+    for _ in range(rng.randint(6, 30)):
+        cx, cy, r = rng.uniform(0, W), rng.uniform(0, H), rng.uniform(30, 0.2 * W)
+        img += rng.uniform(0.05, 0.3) * np.exp(-(((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * r * r)))
+    img += rng.uniform(0, 0.3) * xx / W + rng.uniform(0, 0.2) * yy / H
+    img = _gauss_blur(np.clip(img, 0, 1), rng.uniform(1.0, 3.0)) + rng.normal(0, rng.uniform(0.001, 0.005), size=img.shape)
+    return img.astype(np.float32)
+
+
+def long_bar_frame(W, H, seed, K=60):
+    """Bars that run across most of the frame (edges of 2000-3600 px at 4K): walks of several hundred tiles each
+    (tools/run_long.py, bench.py `worst_case`)."""
+    rng = np.random.RandomState(seed)
+    img = np.full((H, W), 0.5, np.float64)
+    for _ in range(K):
+        c = np.array([rng.uniform(0.3, 0.7) * W, rng.uniform(0.1, 0.9) * H])
+        ang = rng.uniform(-0.25, 0.25) + (np.pi / 2 if rng.rand() < 0.3 else 0.0)
+        d = np.array([np.cos(ang), np.sin(ang)])
+        nrm = np.array([-d[1], d[0]])
+        length = rng.uniform(0.5, 0.95) * (W if abs(d[0]) > 0.7 else H)
+        half_w = rng.uniform(3.0, 12.0)
+        contrast = rng.uniform(0.1, 0.4) * (1 if rng.rand() < 0.5 else -1)
+        ext_x = abs(d[0]) * length / 2 + abs(nrm[0]) * half_w + 2
+        ext_y = abs(d[1]) * length / 2 + abs(nrm[1]) * half_w + 2
+        x0, x1 = int(max(0, c[0] - ext_x)), int(min(W, c[0] + ext_x + 1))
+        y0, y1 = int(max(0, c[1] - ext_y)), int(min(H, c[1] + ext_y + 1))
+        if x1 <= x0 or y1 <= y0:
+            continue
+        yy, xx = np.mgrid[y0:y1, x0:x1]
+        px, py = xx - c[0], yy - c[1]
+        m = (np.abs(px * d[0] + py * d[1]) <= length / 2) & (np.abs(px * nrm[0] + py * nrm[1]) <= half_w)
+        img[y0:y1, x0:x1][m] += contrast
+    img = _gauss_blur(np.clip(img, 0, 1), 1.0) + rng.normal(0, 0.005, size=img.shape)
+    return img.astype(np.float32)

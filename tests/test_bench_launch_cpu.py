@@ -75,3 +75,28 @@ def test_rank_cpus_follows_the_numa_node_of_each_gpu():
         assert how.startswith("numa node 0") and len(cpus) == len(usable) // 4
         seen += cpus
     assert len(set(seen)) == len(seen) and set(seen) <= set(usable)
+
+
+def test_rehearse_collective_runs_the_single_rank_under_the_launcher():
+    """--gpus 1 --rehearse-collective: the one rank is started by torch.distributed.run as well (WORLD_SIZE = 1), so the
+    process group and the gather run on the one GPU of a box; a plain --gpus 1 stays a plain process."""
+    p = _run(["--gpus", "1", "--rehearse-collective", "--dry-run-spawn"])
+    assert p.returncode == 0, p.stderr
+    cmd = json.loads(p.stdout.strip().splitlines()[-1])["spawn"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "1" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+
+
+def test_a_single_rank_may_be_bound_to_its_gpus_numa_node_or_to_another():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    if not os.path.exists("/sys/devices/system/node/node0/cpulist"):
+        import pytest
+
+        pytest.skip("no NUMA information in sysfs")
+    avail = sorted(os.sched_getaffinity(0))
+    node0 = [c for c in bench.cpu_list(open("/sys/devices/system/node/node0/cpulist").read()) if c in set(avail)]
+    cpus, how = bench.rank_cpus(0, 1, None, avail, nodes=[0])
+    assert cpus == node0 and how.startswith("numa node 0")
+    assert bench.rank_cpus(0, 1, None, avail, nodes=[0], numa="none") == (avail, "all")
+    assert bench.rank_cpus(0, 1, None, avail, nodes=[-1]) == (avail, "all")

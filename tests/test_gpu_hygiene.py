@@ -1,0 +1,91 @@
+"""What a library behind the reference's stateless API (src/librectify.h:111-123) owes its host process besides
+results: contexts that fail cleanly when memory runs out, calls that fail cleanly and recover, helper threads that
+sleep between calls."""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    import librectify_amd as L
+
+    L.lib()
+    assert L.device_count() > 0, "GPU tests need a GPU"
+    return L
+
+
+_CREATE_SCRIPT = r"""
+import sys
+sys.path.insert(0, %r)
+import librectify_amd as L
+try:
+    c = L.Context(0)
+except L.LibrectifyError as e:
+    print("ERR", e)
+    sys.exit(0)
+print("CREATED")
+c.close()
+"""
+
+
+@pytest.mark.parametrize("nth", [1, 17, 20, 24, 28, 30])
+def test_context_creation_fails_cleanly_when_an_allocation_fails(L, nth):
+    """lr_context_create makes 30 events, device words and page-locked words; any of them failing must give an error
+    and no context (round 3 ignored the results and faulted in the first kernel).  The hook is read once per process."""
+    env = dict(os.environ, LIBRECTIFY_TEST_CREATE_FAIL=str(nth))
+    r = subprocess.run([sys.executable, "-c", _CREATE_SCRIPT % ROOT], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "ERR" in r.stdout and "lr_context_create" in r.stdout and "CREATED" not in r.stdout, r.stdout
+
+
+def test_a_flood_workspace_that_does_not_fit_fails_the_call_and_the_next_call_recovers(L):
+    from librectify_amd import synth
+
+    img = synth.frame(320, 240, 13, bars=24)
+    ref, _ = O.find_line_segment_groups(img, 3.2, seed=0)
+    c = L.Context(0)
+    try:
+        c.set_seed(0)
+        os.environ["LIBRECTIFY_FLOOD_SLABS"] = "2000000"  # x 2.25 MB: more than the card has
+        try:
+            with pytest.raises(L.LibrectifyError) as ei:
+                c.find_line_segment_groups(img, 3.2)
+            assert "hipMalloc" in str(ei.value)
+        finally:
+            del os.environ["LIBRECTIFY_FLOOD_SLABS"]
+        got = c.find_line_segment_groups(img, 3.2)
+        assert got.tobytes() == ref.tobytes()
+    finally:
+        c.close()
+
+
+def test_staging_helpers_sleep_between_calls(L):
+    """num_threads = 8 starts the context's staging helpers; they stay with the context from call to call and must cost
+    an idle process nothing (round 3: eight threads polling every 20 us)."""
+    from librectify_amd import synth
+
+    img = synth.frame(1920, 1080, 3)  # pageable: goes through the staging copy
+    c = L.Context(0)
+    try:
+        c.set_seed(0)
+        a = c.find_line_segment_groups(img, 19.2, num_threads=8)
+        time.sleep(0.05)  # (past the helpers' spin phase)
+        t0 = time.process_time()
+        time.sleep(0.5)
+        cpu = time.process_time() - t0
+        assert cpu < 0.02, "helpers burnt %.3f s of CPU in 0.5 s of idle time" % cpu
+        b = c.find_line_segment_groups(img, 19.2, num_threads=8)  # ... and wake up for the next frame
+        assert a.tobytes() == b.tobytes() and len(a) > 0
+    finally:
+        c.close()
