@@ -119,6 +119,11 @@ void lr_set_flood_blind_rounds(lr_context* ctx, int rounds);
 /* Comparison hook: the flood's partial commits (a blocked seed commits at once the part of its footprint that no lower
  * seed can reach; on by default, LIBRECTIFY_FLOOD_PARTIAL=0 also switches them off).  Same labels either way. */
 void lr_set_flood_partial_commits(lr_context* ctx, int on);
+/* Comparison hook: the flood's multi-source re-walks (a seed whose walk was long leaves way-points on its footprint; if it
+ * has to walk again, a team of wavefronts starts from the seed and from every way-point at once and keeps what is
+ * connected to the seed; on by default, LIBRECTIFY_FLOOD_MULTI=0 also switches them off).  Same labels either way;
+ * lr_stage_counters [10] counts them. */
+void lr_set_flood_multi_source(lr_context* ctx, int on);
 
 /* ---- stage API (tests, bench) --------------------------------------------------------- */
 /* Stage 1: fused 5x5 derivative filter + magnitude + direction bin + dilated-bin mask +
@@ -172,7 +177,8 @@ int lr_filter_kernel_ms(lr_context* ctx, float* ms);
 /* Extra counters of the last call: [0] seeds, [1] components, [2] flood rounds, [3] labelled pixels, and how the
  * flood's walks were stored: [4] seeds that moved to the second LDS tier, [5] global slabs used, [6] seeds finished by
  * the ordered single-wave tail (storage exhausted); [7] laps of the frame through the pipeline (1 normally); [8] pixels
- * the flood's explorations walked in all rounds together (over [3]: the re-walk factor), [9] their 8x8-tile steps. */
+ * the flood's explorations walked in all rounds together (over [3]: the re-walk factor), [9] their 8x8-tile steps, [10] re-walks that
+ * started from several way-points at once (lr_set_flood_multi_source). */
 int lr_stage_counters(lr_context* ctx, int64_t* out, int count);
 
 /* ---- RANSAC --------------------------------------------------------------------------- */

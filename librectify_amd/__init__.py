@@ -70,7 +70,7 @@ EXPORTS = [
     "lr_stage_counters", "lr_filter_kernel_ms", "lr_ransac_best", "lr_estimate_line_pencils",
     "lr_find_line_segment_groups_batch_host", "lr_find_line_segment_groups_batch_host_ptrs", "lr_host_alloc", "lr_host_free",
     "lr_set_seed_capacity", "lr_set_flood_blind_rounds", "lr_set_flood_staged", "lr_set_batch_streams", "lr_device_malloc", "lr_device_free", "lr_memcpy_h2d", "lr_cht_vanishing_point", "lr_refine_lines", "lr_set_estimator", "lr_ht_weights", "lr_prosac_solve", "lr_estimate_line_pencils_prosac", "lr_direct_solve", "lr_estimate_line_pencils_direct",
-    "lr_estimate_line_pencils_cht", "lr_set_stage_timing", "lr_release_thread_context", "lr_set_flood_partial_commits",
+    "lr_estimate_line_pencils_cht", "lr_set_stage_timing", "lr_release_thread_context", "lr_set_flood_partial_commits", "lr_set_flood_multi_source",
 ]
 
 _lib = None
@@ -146,6 +146,8 @@ def lib():
         L.lr_refine_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
         L.lr_set_flood_partial_commits.argtypes = [C.c_void_p, C.c_int]
         L.lr_set_flood_partial_commits.restype = None
+        L.lr_set_flood_multi_source.argtypes = [C.c_void_p, C.c_int]
+        L.lr_set_flood_multi_source.restype = None
         L.lr_release_thread_context.argtypes = []
         L.lr_release_thread_context.restype = None
         L.lr_set_stage_timing.argtypes = [C.c_void_p, C.c_int]
@@ -268,11 +270,11 @@ class Context:
         return ms.value
 
     def stage_counters(self):
-        c = np.zeros(10, np.int64)
-        _check(lib().lr_stage_counters(self._h, _ptr(c), 10))
+        c = np.zeros(11, np.int64)
+        _check(lib().lr_stage_counters(self._h, _ptr(c), 11))
         return dict(seeds=int(c[0]), components=int(c[1]), flood_rounds=int(c[2]), labelled_px=int(c[3]),
                     second_tier_seeds=int(c[4]), slabs=int(c[5]), ordered_tail_seeds=int(c[6]), frame_laps=int(c[7]),
-                    walked_px=int(c[8]), walk_steps=int(c[9]))
+                    walked_px=int(c[8]), walk_steps=int(c[9]), multi_source_walks=int(c[10]))
 
     # ---- full path ----
     def find_line_segment_groups(self, img, min_length, refine=False, num_threads=-1, capacity=None):
@@ -395,6 +397,9 @@ class Context:
 
     def set_flood_partial_commits(self, on=True):
         lib().lr_set_flood_partial_commits(self._h, int(bool(on)))
+
+    def set_flood_multi_source(self, on=True):
+        lib().lr_set_flood_multi_source(self._h, int(bool(on)))
 
     def set_stage_timing(self, on=True):
         """stage timers of the frame calls (off by default: each event record idles the GPU for a few microseconds)"""

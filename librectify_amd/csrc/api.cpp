@@ -215,6 +215,7 @@ void lr_set_seed_capacity(lr_context* ctx, uint32_t cap) { ctx->seed_cap_once = 
 void lr_set_flood_staged(lr_context* ctx, int on) { ctx->flood_staged = on != 0; }
 void lr_set_flood_blind_rounds(lr_context* ctx, int rounds) { ctx->flood_rounds_hint = rounds; }
 void lr_set_flood_partial_commits(lr_context* ctx, int on) { ctx->flood_partial = on != 0; }
+void lr_set_flood_multi_source(lr_context* ctx, int on) { ctx->flood_multi = on != 0; }
 
 int lr_stage_filter(lr_context* ctx, const float* d_image, int width, int height, int stride) {
     return ctx_stage_filter(ctx, d_image, width, height, stride);
@@ -286,12 +287,13 @@ int lr_stage_times(lr_context* ctx, float* ms, int count) {
 }
 
 int lr_stage_counters(lr_context* ctx, int64_t* out, int count) {
-    const int64_t v[10] = {(int64_t)ctx->n_seeds,        (int64_t)ctx->n_comp,         (int64_t)ctx->flood_rounds,
+    const int64_t v[11] = {(int64_t)ctx->n_seeds,        (int64_t)ctx->n_comp,         (int64_t)ctx->flood_rounds,
                            (int64_t)ctx->n_px,           (int64_t)ctx->flood_tiers[0], (int64_t)ctx->flood_tiers[1],
                            (int64_t)ctx->flood_tiers[2], (int64_t)ctx->frame_laps,
                            (int64_t)(((uint64_t)ctx->flood_tiers[5] << 32) | ctx->flood_tiers[4]),
-                           (int64_t)(((uint64_t)ctx->flood_tiers[7] << 32) | ctx->flood_tiers[6])};
-    for (int i = 0; i < count && i < 10; ++i) out[i] = v[i];
+                           (int64_t)(((uint64_t)ctx->flood_tiers[7] << 32) | ctx->flood_tiers[6]),
+                           (int64_t)ctx->flood_tiers[9]};
+    for (int i = 0; i < count && i < 11; ++i) out[i] = v[i];
     return 0;
 }
 

@@ -114,6 +114,7 @@ int launch_flood_ordered(const float* dx, const float* dy, const uint8_t* dmask,
                          BinTrig trig, uint32_t* label, int32_t* seed_size, int32_t* queue, hipStream_t s);
 
 // parallel-round flood (mode 1): per-seed round state, active lists and overflow slabs
+constexpr size_t kFloodWpWords = 8;      // per seed: header (way-points | tiles of the walk << 8) and seven pixel indices
 constexpr size_t kFloodHandWords = 1024;  // per hand-over: header, up to 192 table entries, up to 128 frontier records
 struct FloodBuffers {
     uint32_t* blocked = nullptr;
@@ -127,6 +128,18 @@ struct FloodBuffers {
     uint8_t* dirty = nullptr;       // one mark per 256 pixels of the label image: stamped in the current round
     uint32_t* big_list = nullptr;   // 8192 seeds: this round's hand-over to the second storage tier
     uint32_t* handover = nullptr;   // ... and the state each of their walks had reached (kFloodHandWords words per list entry)
+    // Way-points of long walks (round 4): a seed whose walk covered many tiles leaves kFloodWpWords - 1 pixels spread over its
+    // footprint; if it has to walk again, a team of wavefronts starts from the seed AND from those pixels at once
+    // (kernels_flood.hip: team_walk, kMulti).  One record per seed for the first wp_cap seeds.
+    uint32_t* waypoints = nullptr;
+    uint32_t wp_cap = 0;
+    bool multi_source = true;       // lr_set_flood_multi_source / LIBRECTIFY_FLOOD_MULTI=0: comparison hook, same labels
+    uint32_t* multi_list = nullptr; // way-point seeds of the coming round (8192): walked by a team launch beside the exploration ...
+    hipStream_t aux_stream = nullptr;          // ... on this second stream of the context (nullptr: they go through big_list, after it)
+    const hipEvent_t* fork_events = nullptr;   // one pair per round that forks (enqueue_round)
+    const hipEvent_t* join_events = nullptr;
+    int n_fork_events = 0;
+    int multi_round_last = 4;       // last round (index from 0) that walks its way-point seeds beside its exploration
     void* slab_ring = nullptr;  // n_slabs x slab_ring_cap 16-byte records
     void* slab_hash = nullptr;  // n_slabs x slab_hash_cap 16-byte records
     uint32_t n_slabs = 0, slab_ring_cap = 0, slab_hash_cap = 0;

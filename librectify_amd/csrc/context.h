@@ -62,6 +62,9 @@ struct lr_context {
     uint32_t* label = nullptr;
     int32_t* queue = nullptr;
     lramd::FloodBuffers fb;
+    hipStream_t flood_aux = nullptr;       // second stream of the flood: way-point seeds' team walks beside a round's exploration
+    std::vector<hipEvent_t> flood_fork, flood_join;
+    bool flood_aux_on = true;              // off for the lanes of a batch call (their frames overlap each other instead)
     size_t fb_cap_seeds = 0;
     // stage 4
     uint32_t* comp_rank = nullptr;
@@ -152,8 +155,9 @@ struct lr_context {
     int flood_mode = 1;
     bool flood_big_hint = true;  // did the last frame's walks outgrow the first storage tier? (none yet: assume so)
     bool flood_hold_hint = false;  // did the last frame hold its weakest seeds back?
-    uint32_t flood_tiers[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // last flood: seeds in the second tier, slabs used, seeds of the ordered tail, hold-back, walked px (lo, hi), steps (lo, hi), walks beyond the first tier's table
+    uint32_t flood_tiers[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // last flood: seeds in the second tier, slabs used, seeds of the ordered tail, hold-back, walked px (lo, hi), steps (lo, hi), walks beyond the first tier's table, multi-source re-walks
     bool flood_partial = true;  // partial commits of blocked seeds (kernels_flood.hip); lr_set_flood_partial_commits
+    bool flood_multi = true;    // re-walks of long footprints from several way-points at once (kernels_flood.hip); lr_set_flood_multi_source
     bool flood_staged = false;  // lr_set_flood_staged: the rounds start on the strongest eighth of the seeds (test / experiment hook)
     // Stage timers (HIP events between the stages of a frame): off in the frame calls unless lr_set_stage_timing or
     // LIBRECTIFY_STAGE_TIMES asks -- every event record is a barrier packet in the stream, some 6 us of idle GPU each,

@@ -155,6 +155,18 @@ static int ensure_flood_buffers(lr_context* c) {
         dev_alloc(f.act_a, cs) || dev_alloc(f.act_b, cs) || dev_alloc(f.ctrl, kFloodCtrlWords) || dev_alloc(f.big_list, 8192) || dev_alloc(f.handover, 8192 * kFloodHandWords) ||
         dev_alloc(f.dirty, cs / 256 + 16))
         return 1;
+    f.wp_cap = (uint32_t)std::min<size_t>(std::max<size_t>(cs / 16, 4096), cs);  // (one seed per 16 pixels: the 4K bench frame has one per 200)
+    if (dev_alloc(f.waypoints, (size_t)f.wp_cap * kFloodWpWords) || dev_alloc(f.multi_list, 8192)) return 1;
+    if (!c->flood_aux) {
+        LR_HIP(hipStreamCreateWithFlags(&c->flood_aux, hipStreamNonBlocking));
+        for (int i = 0; i < 8; ++i) {
+            hipEvent_t a = nullptr, b = nullptr;
+            LR_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+            c->flood_fork.push_back(a);
+            LR_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+            c->flood_join.push_back(b);
+        }
+    }
     f.n_slabs = 128;  // 128 x 2.25 MB = 288 MB; only walks over ~1500 tiles (both LDS tiers outgrown) get here
     if (const char* e = std::getenv("LIBRECTIFY_FLOOD_SLABS")) f.n_slabs = (uint32_t)std::max(1, std::atoi(e));
     f.slab_ring_cap = 1u << 14;  // (tile, entry mask) records, 16 B each
@@ -579,11 +591,19 @@ void ctx_destroy(lr_context* c) {
                     c->label, c->queue, c->comp_rank, c->comp_seed, c->comp_off, c->cursor, c->px_a, c->px_b,
                     c->scratch_w, c->d_lines, c->temp, c->d_model, c->d_scores, c->d_best_score, c->d_best_iter,
                     c->fb.blocked, c->fb.count, c->fb.flags, c->fb.state, c->fb.tier, c->fb.act_a, c->fb.act_b,
-                    c->fb.ctrl, c->fb.big_list, c->fb.handover, c->fb.dirty, c->fb.slab_ring, c->fb.slab_hash, c->d_pairs, c->d_peak, c->d_weights,
+                    c->fb.ctrl, c->fb.big_list, c->fb.handover, c->fb.waypoints, c->fb.multi_list, c->fb.dirty, c->fb.slab_ring, c->fb.slab_hash, c->d_pairs, c->d_peak, c->d_weights,
                     c->d_samples, c->d_hcounts, c->comp_large, c->d_tables, c->d_orig, c->d_inl, c->d_flines, c->d_gctl,
                     c->d_gnorm, c->d_models, c->d_refine_table, c->d_refine_edges, c->d_cht_acc, c->d_cht_idx, c->d_cht_peak, c->d_rec, c->d_recflags};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (c->flood_aux) {
+        (void)hipStreamSynchronize(c->flood_aux);
+        (void)hipStreamDestroy(c->flood_aux);
+    }
+    for (auto& e : c->flood_fork)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->flood_join)
+        if (e) (void)hipEventDestroy(e);
     delete static_cast<StagingCrew*>(c->crew);
     c->crew = nullptr;
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
@@ -704,6 +724,16 @@ FloodBuffers flood_buffers_for(lr_context* c) {
     }
     static const bool partial_off = std::getenv("LIBRECTIFY_FLOOD_PARTIAL") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_PARTIAL")) == 0;
     fbuf.partial_commits = !partial_off && c->flood_partial;
+    static const bool multi_off = std::getenv("LIBRECTIFY_FLOOD_MULTI") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_MULTI")) == 0;
+    fbuf.multi_source = !multi_off && c->flood_multi;
+    static const int aux_env = std::getenv("LIBRECTIFY_FLOOD_MULTI_BESIDE") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_MULTI_BESIDE")) : -1;  // (experiment: 0 = after the exploration, N = beside it in rounds 2 .. N + 1)
+    if (c->flood_aux && c->flood_aux_on && aux_env != 0 && c->flood_fork.size() == c->flood_join.size()) {
+        fbuf.aux_stream = c->flood_aux;
+        fbuf.fork_events = c->flood_fork.data();
+        fbuf.join_events = c->flood_join.data();
+        fbuf.n_fork_events = (int)c->flood_fork.size();
+        if (aux_env > 0) fbuf.multi_round_last = aux_env;
+    }
     if (c->flood_staged) fbuf.win_first_shift = 3;
     fbuf.blind_rounds = c->flood_rounds_hint;
     return fbuf;
@@ -2114,12 +2144,18 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
     std::vector<lr_context*> lanes;
     lanes.push_back(c);
     for (int i = 0; i < S - 1; ++i) lanes.push_back(c->workers[i]);
+    const bool caller_multi = c->flood_multi;  // (lane 0 is the caller's own context: its setting comes back after the call)
     for (lr_context* l : lanes) {
         l->ransac_seed = c->ransac_seed;
         l->ransac_iters = c->ransac_iters;
         l->flood_mode = c->flood_mode;
-        l->flood_staged = c->flood_staged;
-        l->flood_partial = c->flood_partial;  // (off unless lr_set_flood_staged: +6 % in round 1, -3 % now)
+        l->flood_staged = c->flood_staged;  // (off unless lr_set_flood_staged: +6 % in round 1, -3 % now)
+        l->flood_partial = c->flood_partial;
+        // Multi-source re-walks shorten a frame's rounds at the price of more work per long walk (eight wavefronts and a
+        // second table entry per tile): worth it when the frame has the GPU to itself, not when S frames share it -- their
+        // rounds overlap each other anyway (profiles/r04_flood_multi_sweep.txt).  LIBRECTIFY_FLOOD_MULTI_LANES=1 keeps them.
+        static const bool multi_lanes = std::getenv("LIBRECTIFY_FLOOD_MULTI_LANES") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_MULTI_LANES")) != 0;
+        l->flood_multi = caller_multi && (S == 1 || multi_lanes);
         l->estimator = c->estimator;
         l->prosac_T_N = c->prosac_T_N;
         l->cht_d = c->cht_d;
@@ -2269,6 +2305,7 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
     for (auto& t : th) t.join();
     if (h_frames) (void)hipStreamSynchronize(c->copy_stream);  // (after an error: nothing may still read the caller's frames)
     for (lr_context* l : lanes) l->sleep_in_wait = false;
+    c->flood_multi = caller_multi;
     for (int si = 0; si < S; ++si)
         if (rc[si]) {
             set_error(err[si]);

@@ -162,6 +162,16 @@ constexpr int kRingBig = 1024, kHashBig = 2048;
 constexpr uint32_t kHandTiles = kHashT * 3 / 4, kHandRecs = kRingT;  // what a first-tier walk can hold when it is handed over
 constexpr uint32_t kHandTable = 4, kHandRing = kHandTable + 3 * kHandTiles;
 static_assert(kHandRing + 3 * kHandRecs <= kFloodHandWords, "hand-over record");
+// Way-points (round 4).  A walk of many tiles is a long dependent chain -- a line's frontier is two records wide, so not even
+// a team of wavefronts gets through it faster than a tile at a time -- and a blocked seed walks its footprint again every
+// round: rounds 2 to 5 of the bench frame lasted 235, 181, 157 us for single walks of 183, 155, 142 tiles while the chip
+// idled.  So a finished walk of at least wp_min_tiles tiles leaves kWpK pixels spread over its footprint (every
+// ntiles / (kWpK + 1)-th tile in order of insertion, which for a line alternates between its two arms), and the seed's
+// next walk starts from the seed AND from those pixels at once, on the eight wavefronts of a team: team_walk<.., true>.
+constexpr uint32_t kWpK = (uint32_t)kFloodWpWords - 1u;
+constexpr uint32_t kWpNone = 0xFFFFFFFFu;
+constexpr uint32_t kWpMaxTiles = 600u;   // the team's table holds an entry per (tile, source) and one per tile: 1536 in all
+constexpr uint32_t kSrcShift = 28u, kSrcMask = 0xF0000000u, kSrcClaim = 0xF0000000u;  // table keys of a multi-source walk
 constexpr uint32_t kBigCap = 8192;  // seeds per round that can move to the second tier (FloodBuffers::big_list)
 constexpr uint32_t kFlagIncomplete = 1u, kFlagSelfFail = 2u;
 constexpr uint32_t kMaxSteps = 1u << 22;  // safety net of the walk loop: more records than an 8K frame has tile visits
@@ -196,6 +206,11 @@ struct FloodArgs {
     uint32_t hold_min_big;                           // walks in the second tier after which the hold-back engages
     uint32_t t1_regional, t1_regional_min;           // ... at t1_regional tiles once the frame has had t1_regional_min walks beyond the first tier's table
     uint32_t t1_wide_tiles, t1_wide_front;           // ... or at this many tiles when its frontier holds this many records
+    uint32_t* waypoints;                             // FloodBuffers::waypoints (kFloodWpWords per seed), wp_cap seeds
+    uint32_t wp_cap;
+    uint32_t wp_min_tiles;                           // walks of at least this many tiles leave way-points (0xFFFFFFFF: never)
+    uint32_t* multi_list;                            // way-point seeds of the coming round (written by the survivors pass), kBigCap entries
+    uint32_t multi_next;                             // the coming round walks that list in a launch of its own, beside its exploration
 };
 // All words but kCtrlGen are set up by flood_init_seeds_kernel every frame; kCtrlGen lives on for the lifetime of
 // the slab memory (hash entries are tagged with it, so a generation must never be reused while old entries are
@@ -231,6 +246,9 @@ enum {
     kCtrlBigSeen = 22,  // 1: the frame had many long walks (kCtrlBigLong) when the current round began -- early hand-over
     kCtrlBarrierNext = 24,  // lowest seed of the next round's list that its exploration launch will not reach (no `rest` launch)
     kCtrlBigLong = 23,  // walks of the frame that really outgrew the first tier (more tiles than its table holds)
+    kCtrlMulti = 25,    // re-walks that started from several way-points at once (diagnostics: lr_stage_counters [10])
+    kCtrlNMulti = 26,   // length of the current round's list of way-point seeds (walked by a launch of their own on a second stream)
+    kCtrlNMultiNext = 27,  // ... of the next round's (being appended by the survivors pass)
     kCtrlWords = 32,
 };
 static_assert(kCtrlWords == kFloodCtrlWords, "control block size");
@@ -864,6 +882,26 @@ __device__ __forceinline__ void stamp_footprint(const FloodArgs& A, uint32_t k, 
     if (__ballot(foreign)) st.blocked = true;
 }
 
+// Way-points of a finished walk (see kWpK): lanes 0 .. kWpK-1 take the (lane + 1) ntiles / (kWpK + 1)-th tile in order of
+// insertion and a walked pixel of it.  Written once per seed: footprints only shrink, the points stay representative.
+template <class Lds>
+__device__ __forceinline__ void save_waypoints(const FloodArgs& A, uint32_t k, const Lds& S, uint32_t ntiles, int lane) {
+    uint32_t* wp = A.waypoints + (size_t)k * kFloodWpWords;
+    if ((uint32_t)lane < kWpK) {
+        const uint32_t i = ((uint32_t)lane + 1u) * ntiles / (kWpK + 1u);
+        const uint32_t slot = S.ord[i];
+        const uint32_t tile = S.hk[slot] - 1u;
+        const uint64_t V = ((uint64_t)S.hv1[slot] << 32) | S.hv0[slot];
+        uint32_t q = kWpNone;  // (a tile whose entry pixels turned out unacceptable holds nothing)
+        if (V != 0ull) {
+            const uint32_t bit = (uint32_t)__builtin_ctzll(V);
+            q = ((tile >> 16) * 8u + (bit >> 3)) * (uint32_t)A.w + (tile & 0xFFFFu) * 8u + (bit & 7u);
+        }
+        wp[1 + lane] = q;
+    }
+    if (lane == 0) wp[0] = kWpK | (ntiles << 8);
+}
+
 // One seed's exploration by one wavefront (see walk).  kFirstTier: a walk that outgrows the store is handed to the
 // second tier (big_list) instead of going on in a slab.
 template <class Lds, bool kFirstTier>
@@ -881,6 +919,8 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
     // flood_partial_commit_kernel) and explores on from there: its walk passes through the pixels labelled with its index.
     const bool own = seed_label == k;
     if (seed_label < kMarkBit && !own) return;  // claimed by an earlier flood: dead (the survivors pass takes it off the list)
+    // on this round's list of way-point seeds: a team walks it right now, in a launch beside this one (enqueue_round)
+    if (kFirstTier && (uni((uint32_t)A.tier[k]) & 2u) != 0u) return;
     if (!own && !(((seed_mask >> b) & 1) && directional(seed_dx, seed_dy, sn, cs) > thr)) {
         if (lane == 0) A.flags[k] = kFlagSelfFail;  // flood() accepts nothing, not even the seed
         return;
@@ -889,7 +929,12 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
     int rc = 1;
     // a walk that outgrew the first tier in an earlier round does not try it again (footprints only shrink, but
     // rarely below 190 tiles from above 1500 px)
-    const bool skip_first = kFirstTier && A.big_cap != 0u && uni((uint32_t)A.tier[k]) != 0u;
+    // ... and a seed that left way-points on a long footprint in an earlier round goes straight to the second tier, whose
+    // team walks it from all of them at once
+    const bool outgrown = kFirstTier && A.big_cap != 0u && (uni((uint32_t)A.tier[k]) & 1u) != 0u;
+    const bool wp_seed = kFirstTier && A.big_cap != 0u && A.wp_min_tiles != 0xFFFFFFFFu && k < A.wp_cap &&
+                         uni(A.waypoints[(size_t)k * kFloodWpWords]) != 0u;
+    const bool skip_first = outgrown || wp_seed;
     if (!skip_first) {
         for (int i = lane; i < Lds::kHashN; i += 64) L.hk[i] = 0u;
         P.pt[lane] = 0u;
@@ -909,8 +954,10 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
         if (pos < A.big_cap) {
             if (lane == 0) {
                 big_list[pos] = k;
-                A.tier[k] = 1;
-                atomicAdd(&A.ctrl[kCtrlBigTotal], 1u);
+                if (!skip_first || outgrown) {  // (a way-point seed has not outgrown anything: it does not count towards the hold-back)
+                    A.tier[k] = 1;  // (bit 1 is clear here: listed seeds left above)
+                    atomicAdd(&A.ctrl[kCtrlBigTotal], 1u);
+                }
             }
             // The second tier goes on from where this walk stands (nothing is stamped yet): the walked sets of its tiles
             // and the frontier records travel with the list entry.  A seed that skipped this tier has nothing to hand over.
@@ -945,6 +992,7 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
         // second tier full this round: carry on in a slab from the state reached
     }
     stamp_footprint(A, k, L, st, lane);
+    if (kFirstTier && rc == 0 && !wp_seed && st.ntiles >= A.wp_min_tiles && k < A.wp_cap) save_waypoints(A, k, L, st.ntiles, lane);
     if (rc != 0) {
         // LDS storage exhausted: move the walk to a global slab and carry on
         uint32_t slab = 0;
@@ -1128,6 +1176,9 @@ constexpr uint32_t kVoidTile = 0xFFFFFFFFu;
 
 struct TeamShared {
     uint32_t tail, end, ntiles, blocked, overflow, cnt, steps, pad;
+    uint32_t adj[8];          // multi-source walk: sources whose regions share a pixel with source i (bit per source)
+    uint32_t reach, ctiles;   // ... sources connected to the seed's own; tiles of the footprint kept
+    uint32_t pad2[2];
 };
 __device__ __forceinline__ uint32_t lds_now(const uint32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1202,6 +1253,39 @@ struct TeamStore {
         rhi[j] = (uint32_t)(E >> 32);
     }
     __device__ void mark_processed(uint32_t i) const { rt[i & (uint32_t)(kRingTeam - 1)] = kVoidTile; }
+    // read-only look-up, per lane (the walk is over: nothing is inserted any more)
+    __device__ bool find_ro(uint32_t tile, uint32_t& slot) const {
+        const uint32_t key = tile + 1u;
+        uint32_t hs = (key * 2654435761u) >> kHashShift;
+        for (int probe = 0; probe < kHashBig; ++probe) {
+            const uint32_t cur = hk[hs];
+            if (cur == key) {
+                slot = hs;
+                return true;
+            }
+            if (cur == 0u) return false;
+            hs = (hs + 1) & (kHashBig - 1);
+        }
+        return false;
+    }
+};
+
+// A multi-source walk keeps, in the SAME table, one entry per (tile, source) -- what that source has seen of the tile as
+// connected to itself -- and one per tile for the pixels claimed so far by anybody; the source (0 = the seed itself,
+// 1.. = way-points) or kSrcClaim sits in the four high bits of the tile id (tile rows stay below 4096: frames of fewer
+// than 2^29 pixels).  Ring records carry the source the same way.  This view hands fetch_tile the plain tile id and
+// directs its look-up to the entry of the record's source.
+struct MultiView {
+    const TeamStore& S;
+    mutable uint32_t tag;
+    __device__ void get(uint32_t i, uint32_t& tile, uint64_t& m) const {
+        uint32_t t;
+        S.get(i, t, m);
+        tag = t & kSrcMask;
+        tile = t & ~kSrcMask;
+    }
+    __device__ bool lookup(uint32_t tile, uint32_t& slot, uint64_t& V) const { return S.lookup(tile | tag, slot, V); }
+    __device__ void value(uint32_t slot, uint64_t& V) const { S.value(slot, V); }
 };
 
 // The same store in GLOBAL memory (one overflow slab of FloodBuffers: 16 Ki ring records, a table of 64 Ki tiles), for a
@@ -1285,8 +1369,8 @@ struct TeamGlobalStore {
 // neighbour records of a step, one direction per lane 0..7 (as push8; no merging with pending records of the same tile:
 // duplicates of a level are taken by different wavefronts at the same time)
 template <class Store>
-__device__ __forceinline__ void team_push8(Store& S, uint32_t tile, uint64_t H, int lane, const PushLane& c) {
-    const uint32_t nt = tile + c.off;
+__device__ __forceinline__ void team_push8(Store& S, uint32_t tile, uint64_t H, int lane, const PushLane& c, uint32_t tag = 0u) {
+    const uint32_t nt = (tile + c.off) | tag;  // (tag: the source of a multi-source walk; lanes whose neighbour lies outside the frame carry no entry)
     const uint32_t key = nt + 1u;
     const uint64_t src = (H >> c.shamt) & (uint64_t)c.msk;
     uint64_t E = (c.spread ? spread_col(src) : src) << c.sh;
@@ -1322,7 +1406,19 @@ __device__ __forceinline__ void team_push8(Store& S, uint32_t tile, uint64_t H, 
 
 // returns 0 when the footprint is complete; 1 when ring or table ran out: *begin_out is then the first ring index that
 // may hold an unprocessed record (processed ones read kVoidTile)
-template <class Store>
+// kMulti (TeamStore only): the records carry a source each -- the seed's own pixel and the way-points its last walk left
+// (kWpK) -- and every source grows its region at once.  A source keeps what it has SEEN as connected to itself in entries of
+// its own (V_s, whole in-tile components as ever) and goes on only from the pixels it was the first of all sources to CLAIM
+// (the tile's claim entry, atomic OR): the regions share the footprint out between them and stop where they meet.  Two
+// regions that touch have seen a common pixel: if p (claimed by s) and q (claimed by s') are neighbours, s pushed a record
+// for q when it claimed p -- the neighbour filter looks at s's OWN entry of q's tile -- and q, though claimed already,
+// entered V_s as well as V_s'.  After the walk (flood_explore_team_kernel) sources with a common pixel in some tile are
+// joined, and the footprint is the union of V_s over the sources joined with source 0 -- exactly the pixels connected to
+// the seed: each V_s is connected and contains its starting point; every pixel on a path from the seed is claimed by some
+// source (induction along the path: a claimed pixel's in-tile component and ring neighbours are all visited by its
+// claimer), and consecutive pixels of the path have claimers that saw a common pixel.  Way-points the footprint has lost
+// grow regions of their own that join nothing and are dropped.
+template <class Store, bool kMulti = false>
 __device__ int team_walk(const FloodArgs& A, uint32_t k, int b, float thr, float sn, float cs, Store& S, int lane,
                          int wave, bool own, uint32_t first_level, uint32_t tile_cap, uint32_t* begin_out, uint32_t* steps_out) {
     TeamShared* sh = S.sh;
@@ -1347,12 +1443,20 @@ __device__ int team_walk(const FloodArgs& A, uint32_t k, int b, float thr, float
         for (uint32_t i = gb + (uint32_t)wave; i < ge; i += kTeamWaves) {
             // room for what the steps in flight may add: eight records and one tile each
             if ((uni(lds_now(&sh->tail)) - gb) + 8u * kTeamWaves > S.ring_cap() ||
-                uni(lds_now(&sh->ntiles)) + kTeamWaves + 1u > min(S.hash_limit(), tile_cap)) {
+                uni(lds_now(&sh->ntiles)) + (kMulti ? 2u : 1u) * kTeamWaves + 1u > min(S.hash_limit(), tile_cap)) {
                 if (lane == 0) sh->overflow = 1u;
                 break;
             }
             if (uni(lds_now(&sh->overflow)) != 0u) break;
-            const TileFetch cur = fetch_tile<0>(A, S, i, lr, lc, rx, ry, ring_lane, fw, G, own);
+            uint32_t tag = 0u;
+            TileFetch cur;
+            if constexpr (kMulti) {
+                const MultiView MV{S, 0u};
+                cur = fetch_tile<0>(A, MV, i, lr, lc, rx, ry, ring_lane, fw, G, own);
+                tag = MV.tag;
+            } else {
+                cur = fetch_tile<0>(A, S, i, lr, lc, rx, ry, ring_lane, fw, G, own);
+            }
             ++steps;
             const uint32_t tile = cur.tile;
             uint64_t Am = cur.inside & m_ne(cur.dm & bin_bit, 0u) & m_gt_f(directional(cur.dx, cur.dy, sn, cs), thr);
@@ -1372,11 +1476,21 @@ __device__ int team_walk(const FloodArgs& A, uint32_t k, int b, float thr, float
                 const uint64_t New = R & ~cur.V;
                 if (New != 0ull) {
                     uint64_t was = 0ull;
-                    if (lane == 0) was = S.add_walked(cur.slot, New);
+                    if constexpr (kMulti) {
+                        uint32_t slot_c;
+                        uint64_t claimed;
+                        (void)S.lookup(tile | kSrcClaim, slot_c, claimed);  // (find or insert)
+                        if (lane == 0) {
+                            was = S.add_walked(slot_c, New);     // claimed before by whichever source
+                            (void)S.add_walked(cur.slot, New);   // seen by this one, claimed or not
+                        }
+                    } else {
+                        if (lane == 0) was = S.add_walked(cur.slot, New);
+                    }
                     const uint64_t first_here = New & ~uni64(was);  // the pixels this step was the first to walk
                     if (first_here != 0ull) {
                         const uint64_t H = Rg & m_ne64(first_here & adj, 0ull);
-                        if (H != 0ull) team_push8(S, tile, H, lane, pc);
+                        if (H != 0ull) team_push8(S, tile, H, lane, pc, tag);
                     }
                 }
             }
@@ -1408,12 +1522,16 @@ __device__ int team_walk(const FloodArgs& A, uint32_t k, int b, float thr, float
 // registers.  A first version counted the wavefronts "trying to claim" in a counter of its own: three and more idle
 // wavefronts then kept each other waiting for ever, each finding another in the middle of its attempt.  Not in the tree.)
 constexpr size_t kTeamLdsBytes = (size_t)(3 * kRingTeam + 3 * kHashBig + 2 * kPend) * 4 + (size_t)kHashBig * 2 + sizeof(TeamShared);
+// from_multi_list: the list is the round's way-point seeds (A.multi_list, written by the last survivors pass) instead of
+// what this round's first tier handed over; nothing comes with its entries.
 __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(FloodArgs A, BinTrig trig,
-                                                                             uint32_t* __restrict__ big_list) {
+                                                                             const uint32_t* __restrict__ big_list,
+                                                                             uint32_t from_multi_list) {
     extern __shared__ uint32_t s_team[];
     const int lane = threadIdx.x & 63, wave = (int)uni(threadIdx.x >> 6);
-    const uint32_t n_big_raw = uni(A.ctrl[kCtrlNBig]);
-    const uint32_t n_big = n_big_raw < A.big_cap ? n_big_raw : A.big_cap;
+    if (uni(A.ctrl[kCtrlNAct]) == 0u) return;  // a round enqueued past the end (or past a stall: the listed seeds are the ordered tail's)
+    const uint32_t n_big_raw = uni(A.ctrl[from_multi_list ? kCtrlNMulti : kCtrlNBig]);
+    const uint32_t n_big = from_multi_list ? min(n_big_raw, kBigCap) : (n_big_raw < A.big_cap ? n_big_raw : A.big_cap);
     uint32_t* ring = s_team;
     uint32_t* hash = ring + 3 * kRingTeam;
     uint32_t* pend = hash + 3 * kHashBig;
@@ -1422,6 +1540,9 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
     TeamStore S{ring, ring + kRingTeam, ring + 2 * kRingTeam, hash, hash + kHashBig, hash + 2 * kHashBig, ord, sh};
     for (uint32_t ai = uni(blockIdx.x); ai < n_big; ai += gridDim.x) {
         const uint32_t k = uni(big_list[ai]);
+        // (a listed seed above the round's window is not walked at all, like every seed there: a commit is only valid if
+        // every lower active seed has walked)
+        if (from_multi_list && k >= uni(A.ctrl[kCtrlWindow])) continue;
         const int s = (int)uni((uint32_t)A.seed_idx[k]);
         const int b = (int)uni((uint32_t)A.seed_bin[k]);
         const float thr = __uint_as_float(uni(__float_as_uint(A.seed_thr[k])));
@@ -1435,51 +1556,98 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
             if (threadIdx.x == 0) A.flags[k] = kFlagSelfFail;
             continue;
         }
-        __syncthreads();  // the previous seed's table is no longer read
-        for (int i = (int)threadIdx.x; i < kHashBig; i += 64 * kTeamWaves) {
-            S.hk[i] = 0u;
-            S.hv0[i] = 0u;
-            S.hv1[i] = 0u;
-        }
         // what the first tier handed over with this entry (A.big_cap entries at most, so ai is its position in the list)
         const uint32_t* hb = A.handover + (size_t)ai * kFloodHandWords;
-        const uint32_t h_tiles = min(uni(hb[0]), kHandTiles), h_recs = min(uni(hb[1]), kHandRecs);
-        const uint32_t first_level = h_recs ? h_recs : 1u;
-        __syncthreads();  // (table cleared)
-        if (h_recs) {
-            for (uint32_t t = threadIdx.x; t < h_tiles; t += 64u * kTeamWaves) {
-                const uint32_t key = hb[kHandTable + 3u * t];
-                uint32_t hs = (key * 2654435761u) >> TeamStore::kHashShift;
-                while (atomicCAS(&S.hk[hs], 0u, key) != 0u) hs = (hs + 1u) & (uint32_t)(kHashBig - 1);  // (the tiles are distinct)
-                S.hv0[hs] = hb[kHandTable + 3u * t + 1u];
-                S.hv1[hs] = hb[kHandTable + 3u * t + 2u];
-                S.ord[t] = (uint16_t)hs;
-            }
-            for (uint32_t t = threadIdx.x; t < h_recs; t += 64u * kTeamWaves) {
-                S.rt[t] = hb[kHandRing + 3u * t];
-                S.rlo[t] = hb[kHandRing + 3u * t + 1u];
-                S.rhi[t] = hb[kHandRing + 3u * t + 2u];
-            }
-        }
-        if (threadIdx.x == 0) {
-            if (!h_recs) {
-                const int sr = s / A.w, sc = s - sr * A.w;
-                const uint64_t m = 1ull << ((sr & 7) * 8 + (sc & 7));
-                S.rt[0] = ((uint32_t)(sr >> 3) << 16) | (uint32_t)(sc >> 3);
-                S.rlo[0] = (uint32_t)m;
-                S.rhi[0] = (uint32_t)(m >> 32);
-            }
-            sh->tail = first_level;
-            sh->end = first_level;
-            sh->ntiles = h_recs ? h_tiles : 0u;
-            sh->blocked = 0u;
-            sh->overflow = 0u;
-            sh->cnt = 0u;
-            sh->steps = h_recs ? hb[2] : 0u;
-        }
-        __syncthreads();
+        const uint32_t h_recs_in = from_multi_list ? 0u : min(uni(hb[1]), kHandRecs);
+        // A seed that left way-points on its footprint (save_waypoints) and comes without a walk in progress is walked from
+        // all of them at once (team_walk, kMulti).  Should the table run out -- two entries a tile -- it starts again, plainly.
+        const uint32_t wp_hdr = (A.wp_min_tiles != 0xFFFFFFFFu && k < A.wp_cap) ? uni(A.waypoints[(size_t)k * kFloodWpWords]) : 0u;
+        const bool multi = h_recs_in == 0u && wp_hdr != 0u && (wp_hdr >> 8) <= kWpMaxTiles;
         uint32_t begin = 0u, my_steps = 0u;
-        int rc = team_walk(A, k, b, thr, sn, cs, S, lane, wave, own, first_level, A.team_tiles, &begin, &my_steps);
+        int rc = 0;
+        bool did_multi = false;
+        if (multi) {
+            __syncthreads();  // the previous seed's table is no longer read
+            for (int i = (int)threadIdx.x; i < kHashBig; i += 64 * kTeamWaves) {
+                S.hk[i] = 0u;
+                S.hv0[i] = 0u;
+                S.hv1[i] = 0u;
+            }
+            if (threadIdx.x <= kWpK) {  // source 0: the seed's own pixel; 1 .. kWpK: the way-points
+                const uint32_t t = threadIdx.x;
+                uint32_t q = t == 0u ? (uint32_t)s : A.waypoints[(size_t)k * kFloodWpWords + t];
+                uint64_t m = 0ull;
+                if (q == kWpNone || q >= (uint32_t)A.w * (uint32_t)A.h) q = (uint32_t)s;  // (no way-point here: an empty record)
+                else m = 1ull << (((q / (uint32_t)A.w) & 7u) * 8u + ((q % (uint32_t)A.w) & 7u));
+                const uint32_t qr = q / (uint32_t)A.w, qc = q % (uint32_t)A.w;
+                S.rt[t] = (((qr >> 3) << 16) | (qc >> 3)) | (t << kSrcShift);
+                S.rlo[t] = (uint32_t)m;
+                S.rhi[t] = (uint32_t)(m >> 32);
+                sh->adj[t] = 0u;
+            }
+            if (threadIdx.x == 0) {
+                sh->tail = kWpK + 1u;
+                sh->end = kWpK + 1u;
+                sh->ntiles = 0u;
+                sh->blocked = 0u;
+                sh->overflow = 0u;
+                sh->cnt = 0u;
+                sh->steps = 0u;
+                sh->reach = 0u;
+                sh->ctiles = 0u;
+            }
+            __syncthreads();
+            uint32_t multi_steps = 0u;
+            rc = team_walk<TeamStore, true>(A, k, b, thr, sn, cs, S, lane, wave, own, kWpK + 1u, A.team_tiles, &begin, &multi_steps);
+            my_steps += multi_steps;
+            did_multi = rc == 0;
+        }
+        if (!did_multi) {
+            __syncthreads();  // the previous seed's table is no longer read
+            for (int i = (int)threadIdx.x; i < kHashBig; i += 64 * kTeamWaves) {
+                S.hk[i] = 0u;
+                S.hv0[i] = 0u;
+                S.hv1[i] = 0u;
+            }
+            // what the first tier handed over with this entry (A.big_cap entries at most, so ai is its position in the list)
+            const uint32_t* hb = A.handover + (size_t)ai * kFloodHandWords;
+            const uint32_t h_tiles = min(uni(hb[0]), kHandTiles), h_recs = h_recs_in;
+            const uint32_t first_level = h_recs ? h_recs : 1u;
+            __syncthreads();  // (table cleared)
+            if (h_recs) {
+                for (uint32_t t = threadIdx.x; t < h_tiles; t += 64u * kTeamWaves) {
+                    const uint32_t key = hb[kHandTable + 3u * t];
+                    uint32_t hs = (key * 2654435761u) >> TeamStore::kHashShift;
+                    while (atomicCAS(&S.hk[hs], 0u, key) != 0u) hs = (hs + 1u) & (uint32_t)(kHashBig - 1);  // (the tiles are distinct)
+                    S.hv0[hs] = hb[kHandTable + 3u * t + 1u];
+                    S.hv1[hs] = hb[kHandTable + 3u * t + 2u];
+                    S.ord[t] = (uint16_t)hs;
+                }
+                for (uint32_t t = threadIdx.x; t < h_recs; t += 64u * kTeamWaves) {
+                    S.rt[t] = hb[kHandRing + 3u * t];
+                    S.rlo[t] = hb[kHandRing + 3u * t + 1u];
+                    S.rhi[t] = hb[kHandRing + 3u * t + 2u];
+                }
+            }
+            if (threadIdx.x == 0) {
+                if (!h_recs) {
+                    const int sr = s / A.w, sc = s - sr * A.w;
+                    const uint64_t m = 1ull << ((sr & 7) * 8 + (sc & 7));
+                    S.rt[0] = ((uint32_t)(sr >> 3) << 16) | (uint32_t)(sc >> 3);
+                    S.rlo[0] = (uint32_t)m;
+                    S.rhi[0] = (uint32_t)(m >> 32);
+                }
+                sh->tail = first_level;
+                sh->end = first_level;
+                sh->ntiles = h_recs ? h_tiles : 0u;
+                sh->blocked = 0u;
+                sh->overflow = 0u;
+                sh->cnt = 0u;
+                sh->steps = h_recs ? hb[2] : 0u;
+            }
+            __syncthreads();
+            rc = team_walk(A, k, b, thr, sn, cs, S, lane, wave, own, first_level, A.team_tiles, &begin, &my_steps);
+        }
         // (team_walk ends behind a barrier: every wavefront sees the final table)
         WalkState st{0u, 0u, 0u, 0u, false, 0u, 0u};
         uint32_t px = 0u;
@@ -1552,7 +1720,80 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
                 st.ntiles = nt;
             }
         }
-        if (!in_slab) {
+        if (did_multi) {
+            // Which sources belong to the seed?  Two sources that have seen a common pixel are joined (see team_walk); the
+            // footprint is what the sources joined with source 0 have seen.
+            for (int i = (int)threadIdx.x; i < kHashBig; i += 64 * kTeamWaves) {
+                const uint32_t key = S.hk[i];
+                if (key == 0u) continue;
+                const uint32_t tk = key - 1u, src = tk >> kSrcShift;
+                if (src == 0u || src > kWpK) continue;  // (source 0 is met from the other side; claim entries join nobody)
+                const uint64_t V = S.peek_walked((uint32_t)i);
+                if (V == 0ull) continue;
+                for (uint32_t s2 = 0u; s2 < src; ++s2) {
+                    uint32_t sl;
+                    if (S.find_ro((tk & ~kSrcMask) | (s2 << kSrcShift), sl) && (S.peek_walked(sl) & V) != 0ull) {
+                        atomicOr(&sh->adj[src], 1u << s2);
+                        atomicOr(&sh->adj[s2], 1u << src);
+                    }
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t reach = 1u;
+                for (;;) {
+                    uint32_t nr = reach;
+                    for (uint32_t s2 = 0u; s2 <= kWpK; ++s2)
+                        if ((reach >> s2) & 1u) nr |= sh->adj[s2];
+                    if (nr == reach) break;
+                    reach = nr;
+                }
+                sh->reach = reach;
+                atomicAdd(&A.ctrl[kCtrlMulti], 1u);
+            }
+            __syncthreads();
+            // Stamps and pixel count, tile by tile over the claim entries (one per tile of whatever any source walked): the
+            // tile's share of the footprint is what the joined sources have seen of it, looked up by lanes 0 .. kWpK side by side.
+            const uint32_t reach = sh->reach, nt = sh->ntiles, mine = kMarkBit | k;
+            const int lr = lane >> 3, lc = lane & 7;
+            bool foreign = false;
+            uint32_t ctl = 0u;
+            for (uint32_t i = (uint32_t)wave; i < nt; i += kTeamWaves) {
+                const uint32_t slot = uni((uint32_t)S.ord[i]);
+                const uint32_t tk = uni(S.hk[slot]) - 1u;
+                if ((tk & kSrcMask) != kSrcClaim) continue;
+                const uint32_t T = tk & ~kSrcMask;
+                uint32_t u0 = 0u, u1 = 0u;
+                if ((uint32_t)lane <= kWpK && ((reach >> lane) & 1u)) {
+                    uint32_t sl;
+                    if (S.find_ro(T | ((uint32_t)lane << kSrcShift), sl)) {
+                        u0 = S.hv0[sl];
+                        u1 = S.hv1[sl];
+                    }
+                }
+#pragma unroll
+                for (int off = 4; off >= 1; off >>= 1) {
+                    u0 |= (uint32_t)__shfl_xor((int)u0, off);
+                    u1 |= (uint32_t)__shfl_xor((int)u1, off);
+                }
+                const uint64_t U = uni64(u0, u1);
+                if (U == 0ull) continue;
+                ctl += 1u;
+                if (lane == 0) px += (uint32_t)__popcll(U);
+                if ((U >> lane) & 1ull) {
+                    const size_t q = (size_t)((T >> 16) * 8 + lr) * A.w + ((T & 0xFFFFu) * 8 + lc);
+                    const uint32_t old = atomicMin(&A.label[q], mine);
+                    A.dirty[q >> 8] = 1;
+                    if (old > mine) {
+                        if (old != kLabelFree) A.blocked[old & ~kMarkBit] = 1u;
+                    } else if (old < mine && old >= kMarkBit) {
+                        foreign = true;
+                    }
+                }
+            }
+            if (__ballot(foreign)) st.blocked = true;
+            if (lane == 0 && ctl) atomicAdd(&sh->ctiles, ctl);
+        } else if (!in_slab) {
             st.ntiles = sh->ntiles;
             stamp_footprint(A, k, S, st, lane, (uint32_t)wave * 8u, 8u * kTeamWaves);
             for (int i = (int)threadIdx.x; i < kHashBig; i += 64 * kTeamWaves) px += (uint32_t)__popc(S.hv0[i]) + (uint32_t)__popc(S.hv1[i]);
@@ -1569,6 +1810,10 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
         st.cnt = sh->cnt;
         st.steps = sh->steps;
         st.blocked = sh->blocked != 0u;
+        if (did_multi) st.ntiles = sh->ctiles;
+        // a long walk that came here for the first time (handed over by the first tier) leaves its way-points now
+        if (!did_multi && !in_slab && rc == 0 && wp_hdr == 0u && k < A.wp_cap && st.ntiles >= A.wp_min_tiles && st.ntiles <= kWpMaxTiles)
+            save_waypoints(A, k, S, st.ntiles, lane);
         if (rc != 0 && lane == 0) {  // no slab to go to, or the slab ran out as well: the ordered tail will finish this seed
             A.flags[k] = kFlagIncomplete;
             atomicMin(&A.ctrl[kCtrlBarrier], k);
@@ -1714,6 +1959,8 @@ __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift, u
     ctrl[kCtrlBarrierNext] = 0xFFFFFFFFu;
     ctrl[kCtrlSlabs] = 0u;
     ctrl[kCtrlNBig] = 0u;
+    ctrl[kCtrlNMulti] = progress ? ld_agent(&ctrl[kCtrlNMultiNext]) : 0u;
+    ctrl[kCtrlNMultiNext] = 0u;
     ctrl[kCtrlBigSeen] = ld_agent(&ctrl[kCtrlBigLong]) >= regional_min ? 1u : 0u;
 }
 
@@ -1760,6 +2007,21 @@ __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, const
                     A.blocked[k] = 0u;
                     A.count[k] = 0u;
                     A.flags[k] = 0u;
+                    // A survivor that left way-points on a long footprint: the coming round walks it from all of them at once
+                    // (team_walk, kMulti) in a launch of its own BESIDE the round's exploration, which passes it over (tier
+                    // bit 1).  (A few hundred such seeds a round at most: one atomic each.)
+                    uint8_t t = (uint8_t)(A.tier[k] & 1u);
+                    if (A.multi_next != 0u && k < window && k < A.wp_cap) {
+                        const uint32_t hdr = A.waypoints[(size_t)k * kFloodWpWords];
+                        if (hdr != 0u && (hdr >> 8) <= kWpMaxTiles) {
+                            const uint32_t pos = atomicAdd(&A.ctrl[kCtrlNMultiNext], 1u);
+                            if (pos < kBigCap) {
+                                A.multi_list[pos] = k;
+                                t |= 2u;
+                            }
+                        }
+                    }
+                    A.tier[k] = t;
                 }
             }
         }
@@ -1820,7 +2082,8 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
                                                                int32_t* __restrict__ seed_size, uint32_t* __restrict__ ctrl,
                                                                uint8_t* __restrict__ dirty, uint32_t n_runs,
                                                                int win_first_shift, int hold_pct, uint32_t hold_from_start,
-                                                               uint32_t* __restrict__ label, size_t npix) {
+                                                               uint32_t* __restrict__ label, size_t npix,
+                                                               uint32_t* __restrict__ waypoints, uint32_t wp_cap) {
     // (the label image is set to "free" here as well: one launch less in front of the first round)
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) label[i] = kLabelFree;
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
@@ -1842,6 +2105,9 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
         ctrl[kCtrlBigTotal] = 0u;
         ctrl[kCtrlBigLong] = 0u;
         ctrl[kCtrlBigSeen] = 0u;
+        ctrl[kCtrlMulti] = 0u;
+        ctrl[kCtrlNMulti] = 0u;
+        ctrl[kCtrlNMultiNext] = 0u;
         ctrl[kCtrlSlabTotal] = 0u;
         ctrl[kCtrlBarrier] = 0xFFFFFFFFu;
         ctrl[kCtrlBarrierNext] = 0xFFFFFFFFu;
@@ -1858,6 +2124,7 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
     }
     for (uint32_t r = k; r < n_runs; r += gridDim.x * 256) dirty[r] = 0;  // (all clear after a flood that ran to its end)
     if (k >= n_seeds) return;
+    if (k < wp_cap) waypoints[(size_t)k * kFloodWpWords] = 0u;
     act[k] = k;
     state[k] = 0;
     tier[k] = 0;
@@ -2098,6 +2365,13 @@ FloodArgs flood_args(const FloodBuffers& B, const FloodFrame& F, bool use_big) {
     static const int t1f_env = std::getenv("LIBRECTIFY_FLOOD_T1_WIDE_FRONT") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_T1_WIDE_FRONT")) : 6;
     A.t1_wide_tiles = t1w_env > 0 ? (uint32_t)t1w_env : 0xFFFFFFFFu;
     A.t1_wide_front = (uint32_t)std::max(t1f_env, 1);
+    // way-points: walks of this many tiles leave them (LIBRECTIFY_FLOOD_MULTI_MIN; profiles/r04_flood_multi_sweep.txt)
+    static const int wp_min_env = std::getenv("LIBRECTIFY_FLOOD_MULTI_MIN") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_MULTI_MIN")) : 100;
+    A.waypoints = B.waypoints;
+    A.wp_cap = B.waypoints ? B.wp_cap : 0u;
+    A.multi_list = B.multi_list;
+    A.multi_next = 0u;
+    A.wp_min_tiles = (B.multi_source && B.waypoints && use_big) ? (uint32_t)std::max(wp_min_env, (int)kWpK + 1) : 0xFFFFFFFFu;
     static const int g_cap_env = std::getenv("LIBRECTIFY_FLOOD_PARTIAL_STEPS") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_PARTIAL_STEPS")) : 16;
     A.g_cap = g_cap_env > 0 ? (uint32_t)g_cap_env : kMaxSteps;
     return A;
@@ -2138,16 +2412,33 @@ void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& 
     FloodArgs A = A0;
     A.no_rest = (grid < F.seed_cap && !has_rest(index)) ? 1u : 0u;
     A.next_reach = (grid_of(index + 1) < F.seed_cap && !has_rest(index + 1)) ? grid_of(index + 1) : 0xFFFFFFFFu;
+    // Way-point seeds listed by the last survivors pass are walked by teams in a launch of their own on the context's second
+    // stream, BESIDE this round's exploration (one stream runs its kernels one after the other, and hipExtAnyOrderLaunch is
+    // not honoured on gfx950: tools/ubench/anyorder.hip): fork behind the last round, join in front of the commit passes.
+    // Only in the rounds that have such walks to speak of (2 .. kMultiRoundLast + 1): a fork and a join are two event
+    // packets a round.
+    const bool multi_now = B.aux_stream != nullptr && A.wp_min_tiles != 0xFFFFFFFFu && use_big && index >= 1 && index <= B.multi_round_last &&
+                           index < B.n_fork_events && !g_flood_debug;
+    A.multi_next = (B.aux_stream != nullptr && A.wp_min_tiles != 0xFFFFFFFFu && use_big && index + 1 >= 1 && index + 1 <= B.multi_round_last &&
+                    index + 1 < B.n_fork_events && !g_flood_debug) ? 1u : 0u;
+    if (multi_now) {
+        (void)hipEventRecord(B.fork_events[index], s);
+        (void)hipStreamWaitEvent(B.aux_stream, B.fork_events[index], 0);
+        hipLaunchKernelGGL(flood_explore_team_kernel, dim3(std::min<uint32_t>(F.seed_cap, kTeamGrid)), dim3(64 * kTeamWaves),
+                           kTeamLdsBytes, B.aux_stream, A, F.trig, B.multi_list, 1u);
+        (void)hipEventRecord(B.join_events[index], B.aux_stream);
+    }
     hipLaunchKernelGGL(flood_explore_kernel, dim3(grid), dim3(64), 0, s, A, F.trig, act, B.big_list);
     if (has_rest(index))  // entries past the guess, if any
         hipLaunchKernelGGL(flood_explore_rest_kernel, dim3(1024), dim3(64), 0, s, A, F.trig, act, B.big_list, grid);
     static const bool team = !(std::getenv("LIBRECTIFY_FLOOD_TEAM") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_TEAM")) == 0);
     if (use_big && team)
         hipLaunchKernelGGL(flood_explore_team_kernel, dim3(std::min<uint32_t>(F.seed_cap, kTeamGrid)), dim3(64 * kTeamWaves),
-                           kTeamLdsBytes, s, A, F.trig, B.big_list);
+                           kTeamLdsBytes, s, A, F.trig, B.big_list, 0u);
     else if (use_big)
         hipLaunchKernelGGL(flood_explore_big_kernel, dim3(std::min<uint32_t>(F.seed_cap, kBigCap)), dim3(64), kBigLdsBytes, s,
                            A, F.trig, B.big_list);
+    if (multi_now) (void)hipStreamWaitEvent(s, B.join_events[index], 0);
     if (g_flood_debug) (void)hipEventRecord(dbg1, s);
     if (g_flood_debug) {
         uint32_t n = 0;
@@ -2214,7 +2505,8 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
         const uint32_t blocks = std::max<uint32_t>(seed_blocks, (uint32_t)std::min<size_t>((npix + 255) / 256, 4096));
         hipLaunchKernelGGL(flood_init_seeds_kernel, dim3(blocks), dim3(256), 0, s, F.d_n_seeds, F.seed_cap, B.act_a, B.state,
                            B.tier, B.blocked, B.count, B.flags, F.seed_size, B.ctrl, B.dirty,
-                           (uint32_t)((npix + 255) >> 8), win_first_shift, hold_pct, hold_start ? 1u : 0u, F.label, npix);
+                           (uint32_t)((npix + 255) >> 8), win_first_shift, hold_pct, hold_start ? 1u : 0u, F.label, npix,
+                           B.waypoints, B.wp_cap);
     }
     FloodArgs A = flood_args(B, F, P->use_big);
     A.win_shift = (uint32_t)win_growth;
@@ -2286,6 +2578,7 @@ int flood_finish(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, u
         tiers_out[6] = h_ctrl[kCtrlSteps];
         tiers_out[7] = h_ctrl[kCtrlSteps + 1];
         tiers_out[8] = h_ctrl[kCtrlBigLong];
+        tiers_out[9] = h_ctrl[kCtrlMulti];
     }
     return 0;
 }

@@ -313,6 +313,92 @@ def test_partial_commits_change_the_work_not_the_labels(L, ctx):
     assert stats[True]["flood_rounds"] <= stats[False]["flood_rounds"]
 
 
+def test_multi_source_rewalks_change_the_time_not_the_labels(L, ctx):
+    """Round 4: a seed whose walk was long leaves way-points on its footprint, and its next walk starts from the seed and
+    from all of them at once on a team of wavefronts, keeping what is connected to the seed (kernels_flood.hip: team_walk,
+    kMulti).  Label image, flood sizes and records with and without, against the oracle; through the hooks that make the
+    team's table run out in the middle of such a walk (6: it starts again plainly and moves into a slab; 7: no slab);
+    the counter proves that such walks really ran."""
+    from librectify_amd import synth
+
+    used = {}
+    try:
+        for name, img in (("bars", synth.frame(1920, 1080, 7)), ("long", synth.long_bar_frame(1920, 1080, 3, K=24))):
+            ref = O.find_line_segments(img)
+            for on in (True, False):
+                ctx.set_flood_multi_source(on)
+                for mode in (1, 6, 7):
+                    ctx.set_flood_mode(mode)
+                    ctx.stage_filter_host(img)
+                    ctx.stage_seeds()
+                    ctx.stage_flood()
+                    used[(name, on, mode)] = ctx.stage_counters()
+                    np.testing.assert_array_equal(ctx.download(L.BUF_LABEL), ref["label"])
+                    _assert_lines_equal(ctx.stage_fit(), ref["lines"])
+    finally:
+        ctx.set_flood_multi_source(True)
+        ctx.set_flood_mode(1)
+    # (way-points are left by walks of a hundred tiles and more: the long bars have them, in every mode)
+    assert used[("long", True, 1)]["multi_source_walks"] > 0 and used[("long", False, 1)]["multi_source_walks"] == 0
+
+
+def test_multi_source_rewalks_from_way_points_on_nearly_every_walk(L):
+    """LIBRECTIFY_FLOOD_MULTI_MIN=8 (read once per process: a child process) lets every walk of eight tiles and more leave
+    way-points, so that thousands of re-walks per frame start from several sources -- way-points that the footprint has
+    lost in the meantime, sources that never meet, tables that run out (modes 6 / 7) included.  Synthetic bars, long bars,
+    soft regions and the reference's doc image, all against the oracle."""
+    import subprocess
+    import sys
+
+    code = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np
+import oracle_lib as O
+import librectify_amd as L
+from librectify_amd import synth
+g = np.load(os.path.join(%r, "tests", "golden", "doc_image_gray.npy")).astype(np.float32) / np.float32(256.0)
+frames = [synth.frame(1920, 1080, 21), synth.frame(960, 540, 4, bars=40), synth.long_bar_frame(1280, 720, 5, K=20),
+          synth.region_frame(640, 480, 501), np.ascontiguousarray(g)]
+ctx = L.Context(0); ctx.set_seed(0)
+walks = 0
+for img in frames:
+    ref = O.find_line_segments(img)
+    for mode in (1, 6, 7):
+        ctx.set_flood_mode(mode)
+        ctx.stage_filter_host(img); ctx.stage_seeds(); ctx.stage_flood()
+        walks += ctx.stage_counters()["multi_source_walks"]
+        assert (ctx.download(L.BUF_LABEL) == ref["label"]).all(), "labels differ"
+        assert ctx.stage_fit().tobytes() == ref["lines"].tobytes(), "records differ"
+assert walks > 1000, walks
+print("ok", walks)
+""" % (ROOT, ROOT, ROOT)
+    env = dict(os.environ, LIBRECTIFY_FLOOD_MULTI_MIN="8")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().startswith("ok"), (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_multi_source_rewalks_at_full_size_equal_the_ordered_flood(L, ctx):
+    """3840x2160 bench frames 2..4 (frame 1 is test_parallel_flood_equals_ordered_flood_at_full_size): parallel rounds with
+    multi-source re-walks against the single-wave ordered kernel."""
+    from librectify_amd import synth
+
+    for seed in (2, 3, 4):
+        img = synth.frame(3840, 2160, seed)
+        out = {}
+        for mode in (0, 1):
+            ctx.set_flood_mode(mode)
+            ctx.stage_filter_host(img)
+            ctx.stage_seeds()
+            ctx.stage_flood()
+            if mode == 1:
+                assert ctx.stage_counters()["multi_source_walks"] > 0
+            out[mode] = (ctx.download(L.BUF_LABEL), ctx.download(L.BUF_SEED_SIZE))
+        ctx.set_flood_mode(1)
+        np.testing.assert_array_equal(out[0][0], out[1][0])
+        np.testing.assert_array_equal(out[0][1], out[1][1])
+
+
 def test_drop_in_thread_context_can_be_released_and_comes_back(L):
     """lr_release_thread_context: the calling thread's drop-in context (workspace, slabs, staging threads) is freed at once;
     the next call through the reference's entry makes a new one and gives the same records."""
