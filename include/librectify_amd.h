@@ -96,6 +96,18 @@ int lr_find_line_segment_groups_batch_host_ptrs(lr_context* ctx, const float* co
                                                 int height, int stride, float min_length, int refine, int num_threads,
                                                 LineSegment* out, int capacity, int* n_lines,
                                                 const RectificationConfig* cfg, ImageTransform* transforms);
+/* The same batch over SEVERAL devices of this process -- what a C / C++ caller of the reference's kind (one process, no
+ * launcher: src/autorectify.cpp:136,350) needs to use the eight GPUs of a node.  Frames are dealt in contiguous blocks of
+ * ceil(batch / n_devices), block i to devices[i]; every entry of the list gets a context of its own (kept with `ctx` from
+ * call to call, configured like `ctx`: seed, iterations, estimator, lr_set_batch_streams lanes per device) with its own
+ * uploader, copy stream, lanes and pool, driven by a host thread of its own; results land in the caller's arrays as for
+ * the single-device call.  A device may be listed more than once (two independent lane sets on one GPU: how the call is
+ * tested on a one-GPU box).  No collective: it is one process.  `ctx` itself only carries the settings. */
+int lr_find_line_segment_groups_batch_host_multi(lr_context* ctx, const int* devices, int n_devices,
+                                                 const float* const* frames, int batch, int width, int height, int stride,
+                                                 float min_length, int refine, int num_threads, LineSegment* out,
+                                                 int capacity, int* n_lines, const RectificationConfig* cfg,
+                                                 ImageTransform* transforms);
 /* Page-locked host memory for frames (hipHostMalloc / hipHostFree): uploads from it skip the staging copy. */
 int lr_host_alloc(lr_context* ctx, size_t bytes, void** out);
 int lr_host_free(lr_context* ctx, void* p);
@@ -119,10 +131,12 @@ void lr_set_flood_blind_rounds(lr_context* ctx, int rounds);
 /* Comparison hook: the flood's partial commits (a blocked seed commits at once the part of its footprint that no lower
  * seed can reach; on by default, LIBRECTIFY_FLOOD_PARTIAL=0 also switches them off).  Same labels either way. */
 void lr_set_flood_partial_commits(lr_context* ctx, int on);
-/* Comparison hook: the flood's multi-source re-walks (a seed whose walk was long leaves way-points on its footprint; if it
- * has to walk again, a team of wavefronts starts from the seed and from every way-point at once and keeps what is
- * connected to the seed; on by default, LIBRECTIFY_FLOOD_MULTI=0 also switches them off).  Same labels either way;
- * lr_stage_counters [10] counts them. */
+/* Opt-in (round 4): the flood's multi-source re-walks.  A seed whose walk covered a hundred tiles or more leaves way-points
+ * on its footprint; if it has to walk again, a team of wavefronts starts from the seed and from every way-point at once,
+ * beside the round's exploration on a second stream, and keeps what is connected to the seed.  Same labels either way
+ * (exact by construction, tested against the oracle); on the bench frames the late rounds get 25 % shorter and the whole
+ * flood 2-10 %, frames of regions and of very long bars lose as much, hence off by default.
+ * LIBRECTIFY_FLOOD_MULTI=1 turns it on for every new context; lr_stage_counters [10] counts such walks. */
 void lr_set_flood_multi_source(lr_context* ctx, int on);
 
 /* ---- stage API (tests, bench) --------------------------------------------------------- */

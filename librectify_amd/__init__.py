@@ -71,6 +71,7 @@ EXPORTS = [
     "lr_find_line_segment_groups_batch_host", "lr_find_line_segment_groups_batch_host_ptrs", "lr_host_alloc", "lr_host_free",
     "lr_set_seed_capacity", "lr_set_flood_blind_rounds", "lr_set_flood_staged", "lr_set_batch_streams", "lr_device_malloc", "lr_device_free", "lr_memcpy_h2d", "lr_cht_vanishing_point", "lr_refine_lines", "lr_set_estimator", "lr_ht_weights", "lr_prosac_solve", "lr_estimate_line_pencils_prosac", "lr_direct_solve", "lr_estimate_line_pencils_direct",
     "lr_estimate_line_pencils_cht", "lr_set_stage_timing", "lr_release_thread_context", "lr_set_flood_partial_commits", "lr_set_flood_multi_source",
+    "lr_find_line_segment_groups_batch_host_multi",
 ]
 
 _lib = None
@@ -118,6 +119,7 @@ def lib():
         L.lr_find_line_segment_groups_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.lr_find_line_segment_groups_batch_host.argtypes = L.lr_find_line_segment_groups_batch_device.argtypes
         L.lr_find_line_segment_groups_batch_host_ptrs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.lr_find_line_segment_groups_batch_host_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.lr_host_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         L.lr_host_free.argtypes = [C.c_void_p, C.c_void_p]
         L.lr_stage_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -332,9 +334,10 @@ class Context:
         _check(lib().lr_find_line_segment_groups_batch_device(self._h, C.c_void_p(dptr), image_stride, batch, w, h, w, min_length, int(refine), -1, _ptr(out), capacity, _ptr(n), C.byref(cfg), C.byref(tf)))
         return out, n, tf
 
-    def find_line_segment_groups_batch_host(self, frames, min_length, refine=False, num_threads=-1, capacity=4096, cfg=None, out=None):
+    def find_line_segment_groups_batch_host(self, frames, min_length, refine=False, num_threads=-1, capacity=4096, cfg=None, out=None, devices=None):
         """frames: float32 array [B, H, W] (rows contiguous; any row/frame strides) or a list of 2-D float32 arrays
-        of one shape, in HOST memory (pageable, or page-locked as host_alloc returns it)."""
+        of one shape, in HOST memory (pageable, or page-locked as host_alloc returns it).  devices: a list of device
+        indices to deal the frames over in contiguous blocks (lr_find_line_segment_groups_batch_host_multi)."""
         if isinstance(frames, np.ndarray) and frames.ndim == 3:
             assert frames.dtype == np.float32 and frames.strides[2] == 4
             batch, h, w = frames.shape
@@ -353,6 +356,10 @@ class Context:
         tf = (ImageTransform * batch)()
         cfg = cfg or RectificationConfig()
         self.shape = (h, w)
+        if devices is not None:
+            devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+            _check(lib().lr_find_line_segment_groups_batch_host_multi(self._h, devs, len(devices), ptrs, batch, w, h, stride, min_length, int(refine), num_threads, _ptr(out), capacity, _ptr(n), C.byref(cfg), C.byref(tf)))
+            return out, n, tf
         _check(lib().lr_find_line_segment_groups_batch_host_ptrs(self._h, ptrs, batch, w, h, stride, min_length, int(refine), num_threads, _ptr(out), capacity, _ptr(n), C.byref(cfg), C.byref(tf)))
         return out, n, tf
 

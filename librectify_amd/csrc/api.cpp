@@ -182,6 +182,15 @@ int lr_find_line_segment_groups_batch_host_ptrs(lr_context* ctx, const float* co
                                       out, capacity, n_lines, cfg, transforms);
 }
 
+int lr_find_line_segment_groups_batch_host_multi(lr_context* ctx, const int* devices, int n_devices,
+                                                 const float* const* frames, int batch, int width, int height, int stride,
+                                                 float min_length, int refine, int num_threads, LineSegment* out,
+                                                 int capacity, int* n_lines, const RectificationConfig* cfg,
+                                                 ImageTransform* transforms) {
+    return ctx_find_groups_batch_host_multi(ctx, devices, n_devices, frames, batch, width, height, stride, min_length,
+                                            refine != 0, num_threads, out, capacity, n_lines, cfg, transforms);
+}
+
 int lr_host_alloc(lr_context* ctx, size_t bytes, void** out) {
     LR_HIP(hipSetDevice(ctx->device));
     LR_HIP(hipHostMalloc(out, bytes));

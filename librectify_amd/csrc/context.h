@@ -134,6 +134,7 @@ struct lr_context {
     hipEvent_t prosac_ev[2] = {nullptr, nullptr};  // end of a chunk's work on the stream
     std::vector<int> prosac_imin;    // prosac.h's Imin(2, n) by n (constants of prosac.h:62-66 only)
     std::vector<lr_context*> workers;  // extra contexts (own stream + workspace) for frames in flight in batch calls
+    std::vector<lr_context*> peers;    // one context per entry of the device list of the last multi-device batch call (each with its own lanes)
     int batch_streams = 4;
     int estimator = 0;            // 0 = RANSAC (reference default), 1 = PROSAC, 2 = DirectEstimator, 3 = diamond space (CHT)
     int prosac_T_N = -1;
@@ -157,7 +158,7 @@ struct lr_context {
     bool flood_hold_hint = false;  // did the last frame hold its weakest seeds back?
     uint32_t flood_tiers[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // last flood: seeds in the second tier, slabs used, seeds of the ordered tail, hold-back, walked px (lo, hi), steps (lo, hi), walks beyond the first tier's table, multi-source re-walks
     bool flood_partial = true;  // partial commits of blocked seeds (kernels_flood.hip); lr_set_flood_partial_commits
-    bool flood_multi = true;    // re-walks of long footprints from several way-points at once (kernels_flood.hip); lr_set_flood_multi_source
+    bool flood_multi = false;   // re-walks of long footprints from several way-points at once (kernels_flood.hip): opt-in, lr_set_flood_multi_source / LIBRECTIFY_FLOOD_MULTI=1
     bool flood_staged = false;  // lr_set_flood_staged: the rounds start on the strongest eighth of the seeds (test / experiment hook)
     // Stage timers (HIP events between the stages of a frame): off in the frame calls unless lr_set_stage_timing or
     // LIBRECTIFY_STAGE_TIMES asks -- every event record is a barrier packet in the stream, some 6 us of idle GPU each,
@@ -218,6 +219,13 @@ int ctx_find_groups_batch_device(lr_context* c, const float* d_images, size_t im
 int ctx_find_groups_batch_host(lr_context* c, const float* const* frames, int batch, int w, int h, int stride,
                                float min_length, bool refine, int num_threads, LineSegment* out, int capacity,
                                int* n_lines, const RectificationConfig* cfg, ImageTransform* transforms);
+// The same over several devices of this process ("one host thread + stream set per device"): frames are
+// dealt in contiguous blocks of ceil(batch / n_devices), block i to devices[i] (a device may be listed more than once:
+// every entry gets a lane set of its own), results land in the caller's arrays; no collective, it is one process.
+int ctx_find_groups_batch_host_multi(lr_context* c, const int* devices, int n_devices, const float* const* frames, int batch,
+                                     int w, int h, int stride, float min_length, bool refine, int num_threads,
+                                     LineSegment* out, int capacity, int* n_lines, const RectificationConfig* cfg,
+                                     ImageTransform* transforms);
 // Enqueues the upload of a host frame into device slot `slot` on the copy stream and records ev_up[slot];
 // the caller makes its compute stream wait on that event.  num_threads: the reference's knob (threading.h:24-27),
 // here the number of host threads that stage a pageable frame (< 0: serial, as there).

@@ -158,7 +158,13 @@ static int ensure_flood_buffers(lr_context* c) {
     f.wp_cap = (uint32_t)std::min<size_t>(std::max<size_t>(cs / 16, 4096), cs);  // (one seed per 16 pixels: the 4K bench frame has one per 200)
     if (dev_alloc(f.waypoints, (size_t)f.wp_cap * kFloodWpWords) || dev_alloc(f.multi_list, 8192)) return 1;
     if (!c->flood_aux) {
-        LR_HIP(hipStreamCreateWithFlags(&c->flood_aux, hipStreamNonBlocking));
+        // At a priority of its own: HIP maps streams onto a few hardware queues, and a second stream that lands on the queue
+        // of the first runs BEHIND it -- fork and join then cost two barriers a round and buy nothing (seen in bench.py, whose
+        // process has thirteen streams: flood 1.28 -> 1.80 ms).  Streams of different priorities never share a queue.
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
+        if (hi == lo) LR_HIP(hipStreamCreateWithFlags(&c->flood_aux, hipStreamNonBlocking));
+        else LR_HIP(hipStreamCreateWithPriority(&c->flood_aux, hipStreamNonBlocking, hi));
         for (int i = 0; i < 8; ++i) {
             hipEvent_t a = nullptr, b = nullptr;
             LR_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
@@ -574,6 +580,7 @@ int ctx_create(int device, lr_context** out) {
     const char* env = std::getenv("LIBRECTIFY_SEED");
     c->ransac_seed = env ? std::strtoull(env, nullptr, 0) : 0ull;
     c->timing_on = std::getenv("LIBRECTIFY_STAGE_TIMES") != nullptr;
+    if (const char* e = std::getenv("LIBRECTIFY_FLOOD_MULTI")) c->flood_multi = std::atoi(e) != 0;  // (opt-in: DESIGN.md section 7, round 4)
     const char* fm = std::getenv("LIBRECTIFY_FLOOD_MODE");
     if (fm) c->flood_mode = std::atoi(fm);
     *out = c;
@@ -584,6 +591,8 @@ void ctx_destroy(lr_context* c) {
     if (!c) return;
     for (lr_context* wc : c->workers) ctx_destroy(wc);
     c->workers.clear();
+    for (lr_context* pc : c->peers) ctx_destroy(pc);
+    c->peers.clear();
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->d_img_slot[0], c->d_img_slot[1], c->dx, c->dy, c->dmask, c->cand, c->cand_count, c->tile_max, c->tile_pass, c->tile_off,
@@ -724,8 +733,7 @@ FloodBuffers flood_buffers_for(lr_context* c) {
     }
     static const bool partial_off = std::getenv("LIBRECTIFY_FLOOD_PARTIAL") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_PARTIAL")) == 0;
     fbuf.partial_commits = !partial_off && c->flood_partial;
-    static const bool multi_off = std::getenv("LIBRECTIFY_FLOOD_MULTI") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_MULTI")) == 0;
-    fbuf.multi_source = !multi_off && c->flood_multi;
+    fbuf.multi_source = c->flood_multi;
     static const int aux_env = std::getenv("LIBRECTIFY_FLOOD_MULTI_BESIDE") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_MULTI_BESIDE")) : -1;  // (experiment: 0 = after the exploration, N = beside it in rounds 2 .. N + 1)
     if (c->flood_aux && c->flood_aux_on && aux_env != 0 && c->flood_fork.size() == c->flood_join.size()) {
         fbuf.aux_stream = c->flood_aux;
@@ -2330,6 +2338,87 @@ int ctx_find_groups_batch_host(lr_context* c, const float* const* frames, int ba
                                int* n_lines, const RectificationConfig* cfg, ImageTransform* transforms) {
     return find_groups_batch(c, nullptr, 0, frames, batch, w, h, stride, min_length, refine, num_threads, out, capacity,
                              n_lines, cfg, transforms);
+}
+
+// One batch call over several devices of this process.  Every entry of the device list has a context of its own (kept
+// with `c` from call to call), configured like `c`, with its own uploader, copy stream, lanes and pool; a host thread per
+// entry runs the single-device batch call on its contiguous block of the frames.
+int ctx_find_groups_batch_host_multi(lr_context* c, const int* devices, int n_devices, const float* const* frames, int batch,
+                                     int w, int h, int stride, float min_length, bool refine, int num_threads,
+                                     LineSegment* out, int capacity, int* n_lines, const RectificationConfig* cfg,
+                                     ImageTransform* transforms) {
+    if (batch <= 0) return 0;
+    if (n_devices <= 0 || devices == nullptr) {
+        set_error("multi-device batch: empty device list");
+        return 1;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
+    for (int i = 0; i < n_devices; ++i)
+        if (devices[i] < 0 || devices[i] >= ndev) {
+            set_error("multi-device batch: device index out of range");
+            return 1;
+        }
+    // the contexts of the list (re-made where the list changed)
+    if ((int)c->peers.size() > n_devices) {
+        for (size_t i = (size_t)n_devices; i < c->peers.size(); ++i) ctx_destroy(c->peers[i]);
+        c->peers.resize((size_t)n_devices);
+    }
+    c->peers.resize((size_t)n_devices, nullptr);
+    for (int i = 0; i < n_devices; ++i) {
+        if (c->peers[(size_t)i] && c->peers[(size_t)i]->device != devices[i]) {
+            ctx_destroy(c->peers[(size_t)i]);
+            c->peers[(size_t)i] = nullptr;
+        }
+        if (!c->peers[(size_t)i] && ctx_create(devices[i], &c->peers[(size_t)i])) {
+            (void)hipSetDevice(c->device);
+            return 1;
+        }
+        lr_context* p = c->peers[(size_t)i];
+        p->ransac_seed = c->ransac_seed;
+        p->ransac_iters = c->ransac_iters;
+        p->flood_mode = c->flood_mode;
+        p->flood_staged = c->flood_staged;
+        p->flood_partial = c->flood_partial;
+        p->flood_multi = c->flood_multi;
+        p->estimator = c->estimator;
+        p->prosac_T_N = c->prosac_T_N;
+        p->cht_d = c->cht_d;
+        p->timing_on = c->timing_on;
+        p->batch_streams = c->batch_streams;
+    }
+    const int per = (batch + n_devices - 1) / n_devices;  // contiguous blocks of ceil(B / G) frames
+    std::vector<int> rc((size_t)n_devices, 0);
+    std::vector<std::string> err((size_t)n_devices);
+    auto run = [&](int i) {
+        const int b0 = std::min(batch, i * per), b1 = std::min(batch, b0 + per);
+        if (b1 <= b0) return;
+        lr_context* p = c->peers[(size_t)i];
+        if (hipSetDevice(p->device) != hipSuccess) {
+            rc[(size_t)i] = 1;
+            err[(size_t)i] = "hipSetDevice failed";
+            return;
+        }
+        // (a share of the staging threads each: they all copy out of the same host memory)
+        const int nt = num_threads > 1 ? std::max(2, num_threads / std::min(n_devices, (batch + per - 1) / per)) : num_threads;
+        if (ctx_find_groups_batch_host(p, frames + b0, b1 - b0, w, h, stride, min_length, refine, nt,
+                                       out ? out + (size_t)b0 * capacity : nullptr, capacity, n_lines ? n_lines + b0 : nullptr, cfg,
+                                       transforms ? transforms + b0 : nullptr)) {
+            rc[(size_t)i] = 1;
+            err[(size_t)i] = get_error();  // (thread-local: carried back to the caller below)
+        }
+    };
+    std::vector<std::thread> th;
+    for (int i = 1; i < n_devices; ++i) th.emplace_back(run, i);
+    run(0);
+    for (auto& t : th) t.join();
+    (void)hipSetDevice(c->device);
+    for (int i = 0; i < n_devices; ++i)
+        if (rc[(size_t)i]) {
+            set_error("device list entry " + std::to_string(i) + " (device " + std::to_string(devices[i]) + "): " + err[(size_t)i]);
+            return 1;
+        }
+    return 0;
 }
 
 }  // namespace lramd

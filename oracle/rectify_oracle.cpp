@@ -174,11 +174,22 @@ void conv_gradients(const float* img, int w, int h, float* dx, float* dy, const 
     float d[5], g[5];
     gauss_deriv_factors(EDGE_KERNEL_SIZE, EDGE_KERNEL_SIGMA, d, g);
     const float d1 = d[3], d2 = d[4], g1 = g[3], g2 = g[4];
-    std::vector<float> hx(size_t(w) * h, 0.0f), hs(size_t(w) * h, 0.0f);
-    std::fill(dx, dx + size_t(w) * h, 0.0f);
-    std::fill(dy, dy + size_t(w) * h, 0.0f);
+    // Frame-sized work planes are kept from call to call (per calling thread) and first touched inside the parallel loops
+    // that fill them: allocating and zero-filling 33 MB vectors on the calling thread, call after call, cost the threaded
+    // runs more than their loops took (round 3: "gradients" slower on 128 threads than on one).  Every element that is
+    // read below is written first: rows 0 .. h-1, columns 2 .. w-3.
+    static thread_local std::vector<float> tl_hx, tl_hs;  // (referred to through references: a worker's own would be empty)
+    std::vector<float>&hx = tl_hx, &hs = tl_hs;
+    if (hx.size() != size_t(w) * h) {
+        hx = std::vector<float>();
+        hs = std::vector<float>();
+        hx.resize(size_t(w) * h);
+        hs.resize(size_t(w) * h);
+    }
 #pragma omp parallel for num_threads(ctx.get()) if (ctx.enabled())
     for (int r = 0; r < h; ++r) {
+        std::fill(dx + size_t(r) * w, dx + size_t(r + 1) * w, 0.0f);  // conv_2d's zero border (filter.cpp:83)
+        std::fill(dy + size_t(r) * w, dy + size_t(r + 1) * w, 0.0f);
         const float* I = img + size_t(r) * w;
         for (int x = 2; x < w - 2; ++x) {
             float a1 = I[x + 1] - I[x - 1], a2 = I[x + 2] - I[x - 2];
@@ -262,14 +273,19 @@ void binary_dilate(const uint8_t* in, int w, int h, uint8_t* out, const ThreadCo
 void gradient_directions(const float* dx, const float* dy, int w, int h, int n_bins, int32_t* grad_bin,
                          std::vector<std::vector<float>>& grad, const ThreadContext& ctx) {
     size_t n = size_t(w) * h;
-    std::vector<float> grad_max(n, 0.0f);
+    static thread_local std::vector<float> tl_grad_max;  // (kept from call to call, as the planes are: see conv_gradients)
+    std::vector<float>& grad_max = tl_grad_max;
+    grad_max.assign(n, 0.0f);
     std::fill(grad_bin, grad_bin + n, 0);  // reference leaves it uninitialised (:128); canonical: 0
-    grad.assign(n_bins, std::vector<float>());
+    if (int(grad.size()) != n_bins) grad.assign(n_bins, std::vector<float>());
     std::vector<float> st(n_bins), ct(n_bins);
     bin_trig(n_bins, st.data(), ct.data());
 #pragma omp parallel for num_threads(ctx.get()) if (ctx.enabled())
     for (int i = 0; i < n_bins; ++i) {
-        grad[i].resize(n);
+        if (grad[i].size() != n) {
+            grad[i] = std::vector<float>();
+            grad[i].resize(n);
+        }
         for (size_t p = 0; p < n; ++p) grad[i][p] = directional(dx[p], dy[p], st[i], ct[i]);
     }
     // :152-156 serial in the reference
@@ -282,7 +298,9 @@ void gradient_directions(const float* dx, const float* dy, int w, int h, int n_b
     }
 #pragma omp parallel for num_threads(ctx.get()) if (ctx.enabled())
     for (int i = 0; i < n_bins; ++i) {
-        std::vector<uint8_t> eq(n), mask(n);
+        static thread_local std::vector<uint8_t> eq, mask;  // (per OpenMP thread)
+        eq.resize(n);
+        mask.resize(n);
         for (size_t p = 0; p < n; ++p) eq[p] = grad_bin[p] == i;
         binary_dilate(eq.data(), w, h, mask.data(), ThreadContext(-1));
         for (size_t p = 0; p < n; ++p)
@@ -293,7 +311,8 @@ void gradient_directions(const float* dx, const float* dy, int w, int h, int n_b
 // filter.cpp:29-43
 void maximum_filter(const float* img, int w, int h, int size, float* out, const ThreadContext& ctx) {
     int n = 2 * size + 1;
-    std::fill(out, out + size_t(w) * h, 0.0f);
+#pragma omp parallel for num_threads(ctx.get()) if (ctx.enabled())
+    for (int i = 0; i < h; ++i) std::fill(out + size_t(i) * w, out + size_t(i + 1) * w, 0.0f);
 #pragma omp parallel for num_threads(ctx.get()) if (ctx.enabled())
     for (int i = 0; i < h - n + 1; ++i)
         for (int j = 0; j < w - n + 1; ++j) {
@@ -311,7 +330,9 @@ struct PeakPoint {
 
 // filter.cpp:161-195; tie order made canonical (value desc, row asc, col asc)
 std::vector<PeakPoint> find_peaks(const float* img, int w, int h, int size, float min_value, const ThreadContext& ctx) {
-    std::vector<float> max_im(size_t(w) * h);
+    static thread_local std::vector<float> tl_max_im;
+    std::vector<float>& max_im = tl_max_im;
+    max_im.resize(size_t(w) * h);
     maximum_filter(img, w, h, size, max_im.data(), ctx);
     std::vector<PeakPoint> res;
     res.reserve(1024);
@@ -451,11 +472,23 @@ std::vector<LineSegment> find_line_segments(const float* img, int w, int h, int 
     using clk = std::chrono::steady_clock;
     auto t0 = clk::now();
     size_t n = size_t(w) * h;
-    std::vector<float> dx(n), dy(n), mag(n);
+    // (work planes kept from call to call: see conv_gradients.  The names below are references to the CALLING thread's
+    // planes: inside an OpenMP region a thread_local name would mean the worker's own, empty ones.)
+    static thread_local std::vector<float> tl_dx, tl_dy, tl_mag;
+    static thread_local std::vector<int32_t> tl_grad_bin;
+    static thread_local std::vector<std::vector<float>> tl_grad;
+    std::vector<float>&dx = tl_dx, &dy = tl_dy, &mag = tl_mag;
+    std::vector<int32_t>& grad_bin = tl_grad_bin;
+    std::vector<std::vector<float>>& grad = tl_grad;
+    if (dx.size() != n) {
+        for (auto* v : {&dx, &dy, &mag}) {
+            *v = std::vector<float>();
+            v->resize(n);
+        }
+        grad_bin.resize(n);
+    }
     image_gradients(img, w, h, dx.data(), dy.data(), mag.data(), ctx);
     auto t1 = clk::now();
-    std::vector<int32_t> grad_bin(n);
-    std::vector<std::vector<float>> grad;
     gradient_directions(dx.data(), dy.data(), w, h, 8, grad_bin.data(), grad, ctx);
     auto t2 = clk::now();
     float mx = 0.0f;

@@ -336,7 +336,7 @@ def test_multi_source_rewalks_change_the_time_not_the_labels(L, ctx):
                     np.testing.assert_array_equal(ctx.download(L.BUF_LABEL), ref["label"])
                     _assert_lines_equal(ctx.stage_fit(), ref["lines"])
     finally:
-        ctx.set_flood_multi_source(True)
+        ctx.set_flood_multi_source(False)
         ctx.set_flood_mode(1)
     # (way-points are left by walks of a hundred tiles and more: the long bars have them, in every mode)
     assert used[("long", True, 1)]["multi_source_walks"] > 0 and used[("long", False, 1)]["multi_source_walks"] == 0
@@ -373,7 +373,7 @@ for img in frames:
 assert walks > 1000, walks
 print("ok", walks)
 """ % (ROOT, ROOT, ROOT)
-    env = dict(os.environ, LIBRECTIFY_FLOOD_MULTI_MIN="8")
+    env = dict(os.environ, LIBRECTIFY_FLOOD_MULTI_MIN="8", LIBRECTIFY_FLOOD_MULTI="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().startswith("ok"), (r.stdout[-500:], r.stderr[-1500:])
 
@@ -383,6 +383,7 @@ def test_multi_source_rewalks_at_full_size_equal_the_ordered_flood(L, ctx):
     multi-source re-walks against the single-wave ordered kernel."""
     from librectify_amd import synth
 
+    ctx.set_flood_multi_source(True)
     for seed in (2, 3, 4):
         img = synth.frame(3840, 2160, seed)
         out = {}
@@ -397,6 +398,31 @@ def test_multi_source_rewalks_at_full_size_equal_the_ordered_flood(L, ctx):
         ctx.set_flood_mode(1)
         np.testing.assert_array_equal(out[0][0], out[1][0])
         np.testing.assert_array_equal(out[0][1], out[1][1])
+    ctx.set_flood_multi_source(False)
+
+
+def test_multi_device_batch_call_deals_contiguous_blocks(L, ctx):
+    """lr_find_line_segment_groups_batch_host_multi (one host thread + stream set per device, contiguous
+    blocks of ceil(B / G) frames, results in the caller's arrays, no collective in one process).  On a one-GPU box the
+    device list names device 0 two and three times -- independent lane sets, uploaders and pools -- against the
+    single-device call and single frames; an odd batch, more list entries than frames, a bad device index."""
+    from librectify_amd import synth
+
+    w, h = 640, 480
+    frames = np.stack([synth.frame(w, h, 300 + i, bars=20 + i) for i in range(7)])
+    ctx.set_seed(0)
+    ctx.set_batch_streams(3)
+    single = [ctx.find_line_segment_groups(f, 6.4) for f in frames]
+    out1, n1, tf1 = ctx.find_line_segment_groups_batch_host(frames, 6.4, num_threads=4, capacity=2048)
+    for devs in ([0, 0], [0, 0, 0], [0] * 9):
+        out, n, tf = ctx.find_line_segment_groups_batch_host(frames, 6.4, num_threads=4, capacity=2048, devices=devs)
+        for b in range(len(frames)):
+            assert n[b] == n1[b] == len(single[b])
+            _assert_lines_equal(out[b][: n[b]], single[b])
+            np.testing.assert_array_equal(tf[b].as_array(), tf1[b].as_array())
+    with pytest.raises(L.LibrectifyError):
+        ctx.find_line_segment_groups_batch_host(frames, 6.4, capacity=2048, devices=[0, L.device_count()])
+    ctx.set_batch_streams(4)
 
 
 def test_drop_in_thread_context_can_be_released_and_comes_back(L):
