@@ -462,8 +462,9 @@ def main(argv=None):
                     "fill and drain (first uploads, last frames on fewer lanes) are inside the timed region")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
-    ap.add_argument("--host-memory", choices=["pageable", "pinned"], default="pageable",
-                    help="where the timed region's frames live (the other kind and the device-resident rate are extra legs)")
+    ap.add_argument("--host-memory", choices=["pageable", "pinned", "device"], default="pageable",
+                    help="where the timed region's frames live (the other kind and the device-resident rate are extra legs); "
+                         "'device' = already in HBM: a diagnostic, NOT the metric (the line's workload says so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true")
     ap.add_argument("--roofline-only", action="store_true",
@@ -634,6 +635,8 @@ def main(argv=None):
     kind = args.host_memory
     if kind == "pinned":
         wl.ensure_pinned()
+    if kind == "device":
+        wl.ensure_device()
 
     if args.roofline_only:
         args.steps = args.warmup = 0
@@ -741,9 +744,10 @@ def main(argv=None):
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%dx%d frames in %s HOST memory -> find_line_segment_groups + compute_rectification_transform per frame "
-                            "(lr_find_line_segment_groups_batch_host): H2D of every frame and D2H of its results are inside the timed "
-                            "region; default constants, refine=false, min_length=max(W,H)/100" % (w, h, kind),
+                "workload": ("%dx%d frames in %s HOST memory -> find_line_segment_groups + compute_rectification_transform per frame "
+                             "(lr_find_line_segment_groups_batch_host): H2D of every frame and D2H of its results are inside the timed "
+                             "region; default constants, refine=false, min_length=max(W,H)/100" % (w, h, kind)) if kind != "device" else
+                            ("DIAGNOSTIC, not the metric: %dx%d frames already resident in HBM (no H2D in the timed region)" % (w, h)),
                 "frames_per_step_all_gpus": total_frames,
                 "frames_in_flight_per_gpu": S,
                 "staging_threads": args.staging_threads,

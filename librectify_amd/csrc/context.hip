@@ -13,6 +13,8 @@
 #include <cstring>
 #include <random>
 #include <thread>
+#include <pthread.h>
+#include <sched.h>
 #if defined(__SSE2__)
 #include <immintrin.h>
 #endif
@@ -223,12 +225,71 @@ bool is_page_locked(const void* p) {
     return a.type == hipMemoryTypeHost;
 }
 
-int staging_threads(int num_threads) {
+int staging_threads(int num_threads, size_t frame_bytes = 0) {
     // reference threading.h:24-27: t < 0 is the serial mode, otherwise min(t, available) threads (t = 0 is
-    // ill-defined there: one thread here).  Eight threads saturate the copy into the staging buffer.
+    // ill-defined there: one thread here).  Eight threads saturate the copy into the staging buffer of a 4K frame; a frame
+    // of more than 64 MB (8192^2: 268 MB) is one long copy in front of one long transfer, and sixteen get its first bands
+    // onto the link sooner (round 4).
     if (num_threads <= 1) return 1;
     const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
-    return std::min(std::min(num_threads, hw), 8);
+    return std::min(std::min(num_threads, hw), frame_bytes > ((size_t)64 << 20) ? 16 : 8);
+}
+
+// The host cores next to a device: those of the NUMA node its PCI function sits on (sysfs), as far as this process may use
+// them; empty if unknown.  Staging helpers bind themselves there: copies by cores of the other socket reach 41 GB/s where
+// the same copies by cores of the device's own node keep the link at 54 (tools/ubench/h2d_placement.hip,
+// profiles/r04_h2d_paths.txt).  LIBRECTIFY_STAGING_BIND=0 leaves the helpers where the scheduler puts them.
+const std::vector<int>& device_node_cpus(int device) {
+    static std::mutex mu;
+    static std::vector<std::vector<int>> cache;
+    static std::vector<char> known;
+    std::lock_guard<std::mutex> lk(mu);
+    if ((int)cache.size() <= device) {
+        cache.resize((size_t)device + 1);
+        known.resize((size_t)device + 1, 0);
+    }
+    if (known[(size_t)device]) return cache[(size_t)device];
+    known[(size_t)device] = 1;
+    std::vector<int>& out = cache[(size_t)device];
+    static const bool off = std::getenv("LIBRECTIFY_STAGING_BIND") && std::atoi(std::getenv("LIBRECTIFY_STAGING_BIND")) == 0;
+    char bus[64] = {0};
+    if (off || hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) return out;
+    for (char* p = bus; *p; ++p) *p = (char)std::tolower((unsigned char)*p);
+    int node = -1;
+    if (FILE* f = std::fopen((std::string("/sys/bus/pci/devices/") + bus + "/numa_node").c_str(), "r")) {
+        if (std::fscanf(f, "%d", &node) != 1) node = -1;
+        std::fclose(f);
+    }
+    if (node < 0) return out;
+    char line[4096] = {0};
+    if (FILE* f = std::fopen(("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist").c_str(), "r")) {
+        if (!std::fgets(line, (int)sizeof(line), f)) line[0] = 0;
+        std::fclose(f);
+    }
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return out;
+    for (const char* p = line; *p;) {  // "0-63,128-191"
+        char* e = nullptr;
+        const long a = std::strtol(p, &e, 10);
+        if (e == p) break;
+        long b = a;
+        if (*e == '-') b = std::strtol(e + 1, &e, 10);
+        for (long cpu = a; cpu <= b && cpu < CPU_SETSIZE; ++cpu)
+            if (CPU_ISSET((int)cpu, &allowed)) out.push_back((int)cpu);
+        p = (*e == ',') ? e + 1 : e;
+        if (*e != ',') break;
+    }
+    return out;
+}
+
+void bind_this_thread_near(int device) {
+    const std::vector<int>& cpus = device_node_cpus(device);
+    if (cpus.empty()) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (int c : cpus) CPU_SET(c, &set);
+    (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);  // (best effort)
 }
 
 }  // namespace
@@ -396,6 +457,7 @@ struct StagingCrew {
                     live.fetch_sub(1, std::memory_order_acq_rel);
                     return;
                 }
+                bind_this_thread_near(c->device);
                 uint32_t last = 0;
                 int spins = 0;
                 while (!quit.load(std::memory_order_acquire)) {
@@ -2031,7 +2093,7 @@ int ctx_find_groups_host(lr_context* c, const float* buffer, int w, int h, int s
         return 0;
     };
     if (c->timing_on) LR_HIP(hipEventRecord(c->ev[0], c->stream));
-    const int T = stage ? staging_threads(num_threads) : 1;  // (the threads share every band: StagingCrew::work)
+    const int T = stage ? staging_threads(num_threads, npix * sizeof(float)) : 1;  // (the threads share every band: StagingCrew::work)
     if (T <= 1) {
         // the calling thread alone (the reference's serial mode, or a page-locked source that needs no staging)
         for (int k = 0; k < n_bands; ++k) {
@@ -2219,8 +2281,9 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
             abort_all.store(1);
             return;
         }
+        if (any_pageable) bind_this_thread_near(c->device);  // (this thread stages too; it is the library's own)
         StagingCrew crew;
-        if (any_pageable) crew.start(c, staging_threads(num_threads) - 1);
+        if (any_pageable) crew.start(c, staging_threads(num_threads, npix * sizeof(float)) - 1);
         for (int i = 0; i < batch; ++i) {
             int slot = -1, spins = 0;
             // a slot whose frame is done (its transfer and its staging buffer are then free as well)
