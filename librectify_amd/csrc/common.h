@@ -98,14 +98,10 @@ size_t seeds_temp_bytes(int n_tiles, size_t max_seeds);
 int launch_seed_select(const uint64_t* cand, const uint32_t* cand_count, const uint32_t* tile_max, int n_tiles,
                        int cand_cap, float seed_keep_ratio, float* maxmag, uint32_t* tile_pass, uint32_t* tile_off, uint64_t* keys,
                        uint32_t key_cap, uint32_t* n_seeds, hipStream_t s);
-int launch_seed_sort(uint64_t* keys_in, uint64_t* keys_out, uint32_t n, void* temp, size_t temp_bytes, hipStream_t s);
-// the seed count stays on the device (*n_seeds, clamped to cap); the launch covers `cap` seeds
-bool seed_order_is_fused(uint32_t cap);
-int launch_seed_order(uint64_t* keys, const uint32_t* n_seeds, uint32_t cap, const float* dx, const float* dy, BinTrig trig,
-                      float trace_tolerance, int32_t* seed_idx, int32_t* seed_bin, float* seed_thr, hipStream_t s);
-int launch_seed_setup(const uint64_t* keys_sorted, const uint32_t* n_seeds, uint32_t cap, const float* dx, const float* dy,
-                      BinTrig trig, float trace_tolerance, int32_t* seed_idx, int32_t* seed_bin, float* seed_thr,
-                      hipStream_t s);
+// the seed count stays on the device (*n_seeds, clamped to cap); the launches cover `cap` seeds.  keys_alt: a second buffer
+// of cap keys (the merge rounds of large frames go back and forth between the two)
+int launch_seed_order(uint64_t* keys, uint64_t* keys_alt, const uint32_t* n_seeds, uint32_t cap, const float* dx, const float* dy,
+                      BinTrig trig, float trace_tolerance, int32_t* seed_idx, int32_t* seed_bin, float* seed_thr, hipStream_t s);
 
 // kernels_flood.hip
 int launch_label_init(uint32_t* label, size_t n, hipStream_t s);

@@ -850,16 +850,9 @@ int enqueue_seeds(lr_context* c) {
     if (launch_seed_select(c->cand, c->cand_count, c->tile_max, fg.n_tiles, fg.cand_cap, c->seed_keep_ratio, c->maxmag,
                            c->tile_pass, c->tile_off, c->keys_a, c->seed_cap, c->d_counts + kCntSeeds, c->stream))
         return 1;
-    if (seed_order_is_fused(c->seed_cap)) {
-        if (launch_seed_order(c->keys_a, c->d_counts + kCntSeeds, c->seed_cap, c->dx, c->dy, c->trig, kTraceTolerance,
-                              c->seed_idx, c->seed_bin, c->seed_thr, c->stream))
-            return 1;
-    } else {
-        if (launch_seed_sort(c->keys_a, c->keys_b, c->seed_cap, c->temp, c->temp_bytes, c->stream)) return 1;
-        if (launch_seed_setup(c->keys_b, c->d_counts + kCntSeeds, c->seed_cap, c->dx, c->dy, c->trig, kTraceTolerance,
-                              c->seed_idx, c->seed_bin, c->seed_thr, c->stream))
-            return 1;
-    }
+    if (launch_seed_order(c->keys_a, c->keys_b, c->d_counts + kCntSeeds, c->seed_cap, c->dx, c->dy, c->trig, kTraceTolerance,
+                          c->seed_idx, c->seed_bin, c->seed_thr, c->stream))
+        return 1;
     if (c->timing_on) LR_HIP(hipEventRecord(c->ev[2], c->stream));
     return 0;
 }

@@ -18,8 +18,6 @@
 #include <cstring>
 #include <vector>
 
-#include <rocprim/rocprim.hpp>
-
 #include "common.h"
 
 namespace lramd {

@@ -7,9 +7,8 @@
 //      ~bits(mag) : 32 | (row*w+col) : 29 | bin : 3
 // which one radix sort delivers.  The candidate lists come per filter tile, so no global
 // atomic counter is touched: per-tile pass counts, one exclusive scan, one ordered write.
+#include <algorithm>
 #include <cstring>
-
-#include <rocprim/rocprim.hpp>
 
 #include "common.h"
 
@@ -140,56 +139,37 @@ __global__ __launch_bounds__(256) void seed_write_kernel(const uint64_t* __restr
     }
 }
 
-// The sort runs on a fixed number of keys (`cap`, chosen by the host before it knows the seed count, so that no
-// host round trip sits between the filter and the flood): the slots past the seeds are filled with the largest key.
-__global__ __launch_bounds__(256) void seed_pad_kernel(uint64_t* __restrict__ keys, uint32_t cap,
-                                                       const uint32_t* __restrict__ n_seeds) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < cap && i >= *n_seeds) keys[i] = ~0ull;
-}
+// ---- the seed order: a sort of our own for every frame size ---------------------------------------------------------------
+// The keys are unique (they end in the pixel index), so a key's place in the order is the number of smaller keys, and
+// counting needs no exchange of data between workgroups:
+//   1. every workgroup of 256 threads sorts a RUN of 1024 keys in LDS (bitonic; slots past the seed count read as the
+//      largest key) -- 40 workgroups for the 40 000 seeds of a 4K frame (round 3: ten workgroups of 4096 keys, 33 us);
+//   2. while there are more than kFinalRuns runs: a merge round -- every key looks up its rank in the neighbouring run of
+//      its pair and writes itself at (own index + that rank) of the merged run, twice as long (keys_a <-> keys_b);
+//   3. every key counts the smaller keys of ALL other runs (branch-free lower bounds, eight runs side by side so that
+//      eight loads are in flight per step instead of one) and writes the seed's record at that rank directly: no sorted key
+//      array, no set-up launch.
+// A 4K frame is 1 + 1 launches (8 + 20 us), an 8192 x 8192 frame with 330 000 seeds 1 + 5 + 1.  rocPRIM's radix sort, which
+// round 3 still used above 131 072 keys (nine launches with its pad and set-up kernels), is gone from the path.
+// The host knows only the CAPACITY the frame runs with (`cap`); the seed count n stays on the device: grids cover the
+// capacity, and everything past n is skipped by count, never by a padding value in memory.
+constexpr uint32_t kRun0 = 1024;      // keys per sorted run of step 1
+constexpr uint32_t kFinalRuns = 16;   // step 3 takes over when the capacity is this many runs or fewer (its cost grows with their number)
 
-__global__ __launch_bounds__(256) void seed_setup_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ n_ptr, uint32_t cap,
-                                                         const float* __restrict__ dx, const float* __restrict__ dy,
-                                                         BinTrig trig, float trace_tolerance,
-                                                         int32_t* __restrict__ seed_idx, int32_t* __restrict__ seed_bin,
-                                                         float* __restrict__ seed_thr) {
-    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t n = min(*n_ptr, cap);
-    if (k >= n) return;
-    const uint32_t lo = (uint32_t)keys[k];
-    const uint32_t idx = lo >> 3;
-    const int b = (int)(lo & 7u);
-    // flood(): min_val = (1 - tolerance) * image(seed) with image = grad[seed_bin] (filter.cpp:112-113)
-    const float v = directional(dx[idx], dy[idx], trig.st[b], trig.ct[b]);
-    seed_idx[k] = (int32_t)idx;
-    seed_bin[k] = b;
-    seed_thr[k] = (1 - trace_tolerance) * v;
-}
-
-// ---- the seed order in two launches (frames of up to kOwnSortCap seeds) -------------------------------------------------
-// rocPRIM sorts the 64-bit keys of a 4K frame in seven launches of 5-14 us, each far from filling the chip; with the
-// pad launch before and the set-up launch after, the sort was nine launches and 60 us of a 1.6 ms frame.  Here: every
-// workgroup sorts 4096 keys in LDS (slots past the seed count read as the largest key: no pad launch), then every key
-// finds its place by counting the smaller keys in each of the other sorted blocks (keys are unique: they end in the pixel
-// index) and writes the seed's record there directly (no sorted key array, no set-up launch).
-constexpr uint32_t kSortBlock = 4096;
-constexpr uint32_t kOwnSortBlocks = 32;
-constexpr uint32_t kOwnSortCap = kSortBlock * kOwnSortBlocks;
-
-// Bitonic sort of 4096 keys by 1024 threads, four consecutive keys per thread: a compare-exchange at distance 1 or 2 is
-// inside a thread, at distance 4..128 inside a wavefront (shuffles, no barrier), and only the ten steps at distance
-// >= 256 go through LDS with a barrier (33 us for the ten blocks of a 4K frame; all 78 steps through LDS: 37 us).
 __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int lane_mask) {
     const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, lane_mask);
     const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), lane_mask);
     return ((uint64_t)hi << 32) | lo;
 }
-__global__ __launch_bounds__(1024) void seed_block_sort_kernel(uint64_t* __restrict__ keys, uint32_t cap,
-                                                               const uint32_t* __restrict__ n_ptr) {
-    __shared__ uint64_t sk[kSortBlock];
+// Bitonic sort of 1024 keys by 256 threads, four consecutive keys per thread: a compare-exchange at distance 1 or 2 is
+// inside a thread, at distance 4..128 inside a wavefront (shuffles, no barrier), and only the three steps at distance
+// >= 256 go through LDS with a barrier.
+__global__ __launch_bounds__(256) void seed_run_sort_kernel(uint64_t* __restrict__ keys, uint32_t cap,
+                                                            const uint32_t* __restrict__ n_ptr) {
+    __shared__ uint64_t sk[kRun0];
     const uint32_t n = min(*n_ptr, cap);
-    const uint32_t base = blockIdx.x * kSortBlock;
-    if (base >= n) return;  // nothing but padding (the ranking pass does not look at such a block)
+    const uint32_t base = blockIdx.x * kRun0;
+    if (base >= n) return;  // nothing of this frame here
     const uint32_t t = threadIdx.x, i0 = 4u * t;
     uint64_t e[4];
 #pragma unroll
@@ -197,7 +177,7 @@ __global__ __launch_bounds__(1024) void seed_block_sort_kernel(uint64_t* __restr
     // element i keeps the smaller of (own, partner) iff it is the lower one of an ascending pair or the upper one of a
     // descending pair
 #define LR_KEEP(own, other, i, j, k) ((((((i) & (j)) == 0u) == (((i) & (k)) == 0u)) == ((other) < (own))) ? (other) : (own))
-    for (uint32_t k = 2; k <= kSortBlock; k <<= 1) {
+    for (uint32_t k = 2; k <= kRun0; k <<= 1) {
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
             if (j >= 256u) {
 #pragma unroll
@@ -229,39 +209,74 @@ __global__ __launch_bounds__(1024) void seed_block_sort_kernel(uint64_t* __restr
 #undef LR_KEEP
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-        if (base + i0 + r < cap) keys[base + i0 + r] = e[r];
+        if (base + i0 + r < n) keys[base + i0 + r] = e[r];  // (the padding stays in the registers)
 }
 
+// keys of run q (length L, a power of two; `valid` of them belong to the frame) that are smaller than `key`: a lower bound
+// in exactly log2 L steps without a data-dependent branch (a position past the valid keys counts as "not smaller")
+__device__ __forceinline__ uint32_t count_below(const uint64_t* __restrict__ run, uint32_t L, uint32_t valid, uint64_t key) {
+    uint32_t lo = 0;
+    for (uint32_t sstep = L >> 1; sstep > 0; sstep >>= 1) {
+        const uint32_t pos = lo + sstep - 1u;
+        const uint64_t v = pos < valid ? run[pos] : ~0ull;
+        lo += v < key ? sstep : 0u;
+    }
+    // (lo counts the keys at positions 0 .. L-2 that are smaller; the last position)
+    return lo + ((lo == L - 1u && L - 1u < valid && run[L - 1u] < key) ? 1u : 0u);
+}
+
+// Step 2: runs of length L merged in pairs into runs of 2 L.
+__global__ __launch_bounds__(256) void seed_merge_kernel(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, uint32_t L,
+                                                         uint32_t cap, const uint32_t* __restrict__ n_ptr) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t n = min(*n_ptr, cap);
+    if (g >= n) return;
+    const uint32_t r = g / L, i = g - r * L, q = r ^ 1u;
+    const uint64_t key = in[g];
+    const uint32_t qbase = q * L;
+    const uint32_t valid = qbase < n ? min(L, n - qbase) : 0u;
+    const uint32_t below = valid ? count_below(in + qbase, L, valid, key) : 0u;
+    out[(size_t)(r & ~1u) * L + i + below] = key;
+}
+
+// Step 3: ranks among all runs, and the seed records at their ranks.
 __global__ __launch_bounds__(256) void seed_rank_setup_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ n_ptr,
-                                                              uint32_t cap, const float* __restrict__ dx,
+                                                              uint32_t cap, uint32_t L, const float* __restrict__ dx,
                                                               const float* __restrict__ dy, BinTrig trig, float trace_tolerance,
                                                               int32_t* __restrict__ seed_idx, int32_t* __restrict__ seed_bin,
                                                               float* __restrict__ seed_thr) {
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
     const uint32_t n = min(*n_ptr, cap);
-    const uint32_t n_blocks = (n + kSortBlock - 1) / kSortBlock;
-    const uint32_t mine = g / kSortBlock;
-    // The block sort writes (and pads with the largest key) only the slots below `cap`: a last block that `cap` cuts
-    // short has nothing of this frame beyond it (zeros of a fresh allocation or an earlier frame's keys), and when `cap`
-    // is the frame's pixel count there is no memory there at all.
-    if (mine >= n_blocks || g >= cap) return;
+    if (g >= n) return;
+    const uint32_t n_runs = (n + L - 1u) / L;
+    const uint32_t mine = g / L;
     const uint64_t key = keys[g];
-    if (key == ~0ull) return;  // padding of the last block
-    uint32_t rank = g - mine * kSortBlock;
-    for (uint32_t b = 0; b < n_blocks; ++b) {
-        if (b == mine) continue;
-        const uint64_t* __restrict__ blk = keys + (size_t)b * kSortBlock;
-        uint32_t lo = 0, len = min(kSortBlock, cap - b * kSortBlock);  // count of keys below `key` in a sorted block
-        while (len > 0) {
-            const uint32_t half = len >> 1;
-            if (blk[lo + half] < key) {
-                lo += half + 1;
-                len -= half + 1;
-            } else {
-                len = half;
-            }
+    uint32_t rank = g - mine * L;
+    // eight runs side by side: the eight lower bounds advance in lock step, eight loads in flight per step
+    for (uint32_t q0 = 0; q0 < n_runs; q0 += 8u) {
+        uint32_t lo[8], valid[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t q = q0 + (uint32_t)j;
+            lo[j] = 0u;
+            valid[j] = (q < n_runs && q != mine) ? min(L, n - q * L) : 0u;
         }
-        rank += lo;
+        for (uint32_t sstep = L >> 1; sstep > 0; sstep >>= 1) {
+            uint64_t v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t pos = lo[j] + sstep - 1u;
+                v[j] = pos < valid[j] ? keys[(size_t)(q0 + (uint32_t)j) * L + pos] : ~0ull;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) lo[j] += v[j] < key ? sstep : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            // (the last position of a full run: see count_below)
+            if (lo[j] == L - 1u && L - 1u < valid[j] && keys[(size_t)(q0 + (uint32_t)j) * L + L - 1u] < key) lo[j] += 1u;
+            rank += lo[j];
+        }
     }
     const uint32_t low = (uint32_t)key;
     const uint32_t idx = low >> 3;
@@ -275,28 +290,33 @@ __global__ __launch_bounds__(256) void seed_rank_setup_kernel(const uint64_t* __
 
 }  // namespace
 
-// true when launch_seed_order handles this capacity itself (else: seed_pad + launch_seed_sort + launch_seed_setup)
-bool seed_order_is_fused(uint32_t cap) {
-    static const bool rocprim_only = std::getenv("LIBRECTIFY_SEED_SORT_ROCPRIM") != nullptr;  // (comparison knob)
-    return !rocprim_only && cap <= kOwnSortCap;
-}
-
-int launch_seed_order(uint64_t* keys, const uint32_t* n_seeds, uint32_t cap, const float* dx, const float* dy, BinTrig trig,
-                      float trace_tolerance, int32_t* seed_idx, int32_t* seed_bin, float* seed_thr, hipStream_t s) {
+// keys / keys_alt: two buffers of at least `cap` keys; the unsorted keys are in `keys`
+int launch_seed_order(uint64_t* keys, uint64_t* keys_alt, const uint32_t* n_seeds, uint32_t cap, const float* dx, const float* dy,
+                      BinTrig trig, float trace_tolerance, int32_t* seed_idx, int32_t* seed_bin, float* seed_thr, hipStream_t s) {
     if (cap == 0) return 0;
-    const uint32_t nb = (cap + kSortBlock - 1) / kSortBlock;
-    hipLaunchKernelGGL(seed_block_sort_kernel, dim3(nb), dim3(1024), 0, s, keys, cap, n_seeds);
-    hipLaunchKernelGGL(seed_rank_setup_kernel, dim3((nb * kSortBlock + 255) / 256), dim3(256), 0, s, keys, n_seeds, cap, dx, dy,
-                       trig, trace_tolerance, seed_idx, seed_bin, seed_thr);
+    const uint32_t runs0 = (cap + kRun0 - 1) / kRun0;
+    hipLaunchKernelGGL(seed_run_sort_kernel, dim3(runs0), dim3(256), 0, s, keys, cap, n_seeds);
+    uint32_t L = kRun0, runs = runs0;
+    uint64_t* cur = keys;
+    uint64_t* nxt = keys_alt;
+    // (step 3 costs (keys) x (runs) x log2 L loads, a merge round (keys) x log2 L and a launch: merge while step 3 would be
+    // the larger part -- an 8192 x 8192 frame with room for 490 000 seeds goes down to 8 runs in six rounds)
+    while (runs > kFinalRuns || (uint64_t)cap * runs > ((uint64_t)4 << 20)) {
+        hipLaunchKernelGGL(seed_merge_kernel, dim3((cap + 255) / 256), dim3(256), 0, s, cur, nxt, L, cap, n_seeds);
+        std::swap(cur, nxt);
+        L *= 2u;
+        runs = (runs + 1u) / 2u;
+    }
+    hipLaunchKernelGGL(seed_rank_setup_kernel, dim3((cap + 255) / 256), dim3(256), 0, s, cur, n_seeds, cap, L, dx, dy, trig,
+                       trace_tolerance, seed_idx, seed_bin, seed_thr);
     LR_HIP(hipGetLastError());
     return 0;
 }
 
 size_t seeds_temp_bytes(int n_tiles, size_t max_seeds) {
     (void)n_tiles;
-    size_t b = 0;
-    (void)rocprim::radix_sort_keys(nullptr, b, (uint64_t*)nullptr, (uint64_t*)nullptr, max_seeds, 0u, 64u);
-    return b + 256;
+    (void)max_seeds;
+    return 256;  // (the seed order needs no scratch beyond the two key buffers)
 }
 
 int launch_seed_select(const uint64_t* cand, const uint32_t* cand_count, const uint32_t* tile_max, int n_tiles,
@@ -308,25 +328,6 @@ int launch_seed_select(const uint64_t* cand, const uint32_t* cand_count, const u
     hipLaunchKernelGGL(seed_scan_kernel, dim3(1), dim3(1024), 0, s, tile_pass, n_tiles, tile_off, n_seeds);
     hipLaunchKernelGGL(seed_write_kernel, dim3(blocks), dim3(256), 0, s, cand, cand_count, n_tiles, cand_cap, maxmag,
                        seed_keep_ratio, tile_pass, tile_off, keys, key_cap);
-    if (!seed_order_is_fused(key_cap))
-        hipLaunchKernelGGL(seed_pad_kernel, dim3((key_cap + 255) / 256), dim3(256), 0, s, keys, key_cap, n_seeds);
-    LR_HIP(hipGetLastError());
-    return 0;
-}
-
-int launch_seed_sort(uint64_t* keys_in, uint64_t* keys_out, uint32_t n, void* temp, size_t temp_bytes,
-                     hipStream_t s) {
-    if (n == 0) return 0;
-    LR_HIP(rocprim::radix_sort_keys(temp, temp_bytes, keys_in, keys_out, (size_t)n, 0u, 64u, s));
-    return 0;
-}
-
-int launch_seed_setup(const uint64_t* keys_sorted, const uint32_t* n_seeds, uint32_t cap, const float* dx, const float* dy,
-                      BinTrig trig, float trace_tolerance, int32_t* seed_idx, int32_t* seed_bin, float* seed_thr,
-                      hipStream_t s) {
-    if (cap == 0) return 0;
-    hipLaunchKernelGGL(seed_setup_kernel, dim3((cap + 255) / 256), dim3(256), 0, s, keys_sorted, n_seeds, cap, dx, dy, trig,
-                       trace_tolerance, seed_idx, seed_bin, seed_thr);
     LR_HIP(hipGetLastError());
     return 0;
 }
