@@ -1499,6 +1499,10 @@ struct RefineParams {
     double cos_gate = 0.99;    // |d_i . d_j| below this: not parallel enough           (:369)
     double max_offset = 0.02;  // normal offset of both endpoints, in units of the longer segment's length (:382)
     double lo = -0.5, hi = 1.5;  // overlap window along the longer segment (:385)
+    // Segments no longer than this take no part in the pair graph (they pass through unmerged).  Today's reference has no
+    // such gate (0); the version that made the doc/ artefacts behaves as if it had one near 6 px (tools/sweep_refine_pins.py:
+    // 791 -> 831 of the 848 golden rows).
+    double min_pair_length = 0.0;
 };
 std::vector<LineSegment> postprocess_lines_segments(const std::vector<LineSegment>& lines, const ThreadContext& ctx,
                                                     const RefineParams& P = RefineParams()) {  // :332-444
@@ -1516,8 +1520,10 @@ std::vector<LineSegment> postprocess_lines_segments(const std::vector<LineSegmen
 #pragma omp parallel for schedule(dynamic, 1) num_threads(ctx.get()) if (ctx.enabled())
     for (int i = 0; i < n; ++i) {
         const auto& li = lines[i];
+        if (!(double(l[i]) > P.min_pair_length)) continue;
         for (int j = i + 1; j < n; ++j) {
             const auto& lj = lines[j];
+            if (!(double(l[j]) > P.min_pair_length)) continue;
             if (std::fabs(d[i].x * d[j].x + d[i].y * d[j].y) < P.cos_gate) continue;
             float w00, w01, w10, w11;  // W(row, col): rows = the two endpoints, col0 = along, col1 = normal
             if (l[i] < l[j]) {
@@ -1659,8 +1665,10 @@ int orc_filter_lines(const LineSegment* in, int n, float min_length, LineSegment
 }
 
 // refine with other constants than today's (experiment / pin sweep only)
-int orc_refine_lines_params(const LineSegment* in, int n, double cos_gate, double max_offset, double lo, double hi, LineSegment* out) {
+int orc_refine_lines_params(const LineSegment* in, int n, double cos_gate, double max_offset, double lo, double hi, double min_pair_length,
+                            LineSegment* out) {
     RefineParams P;
+    P.min_pair_length = min_pair_length;
     P.cos_gate = cos_gate;
     P.max_offset = max_offset;
     P.lo = lo;

@@ -180,11 +180,11 @@ def refine_lines(lines, num_threads=-1):
     return out[:n].copy()
 
 
-def refine_lines_params(lines, cos_gate=0.99, max_offset=0.02, lo=-0.5, hi=1.5):
+def refine_lines_params(lines, cos_gate=0.99, max_offset=0.02, lo=-0.5, hi=1.5, min_pair_length=0.0):
     """postprocess_lines_segments with other constants than today's (pin sweep, tests/test_oracle_pins.py)"""
     lines = as_lines(lines)
     out = np.zeros(len(lines), LINE_DTYPE)
-    n = lib().orc_refine_lines_params(_p(lines), C.c_int(len(lines)), C.c_double(cos_gate), C.c_double(max_offset), C.c_double(lo), C.c_double(hi), _p(out))
+    n = lib().orc_refine_lines_params(_p(lines), C.c_int(len(lines)), C.c_double(cos_gate), C.c_double(max_offset), C.c_double(lo), C.c_double(hi), C.c_double(min_pair_length), _p(out))
     return out[:n].copy()
 
 

@@ -85,6 +85,14 @@ def test_pin5_refine_structural_kat():
     old = _golden_hits(O.filter_lines(O.refine_lines_params(raw, 0.98, 0.05, -0.2, 1.2), 10.0), gold)
     assert (old & ~base).sum() >= 115, (old & ~base).sum()
     assert old.sum() >= 780, old.sum()
+    # Round 4: 43 of the 57 rows still unexplained were detector rows that this refine merged with a neighbouring fragment of
+    # 3-5 px and the reference's did not.  With fragments of at most 5.9 px kept out of the pair graph (a pre-merge length
+    # gate: today's reference has none; LINE_MIN_LENGTH is 5) the same constants reproduce 831 of the 848 rows, and 835 when
+    # the lines arrive in a slightly different order (the golden run was threaded: tools/sweep_refine_pins.py order).  The
+    # 13 rows left are listed in DESIGN.md section 2.
+    gated = _golden_hits(O.filter_lines(O.refine_lines_params(raw, 0.98, 0.05, -0.2, 1.2, 5.9), 10.0), gold)
+    assert gated.sum() >= 825, gated.sum()
+    assert (gated & ~base).sum() >= 120 and (base & ~gated).sum() <= 10, ((gated & ~base).sum(), (base & ~gated).sum())
     today = _golden_hits(O.filter_lines(O.refine_lines(raw), 10.0), gold)
     assert (today & ~base).sum() >= 45, (today & ~base).sum()
     # the parameterised entry with today's constants is the production refine

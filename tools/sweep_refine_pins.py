@@ -34,6 +34,35 @@ if len(sys.argv) > 1 and sys.argv[1] == 'fine':
     GRID = list(itertools.product([0.97, 0.98, 0.99, 0.995], [0.045, 0.05, 0.06, 0.075, 0.1], [-0.3, -0.25, -0.2, -0.1], [1.1, 1.2, 1.25, 1.3]))
 
 
+def gate_and_order(raw, gold, base):
+    """Round 4: the 57 golden rows that no constants explained.  43 of them were detector rows that
+    the swept refine merged with a fragment of 3-5 px -- so: a pre-merge length gate (fragments no longer than `gate` px
+    take no part in the pair graph), swept with the constants; and the order of the lines (the forward-only graph walk
+    of line_detector.cpp:277-329 depends on it, and the golden run was threaded: its rows are not in seed order)."""
+    L = np.hypot(raw["x2"] - raw["x1"], raw["y2"] - raw["y1"])
+    rows = []
+    for gate in (0.0, 3.0, 4.0, 5.0, 5.5, 5.9, 6.0, 6.2, 6.5, 7.0, 8.0, 10.0):
+        for params in itertools.product((0.975, 0.98, 0.985, 0.99), (0.045, 0.05, 0.055), (-0.25, -0.2, -0.15), (1.15, 1.2, 1.25)):
+            h = hits_of(O.filter_lines(O.refine_lines_params(raw, *params, gate), 10.0), gold)
+            rows.append((int(h.sum()), gate) + params)
+    rows.sort(reverse=True)
+    print("pre-merge length gate x constants, best twelve (golden rows matched, gate, cos_gate, offset, lo, hi):")
+    for r in rows[:12]:
+        print("   ", r)
+    best = rows[0]
+    print("by gate (best constants each):", {g: max(r[0] for r in rows if r[1] == g) for g in sorted({r[1] for r in rows})})
+    seed_order = hits_of(O.filter_lines(O.refine_lines_params(raw, *best[2:], best[1]), 10.0), gold)
+    union = seed_order.copy()
+    rng = np.random.RandomState(1)
+    for _ in range(80):  # near-seed orders: shuffles inside windows of 4 .. 64 lines
+        p = np.arange(len(raw))
+        w = rng.choice([4, 8, 16, 32, 64])
+        for s0 in range(0, len(p), w):
+            rng.shuffle(p[s0 : s0 + w])
+        union |= hits_of(O.filter_lines(O.refine_lines_params(raw[p], *best[2:], best[1]), 10.0), gold)
+    print("seed order: %d rows; matched under some near-seed order of the lines: %d; never: %s" % (seed_order.sum(), union.sum(), np.nonzero(~union)[0].tolist()))
+
+
 def main():
     gray = np.load(os.path.join(G, "doc_image_gray.npy"))
     img = gray.astype(np.float32) / np.float32(256.0)
@@ -41,6 +70,8 @@ def main():
     raw = O.find_line_segments(img, tolerance=0.3, want_label=False)["lines"]
     base = hits_of(O.filter_lines(raw, 10.0), gold)
     print("no refine: %d of %d golden rows; the other %d are the refine products" % (base.sum(), len(gold), (~base).sum()))
+    if len(sys.argv) > 1 and sys.argv[1] == "gate":
+        return gate_and_order(raw, gold, base)
     best = (0, None)
     rows = []
     for cg, off, lo, hi in GRID:
