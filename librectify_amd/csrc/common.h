@@ -223,10 +223,14 @@ struct PencilSoA {  // device pointers, n entries each (lines of the current rou
     const float* hy;
     const float* hz;
 };
+constexpr int kRansacBestSlots = 32;  // 64-bit words the scoring workgroups reduce their best (score, iteration) into
+// one solve (scoring launch + read-out): best score bits and iteration arrive in host_best[0..1] (page-locked); best_slots:
+// zeroed device words (kRansacBestSlots x 8 bytes), left zeroed
 int launch_ransac_score(PencilSoA m, uint32_t n, float tol, float degeneracy_tol, uint32_t n_iter, uint64_t seed,
-                        uint32_t round, float* scores, hipStream_t s);
+                        uint32_t round, unsigned long long* best_slots, uint32_t* host_best, hipStream_t s);
+// peeling rounds: the best lands in best_slots, which the round's peel launch reads and clears
 int launch_ransac_score_dev(PencilSoA m, const uint32_t* gctl, int max_models, float tol, float degeneracy_tol,
-                            uint32_t n_iter, uint64_t seed, float* scores, hipStream_t s);
+                            uint32_t n_iter, uint64_t seed, unsigned long long* best_slots, hipStream_t s);
 
 // kernels_groups.hip: filter_lines and the vanishing-point peeling on the device
 struct PencilTable {  // PencilSoA plus the index of each entry in the frame's list of filtered lines
@@ -256,10 +260,9 @@ int launch_pencil_model(const LineSegment* lines, const uint32_t* gctl, const fl
                         PencilTable round0, uint32_t line_cap, hipStream_t s);
 int launch_result_gather(const uint32_t* counts, const uint32_t* gctl, const float* models, const LineSegment* lines,
                          uint32_t cap_lines, void* host_block, hipStream_t s);
-int launch_peel(PencilTable cur, PencilTable nxt, PencilTable all, const float* scores, uint32_t n_iter, uint64_t seed,
+int launch_peel(PencilTable cur, PencilTable nxt, PencilTable all, unsigned long long* best_slots, uint64_t seed,
                 float tol, float garbage_tol, int max_models, uint32_t* gctl, float* stage4 /* 4 floats per line */,
                 LineSegment* lines, float* models, hipStream_t s);
-int launch_ransac_argmax(const float* scores, uint32_t n_iter, float* best_score, int32_t* best_iter, hipStream_t s);
 int launch_cht_accumulate(PencilSoA m, uint32_t n, int d, unsigned long long* acc, hipStream_t s);
 int launch_cht_votes(PencilSoA m, const uint32_t* idx, uint32_t n, int d, unsigned long long* acc, bool subtract,
                      unsigned long long* n_votes, hipStream_t s);

@@ -111,9 +111,7 @@ struct lr_context {
     float* d_model = nullptr;  // 8 arrays of cap_lines
     float* h_model = nullptr;  // pinned mirror
     size_t cap_iter = 0;
-    float* d_scores = nullptr;
-    float* d_best_score = nullptr;
-    int32_t* d_best_iter = nullptr;
+    unsigned long long* d_best_slots = nullptr;  // kRansacBestSlots words: a scoring launch's best (score, iteration), cleared by its reader
     // PROSAC / Hough weights (opt-in estimator)
     int32_t* d_pairs = nullptr;   // 2 x ht_pairs
     int32_t* h_pairs = nullptr;

@@ -203,12 +203,7 @@ int ctx_ensure_ransac_capacity(lr_context* c, size_t n_lines, size_t n_iter) {
         LR_HIP(hipHostMalloc((void**)&c->h_model, 8 * cl * sizeof(float)));
         c->cap_lines = cl;
     }
-    if (n_iter > c->cap_iter) {
-        LR_HIP(hipStreamSynchronize(c->stream));
-        const size_t ci = std::max<size_t>(n_iter, 16384);
-        if (dev_alloc(c->d_scores, ci)) return 1;
-        c->cap_iter = ci;
-    }
+    (void)n_iter;  // (scores are not stored any more: kernels_ransac.hip)
     return 0;
 }
 
@@ -624,12 +619,12 @@ int ctx_create(int device, lr_context** out) {
         check(hipMalloc((void**)&c->d_gctl, kGcWords * sizeof(uint32_t)), "hipMalloc(peeling control block)");
         check(hipMalloc((void**)&c->d_gnorm, 4 * sizeof(float)), "hipMalloc(normalisation)");
         check(hipMalloc((void**)&c->d_models, 64 * sizeof(float)), "hipMalloc(models)");
-        check(hipMalloc((void**)&c->d_best_score, sizeof(float)), "hipMalloc(best score)");
-        check(hipMalloc((void**)&c->d_best_iter, sizeof(int32_t)), "hipMalloc(best iteration)");
+        check(hipMalloc((void**)&c->d_best_slots, kRansacBestSlots * sizeof(unsigned long long)), "hipMalloc(best slots)");
         check(hipHostMalloc((void**)&c->h_counts, 64 * sizeof(uint32_t)), "hipHostMalloc(counts)");
         check(hipHostMalloc((void**)&c->h_best, 2 * sizeof(float)), "hipHostMalloc(best)");
         if (bad == hipSuccess) check(hipMemset(c->d_models, 0, 64 * sizeof(float)), "hipMemset(models)");
         if (bad == hipSuccess) check(hipMemset(c->d_counts, 0, 64 * sizeof(uint32_t)), "hipMemset(counts)");
+        if (bad == hipSuccess) check(hipMemset(c->d_best_slots, 0, kRansacBestSlots * sizeof(unsigned long long)), "hipMemset(best slots)");
         if (bad != hipSuccess) {
             (void)hipGetLastError();
             const std::string msg = std::string("lr_context_create: ") + what + " failed: " + hipGetErrorString(bad);
@@ -660,7 +655,7 @@ void ctx_destroy(lr_context* c) {
     void* ptrs[] = {c->d_img_slot[0], c->d_img_slot[1], c->dx, c->dy, c->dmask, c->cand, c->cand_count, c->tile_max, c->tile_pass, c->tile_off,
                     c->maxmag, c->keys_a, c->keys_b, c->d_counts, c->seed_idx, c->seed_bin, c->seed_thr, c->seed_size,
                     c->label, c->queue, c->comp_rank, c->comp_seed, c->comp_off, c->cursor, c->px_a, c->px_b,
-                    c->scratch_w, c->d_lines, c->temp, c->d_model, c->d_scores, c->d_best_score, c->d_best_iter,
+                    c->scratch_w, c->d_lines, c->temp, c->d_model, c->d_best_slots,
                     c->fb.blocked, c->fb.count, c->fb.flags, c->fb.state, c->fb.tier, c->fb.act_a, c->fb.act_b,
                     c->fb.ctrl, c->fb.big_list, c->fb.handover, c->fb.waypoints, c->fb.multi_list, c->fb.dirty, c->fb.slab_ring, c->fb.slab_hash, c->d_pairs, c->d_peak, c->d_weights,
                     c->d_samples, c->d_hcounts, c->comp_large, c->d_tables, c->d_orig, c->d_inl, c->d_flines, c->d_gctl,
@@ -749,12 +744,7 @@ int ensure_group_capacity(lr_context* c, size_t n_lines, size_t n_iter) {
         if (dev_alloc(c->d_flines, n_lines + 16)) return 1;
         c->cap_flines = n_lines + 16;
     }
-    if (n_iter > c->cap_iter) {
-        LR_HIP(hipStreamSynchronize(c->stream));
-        const size_t ci = std::max<size_t>(n_iter, 16384);
-        if (dev_alloc(c->d_scores, ci)) return 1;
-        c->cap_iter = ci;
-    }
+    (void)n_iter;  // (scores are not stored any more: kernels_ransac.hip)
     return 0;
 }
 
@@ -951,9 +941,9 @@ int enqueue_groups(lr_context* c, uint32_t line_cap, int max_models, float inlie
     for (int k = 0; k < max_models; ++k) {
         if (n_iter > 0 &&
             launch_ransac_score_dev(tab[k & 1].soa(), c->d_gctl, max_models, tol, degeneracy_tol, (uint32_t)n_iter, seed,
-                                    c->d_scores, c->stream))
+                                    c->d_best_slots, c->stream))
             return 1;
-        if (launch_peel(tab[k & 1], tab[(k + 1) & 1], all, c->d_scores, (uint32_t)std::max(n_iter, 0), seed, tol, garbage_tol,
+        if (launch_peel(tab[k & 1], tab[(k + 1) & 1], all, c->d_best_slots, seed, tol, garbage_tol,
                         max_models, c->d_gctl, c->d_inl, c->d_flines, c->d_models, c->stream))
             return 1;
     }
@@ -1108,12 +1098,10 @@ int ctx_ransac_best(lr_context* c, const PencilModel& model, const std::vector<i
     LR_HIP(hipMemcpyAsync(c->d_model, hm, 8 * n * sizeof(float), hipMemcpyHostToDevice, c->stream));
     PencilSoA m{c->d_model + 0 * n, c->d_model + 1 * n, c->d_model + 2 * n, c->d_model + 3 * n,
                 c->d_model + 4 * n, c->d_model + 5 * n, c->d_model + 6 * n, c->d_model + 7 * n};
-    if (launch_ransac_score(m, (uint32_t)n, tol, model.degeneracy_tol, (uint32_t)n_iter, seed, round, c->d_scores,
-                            c->stream))
+    // scoring launch + read-out: (score bits, iteration) arrive in the page-locked pair, no copy commands
+    if (launch_ransac_score(m, (uint32_t)n, tol, model.degeneracy_tol, (uint32_t)n_iter, seed, round, c->d_best_slots,
+                            reinterpret_cast<uint32_t*>(c->h_best), c->stream))
         return 1;
-    if (launch_ransac_argmax(c->d_scores, (uint32_t)n_iter, c->d_best_score, c->d_best_iter, c->stream)) return 1;
-    LR_HIP(hipMemcpyAsync(&c->h_best[0], c->d_best_score, sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    LR_HIP(hipMemcpyAsync(&c->h_best[1], c->d_best_iter, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     LR_HIP(hipStreamSynchronize(c->stream));
     int32_t it;
     std::memcpy(&it, &c->h_best[1], sizeof(it));

@@ -265,7 +265,7 @@ __device__ void smallest_eigenvector_3x3(const float c[9], float out[3]) {
 // its line of the first 1024 in registers from the start, and the inliers are staged in LDS for the refit's sums.
 constexpr uint32_t kStage = 2048;
 __global__ __launch_bounds__(kWG) void peel_kernel(PencilTable cur, PencilTable nxt, PencilTable all,
-                                                   const float* __restrict__ scores, uint32_t n_iter, uint64_t seed,
+                                                   unsigned long long* __restrict__ best_slots, uint64_t seed,
                                                    float tol, float garbage_tol, int max_models,
                                                    uint32_t* __restrict__ gctl, float4* __restrict__ stage_g,
                                                    LineSegment* __restrict__ lines, float* __restrict__ models) {
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kWG) void peel_kernel(PencilTable cur, PencilTable 
     const uint32_t n = gctl[kGcActive];
     const uint32_t round = gctl[kGcRound];
     // estimator.h:115: while (num_observations >= minimum_set_size && k < max_structures)
-    if (gctl[kGcRemaining] < 2u || round >= (uint32_t)max_models) return;
+    if (gctl[kGcRemaining] < 2u || round >= (uint32_t)max_models) return;  // (the round's scoring launch left as well: the slots are clear)
 
 #ifdef LR_PEEL_TIMING
     unsigned long long tm[6];
@@ -293,39 +293,26 @@ __global__ __launch_bounds__(kWG) void peel_kernel(PencilTable cur, PencilTable 
         r_hx = cur.hx[i]; r_hy = cur.hy[i]; r_hz = cur.hz[i]; r_orig = cur.orig[i];
     }
 
-    // -- first strictly best hypothesis: highest score, lowest iteration among equals; none if no score is positive
-    float bv = 0.f;
-    int bi = -1;
-    for (uint32_t i = threadIdx.x; i < n_iter; i += kWG) {
-        const float v = scores[i];
-        if (v > bv) {
-            bv = v;
-            bi = (int)i;
-        }
-    }
+    // -- first strictly best hypothesis: highest score, lowest iteration among equals; none if no score is positive.  The
+    // scoring launch has reduced it into kRansacBestSlots words (score bits : 32 | ~iteration : 32, kernels_ransac.hip);
+    // they are read and cleared here for the next round's scoring.  (Without a scoring launch they are zero: none.)
+    if (threadIdx.x < 64) {
+        unsigned long long key = threadIdx.x < (unsigned)kRansacBestSlots ? best_slots[threadIdx.x] : 0ull;
+        if (threadIdx.x < (unsigned)kRansacBestSlots) best_slots[threadIdx.x] = 0ull;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const float ov = __shfl_xor(bv, off);
-        const int oi = __shfl_xor(bi, off);
-        if (ov > bv || (ov == bv && oi >= 0 && (bi < 0 || oi < bi))) {
-            bv = ov;
-            bi = oi;
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(key >> 32), off) << 32) |
+                                         (uint32_t)__shfl_xor((int)(uint32_t)key, off);
+            key = o > key ? o : key;
         }
-    }
-    if (lane == 0) {
-        s_bv[wv] = bv;
-        s_bi[wv] = bi;
+        if (threadIdx.x == 0) {
+            s_bv[0] = __uint_as_float((uint32_t)(key >> 32));
+            s_bi[0] = key ? (int)(0xFFFFFFFFu - (uint32_t)key) : -1;
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 1; k < kWaves; ++k) {
-            const float ov = s_bv[k];
-            const int oi = s_bi[k];
-            if (ov > bv || (ov == bv && oi >= 0 && (bi < 0 || oi < bi))) {
-                bv = ov;
-                bi = oi;
-            }
-        }
+        const int bi = s_bi[0];
         // the hypothesis itself: h_a x h_b of the winning sample (line_pencil.cpp:101-108); (0, 0, 0) if there is none
         // (the reference leaves it uninitialised, estimator.h:39)
         float hx = 0.f, hy = 0.f, hz = 0.f;
@@ -489,10 +476,10 @@ int launch_pencil_model(const LineSegment* lines, const uint32_t* gctl, const fl
     return 0;
 }
 
-int launch_peel(PencilTable cur, PencilTable nxt, PencilTable all, const float* scores, uint32_t n_iter, uint64_t seed,
+int launch_peel(PencilTable cur, PencilTable nxt, PencilTable all, unsigned long long* best_slots, uint64_t seed,
                 float tol, float garbage_tol, int max_models, uint32_t* gctl, float* stage4, LineSegment* lines,
                 float* models, hipStream_t s) {
-    hipLaunchKernelGGL(peel_kernel, dim3(1), dim3(kWG), 0, s, cur, nxt, all, scores, n_iter, seed, tol, garbage_tol,
+    hipLaunchKernelGGL(peel_kernel, dim3(1), dim3(kWG), 0, s, cur, nxt, all, best_slots, seed, tol, garbage_tol,
                        max_models, gctl, reinterpret_cast<float4*>(stage4), lines, models);
     LR_HIP(hipGetLastError());
     return 0;

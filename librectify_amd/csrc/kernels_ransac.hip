@@ -132,12 +132,14 @@ __device__ __forceinline__ void inlier_estimate2(const f2 cx, const f2 cy, const
 // gctl != nullptr: line count and round come from the device (peeling rounds enqueued blindly, kernels_groups.hip);
 // the kernel then leaves at once when the peeling is over.
 constexpr int kScoreChunk = 512;
+constexpr uint32_t kBestSlots = (uint32_t)kRansacBestSlots;
 template <int kH>
 __global__ __launch_bounds__(256) void ransac_score_kernel(PencilSoA m, uint32_t n_host, float tol, float degeneracy_tol,
                                                            uint32_t n_iter, uint64_t seed, uint32_t round_host,
                                                            const uint32_t* __restrict__ gctl, int max_models,
-                                                           float* __restrict__ scores) {
+                                                           unsigned long long* __restrict__ best_slots) {
     __shared__ float s_tab[2][5][kScoreChunk];
+    __shared__ unsigned long long s_key[4];
     const int lane = threadIdx.x & 63;
     const uint32_t hyp0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kH;
     if (blockIdx.x * 4u * kH >= n_iter) return;  // (whole workgroup)
@@ -206,53 +208,47 @@ __global__ __launch_bounds__(256) void ransac_score_kernel(PencilSoA m, uint32_t
             }
         }
     }
+    // The scores themselves are never stored: all that estimator.h:62-70 keeps of an iteration is whether it is the first
+    // strictly best one.  Positive scores order like their bit patterns, so "highest score, lowest iteration among equals" is
+    // the maximum of score bits : 32 | ~iteration : 32, taken per wavefront, per workgroup, and with one 64-bit atomic into
+    // one of kBestSlots device words (round 3 wrote 10 000 scores and scanned them in a second launch).
+    unsigned long long key = 0ull;
 #pragma unroll
     for (int j = 0; j < kH; ++j) {
         const float score = wave_tree(acc[j]);
-        if (lane == 0 && hyp0 + (uint32_t)j < n_iter) scores[hyp0 + j] = valid[j] ? score : -1.0f;
+        const uint32_t it = hyp0 + (uint32_t)j;
+        if (valid[j] && it < n_iter && score > 0.0f) {
+            const unsigned long long k = ((unsigned long long)__float_as_uint(score) << 32) | (unsigned long long)(0xFFFFFFFFu - it);
+            key = k > key ? k : key;
+        }
     }
+    if (lane == 0) s_key[threadIdx.x >> 6] = key;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int wv = 1; wv < 4; ++wv) key = s_key[wv] > key ? s_key[wv] : key;
+    // (fire and forget: no returned value is waited for -- a device-scope atomic is a microsecond's round trip, and a
+    // workgroup that waits for two of them at its end made the 8 us scoring launches of a frame 3 us longer; twenty
+    // same-address atomics per slot are nothing)
+    if (key != 0ull) (void)__hip_atomic_fetch_max(&best_slots[blockIdx.x % kBestSlots], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// First strictly best hypothesis: max score, ties to the lowest iteration; -1 if none scored > 0.
-__global__ __launch_bounds__(1024) void ransac_argmax_kernel(const float* __restrict__ scores, uint32_t n_iter,
-                                                             float* __restrict__ best_score,
-                                                             int32_t* __restrict__ best_iter) {
-    __shared__ float s_v[16];
-    __shared__ int s_i[16];
-    float bv = 0.f;
-    int bi = -1;
-    for (uint32_t i = threadIdx.x; i < n_iter; i += 1024) {
-        const float v = scores[i];
-        if (v > bv) {
-            bv = v;
-            bi = (int)i;
-        }
-    }
+// lr_ransac_best: the slots' maximum goes straight into page-locked host memory (score bits, iteration; -1 if nothing
+// scored), and the slots are cleared for the next solve.  (A last-workgroup-done finish inside the scoring launch was built
+// first: its tickets -- device-scope atomics WITH a returned value, one or two per workgroup -- cost more than this launch:
+// 62 us a solve of 10 000 hypotheses against 56 before, 1.02 ms against 0.94 at 100 000.)
+__global__ __launch_bounds__(64) void ransac_best_readout_kernel(unsigned long long* __restrict__ best_slots,
+                                                                 uint32_t* __restrict__ host_best) {
+    unsigned long long key = threadIdx.x < kBestSlots ? best_slots[threadIdx.x] : 0ull;
+    if (threadIdx.x < kBestSlots) best_slots[threadIdx.x] = 0ull;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
-        const float ov = __shfl_xor(bv, off);
-        const int oi = __shfl_xor(bi, off);
-        if (ov > bv || (ov == bv && oi >= 0 && (bi < 0 || oi < bi))) {
-            bv = ov;
-            bi = oi;
-        }
+        const unsigned long long o = ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(key >> 32), off) << 32) |
+                                     (uint32_t)__shfl_xor((int)(uint32_t)key, off);
+        key = o > key ? o : key;
     }
-    if ((threadIdx.x & 63) == 0) {
-        s_v[threadIdx.x >> 6] = bv;
-        s_i[threadIdx.x >> 6] = bi;
-    }
-    __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 1; k < 16; ++k) {
-            const float ov = s_v[k];
-            const int oi = s_i[k];
-            if (ov > bv || (ov == bv && oi >= 0 && (bi < 0 || oi < bi))) {
-                bv = ov;
-                bi = oi;
-            }
-        }
-        *best_score = bv;
-        *best_iter = bi;
+        host_best[0] = (uint32_t)(key >> 32);
+        host_best[1] = key ? 0xFFFFFFFFu - (uint32_t)key : 0xFFFFFFFFu;
     }
 }
 
@@ -777,42 +773,40 @@ int launch_ht_weights(PencilSoA m, uint32_t n, const int32_t* pa, const int32_t*
 
 // Hypotheses per wavefront: eight when there are enough of them to fill the chip with waves anyway, else four
 static void launch_score(PencilSoA m, uint32_t n, float tol, float degeneracy_tol, uint32_t n_iter, uint64_t seed,
-                         uint32_t round, const uint32_t* gctl, int max_models, float* scores, hipStream_t s) {
+                         uint32_t round, const uint32_t* gctl, int max_models, unsigned long long* best_slots, hipStream_t s) {
     // (sixteen per wavefront were measured too: 8.1e7 hypotheses/s against 1.1e8 with eight -- the registers of sixteen
     // accumulators and hypotheses halve the waves per SIMD)
     if (n_iter >= 65536u) {
         hipLaunchKernelGGL(ransac_score_kernel<8>, dim3((n_iter + 31) / 32), dim3(256), 0, s, m, n, tol, degeneracy_tol,
-                           n_iter, seed, round, gctl, max_models, scores);
+                           n_iter, seed, round, gctl, max_models, best_slots);
     } else {
         hipLaunchKernelGGL(ransac_score_kernel<4>, dim3((n_iter + 15) / 16), dim3(256), 0, s, m, n, tol, degeneracy_tol,
-                           n_iter, seed, round, gctl, max_models, scores);
+                           n_iter, seed, round, gctl, max_models, best_slots);
     }
 }
 
+// One solve: the scoring launch and a one-wavefront read-out; best score (bits) and iteration land in host_best[0..1]
+// (page-locked memory).  best_slots: kRansacBestSlots zeroed 64-bit words, left zeroed again.
 int launch_ransac_score(PencilSoA m, uint32_t n, float tol, float degeneracy_tol, uint32_t n_iter, uint64_t seed,
-                        uint32_t round, float* scores, hipStream_t s) {
+                        uint32_t round, unsigned long long* best_slots, uint32_t* host_best, hipStream_t s) {
     if (n < 2 || n_iter == 0) {
         set_error("launch_ransac_score: need at least 2 lines and 1 iteration");
         return 1;
     }
-    launch_score(m, n, tol, degeneracy_tol, n_iter, seed, round, nullptr, 0, scores, s);
+    launch_score(m, n, tol, degeneracy_tol, n_iter, seed, round, nullptr, 0, best_slots, s);
+    hipLaunchKernelGGL(ransac_best_readout_kernel, dim3(1), dim3(64), 0, s, best_slots, host_best);
     LR_HIP(hipGetLastError());
     return 0;
 }
 
 // line count and round from the peeling control block (kernels_groups.hip)
 int launch_ransac_score_dev(PencilSoA m, const uint32_t* gctl, int max_models, float tol, float degeneracy_tol,
-                            uint32_t n_iter, uint64_t seed, float* scores, hipStream_t s) {
+                            uint32_t n_iter, uint64_t seed, unsigned long long* best_slots, hipStream_t s) {
     if (n_iter == 0) return 0;
-    launch_score(m, 0u, tol, degeneracy_tol, n_iter, seed, 0u, gctl, max_models, scores, s);
+    launch_score(m, 0u, tol, degeneracy_tol, n_iter, seed, 0u, gctl, max_models, best_slots, s);
     LR_HIP(hipGetLastError());
     return 0;
 }
 
-int launch_ransac_argmax(const float* scores, uint32_t n_iter, float* best_score, int32_t* best_iter, hipStream_t s) {
-    hipLaunchKernelGGL(ransac_argmax_kernel, dim3(1), dim3(1024), 0, s, scores, n_iter, best_score, best_iter);
-    LR_HIP(hipGetLastError());
-    return 0;
-}
 
 }  // namespace lramd
