@@ -100,6 +100,45 @@ def test_config_4_batch_of_1080p_frames_matches_oracle(L, ctx):
         np.testing.assert_array_equal(tf_h[i].as_array(), Tr)
 
 
+def test_config_4_all_512_frames_same_results_from_pageable_pinned_device_and_two_lane_sets(L, ctx):
+    """BASELINE configs[3] at its full size: 512 frames 1920x1080 in ONE call (the pool of device frames is recycled some
+    forty times, the lanes take 85 frames each).  The sixteen distinct frames are tied to the oracle by the test above;
+    here every one of the 512 results must equal its base frame's (or its flip's own single-call result), whichever way the
+    frames come in: pageable host memory, page-locked host memory, HBM, and the multi-device call with two lane sets."""
+    from librectify_amd import synth
+
+    w, h, B = 1920, 1080, 512
+    ml = max(w, h) / 100.0
+    base = [synth.frame(w, h, 1000 + i) for i in range(8)]
+    variants = []
+    for b in base:
+        variants += [b, b[:, ::-1], b[::-1, :], b[::-1, ::-1]]
+    frames = np.empty((B, h, w), np.float32)
+    for i in range(B):
+        frames[i] = variants[i % len(variants)]
+    ctx.set_seed(0)
+    ctx.set_batch_streams(6)
+    single = [ctx.find_line_segment_groups(np.ascontiguousarray(v), ml) for v in variants]
+    out = np.zeros((B, 2048), L.LINE_DTYPE)
+
+    def check(res):
+        o, n, tf = res
+        for i in range(B):
+            s = single[i % len(variants)]
+            assert n[i] == len(s), (i, n[i], len(s))
+            assert o[i][: n[i]].tobytes() == s.tobytes(), i
+
+    check(ctx.find_line_segment_groups_batch_host(frames, ml, num_threads=8, capacity=2048, out=out))
+    pinned = ctx.host_alloc((B, h, w))
+    pinned[:] = frames
+    check(ctx.find_line_segment_groups_batch_host(pinned, ml, num_threads=8, capacity=2048, out=out))
+    check(ctx.find_line_segment_groups_batch_host(frames, ml, num_threads=8, capacity=2048, out=out, devices=[0, 0]))
+    ctx.host_free(pinned)
+    d = ctx.device_upload(frames)
+    check(ctx.find_line_segment_groups_batch_device(d, w * h, B, w, h, ml, capacity=2048, out=out))
+    ctx.device_free(d)
+
+
 def test_config_5_8k_tiled_frame_ransac_and_prosac_100k_match_oracle(L, ctx):
     """frame(8192, 8192, 7, 512-px blocks): 326 590 seeds, 162 186 components, 24 007 segments — the sizes where the
     29-bit index packing, the candidate lists and 32-bit offsets are closest to their limits.  Default RANSAC and
