@@ -2163,7 +2163,7 @@ static int ensure_upload_ring(lr_context* c, int R, size_t npix, bool staging) {
         for (float*& p : c->ring_img) LR_HIP(hipMalloc((void**)&p, cap * sizeof(float)));
         c->ring_cap_pix = cap;
     }
-    static const bool lane_debug = std::getenv("LIBRECTIFY_LANE_DEBUG") != nullptr;  // (its timeline times the uploads)
+    static const bool lane_debug = std::getenv("LIBRECTIFY_LANE_DEBUG") != nullptr || std::getenv("LIBRECTIFY_BATCH_STATS") != nullptr;  // (they time the uploads)
     while ((int)c->ring_ev.size() < (int)c->ring_img.size()) {
         hipEvent_t e = nullptr;
         LR_HIP(hipEventCreateWithFlags(&e, lane_debug ? hipEventDefault : hipEventDisableTiming));
@@ -2256,6 +2256,11 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
         if (++spins < 64) std::this_thread::yield();
         else std::this_thread::sleep_for(std::chrono::microseconds(30));
     };
+    // LIBRECTIFY_BATCH_STATS: who waited for whom in this call (host clocks only, nothing is synchronised for it)
+    static const bool batch_stats = std::getenv("LIBRECTIFY_BATCH_STATS") != nullptr;
+    std::atomic<long long> up_wait_us{0}, lane_wait_us{0}, lead_sum_us{0};
+    std::atomic<int> late_frames{0};
+    const double t_call0 = now_ms();
     auto uploader = [&]() {
         if (hipSetDevice(c->device) != hipSuccess) {
             up_err = "hipSetDevice failed";
@@ -2267,12 +2272,14 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
         if (any_pageable) crew.start(c, staging_threads(num_threads, npix * sizeof(float)) - 1);
         for (int i = 0; i < batch; ++i) {
             int slot = -1, spins = 0;
+            const double t_w0 = batch_stats ? now_ms() : 0.0;
             // a slot whose frame is done (its transfer and its staging buffer are then free as well)
             while (slot < 0 && !abort_all.load(std::memory_order_relaxed)) {
                 for (int k = 0; k < R && slot < 0; ++k)
                     if (!slot_busy[(size_t)k].load(std::memory_order_acquire)) slot = k;
                 if (slot < 0) nap(spins);
             }
+            if (batch_stats) up_wait_us.fetch_add((long long)((now_ms() - t_w0) * 1e3));
             if (abort_all.load(std::memory_order_relaxed)) return;
             slot_busy[(size_t)slot].store(1, std::memory_order_relaxed);
             float* stage = is_page_locked(h_frames[i]) ? nullptr : c->ring_stage[(size_t)slot];
@@ -2318,7 +2325,9 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
             int img_stride = stride, slot = -1;
             if (h_frames) {
                 int spins = 0;
+                const double t_w0 = batch_stats ? now_ms() : 0.0;
                 while ((slot = enq[(size_t)b].load(std::memory_order_acquire) - 1) < 0 && !abort_all.load(std::memory_order_relaxed)) nap(spins);
+                if (batch_stats) lane_wait_us.fetch_add((long long)((now_ms() - t_w0) * 1e3));
                 if (slot < 0) return;  // (whoever stopped the batch has the message)
                 if (hipStreamWaitEvent(l->stream, c->ring_ev[(size_t)slot], 0) != hipSuccess) {
                     set_error("hipStreamWaitEvent failed");
@@ -2332,6 +2341,15 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
             std::vector<LineSegment> res;
             const double t_f0 = now_ms();
             if (ctx_find_groups_device(l, img, w, h, img_stride, min_length, refine, res)) return fail();
+            if (batch_stats && h_frames && l->timing_on) {  // (with the stage timers on: ev[0] is the frame's first kernel)
+                float lead = 0.f;
+                if (hipEventElapsedTime(&lead, c->ring_ev[(size_t)slot], l->ev[0]) == hipSuccess) {
+                    lead_sum_us.fetch_add((long long)(lead * 1e3));
+                    if (lead < 0.05f) late_frames.fetch_add(1);
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
             if (lane_debug) {
                 float lead = 0.f;  // how long the frame's upload had been finished when its first kernel started
                 if (h_frames && hipEventElapsedTime(&lead, c->ring_ev[(size_t)slot], l->ev[0]) != hipSuccess) (void)hipGetLastError();
@@ -2355,6 +2373,12 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
     for (int si = 1; si < S; ++si) th.emplace_back(work, si);
     work(0);
     for (auto& t : th) t.join();
+    if (batch_stats && h_frames)
+        std::fprintf(stderr, "batch of %d frames: %.2f ms; the uploader waited %.2f ms for free device frames; the %d lanes waited %.2f ms in all for their frame's transfer to be enqueued\n",
+                     batch, now_ms() - t_call0, up_wait_us.load() * 1e-3, S, lane_wait_us.load() * 1e-3);
+    if (batch_stats && h_frames && c->timing_on)
+        std::fprintf(stderr, "   a frame's transfer was finished %.3f ms (mean) before its first kernel started; %d of %d frames started within 0.05 ms of it (they waited for the link)\n",
+                     lead_sum_us.load() * 1e-3 / batch, late_frames.load(), batch);
     if (h_frames) (void)hipStreamSynchronize(c->copy_stream);  // (after an error: nothing may still read the caller's frames)
     for (lr_context* l : lanes) l->sleep_in_wait = false;
     c->flood_multi = caller_multi;
