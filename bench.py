@@ -57,8 +57,8 @@ sys.path.insert(0, ROOT)
 W4K, H4K = 3840, 2160
 ALGO_BYTES_PER_PX = 18.0  # 4 read + 12 (dx,dy,mag) + 1 (bin) + 1 (peak candidate)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-PMC_FILE = os.path.join("profiles", "r03_pmc_filter_traffic.txt")
-ROCPROF_LEG = os.path.join("profiles", "r03_kernel_stats_roofline_leg.csv")  # rocprofv3 --kernel-trace --stats of `bench.py --roofline-only`
+PMC_FILE = os.path.join("profiles", "r04_pmc_filter_traffic.txt")
+ROCPROF_LEG = os.path.join("profiles", "r04_kernel_stats_roofline_leg.csv")  # rocprofv3 --kernel-trace --stats of `bench.py --roofline-only`
 
 
 def make_frames(n, w, h, seed0, bases=4, out=None):
