@@ -814,7 +814,7 @@ def main(argv=None):
                 "unit": "TFLOP/s",
                 **{k: {"achieved": round(v["line_evaluations_per_s"] * RANSAC_FLOP_PER_EVAL / 1e12, 3),
                        "frac": round(v["line_evaluations_per_s"] * RANSAC_FLOP_PER_EVAL / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4)} for k, v in rr.items()},
-                "note": "whole lr_ransac_best call: table upload, scoring kernel, argmax, one wait",
+                "note": "whole lr_ransac_best call: table upload, scoring launch, read-out of the best into page-locked memory, one wait",
             }
             res["cht"] = cht_rates(ctx)
             if args.config == "frames4k" and wl.B:
