@@ -537,6 +537,286 @@ static int batched(int shift0, int grow, bool seed_level, const std::vector<int>
 }
 
 // scheme 0: every active seed walks every round (what kernels_flood.hip did in r02)
+// ---- scheme 11: NO rounds (dataflow), seed-level commits -------------------------------------------------------------------
+// Every seed walks once at the start; from then on a seed walks again only when a commit took pixels out of its footprint
+// (footprints only shrink, so an untouched footprint stays exact and its stamps stay valid as blockers).  A seed commits
+// as soon as (i) its last walk is complete and untouched since, (ii) no lower active seed's stamps lie on its footprint,
+// (iii) every lower active seed HAS stamps in place (its first walk is over): from that moment on nothing a lower seed does
+// can reach the footprint, because those seeds' footprints only shrink.  While a seed walks again its old stamps (minus
+// what has been committed) stay in place -- a superset of the new footprint, hence conservative.  Time is counted in tile
+// steps; parallelism is unbounded (a lower bound of the critical path) or capped at `conc` walks in flight (strongest
+// first, as the kernel's dispatcher would).  eager = 1: an invalidated seed walks again at once; 0: only when nothing lower
+// blocks what is left of its old footprint (less work, staler blockers).
+#include <queue>
+static int g_pre_rounds = 0;  // bulk-synchronous rounds (scheme 0) in front of the dataflow phase
+static int dataflow(int eager, long conc, const std::vector<int>& ref, long labelled) {
+    std::vector<uint8_t> dm = dmask;
+    std::vector<int> label((size_t)W * H, -1);
+    std::vector<char> pre_gone(NS, 0);
+    long pre_px = 0, pre_steps = 0, pre_crit = 0;
+    for (int r = 0; r < g_pre_rounds; ++r) {  // every active seed walks, the unblocked ones commit, all stamps are erased
+        const int INF = 0x7fffffff;
+        std::vector<int> stamp((size_t)W * H, INF);
+        std::vector<Walk> fp(NS);
+        int longest = 0;
+        for (int k = 0; k < NS; ++k) {
+            if (pre_gone[k]) continue;
+            if (label[sidx[k]] >= 0) {
+                pre_gone[k] = 1;
+                continue;
+            }
+            footprint(k, dm, fp[k]);
+            pre_px += (long)fp[k].px.size();
+            pre_steps += fp[k].tiles;
+            longest = std::max(longest, fp[k].tiles);
+            if (fp[k].px.empty()) pre_gone[k] = 1;
+            for (int p : fp[k].px) stamp[p] = std::min(stamp[p], k);
+        }
+        pre_crit += longest;
+        for (int k = 0; k < NS; ++k) {
+            if (pre_gone[k]) continue;
+            bool free_ = true;
+            for (int p : fp[k].px)
+                if (stamp[p] < k) {
+                    free_ = false;
+                    break;
+                }
+            if (!free_) continue;
+            for (int p : fp[k].px) {
+                label[p] = k;
+                dm[p] = 0;
+            }
+            pre_gone[k] = 1;
+        }
+    }
+    if (g_pre_rounds) printf("   %d round(s) first: %ld px, %ld steps, critical path %ld steps\n", g_pre_rounds, pre_px, pre_steps, pre_crit);
+    struct Seed {
+        std::vector<int> px;       // stamps in place (last complete footprint minus committed pixels)
+        int tiles = 0;
+        int nblock = 0;            // pixels of px whose lowest stamp belongs to a lower seed
+        bool active = true, walking = false, invalid = false, has = false;
+        long finish = 0;
+    };
+    std::vector<Seed> S(NS);
+    // pixel -> seeds stamping it (ascending); only stamped pixels have an entry
+    std::unordered_map<int, std::vector<int>> at;
+    at.reserve((size_t)1 << 23);
+    auto add_stamp = [&](int p, int k) {
+        auto& v = at[p];
+        v.insert(std::lower_bound(v.begin(), v.end(), k), k);
+    };
+    long tot_px = 0, tot_steps = 0, n_walks = 0, now = 0, last_commit = 0;
+    int n_active = NS;
+    struct Ev {
+        long t;
+        int k;
+        bool operator<(const Ev& o) const { return t > o.t || (t == o.t && k > o.k); }
+    };
+    std::priority_queue<Ev> pq;
+    std::vector<int> waiting;  // seeds that want to walk but found no free slot (capped parallelism): ascending
+    long in_flight = 0;
+    Walk w;
+    // prefix gate (iii): the moment every seed below k has finished its first walk
+    std::vector<long> first_finish(NS, -1);
+    std::vector<int> ready;  // candidates to look at for a commit
+    auto start_walk = [&](int k) {
+        S[k].walking = true;
+        S[k].invalid = false;
+        footprint(k, dm, w);  // against what is committed NOW
+        S[k].tiles = w.tiles;
+        // the new footprint is kept aside until the walk is over
+        S[k].finish = now + std::max(1, w.tiles);
+        ++n_walks;
+        tot_px += (long)w.px.size();
+        tot_steps += w.tiles;
+        in_flight++;
+        pq.push({S[k].finish, k});
+        return w.px;  // (copy)
+    };
+    std::vector<std::vector<int>> pending(NS);  // footprint of the walk in flight
+    auto want_walk = [&](int k) {
+        if (!S[k].active || S[k].walking) return;
+        if (in_flight < conc) pending[k] = start_walk(k);
+        else waiting.push_back(k);
+    };
+    auto remove_stamps = [&](int k, const std::vector<int>& px, std::vector<int>& unblocked) {
+        for (int p : px) {
+            auto it = at.find(p);
+            if (it == at.end()) continue;
+            auto& v = it->second;
+            auto pos = std::lower_bound(v.begin(), v.end(), k);
+            if (pos == v.end() || *pos != k) continue;
+            const bool was_min = pos == v.begin();
+            if (!was_min) S[k].nblock--;  // (k was blocked here; the pixel no longer counts for it)
+            v.erase(pos);
+            if (was_min && !v.empty()) {  // the new lowest stamp is no longer blocked HERE
+                const int m = v.front();
+                if (--S[m].nblock == 0) unblocked.push_back(m);
+            }
+            if (v.empty()) at.erase(it);
+        }
+    };
+    std::vector<char> first_done(NS, 0);
+    for (int k = 0; k < NS; ++k) {
+        if (pre_gone[k] || label[sidx[k]] >= 0) {
+            S[k].active = false;
+            --n_active;
+            first_done[k] = 1;
+            continue;
+        }
+        want_walk(k);
+    }
+    std::sort(waiting.begin(), waiting.end());
+    long gate_done = 0;  // seeds [0, gate_done) have finished their first walk
+    while (gate_done < NS && first_done[gate_done]) ++gate_done;
+    auto can_commit = [&](int k) {
+        return S[k].active && S[k].has && !S[k].walking && !S[k].invalid && S[k].nblock == 0 && gate_done > k;
+    };
+    std::vector<int> unblocked;
+    auto try_commit = [&](int k0) {
+        std::vector<int> stack{k0};
+        while (!stack.empty()) {
+            const int k = stack.back();
+            stack.pop_back();
+            if (!can_commit(k)) continue;
+            // commit: every pixel of the footprint is k's
+            S[k].active = false;
+            --n_active;
+            last_commit = now;
+            std::vector<int> px;
+            px.swap(S[k].px);
+            std::vector<int> hit;  // seeds that lose pixels
+            for (int p : px) {
+                label[p] = k;
+                dm[p] = 0;
+                auto it = at.find(p);
+                if (it != at.end()) {
+                    for (int j : it->second)
+                        if (j != k) hit.push_back(j);
+                }
+            }
+            unblocked.clear();
+            remove_stamps(k, px, unblocked);
+            std::sort(hit.begin(), hit.end());
+            hit.erase(std::unique(hit.begin(), hit.end()), hit.end());
+            for (int j : hit) {
+                if (!S[j].active) continue;
+                if (label[sidx[j]] >= 0) {  // its own pixel is taken: skipped for ever
+                    S[j].active = false;
+                    --n_active;
+                    std::vector<int> pj;
+                    pj.swap(S[j].px);
+                    remove_stamps(j, pj, unblocked);
+                    continue;
+                }
+                // drop the committed pixels from its stamps (they are k's now); what is left stays as a conservative blocker
+                std::vector<int> keep, gone;
+                for (int p : S[j].px) (label[p] >= 0 ? gone : keep).push_back(p);
+                remove_stamps(j, gone, unblocked);
+                S[j].px.swap(keep);
+                S[j].invalid = true;
+                if (eager || S[j].nblock == 0) want_walk(j);
+            }
+            for (int m : unblocked) {
+                if (S[m].active && S[m].invalid && !S[m].walking) want_walk(m);  // (lazy policy: now is the time)
+                stack.push_back(m);
+            }
+        }
+    };
+    while (!pq.empty()) {
+        const Ev e = pq.top();
+        pq.pop();
+        now = e.t;
+        const int k = e.k;
+        in_flight--;
+        S[k].walking = false;
+        if (S[k].active) {
+            // the walk is over: its footprint replaces the old stamps -- unless a commit took pixels out of it meanwhile
+            std::vector<int> np;
+            np.swap(pending[k]);
+            bool touched = false;
+            for (int p : np)
+                if (label[p] >= 0) touched = true;
+            unblocked.clear();
+            std::vector<int> old;
+            old.swap(S[k].px);
+            remove_stamps(k, old, unblocked);
+            if (np.empty()) {  // the seed pixel is no longer acceptable: nothing to claim
+                S[k].active = false;
+                --n_active;
+            } else {
+                std::vector<int> keep;
+                for (int p : np)
+                    if (label[p] < 0) keep.push_back(p);
+                S[k].px.swap(keep);
+                S[k].nblock = 0;
+                for (int p : S[k].px) {
+                    add_stamp(p, k);
+                    const auto& v = at[p];
+                    if (v.front() < k) S[k].nblock++;
+                    else if (v.size() > 1 && v[1] > k) {  // k became the lowest here: the former lowest is blocked here now
+                        S[v[1]].nblock++;
+                    }
+                }
+                S[k].has = true;
+                S[k].invalid = touched;
+                if (label[sidx[k]] >= 0) {
+                    S[k].active = false;
+                    --n_active;
+                    std::vector<int> pj;
+                    pj.swap(S[k].px);
+                    remove_stamps(k, pj, unblocked);
+                } else if (touched && (eager || S[k].nblock == 0)) {
+                    want_walk(k);
+                }
+            }
+            if (!first_done[k]) {
+                first_done[k] = 1;
+                while (gate_done < NS && first_done[gate_done]) ++gate_done;
+            }
+            std::vector<int> ub = unblocked;
+            try_commit(k);
+            for (int m : ub) {
+                if (S[m].active && S[m].invalid && !S[m].walking) want_walk(m);
+                try_commit(m);
+            }
+            // the gate may have opened for seeds that were only waiting for it
+            static long gate_seen = 0;
+            if (gate_done > gate_seen) {
+                for (long j = gate_seen; j < gate_done; ++j) try_commit((int)j);
+                gate_seen = gate_done;
+            }
+        } else if (!first_done[k]) {
+            first_done[k] = 1;
+            while (gate_done < NS && first_done[gate_done]) ++gate_done;
+        }
+        // free slots go to the strongest waiting seeds
+        if (!waiting.empty() && in_flight < conc) {
+            std::sort(waiting.begin(), waiting.end());
+            waiting.erase(std::unique(waiting.begin(), waiting.end()), waiting.end());
+            size_t i = 0;
+            for (; i < waiting.size() && in_flight < conc; ++i) {
+                const int j = waiting[i];
+                if (S[j].active && !S[j].walking) pending[j] = start_walk(j);
+            }
+            waiting.erase(waiting.begin(), waiting.begin() + (long)i);
+        }
+        if (pq.empty() && n_active > 0) {  // nobody walks and somebody is left: look once more at everyone
+            for (int j = 0; j < NS; ++j)
+                if (S[j].active) {
+                    if (S[j].invalid && !S[j].walking) want_walk(j);
+                    try_commit(j);
+                }
+        }
+    }
+    long bad = 0;
+    for (size_t i = 0; i < ref.size(); ++i) bad += ref[i] != label[i];
+    printf("scheme 11 (dataflow, %s re-walks, %s): %ld walks, %ld px walked (%.2fx labelled), %ld steps; last commit at t = %ld steps, last walk over at t = %ld; seeds left active %d; label mismatches vs sequential: %ld\n",
+           eager ? "eager" : "lazy", conc >= (long)NS ? "unbounded parallelism" : ("at most " + std::to_string(conc) + " walks in flight").c_str(), n_walks, tot_px,
+           (double)tot_px / labelled, tot_steps, last_commit, now, n_active, bad);
+    return bad != 0 || n_active != 0;
+}
+
 // scheme 1: perfect deferral -- seeds that die in the round never walk or stamp (lower bound of the deferral family)
 // scheme 2: opportunistic deferral in dispatch batches of `conc` walks (strongest first), phases until nothing is left
 //           to walk; a deferred seed is one whose own pixel carries a lower stamp when its batch starts
@@ -565,6 +845,10 @@ int main(int argc, char** argv) {
     long labelled = 0;
     for (int v : ref) labelled += v >= 0;
     printf("%dx%d, %d seeds, %ld labelled px\n", W, H, NS, labelled);
+    if (scheme == 11) {
+        if (argc > 5) g_pre_rounds = atoi(argv[5]);
+        return dataflow(argc > 3 ? atoi(argv[3]) : 1, argc > 4 ? atol(argv[4]) : (long)NS, ref, labelled);
+    }
     if (scheme == 9 || scheme == 10) return batched(argc > 3 ? atoi(argv[3]) : 3, argc > 4 ? atoi(argv[4]) : 2, scheme == 10, ref, labelled);
     if (scheme >= 3 && scheme <= 6) {
         // 3: pixel-level, all walk; 4: + perfect deferral; 5: seed-level commits + perfect deferral (= scheme 1); 6: seed-level, all walk
