@@ -136,6 +136,17 @@ struct FloodBuffers {
     const hipEvent_t* join_events = nullptr;
     int n_fork_events = 0;
     int multi_round_last = 4;       // last round (index from 0) that walks its way-point seeds beside its exploration
+    // Re-walks from the log (round 4; kernels_flood.hip: flood_rewalk_kernel).  A blocked seed walks its footprint again
+    // every round, tile after tile, and rounds 2-5 of a frame last as long as their one longest such walk.  But a footprint
+    // only ever SHRINKS (acceptance is static but for commits), so the next footprint is the connected part around the seed
+    // of (last footprint minus committed pixels): a finished walk leaves its (tile, pixels) records here, and the later
+    // rounds label the components of those records in LDS -- no dependent chain of memory round trips.
+    bool rewalk_logs = false;
+    bool rewalk_big = false;   // the frame is expected to have walks beyond the first tier: their logs are kept too, and a second launch per round works on them
+    uint32_t log_seeds = 0, log_cap = 0;
+    uint32_t* log_off = nullptr;
+    uint32_t* log_len = nullptr;
+    uint32_t* log_buf = nullptr;
     void* slab_ring = nullptr;  // n_slabs x slab_ring_cap 16-byte records
     void* slab_hash = nullptr;  // n_slabs x slab_hash_cap 16-byte records
     uint32_t n_slabs = 0, slab_ring_cap = 0, slab_hash_cap = 0;

@@ -159,6 +159,10 @@ static int ensure_flood_buffers(lr_context* c) {
         return 1;
     f.wp_cap = (uint32_t)std::min<size_t>(std::max<size_t>(cs / 16, 4096), cs);  // (one seed per 16 pixels: the 4K bench frame has one per 200)
     if (dev_alloc(f.waypoints, (size_t)f.wp_cap * kFloodWpWords) || dev_alloc(f.multi_list, 8192)) return 1;
+    // footprint logs (FloodBuffers::rewalk_logs): per-seed words for one seed per 16 pixels, a record per 8 pixels
+    f.log_seeds = f.wp_cap;
+    f.log_cap = (uint32_t)std::min<size_t>(std::max<size_t>(cs / 8, 65536), 1u << 28);
+    if (dev_alloc(f.log_off, f.log_seeds) || dev_alloc(f.log_len, f.log_seeds) || dev_alloc(f.log_buf, (size_t)f.log_cap * 3)) return 1;
     if (!c->flood_aux) {
         // At a priority of its own: HIP maps streams onto a few hardware queues, and a second stream that lands on the queue
         // of the first runs BEHIND it -- fork and join then cost two barriers a round and buy nothing (seen in bench.py, whose
@@ -637,6 +641,7 @@ int ctx_create(int device, lr_context** out) {
     const char* env = std::getenv("LIBRECTIFY_SEED");
     c->ransac_seed = env ? std::strtoull(env, nullptr, 0) : 0ull;
     c->timing_on = std::getenv("LIBRECTIFY_STAGE_TIMES") != nullptr;
+    if (const char* e = std::getenv("LIBRECTIFY_FLOOD_LOGS")) c->flood_logs = std::atoi(e) != 0;
     if (const char* e = std::getenv("LIBRECTIFY_FLOOD_MULTI")) c->flood_multi = std::atoi(e) != 0;  // (opt-in: DESIGN.md section 7, round 4)
     const char* fm = std::getenv("LIBRECTIFY_FLOOD_MODE");
     if (fm) c->flood_mode = std::atoi(fm);
@@ -657,7 +662,7 @@ void ctx_destroy(lr_context* c) {
                     c->label, c->queue, c->comp_rank, c->comp_seed, c->comp_off, c->cursor, c->px_a, c->px_b,
                     c->scratch_w, c->d_lines, c->temp, c->d_model, c->d_best_slots,
                     c->fb.blocked, c->fb.count, c->fb.flags, c->fb.state, c->fb.tier, c->fb.act_a, c->fb.act_b,
-                    c->fb.ctrl, c->fb.big_list, c->fb.handover, c->fb.waypoints, c->fb.multi_list, c->fb.dirty, c->fb.slab_ring, c->fb.slab_hash, c->d_pairs, c->d_peak, c->d_weights,
+                    c->fb.ctrl, c->fb.big_list, c->fb.handover, c->fb.waypoints, c->fb.multi_list, c->fb.log_off, c->fb.log_len, c->fb.log_buf, c->fb.dirty, c->fb.slab_ring, c->fb.slab_hash, c->d_pairs, c->d_peak, c->d_weights,
                     c->d_samples, c->d_hcounts, c->comp_large, c->d_tables, c->d_orig, c->d_inl, c->d_flines, c->d_gctl,
                     c->d_gnorm, c->d_models, c->d_refine_table, c->d_refine_edges, c->d_cht_acc, c->d_cht_idx, c->d_cht_peak, c->d_rec, c->d_recflags};
     for (void* p : ptrs)
@@ -786,6 +791,8 @@ FloodBuffers flood_buffers_for(lr_context* c) {
     static const bool partial_off = std::getenv("LIBRECTIFY_FLOOD_PARTIAL") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_PARTIAL")) == 0;
     fbuf.partial_commits = !partial_off && c->flood_partial;
     fbuf.multi_source = c->flood_multi;
+    fbuf.rewalk_logs = c->flood_logs;
+    fbuf.rewalk_big = c->flood_logbig_hint;  // (the context's last frame had walks beyond the first tier)
     static const int aux_env = std::getenv("LIBRECTIFY_FLOOD_MULTI_BESIDE") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_MULTI_BESIDE")) : -1;  // (experiment: 0 = after the exploration, N = beside it in rounds 2 .. N + 1)
     if (c->flood_aux && c->flood_aux_on && aux_env != 0 && c->flood_fork.size() == c->flood_join.size()) {
         fbuf.aux_stream = c->flood_aux;
@@ -879,6 +886,7 @@ int finish_flood(lr_context* c, bool* extra) {
     if (call_debug)
         std::fprintf(stderr, "flood: %d rounds, %u walks in the second tier, %u of them long, hold-back phase %u (started with it: %d)\n",
                      c->flood_rounds, c->flood_tiers[0], c->flood_tiers[8], c->flood_tiers[3], (int)c->flood_hold_hint);
+    c->flood_logbig_hint = c->flood_tiers[0] > 0;
     static const int hints_env = std::getenv("LIBRECTIFY_FLOOD_HINTS") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_HINTS")) : 1;  // (experiment knob)
     if (hints_env == 0) {  // as in round 2
         c->flood_big_hint = c->flood_tiers[0] > 0 || c->flood_tiers[1] > 0;

@@ -210,6 +210,17 @@ struct FloodArgs {
     uint32_t wp_min_tiles;                           // walks of at least this many tiles leave way-points (0xFFFFFFFF: never)
     uint32_t* multi_list;                            // way-point seeds of the coming round (written by the survivors pass), kBigCap entries
     uint32_t multi_next;                             // the coming round walks that list in a launch of its own, beside its exploration
+    // ---- re-walks from the log (flood_rewalk_kernel): a finished walk of at least log_min_tiles tiles leaves its footprint
+    // as (tile, walked pixels) records; the seed's later rounds work on those records instead of walking the image again
+    uint32_t log_min_tiles;                          // 0xFFFFFFFF: no logs
+    uint32_t log_walk_tiles;                         // a seed with a log walks this many tiles before it turns to the log
+    uint32_t log_max_len;                            // logs of at most this many records are written and used (what the launched kernels' tables hold)
+    uint32_t log_sweep;                              // test hook: every footprint is worked out by sweeps (flood_rewalk_kernel)
+    uint32_t log_seeds;                              // seeds with per-seed words below (FloodBuffers::log_seeds)
+    uint32_t* log_off;                               // first record of the seed's log ...
+    uint32_t* log_len;                               // ... and their number (0: none)
+    uint32_t* log_buf;                               // records: tile, walked lo, walked hi
+    uint32_t log_cap;                                // records the buffer holds
 };
 // All words but kCtrlGen are set up by flood_init_seeds_kernel every frame; kCtrlGen lives on for the lifetime of
 // the slab memory (hash entries are tagged with it, so a generation must never be reused while old entries are
@@ -248,6 +259,9 @@ enum {
     kCtrlMulti = 25,    // re-walks that started from several way-points at once (diagnostics: lr_stage_counters [10])
     kCtrlNMulti = 26,   // length of the current round's list of way-point seeds (walked by a launch of their own on a second stream)
     kCtrlNMultiNext = 27,  // ... of the next round's (being appended by the survivors pass)
+    kCtrlLogTotal = 28,  // footprint-log records handed out this frame
+    kCtrlLogWalks = 29,  // re-walks from logs (diagnostics: lr_stage_counters [11])
+    kCtrlLogGiveUp = 30, // ... that gave their log up (tables too small) [12]
     kCtrlWords = 32,
 };
 static_assert(kCtrlWords == kFloodCtrlWords, "control block size");
@@ -901,6 +915,27 @@ __device__ __forceinline__ void save_waypoints(const FloodArgs& A, uint32_t k, c
     if (lane == 0) wp[0] = kWpK | (ntiles << 8);
 }
 
+// The records of a finished walk (see FloodArgs::log_buf): handed out of one buffer per frame by a counter.  A buffer that
+// is full leaves the seed without a log: it walks.
+template <class Lds>
+__device__ __forceinline__ void save_log(const FloodArgs& A, uint32_t k, const Lds& S, uint32_t ntiles, int lane) {
+    uint32_t off = 0u;
+    if (lane == 0) off = atomicAdd(&A.ctrl[kCtrlLogTotal], ntiles);
+    off = (uint32_t)__shfl((int)off, 0);
+    if (off + ntiles > A.log_cap || off + ntiles < off) return;
+    uint32_t* rec = A.log_buf + (size_t)off * 3u;
+    for (uint32_t i = (uint32_t)lane; i < ntiles; i += 64u) {
+        const uint32_t slot = S.ord[i];
+        rec[3u * i] = S.hk[slot] - 1u;
+        rec[3u * i + 1u] = S.hv0[slot];
+        rec[3u * i + 2u] = S.hv1[slot];
+    }
+    if (lane == 0) {
+        A.log_off[k] = off;
+        A.log_len[k] = ntiles;
+    }
+}
+
 // One seed's exploration by one wavefront (see walk).  kFirstTier: a walk that outgrows the store is handed to the
 // second tier (big_list) instead of going on in a slab.
 template <class Lds, bool kFirstTier>
@@ -933,7 +968,12 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
     const bool outgrown = kFirstTier && A.big_cap != 0u && (uni((uint32_t)A.tier[k]) & 1u) != 0u;
     const bool wp_seed = kFirstTier && A.big_cap != 0u && A.wp_min_tiles != 0xFFFFFFFFu && k < A.wp_cap &&
                          uni(A.waypoints[(size_t)k * kFloodWpWords]) != 0u;
-    const bool skip_first = outgrown || wp_seed;
+    // A seed with a log (save_log) walks a few tiles only: most footprints have shrunk to a handful of tiles by their second
+    // round, and a short walk is cheaper than the records of a long one.  If the walk is not over by then, the seed goes
+    // on this round's list of flood_rewalk_kernel, which runs behind the exploration (nothing is stamped yet).
+    const uint32_t log_n = (kFirstTier && A.log_min_tiles != 0xFFFFFFFFu && k < A.log_seeds) ? uni(A.log_len[k]) : 0u;
+    const bool has_log = log_n != 0u && log_n <= A.log_max_len;
+    const bool skip_first = (outgrown || wp_seed) && !has_log;
     if (!skip_first) {
         for (int i = lane; i < Lds::kHashN; i += 64) L.hk[i] = 0u;
         P.pt[lane] = 0u;
@@ -942,8 +982,21 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
         // (with a second tier behind it, the first hands a walk over at A.t1_tiles tiles, before its table is full: the
         // second tier's team of wavefronts is the faster walker from there on)
         const bool hand_over = kFirstTier && A.big_cap != 0u;
-        rc = walk(A, k, b, thr, sn, cs, L, P, st, lane, own, nullptr, hand_over ? t1_tiles : 0xFFFFFFFFu,
-                  hand_over ? A.t1_wide_tiles : 0xFFFFFFFFu, hand_over ? A.t1_wide_front : 0xFFFFFFFFu);
+        if (has_log) {
+            rc = walk(A, k, b, thr, sn, cs, L, P, st, lane, own, nullptr, A.log_walk_tiles);
+            if (rc != 0) {
+                uint32_t pos = 0;
+                if (lane == 0) pos = atomicAdd(&A.ctrl[kCtrlNMulti], 1u);
+                pos = (uint32_t)__shfl((int)pos, 0);
+                if (pos < kBigCap) {
+                    if (lane == 0) A.multi_list[pos] = k;
+                    return;
+                }
+            }
+        }
+        if (rc != 0)  // (from the start, or from where the budgeted walk stands: the list was full)
+            rc = walk(A, k, b, thr, sn, cs, L, P, st, lane, own, nullptr, hand_over ? t1_tiles : 0xFFFFFFFFu,
+                      hand_over ? A.t1_wide_tiles : 0xFFFFFFFFu, hand_over ? A.t1_wide_front : 0xFFFFFFFFu);
     }
     if (kFirstTier && rc != 0 && A.big_cap != 0u) {
         // outgrew the first tier: start again in the second (nothing is stamped yet, so nothing to undo)
@@ -995,6 +1048,10 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
     // it is, and the second table entry per tile only costs -- natural 4K frame: flood 1.45 -> 1.61 ms without this test)
     if (kFirstTier && rc == 0 && !wp_seed && st.ntiles >= A.wp_min_tiles && st.cnt <= kWpThinPx * st.ntiles && k < A.wp_cap)
         save_waypoints(A, k, L, st.ntiles, lane);
+    // the footprint's records for the seed's later rounds (flood_rewalk_kernel); one log per seed and frame: the records of
+    // ANY finished walk of the seed hold its present footprint
+    if (kFirstTier && rc == 0 && st.ntiles >= A.log_min_tiles && st.ntiles <= A.log_max_len && k < A.log_seeds && uni(A.log_len[k]) == 0u)
+        save_log(A, k, L, st.ntiles, lane);
     if (rc != 0) {
         // LDS storage exhausted: move the walk to a global slab and carry on
         uint32_t slab = 0;
@@ -1817,6 +1874,10 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
         if (!did_multi && !in_slab && rc == 0 && wp_hdr == 0u && k < A.wp_cap && st.ntiles >= A.wp_min_tiles && st.ntiles <= kWpMaxTiles &&
             st.cnt <= kWpThinPx * st.ntiles)
             save_waypoints(A, k, S, st.ntiles, lane);
+        // ... and its records (save_log), for flood_rewalk_kernel
+        if (!did_multi && !in_slab && rc == 0 && st.ntiles >= A.log_min_tiles && st.ntiles <= A.log_max_len && k < A.log_seeds &&
+            uni(A.log_len[k]) == 0u)
+            save_log(A, k, S, st.ntiles, lane);
         if (rc != 0 && lane == 0) {  // no slab to go to, or the slab ran out as well: the ordered tail will finish this seed
             A.flags[k] = kFlagIncomplete;
             atomicMin(&A.ctrl[kCtrlBarrier], k);
@@ -1828,6 +1889,414 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
             // (what makes a frame "regional", explore_body: walks the first tier could not have held, however early they
             // were handed over)
             if (st.ntiles > kHandTiles) atomicAdd(&A.ctrl[kCtrlBigLong], 1u);
+        }
+    }
+}
+
+// ---- Re-walks from the log ---------------------------------------------------------------------------------------------------
+// A footprint is the connected set around the seed in {acceptable, not committed}, acceptance is static, and what borders a
+// footprint is unacceptable or committed for good: a seed's footprint can only shrink, and its next footprint is the
+// connected part around the seed of (ANY earlier footprint of it, minus the pixels committed since).  So the seeds that left
+// a log (save_log) and survive a round are listed by the survivors pass, passed over by the next round's exploration (tier
+// bit 1) and worked out here: the records' pixels are looked at once (every tile's loads in flight together: no chain of
+// dependent round trips, which is all a walk is), the components of each tile's surviving pixels become nodes (a thread a
+// tile, 64-bit masks), nodes of neighbouring tiles that touch are united (a lock-free union-find in LDS: larger root under
+// smaller, path halving), and the pixels of the nodes united with the seed's node are the footprint.  Stamps, counts and the
+// blocked marks are what a walk would have left; the log is rewritten with the new footprint.
+// More than kRwComps components in one tile, or more nodes than the table holds: the seed gives up its log and walks in the
+// next round -- in this one it counts as a walk that did not finish (nothing above it commits).
+constexpr int kRwComps = 6;
+constexpr uint32_t kRwBatch = 16;  // tiles a wavefront has in flight (the pixels of a log are looked at, and stamped, with no chain between them)
+constexpr uint64_t kCol0 = 0x0101010101010101ull, kCol7 = 0x8080808080808080ull;
+__device__ __forceinline__ uint64_t dilate8(uint64_t m) {
+    const uint64_t hz = m | ((m << 1) & ~kCol0) | ((m >> 1) & ~kCol7);
+    return hz | (hz << 8) | (hz >> 8);
+}
+__device__ __forceinline__ uint32_t rw_find(volatile uint32_t* par, uint32_t x) {
+    for (;;) {
+        const uint32_t p = par[x];
+        if (p == x) return x;
+        const uint32_t g = par[p];
+        if (g != p) par[x] = g;  // (any ancestor is a valid parent: a lost or stale write only costs a step)
+        x = g;
+    }
+}
+// (Roots are linked in a scrambled order of the node numbers, not the numbers' own: the nodes of a line are numbered along
+// the line, and "larger under smaller" strings them into one chain as deep as the line is long -- every find then walks it.)
+__device__ __forceinline__ uint32_t rw_order(uint32_t x) { return x * 0x9E3779B1u; }
+__device__ __forceinline__ void rw_union(uint32_t* par, uint32_t a, uint32_t b) {
+    for (;;) {
+        uint32_t ra = rw_find(par, a), rb = rw_find(par, b);
+        if (ra == rb) return;
+        if (rw_order(ra) < rw_order(rb)) {
+            const uint32_t t = ra;
+            ra = rb;
+            rb = t;
+        }
+        if (atomicCAS(&par[ra], ra, rb) == ra) return;  // (a root only ever changes through this exchange)
+    }
+}
+constexpr int kRewalkTiles = 256;       // records a single wavefront's tables hold (the first tier's walks: 192 tiles at most)
+constexpr uint32_t kRewalkGrid = 8192;  // workgroups of a launch: one per entry of the list (kBigCap)
+constexpr int kRewalkThreads = 256;
+constexpr int kRewalkTilesBig = 2048, kRewalkThreadsBig = 1024;  // the second tier's walks (its team's table: 1536 tiles)
+template <int kTiles>
+constexpr size_t rewalk_lds_bytes() {
+    return (size_t)kTiles * 3 * 4 + (size_t)2 * kTiles * 4 + (size_t)2 * kTiles * 3 * 4 + (size_t)4 * kTiles * 4 + (size_t)2 * kTiles * 2 +
+           (size_t)2 * kTiles * 2 + (size_t)kTiles * 2 + (size_t)kTiles;
+}
+#ifdef LR_REWALK_TIMING
+// Diagnostic build (LR_EXTRA_FLAGS=-DLR_REWALK_TIMING, printed by LIBRECTIFY_FLOOD_DEBUG): [0] seeds, [1] records, then
+// s_memtime ticks of thread 0: [2] records in, [3] pixels looked at, [4] components, [5] unions, [6] footprint, [7] stamps.
+__device__ unsigned long long g_rewalk_timing[8];
+#define RW_TICK(i)                                            \
+    if (threadIdx.x == 0) {                                   \
+        const uint64_t t_ = __builtin_amdgcn_s_memtime();     \
+        atomicAdd(&g_rewalk_timing[i], (unsigned long long)(t_ - tlast)); \
+        tlast = t_;                                           \
+    }
+#else
+#define RW_TICK(i)
+#endif
+template <int kThreads, int kTiles>
+__global__ __launch_bounds__(kThreads) void flood_rewalk_kernel(FloodArgs A, const uint32_t* __restrict__ list, uint32_t min_len) {
+    constexpr int kNodes = 2 * kTiles, kHash = 2 * kTiles, kWaves = kThreads / 64, kEdges = 4 * kTiles;
+    static_assert(kNodes <= 65536, "node pairs are packed into 32 bits");
+    constexpr int kHashShift = 32 - __builtin_ctz((unsigned)kHash);
+    extern __shared__ uint32_t s_rw[];
+    uint32_t* tid = s_rw;            // per record: tile,
+    uint32_t* mlo = tid + kTiles;    // pixels (walked; then: walked and still there; then: the new footprint's)
+    uint32_t* mhi = mlo + kTiles;
+    uint32_t* hkey = mhi + kTiles;   // tile + 1 -> record (open addressing)
+    uint32_t* nlo = hkey + kHash;    // per node: pixels,
+    uint32_t* nhi = nlo + kNodes;
+    uint32_t* par = nhi + kNodes;    // parent
+    uint32_t* edge = par + kNodes;   // pairs of touching nodes
+    uint16_t* hidx = reinterpret_cast<uint16_t*>(edge + kEdges);
+    uint16_t* ntile = hidx + kHash;  // (unused but by the diagnostics: the node's record)
+    uint16_t* tfirst = ntile + kNodes;
+    uint8_t* tcomp = reinterpret_cast<uint8_t*>(tfirst + kTiles);
+    __shared__ uint32_t s_nnodes, s_over, s_blocked, s_cnt, s_seed_node, s_nout, s_nedges;
+    const int lane = threadIdx.x & 63, wave = (int)uni(threadIdx.x >> 6);
+    const int lr = lane >> 3, lc = lane & 7;
+    if (uni(A.ctrl[kCtrlNAct]) == 0u) return;  // a round enqueued past the end, or past a stall
+    const uint32_t n_list = min(uni(A.ctrl[kCtrlNMulti]), kBigCap);
+    const uint32_t window = uni(A.ctrl[kCtrlWindow]);
+    for (uint32_t ai = uni(blockIdx.x); ai < n_list; ai += gridDim.x) {
+        const uint32_t k = uni(list[ai]);
+        if (k >= window) continue;  // (not walked at all, like every seed above the window)
+        const uint32_t n = uni(A.log_len[k]);
+        if (n < min_len || n > (uint32_t)kTiles) continue;  // (another instance of this kernel takes it)
+        const uint32_t s = uni((uint32_t)A.seed_idx[k]);
+        const uint32_t seed_label = uni(A.label[s]);
+        const bool own = seed_label == k;
+        if (seed_label < kMarkBit && !own) continue;  // dead: the survivors pass takes it off the list
+        const uint32_t mine = kMarkBit | k;
+        uint32_t* rec = A.log_buf + (size_t)uni(A.log_off[k]) * 3u;
+        __syncthreads();  // (the previous seed's tables are no longer read)
+#ifdef LR_REWALK_TIMING
+        uint64_t tlast = __builtin_amdgcn_s_memtime();
+        if (threadIdx.x == 0) {
+            atomicAdd(&g_rewalk_timing[0], 1ull);
+            atomicAdd(&g_rewalk_timing[1], (unsigned long long)n);
+        }
+#endif
+        for (uint32_t i = threadIdx.x; i < n; i += kThreads) {
+            tid[i] = rec[3u * i];
+            mlo[i] = rec[3u * i + 1u];
+            mhi[i] = rec[3u * i + 2u];
+        }
+        for (uint32_t i = threadIdx.x; i < (uint32_t)kHash; i += kThreads) hkey[i] = 0u;
+        if (threadIdx.x == 0) {
+            s_nnodes = 0u;
+            s_over = 0u;
+            s_blocked = 0u;
+            s_cnt = 0u;
+            s_seed_node = 0xFFFFFFFFu;
+            s_nout = 0u;
+            s_nedges = 0u;
+        }
+        __syncthreads();
+        RW_TICK(2)
+        // (1) which of the logged pixels are still there: free, stamped by this round's walks, or this seed's own ground
+        for (uint32_t i0 = (uint32_t)wave * kRwBatch; i0 < n; i0 += (uint32_t)kWaves * kRwBatch) {
+            uint32_t lab[kRwBatch];
+            bool in[kRwBatch];
+#pragma unroll
+            for (int j = 0; j < (int)kRwBatch; ++j) {
+                const uint32_t i = i0 + (uint32_t)j;
+                lab[j] = 0u;
+                in[j] = false;
+                if (i < n) {
+                    const uint32_t tile = tid[i];
+                    const uint64_t V = ((uint64_t)mhi[i] << 32) | mlo[i];
+                    in[j] = (V >> lane) & 1ull;
+                    if (in[j]) lab[j] = A.label[(size_t)((tile >> 16) * 8 + lr) * A.w + ((tile & 0xFFFFu) * 8 + lc)];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < (int)kRwBatch; ++j) {
+                const uint32_t i = i0 + (uint32_t)j;
+                const uint64_t M = __ballot(in[j] && (lab[j] >= kMarkBit || lab[j] == k));
+                if (i < n && lane == 0) {
+                    mlo[i] = (uint32_t)M;
+                    mhi[i] = (uint32_t)(M >> 32);
+                }
+            }
+        }
+        __syncthreads();
+        RW_TICK(3)
+        // (2) a thread a record: the tile goes into the table, the components of its pixels become nodes
+        const uint32_t seed_tile = ((s / (uint32_t)A.w) >> 3) << 16 | ((s % (uint32_t)A.w) >> 3);
+        const uint64_t seed_bit = 1ull << (((s / (uint32_t)A.w) & 7u) * 8u + ((s % (uint32_t)A.w) & 7u));
+        for (uint32_t t = threadIdx.x; t < n; t += kThreads) {
+            const uint32_t key = tid[t] + 1u;
+            uint32_t hs = (key * 2654435761u) >> kHashShift;
+            while (atomicCAS(&hkey[hs], 0u, key) != 0u) hs = (hs + 1u) & (uint32_t)(kHash - 1);  // (the records' tiles are distinct)
+            hidx[hs] = (uint16_t)t;
+            uint64_t rem = ((uint64_t)mhi[t] << 32) | mlo[t];
+            uint64_t comp[kRwComps];
+            int nc = 0;
+            bool over = false;
+            while (rem != 0ull) {
+                uint64_t c = rem & (~rem + 1ull), prev;
+                do {
+                    prev = c;
+                    c = dilate8(c) & rem;
+                } while (c != prev);
+                rem &= ~c;
+                if (nc == kRwComps) {
+                    over = true;
+                    break;
+                }
+                comp[nc++] = c;
+            }
+            uint32_t first = 0u;
+            if (nc) first = atomicAdd(&s_nnodes, (uint32_t)nc);
+            if (over || first + (uint32_t)nc > (uint32_t)kNodes) {
+                s_over = 1u;
+                nc = 0;
+            }
+            tfirst[t] = (uint16_t)first;
+            tcomp[t] = (uint8_t)nc;
+            for (int c = 0; c < nc; ++c) {
+                nlo[first + c] = (uint32_t)comp[c];
+                nhi[first + c] = (uint32_t)(comp[c] >> 32);
+                par[first + c] = first + (uint32_t)c;
+                ntile[first + c] = (uint16_t)t;
+                if (tid[t] == seed_tile && (comp[c] & seed_bit)) s_seed_node = first + (uint32_t)c;
+            }
+        }
+        __syncthreads();
+        RW_TICK(4)
+        // (tables too small for this log -- more than kRwComps components in a tile, more nodes than the table holds: the
+        // footprint is worked out by sweeps instead, below)
+        bool sweep = uni(s_over) != 0u || uni(s_seed_node) == 0xFFFFFFFFu || A.log_sweep != 0u;
+        if (!sweep) {
+        // (3) nodes of neighbouring tiles that touch are one: east, south, south-east, south-west of every tile
+        for (uint32_t t = threadIdx.x; t < n; t += kThreads) {
+            const int nc = tcomp[t];
+            if (nc == 0) continue;
+            const uint32_t tile = tid[t], first = tfirst[t];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const uint32_t key = tile + (d == 0 ? 1u : d == 1 ? 0x10000u : d == 2 ? 0x10001u : 0xFFFFu) + 1u;
+                uint32_t hs = (key * 2654435761u) >> kHashShift, cur;
+                while ((cur = hkey[hs]) != key && cur != 0u) hs = (hs + 1u) & (uint32_t)(kHash - 1);
+                if (cur != key) continue;
+                const uint32_t u = hidx[hs];
+                const int ncu = tcomp[u];
+                const uint32_t ufirst = tfirst[u];
+                for (int c = 0; c < nc; ++c) {
+                    const uint64_t a = ((uint64_t)nhi[first + c] << 32) | nlo[first + c];
+                    uint64_t e;  // the pixels of the neighbouring tile that touch this node
+                    if (d == 0) {
+                        e = (a >> 7) & kCol0;
+                        e |= (e << 8) | (e >> 8);
+                    } else if (d == 1) {
+                        e = a >> 56;
+                        e = (e | (e << 1) | (e >> 1)) & 0xFFull;
+                    } else if (d == 2) {
+                        e = a >> 63;
+                    } else {
+                        e = ((a >> 56) & 1ull) << 7;
+                    }
+                    if (e == 0ull) continue;
+                    for (int cu = 0; cu < ncu; ++cu) {
+                        const uint64_t bmask = ((uint64_t)nhi[ufirst + cu] << 32) | nlo[ufirst + cu];
+                        if (e & bmask) {
+                            // (the pair is only noted here: a union is a chain of dependent LDS round trips, and inside these
+                            // divergent loops the wavefront would pay it once per (direction, node, node) combination)
+                            const uint32_t pos = atomicAdd(&s_nedges, 1u);
+                            if (pos < (uint32_t)kEdges) edge[pos] = ((first + (uint32_t)c) << 16) | (ufirst + (uint32_t)cu);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t n_edges = uni(s_nedges);
+        if (n_edges > (uint32_t)kEdges) sweep = true;  // (never seen: four pairs a tile)
+        else {
+        for (uint32_t e = threadIdx.x; e < n_edges; e += kThreads) rw_union(par, edge[e] >> 16, edge[e] & 0xFFFFu);
+        __syncthreads();
+        RW_TICK(5)
+        // (4) the footprint: the pixels of the nodes united with the seed's
+        const uint32_t root = rw_find(par, s_seed_node);
+        for (uint32_t t = threadIdx.x; t < n; t += kThreads) {
+            const int nc = tcomp[t];
+            const uint32_t first = tfirst[t];
+            uint64_t V = 0ull;
+            for (int c = 0; c < nc; ++c)
+                if (rw_find(par, first + (uint32_t)c) == root) V |= ((uint64_t)nhi[first + c] << 32) | nlo[first + c];
+            mlo[t] = (uint32_t)V;
+            mhi[t] = (uint32_t)(V >> 32);
+        }
+        }
+        }
+        if (sweep) {
+            // The slow way, for logs the tables cannot take (noisy regions: many small components a tile): every tile keeps the
+            // set R of its pixels reached so far; a sweep pulls in what the eight neighbours' sets touch and closes it inside the
+            // tile; sweeps until nothing changes (as many as the footprint is tiles deep -- such logs are blobs, not lines).
+            // R lives where the nodes' pixels were; stale or torn reads of a neighbour's R only delay (R grows monotonically).
+            __syncthreads();
+            for (uint32_t t = threadIdx.x; t < n; t += kThreads) {
+                const uint64_t R0 = tid[t] == seed_tile ? seed_bit : 0ull;
+                nlo[t] = (uint32_t)R0;
+                nhi[t] = (uint32_t)(R0 >> 32);
+            }
+            bool failed = true;
+            for (uint32_t it = 0; it < 8u * (uint32_t)kTiles + 64u; ++it) {
+                __syncthreads();
+                if (threadIdx.x == 0) s_over = 0u;  // (reused: "something changed in this sweep")
+                __syncthreads();
+                bool changed = false;
+                for (uint32_t t = threadIdx.x; t < n; t += kThreads) {
+                    const uint64_t M = ((uint64_t)mhi[t] << 32) | mlo[t];
+                    if (M == 0ull) continue;
+                    const uint64_t R = ((uint64_t)nhi[t] << 32) | nlo[t];
+                    const uint32_t tile = tid[t];
+                    uint64_t in = 0ull;
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) {
+                        // the neighbour in direction d (E, W, S, N, SE, NW, SW, NE) and what of this tile its set touches
+                        const uint32_t delta = d == 0 ? 1u : d == 1 ? 0xFFFFFFFFu : d == 2 ? 0x10000u : d == 3 ? 0xFFFF0000u : d == 4 ? 0x10001u
+                                               : d == 5 ? 0xFFFEFFFFu : d == 6 ? 0xFFFFu : 0xFFFF0001u;
+                        const uint32_t key = tile + delta + 1u;
+                        uint32_t hs = (key * 2654435761u) >> kHashShift, cur;
+                        while ((cur = hkey[hs]) != key && cur != 0u) hs = (hs + 1u) & (uint32_t)(kHash - 1);
+                        if (cur != key) continue;
+                        const uint32_t u = hidx[hs];
+                        const uint64_t a = ((uint64_t)nhi[u] << 32) | nlo[u];
+                        uint64_t e;
+                        if (d == 0) {  // from the east neighbour: its column 0 touches this tile's column 7
+                            e = (a & kCol0) << 7;
+                            e |= (e << 8) | (e >> 8);
+                        } else if (d == 1) {
+                            e = (a >> 7) & kCol0;
+                            e |= (e << 8) | (e >> 8);
+                        } else if (d == 2) {  // from the south neighbour: its row 0 touches this tile's row 7
+                            e = a & 0xFFull;
+                            e = ((e | (e << 1) | (e >> 1)) & 0xFFull) << 56;
+                        } else if (d == 3) {
+                            e = a >> 56;
+                            e = (e | (e << 1) | (e >> 1)) & 0xFFull;
+                        } else if (d == 4) {
+                            e = (a & 1ull) << 63;
+                        } else if (d == 5) {
+                            e = a >> 63;
+                        } else if (d == 6) {  // south-west neighbour: its (row 0, column 7) touches this tile's (row 7, column 0)
+                            e = ((a >> 7) & 1ull) << 56;
+                        } else {
+                            e = ((a >> 56) & 1ull) << 7;
+                        }
+                        in |= e;
+                    }
+                    uint64_t x = R | (in & M), prev;
+                    do {
+                        prev = x;
+                        x = dilate8(x) & M;
+                    } while (x != prev);
+                    if (x != R) {
+                        nlo[t] = (uint32_t)x;
+                        nhi[t] = (uint32_t)(x >> 32);
+                        changed = true;
+                    }
+                }
+                if (changed) s_over = 1u;
+                __syncthreads();
+                if (uni(s_over) == 0u) {
+                    failed = false;
+                    break;
+                }
+            }
+            __syncthreads();
+            if (failed) {  // (never: a footprint is at most as deep as it has tiles)
+                if (threadIdx.x == 0) {
+                    A.flags[k] = kFlagIncomplete;
+                    atomicMin(&A.ctrl[kCtrlBarrier], k);
+                    A.log_len[k] = 0u;
+                }
+                continue;
+            }
+            for (uint32_t t = threadIdx.x; t < n; t += kThreads) {
+                mlo[t] = nlo[t];
+                mhi[t] = nhi[t];
+            }
+            if (threadIdx.x == 0) atomicAdd(&A.ctrl[kCtrlLogGiveUp], 1u);
+        }
+        __syncthreads();
+        // (4) the footprint: the pixels of the nodes united with the seed's
+        uint32_t my_cnt = 0u;
+        for (uint32_t t = threadIdx.x; t < n; t += kThreads) {
+            const uint64_t V = ((uint64_t)mhi[t] << 32) | mlo[t];
+            if (V != 0ull) {  // the log shrinks with the footprint (every record was read into LDS above; their order is free)
+                const uint32_t pos = atomicAdd(&s_nout, 1u);
+                rec[3u * pos] = tid[t];
+                rec[3u * pos + 1u] = (uint32_t)V;
+                rec[3u * pos + 2u] = (uint32_t)(V >> 32);
+            }
+            my_cnt += (uint32_t)__popcll(V);
+        }
+        if (my_cnt) atomicAdd(&s_cnt, my_cnt);
+        __syncthreads();
+        RW_TICK(6)
+        // (5) stamps, as stamp_footprint leaves them
+        bool foreign = false;
+        for (uint32_t i0 = (uint32_t)wave * kRwBatch; i0 < n; i0 += (uint32_t)kWaves * kRwBatch) {
+            uint32_t old[kRwBatch];
+#pragma unroll
+            for (int j = 0; j < (int)kRwBatch; ++j) {
+                old[j] = kLabelFree;
+                const uint32_t i = i0 + (uint32_t)j;
+                if (i < n) {
+                    const uint32_t tile = tid[i];
+                    const uint64_t V = ((uint64_t)mhi[i] << 32) | mlo[i];
+                    if ((V >> lane) & 1ull) {
+                        const size_t q = (size_t)((tile >> 16) * 8 + lr) * A.w + ((tile & 0xFFFFu) * 8 + lc);
+                        old[j] = atomicMin(&A.label[q], mine);
+                        A.dirty[q >> 8] = 1;
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < (int)kRwBatch; ++j) {
+                if (old[j] > mine) {
+                    if (old[j] != kLabelFree) A.blocked[old[j] & ~kMarkBit] = 1u;
+                } else if (old[j] < mine && old[j] >= kMarkBit) {
+                    foreign = true;
+                }
+            }
+        }
+        if (__ballot(foreign) && lane == 0) s_blocked = 1u;
+        __syncthreads();
+        RW_TICK(7)
+        if (threadIdx.x == 0) {
+            A.count[k] = s_cnt;
+            A.log_len[k] = s_nout;
+            if (s_blocked) A.blocked[k] = 1u;
+            A.flags[k] |= n << 8;  // (diagnostics: records looked at)
+            atomicAdd(&A.ctrl[kCtrlLogWalks], 1u);
         }
     }
 }
@@ -2086,7 +2555,8 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
                                                                uint8_t* __restrict__ dirty, uint32_t n_runs,
                                                                int win_first_shift, int hold_pct, uint32_t hold_from_start,
                                                                uint32_t* __restrict__ label, size_t npix,
-                                                               uint32_t* __restrict__ waypoints, uint32_t wp_cap) {
+                                                               uint32_t* __restrict__ waypoints, uint32_t wp_cap,
+                                                               uint32_t* __restrict__ log_len, uint32_t log_seeds) {
     // (the label image is set to "free" here as well: one launch less in front of the first round)
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) label[i] = kLabelFree;
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
@@ -2111,6 +2581,9 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
         ctrl[kCtrlMulti] = 0u;
         ctrl[kCtrlNMulti] = 0u;
         ctrl[kCtrlNMultiNext] = 0u;
+        ctrl[kCtrlLogTotal] = 0u;
+        ctrl[kCtrlLogWalks] = 0u;
+        ctrl[kCtrlLogGiveUp] = 0u;
         ctrl[kCtrlSlabTotal] = 0u;
         ctrl[kCtrlBarrier] = 0xFFFFFFFFu;
         ctrl[kCtrlBarrierNext] = 0xFFFFFFFFu;
@@ -2128,6 +2601,7 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
     for (uint32_t r = k; r < n_runs; r += gridDim.x * 256) dirty[r] = 0;  // (all clear after a flood that ran to its end)
     if (k >= n_seeds) return;
     if (k < wp_cap) waypoints[(size_t)k * kFloodWpWords] = 0u;
+    if (k < log_seeds) log_len[k] = 0u;
     act[k] = k;
     state[k] = 0;
     tier[k] = 0;
@@ -2224,6 +2698,17 @@ static void flood_debug_round(const FloodBuffers& B, const FloodFrame& F, uint32
     (void)hipMemcpy(actv.data(), act, n_act * sizeof(uint32_t), hipMemcpyDeviceToHost);
     (void)hipMemcpy(cnt.data(), B.count, n_seeds * sizeof(uint32_t), hipMemcpyDeviceToHost);
     (void)hipMemcpy(blk.data(), B.blocked, n_seeds * sizeof(uint32_t), hipMemcpyDeviceToHost);
+#ifdef LR_REWALK_TIMING
+    {
+        unsigned long long t[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_rewalk_timing), sizeof(t));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rewalk_timing), z, sizeof(z));
+        if (t[0] > 0)
+            std::fprintf(stderr, "  re-walks from logs: %llu seeds, %llu records; s_memtime ticks per seed: records in %.0f, pixels %.0f, components %.0f, "
+                         "unions %.0f, footprint %.0f, stamps %.0f\n", t[0], t[1], (double)t[2] / t[0], (double)t[3] / t[0], (double)t[4] / t[0],
+                         (double)t[5] / t[0], (double)t[6] / t[0], (double)t[7] / t[0]);
+    }
+#endif
 #ifdef LR_WALK_TIMING
     {
         unsigned long long t[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -2375,6 +2860,21 @@ FloodArgs flood_args(const FloodBuffers& B, const FloodFrame& F, bool use_big) {
     A.multi_list = B.multi_list;
     A.multi_next = 0u;
     A.wp_min_tiles = (B.multi_source && B.waypoints && use_big) ? (uint32_t)std::max(wp_min_env, (int)kWpK + 1) : 0xFFFFFFFFu;
+    // logs: walks of this many tiles leave one (LIBRECTIFY_FLOOD_LOG_MIN); with logs there are no way-points
+    static const int log_min_env = std::getenv("LIBRECTIFY_FLOOD_LOG_MIN") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_LOG_MIN")) : 12;
+    const bool logs = B.rewalk_logs && B.log_buf && B.log_off && B.log_len && B.multi_list;
+    A.log_min_tiles = logs ? (uint32_t)std::max(log_min_env, 1) : 0xFFFFFFFFu;
+    static const int log_walk_env = std::getenv("LIBRECTIFY_FLOOD_LOG_WALK") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_LOG_WALK")) : 12;
+    A.log_walk_tiles = (uint32_t)std::max(log_walk_env, 3);
+    static const bool log_sweep_env = std::getenv("LIBRECTIFY_FLOOD_LOG_SWEEP") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_LOG_SWEEP")) != 0;
+    A.log_sweep = log_sweep_env ? 1u : 0u;
+    A.log_max_len = (B.rewalk_big && use_big) ? (uint32_t)kRewalkTilesBig : (uint32_t)kRewalkTiles;
+    A.log_seeds = logs ? B.log_seeds : 0u;
+    A.log_off = B.log_off;
+    A.log_len = B.log_len;
+    A.log_buf = B.log_buf;
+    A.log_cap = B.log_cap;
+    if (logs) A.wp_min_tiles = 0xFFFFFFFFu;
     static const int g_cap_env = std::getenv("LIBRECTIFY_FLOOD_PARTIAL_STEPS") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_PARTIAL_STEPS")) : 16;
     A.g_cap = g_cap_env > 0 ? (uint32_t)g_cap_env : kMaxSteps;
     return A;
@@ -2424,6 +2924,7 @@ void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& 
                            index < B.n_fork_events && !g_flood_debug;
     A.multi_next = (B.aux_stream != nullptr && A.wp_min_tiles != 0xFFFFFFFFu && use_big && index + 1 >= 1 && index + 1 <= B.multi_round_last &&
                     index + 1 < B.n_fork_events && !g_flood_debug) ? 1u : 0u;
+    const bool logs = A.log_min_tiles != 0xFFFFFFFFu;
     if (multi_now) {
         (void)hipEventRecord(B.fork_events[index], s);
         (void)hipStreamWaitEvent(B.aux_stream, B.fork_events[index], 0);
@@ -2442,6 +2943,12 @@ void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& 
         hipLaunchKernelGGL(flood_explore_big_kernel, dim3(std::min<uint32_t>(F.seed_cap, kBigCap)), dim3(64), kBigLdsBytes, s,
                            A, F.trig, B.big_list);
     if (multi_now) (void)hipStreamWaitEvent(s, B.join_events[index], 0);
+    if (logs && index >= 1)
+        hipLaunchKernelGGL((flood_rewalk_kernel<kRewalkThreads, kRewalkTiles>), dim3(std::min<uint32_t>(F.seed_cap, kRewalkGrid)), dim3(kRewalkThreads),
+                           rewalk_lds_bytes<kRewalkTiles>(), s, A, B.multi_list, 1u);
+    if (logs && index >= 1 && A.log_max_len > (uint32_t)kRewalkTiles)
+        hipLaunchKernelGGL((flood_rewalk_kernel<kRewalkThreadsBig, kRewalkTilesBig>), dim3(std::min<uint32_t>(F.seed_cap, 1024u)),
+                           dim3(kRewalkThreadsBig), rewalk_lds_bytes<kRewalkTilesBig>(), s, A, B.multi_list, (uint32_t)kRewalkTiles + 1u);
     if (g_flood_debug) (void)hipEventRecord(dbg1, s);
     if (g_flood_debug) {
         uint32_t n = 0;
@@ -2495,7 +3002,9 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(flood_explore_big_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigLdsBytes) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(flood_explore_team_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTeamLdsBytes) != hipSuccess) {
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTeamLdsBytes) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(flood_rewalk_kernel<kRewalkThreadsBig, kRewalkTilesBig>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)rewalk_lds_bytes<kRewalkTilesBig>()) != hipSuccess) {
                 set_error("flood: cannot reserve the second-tier LDS");
                 return 1;
             }
@@ -2509,7 +3018,7 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
         hipLaunchKernelGGL(flood_init_seeds_kernel, dim3(blocks), dim3(256), 0, s, F.d_n_seeds, F.seed_cap, B.act_a, B.state,
                            B.tier, B.blocked, B.count, B.flags, F.seed_size, B.ctrl, B.dirty,
                            (uint32_t)((npix + 255) >> 8), win_first_shift, hold_pct, hold_start ? 1u : 0u, F.label, npix,
-                           B.waypoints, B.wp_cap);
+                           B.waypoints, B.wp_cap, B.log_len, B.log_len ? B.log_seeds : 0u);
     }
     FloodArgs A = flood_args(B, F, P->use_big);
     A.win_shift = (uint32_t)win_growth;
@@ -2582,6 +3091,8 @@ int flood_finish(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, u
         tiers_out[7] = h_ctrl[kCtrlSteps + 1];
         tiers_out[8] = h_ctrl[kCtrlBigLong];
         tiers_out[9] = h_ctrl[kCtrlMulti];
+        tiers_out[10] = h_ctrl[kCtrlLogWalks];
+        tiers_out[11] = h_ctrl[kCtrlLogGiveUp];
     }
     return 0;
 }

@@ -817,6 +817,172 @@ static int dataflow(int eager, long conc, const std::vector<int>& ref, long labe
     return bad != 0 || n_active != 0;
 }
 
+
+// ---- scheme 12: rounds, but a seed whose last footprint lost no pixel to a commit does not walk again -------------------------
+// A footprint changes only through commits of its own pixels (acceptance is static, what borders a footprint is unacceptable
+// or committed for good).  So a blocked seed whose logged footprint is untouched re-stamps the log -- parallel atomics, no
+// dependent chain -- and its round is EXACTLY what a walk would have given.  `min_tiles`: only walks of at least so many
+// tiles keep a log.  Reported per round: the longest walk that was needed against the longest walk of the plain schedule.
+static int rounds_lazy(int min_tiles, const std::vector<int>& ref, long labelled) {
+    std::vector<uint8_t> dm = dmask;
+    std::vector<int> label((size_t)W * H, -1);
+    std::vector<char> gone(NS, 0);
+    std::vector<Walk> fp(NS);
+    std::vector<char> has(NS, 0);
+    const int INF = 0x7fffffff;
+    long steps_all = 0, steps_needed = 0, crit_all = 0, crit_needed = 0, restamp_tiles = 0;
+    int rounds = 0, n_active = NS;
+    while (n_active > 0) {
+        std::vector<int> stamp((size_t)W * H, INF);
+        int longest_all = 0, longest_needed = 0, skipped = 0, walked = 0, longest_restamp = 0;
+        for (int k = 0; k < NS; ++k) {
+            if (gone[k]) continue;
+            if (label[sidx[k]] >= 0) {
+                gone[k] = 1;
+                --n_active;
+                continue;
+            }
+            bool reuse = false;
+            if (has[k]) {
+                reuse = true;
+                for (int p : fp[k].px)
+                    if (label[p] >= 0) {
+                        reuse = false;
+                        break;
+                    }
+            }
+            if (!reuse) {
+                footprint(k, dm, fp[k]);
+                has[k] = fp[k].tiles >= min_tiles;
+                steps_needed += fp[k].tiles;
+                longest_needed = std::max(longest_needed, fp[k].tiles);
+                ++walked;
+            } else {
+                ++skipped;
+                restamp_tiles += fp[k].tiles;
+                longest_restamp = std::max(longest_restamp, fp[k].tiles);
+            }
+            steps_all += fp[k].tiles;
+            longest_all = std::max(longest_all, fp[k].tiles);
+            if (fp[k].px.empty()) {
+                gone[k] = 1;
+                --n_active;
+            }
+            for (int p : fp[k].px) stamp[p] = std::min(stamp[p], k);
+        }
+        int committed = 0;
+        for (int k = 0; k < NS; ++k) {
+            if (gone[k]) continue;
+            bool free_ = true;
+            for (int p : fp[k].px)
+                if (stamp[p] < k) {
+                    free_ = false;
+                    break;
+                }
+            if (!free_) continue;
+            for (int p : fp[k].px) {
+                label[p] = k;
+                dm[p] = 0;
+            }
+            gone[k] = 1;
+            --n_active;
+            ++committed;
+        }
+        ++rounds;
+        crit_all += longest_all;
+        crit_needed += longest_needed;
+        printf("  round %d: walked %d (longest %d), re-stamped from the log %d (longest log %d tiles); plain schedule's longest walk %d; committed %d, left %d\n",
+               rounds, walked, longest_needed, skipped, longest_restamp, longest_all, committed, n_active);
+    }
+    long bad = 0;
+    for (size_t i = 0; i < ref.size(); ++i) bad += ref[i] != label[i];
+    printf("scheme 12 (rounds, untouched footprints of >= %d tiles are re-stamped, not walked): %d rounds; steps %ld -> %ld; sum of the rounds' longest walks %ld -> %ld; %ld tiles re-stamped; label mismatches vs sequential: %ld\n",
+           min_tiles, rounds, steps_all, steps_needed, crit_all, crit_needed, restamp_tiles, bad);
+    return bad != 0;
+}
+
+
+// ---- scheme 13: rounds with the LAZY rule of scheme 11 ---------------------------------------------------------------------------
+// A blocked seed remembers the lowest seed whose stamp lay on its footprint.  While that seed is unresolved it does not walk:
+// it re-stamps its logged footprint minus what has been committed since (a superset of its present footprint, hence a
+// conservative blocker for higher seeds; itself it stays blocked).  When the blocker is resolved it walks again.  A seed that
+// comes out unblocked on a log that commits have touched walks in the next round before it may commit.
+// `min_tiles`: only walks of at least so many tiles are treated this way (the others walk every round).
+static int rounds_parked(int min_tiles, const std::vector<int>& ref, long labelled) {
+    std::vector<uint8_t> dm = dmask;
+    std::vector<int> label((size_t)W * H, -1);
+    std::vector<char> gone(NS, 0), has(NS, 0), stale(NS, 0);
+    std::vector<int> blocker(NS, -1);
+    std::vector<Walk> fp(NS);
+    const int INF = 0x7fffffff;
+    long steps_all = 0, steps_needed = 0, crit_needed = 0, restamp_tiles = 0;
+    int rounds = 0, n_active = NS;
+    while (n_active > 0 && rounds < 200) {
+        std::vector<int> stamp((size_t)W * H, INF);
+        int longest_needed = 0, skipped = 0, walked = 0, longest_restamp = 0;
+        for (int k = 0; k < NS; ++k) {
+            if (gone[k]) continue;
+            if (label[sidx[k]] >= 0) {
+                gone[k] = 1;
+                --n_active;
+                continue;
+            }
+            const bool park = has[k] && blocker[k] >= 0 && !gone[blocker[k]];
+            if (!park) {
+                footprint(k, dm, fp[k]);
+                has[k] = fp[k].tiles >= min_tiles;
+                stale[k] = 0;
+                steps_needed += fp[k].tiles;
+                longest_needed = std::max(longest_needed, fp[k].tiles);
+                ++walked;
+            } else {
+                std::vector<int> keep;
+                for (int p : fp[k].px)
+                    if (label[p] < 0) keep.push_back(p);
+                if (keep.size() != fp[k].px.size()) stale[k] = 1;
+                fp[k].px.swap(keep);
+                ++skipped;
+                restamp_tiles += fp[k].tiles;
+                longest_restamp = std::max(longest_restamp, fp[k].tiles);
+            }
+            if (fp[k].px.empty()) {
+                gone[k] = 1;
+                --n_active;
+            }
+            for (int p : fp[k].px) stamp[p] = std::min(stamp[p], k);
+        }
+        int committed = 0;
+        for (int k = 0; k < NS; ++k) {
+            if (gone[k]) continue;
+            int low = INF;
+            for (int p : fp[k].px) low = std::min(low, stamp[p]);
+            if (low < k) {
+                blocker[k] = low;
+                continue;
+            }
+            blocker[k] = -1;
+            if (stale[k]) continue;  // unblocked on a stale log: walks next round
+            for (int p : fp[k].px) {
+                label[p] = k;
+                dm[p] = 0;
+            }
+            gone[k] = 1;
+            --n_active;
+            ++committed;
+        }
+        ++rounds;
+        crit_needed += longest_needed;
+        printf("  round %d: walked %d (longest %d), re-stamped %d (longest log %d tiles); committed %d, left %d\n", rounds, walked, longest_needed, skipped,
+               longest_restamp, committed, n_active);
+    }
+    long bad = 0;
+    for (size_t i = 0; i < ref.size(); ++i) bad += ref[i] != label[i];
+    printf("scheme 13 (rounds, lazy rule for walks of >= %d tiles): %d rounds; steps %ld; sum of the rounds' longest walks %ld; %ld tiles re-stamped; left %d; label mismatches vs sequential: %ld\n",
+           min_tiles, rounds, steps_needed, crit_needed, restamp_tiles, n_active, bad);
+    (void)steps_all;
+    return bad != 0;
+}
+
 // scheme 1: perfect deferral -- seeds that die in the round never walk or stamp (lower bound of the deferral family)
 // scheme 2: opportunistic deferral in dispatch batches of `conc` walks (strongest first), phases until nothing is left
 //           to walk; a deferred seed is one whose own pixel carries a lower stamp when its batch starts
@@ -845,6 +1011,8 @@ int main(int argc, char** argv) {
     long labelled = 0;
     for (int v : ref) labelled += v >= 0;
     printf("%dx%d, %d seeds, %ld labelled px\n", W, H, NS, labelled);
+    if (scheme == 12) return rounds_lazy(argc > 3 ? atoi(argv[3]) : 0, ref, labelled);
+    if (scheme == 13) return rounds_parked(argc > 3 ? atoi(argv[3]) : 0, ref, labelled);
     if (scheme == 11) {
         if (argc > 5) g_pre_rounds = atoi(argv[5]);
         return dataflow(argc > 3 ? atoi(argv[3]) : 1, argc > 4 ? atol(argv[4]) : (long)NS, ref, labelled);
