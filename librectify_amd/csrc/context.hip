@@ -791,7 +791,8 @@ FloodBuffers flood_buffers_for(lr_context* c) {
     static const bool partial_off = std::getenv("LIBRECTIFY_FLOOD_PARTIAL") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_PARTIAL")) == 0;
     fbuf.partial_commits = !partial_off && c->flood_partial;
     fbuf.multi_source = c->flood_multi;
-    fbuf.rewalk_logs = c->flood_logs;
+    fbuf.rewalk_logs = c->flood_logs && !c->flood_multi;  // (way-points, when asked for, instead)
+    fbuf.log_sweep = c->flood_log_sweep;
     fbuf.rewalk_big = c->flood_logbig_hint;  // (the context's last frame had walks beyond the first tier)
     static const int aux_env = std::getenv("LIBRECTIFY_FLOOD_MULTI_BESIDE") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_MULTI_BESIDE")) : -1;  // (experiment: 0 = after the exploration, N = beside it in rounds 2 .. N + 1)
     if (c->flood_aux && c->flood_aux_on && aux_env != 0 && c->flood_fork.size() == c->flood_join.size()) {
@@ -2204,6 +2205,7 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
     lanes.push_back(c);
     for (int i = 0; i < S - 1; ++i) lanes.push_back(c->workers[i]);
     const bool caller_multi = c->flood_multi;  // (lane 0 is the caller's own context: its setting comes back after the call)
+    const bool caller_logs = c->flood_logs;
     for (lr_context* l : lanes) {
         l->ransac_seed = c->ransac_seed;
         l->ransac_iters = c->ransac_iters;
@@ -2215,6 +2217,12 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
         // rounds overlap each other anyway (profiles/r04_flood_multi_sweep.txt).  LIBRECTIFY_FLOOD_MULTI_LANES=1 keeps them.
         static const bool multi_lanes = std::getenv("LIBRECTIFY_FLOOD_MULTI_LANES") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_MULTI_LANES")) != 0;
         l->flood_multi = caller_multi && (S == 1 || multi_lanes);
+        // Re-walks from the logs likewise: they shorten a frame's later rounds (single 4K frames: flood 1.31 -> 0.94 ms) by
+        // work of their own in round two, and S frames in flight gain nothing from shorter rounds: 9.8 -> 9.3 Gpix/s with
+        // them (profiles/r04_flood_logs.txt).  LIBRECTIFY_FLOOD_LOGS_LANES=1 keeps them.
+        static const bool logs_lanes = std::getenv("LIBRECTIFY_FLOOD_LOGS_LANES") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_LOGS_LANES")) != 0;
+        l->flood_logs = caller_logs && (S == 1 || logs_lanes);
+        l->flood_log_sweep = c->flood_log_sweep;
         l->estimator = c->estimator;
         l->prosac_T_N = c->prosac_T_N;
         l->cht_d = c->cht_d;
@@ -2390,6 +2398,7 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
     if (h_frames) (void)hipStreamSynchronize(c->copy_stream);  // (after an error: nothing may still read the caller's frames)
     for (lr_context* l : lanes) l->sleep_in_wait = false;
     c->flood_multi = caller_multi;
+    c->flood_logs = caller_logs;
     for (int si = 0; si < S; ++si)
         if (rc[si]) {
             set_error(err[si]);
@@ -2457,6 +2466,8 @@ int ctx_find_groups_batch_host_multi(lr_context* c, const int* devices, int n_de
         p->flood_staged = c->flood_staged;
         p->flood_partial = c->flood_partial;
         p->flood_multi = c->flood_multi;
+        p->flood_logs = c->flood_logs;
+        p->flood_log_sweep = c->flood_log_sweep;
         p->estimator = c->estimator;
         p->prosac_T_N = c->prosac_T_N;
         p->cht_d = c->cht_d;

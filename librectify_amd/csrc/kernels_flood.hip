@@ -173,6 +173,7 @@ constexpr uint32_t kWpMaxTiles = 600u;   // the team's table holds an entry per 
 constexpr uint32_t kSrcShift = 28u, kSrcMask = 0xF0000000u, kSrcClaim = 0xF0000000u;  // table keys of a multi-source walk
 constexpr uint32_t kBigCap = 8192;  // seeds per round that can move to the second tier (FloodBuffers::big_list)
 constexpr uint32_t kFlagIncomplete = 1u, kFlagSelfFail = 2u;
+constexpr uint32_t kLogShrunk = 0x80000000u;  // FloodArgs::log_len: the log has been cut down to a later footprint by flood_rewalk_kernel
 constexpr uint32_t kMaxSteps = 1u << 22;  // safety net of the walk loop: more records than an 8K frame has tile visits
 
 struct FloodArgs {
@@ -971,7 +972,8 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
     // A seed with a log (save_log) walks a few tiles only: most footprints have shrunk to a handful of tiles by their second
     // round, and a short walk is cheaper than the records of a long one.  If the walk is not over by then, the seed goes
     // on this round's list of flood_rewalk_kernel, which runs behind the exploration (nothing is stamped yet).
-    const uint32_t log_n = (kFirstTier && A.log_min_tiles != 0xFFFFFFFFu && k < A.log_seeds) ? uni(A.log_len[k]) : 0u;
+    const uint32_t log_w = (kFirstTier && A.log_min_tiles != 0xFFFFFFFFu && k < A.log_seeds) ? uni(A.log_len[k]) : 0u;
+    const uint32_t log_n = log_w & ~kLogShrunk;
     const bool has_log = log_n != 0u && log_n <= A.log_max_len;
     const bool skip_first = (outgrown || wp_seed) && !has_log;
     if (!skip_first) {
@@ -983,7 +985,10 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
         // second tier's team of wavefronts is the faster walker from there on)
         const bool hand_over = kFirstTier && A.big_cap != 0u;
         if (has_log) {
-            rc = walk(A, k, b, thr, sn, cs, L, P, st, lane, own, nullptr, A.log_walk_tiles);
+            // (a log that the last round has already cut down to the footprint of then, and that is still twice the budget
+            // long, goes on the list at once: the walk would only find out the same, 12 steps later)
+            const bool direct = (log_w & kLogShrunk) != 0u && log_n >= 2u * A.log_walk_tiles;
+            if (!direct) rc = walk(A, k, b, thr, sn, cs, L, P, st, lane, own, nullptr, A.log_walk_tiles);
             if (rc != 0) {
                 uint32_t pos = 0;
                 if (lane == 0) pos = atomicAdd(&A.ctrl[kCtrlNMulti], 1u);
@@ -1985,7 +1990,7 @@ __global__ __launch_bounds__(kThreads) void flood_rewalk_kernel(FloodArgs A, con
     for (uint32_t ai = uni(blockIdx.x); ai < n_list; ai += gridDim.x) {
         const uint32_t k = uni(list[ai]);
         if (k >= window) continue;  // (not walked at all, like every seed above the window)
-        const uint32_t n = uni(A.log_len[k]);
+        const uint32_t n = uni(A.log_len[k]) & ~kLogShrunk;
         if (n < min_len || n > (uint32_t)kTiles) continue;  // (another instance of this kernel takes it)
         const uint32_t s = uni((uint32_t)A.seed_idx[k]);
         const uint32_t seed_label = uni(A.label[s]);
@@ -2293,7 +2298,7 @@ __global__ __launch_bounds__(kThreads) void flood_rewalk_kernel(FloodArgs A, con
         RW_TICK(7)
         if (threadIdx.x == 0) {
             A.count[k] = s_cnt;
-            A.log_len[k] = s_nout;
+            A.log_len[k] = s_nout | kLogShrunk;
             if (s_blocked) A.blocked[k] = 1u;
             A.flags[k] |= n << 8;  // (diagnostics: records looked at)
             atomicAdd(&A.ctrl[kCtrlLogWalks], 1u);
@@ -2861,13 +2866,13 @@ FloodArgs flood_args(const FloodBuffers& B, const FloodFrame& F, bool use_big) {
     A.multi_next = 0u;
     A.wp_min_tiles = (B.multi_source && B.waypoints && use_big) ? (uint32_t)std::max(wp_min_env, (int)kWpK + 1) : 0xFFFFFFFFu;
     // logs: walks of this many tiles leave one (LIBRECTIFY_FLOOD_LOG_MIN); with logs there are no way-points
-    static const int log_min_env = std::getenv("LIBRECTIFY_FLOOD_LOG_MIN") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_LOG_MIN")) : 12;
+    static const int log_min_env = std::getenv("LIBRECTIFY_FLOOD_LOG_MIN") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_LOG_MIN")) : 16;
     const bool logs = B.rewalk_logs && B.log_buf && B.log_off && B.log_len && B.multi_list;
     A.log_min_tiles = logs ? (uint32_t)std::max(log_min_env, 1) : 0xFFFFFFFFu;
     static const int log_walk_env = std::getenv("LIBRECTIFY_FLOOD_LOG_WALK") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_LOG_WALK")) : 12;
     A.log_walk_tiles = (uint32_t)std::max(log_walk_env, 3);
     static const bool log_sweep_env = std::getenv("LIBRECTIFY_FLOOD_LOG_SWEEP") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_LOG_SWEEP")) != 0;
-    A.log_sweep = log_sweep_env ? 1u : 0u;
+    A.log_sweep = (log_sweep_env || B.log_sweep) ? 1u : 0u;
     A.log_max_len = (B.rewalk_big && use_big) ? (uint32_t)kRewalkTilesBig : (uint32_t)kRewalkTiles;
     A.log_seeds = logs ? B.log_seeds : 0u;
     A.log_off = B.log_off;
@@ -2962,7 +2967,9 @@ void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& 
         (void)hipEventDestroy(dbg1);
     }
     static const int g_rounds_env = std::getenv("LIBRECTIFY_FLOOD_PARTIAL_ROUNDS") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_PARTIAL_ROUNDS")) : 1000;
-    if (B.partial_commits && index < g_rounds_env)
+    // (with the logs the later rounds' re-walks are cheap, and what the partial commits save there no longer pays their
+    // launch: 0.970 -> 0.935 ms over the four bench frames, same rounds)
+    if (B.partial_commits && index < (logs && g_rounds_env == 1000 ? 3 : g_rounds_env))
         hipLaunchKernelGGL(flood_partial_commit_kernel, dim3(grid), dim3(64), 0, s, A, act,
                            const_cast<uint8_t*>(F.dmask));
     hipLaunchKernelGGL(flood_commit_pixels_kernel, dim3(pix_blocks), dim3(256), 0, s, A, F.label, npix,

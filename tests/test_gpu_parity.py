@@ -313,6 +313,44 @@ def test_partial_commits_change_the_work_not_the_labels(L, ctx):
     assert stats[True]["flood_rounds"] <= stats[False]["flood_rounds"]
 
 
+def test_rewalks_from_the_logs_change_the_time_not_the_labels(L, ctx):
+    """Round 4: a finished walk of sixteen tiles or more leaves its footprint as (tile, pixels) records, and the seed's later
+    rounds work the footprint out from them -- components of the records' pixels that are still there, united across tiles in
+    LDS (kernels_flood.hip: flood_rewalk_kernel) -- instead of walking again.  Label image and records against the oracle
+    with the logs off, on, and on with every log through the fall-back path (sweeps); on frames of bars, long bars (logs of
+    the second tier's walks: the larger tables), regions and noise (tiles of many components: the fall-back on its own);
+    through the storage hooks.  The counters prove that each path really ran."""
+    from librectify_amd import synth
+
+    rng = np.random.RandomState(5)
+    noisy = synth.frame(1280, 720, 9, bars=30) + rng.normal(0, 0.02, size=(720, 1280)).astype(np.float32)
+    frames = (("bars", synth.frame(1920, 1080, 7)), ("long", synth.long_bar_frame(1920, 1080, 3, K=24)), ("regions", _regions(1280, 720, 4)),
+              ("noise", noisy.astype(np.float32)))
+    used = {}
+    try:
+        for name, img in frames:
+            ref = O.find_line_segments(img)
+            for logs in (1, 0, 2):
+                ctx.set_flood_logs(logs)
+                for mode in (1, 6, 7) if name in ("bars", "long") else (1,):
+                    ctx.set_flood_mode(mode)
+                    for rep in range(2):  # (the second frame on the context starts with the hints of the first)
+                        ctx.stage_filter_host(img)
+                        ctx.stage_seeds()
+                        ctx.stage_flood()
+                        used[(name, logs, mode)] = ctx.stage_counters()
+                        np.testing.assert_array_equal(ctx.download(L.BUF_LABEL), ref["label"])
+                        _assert_lines_equal(ctx.stage_fit(), ref["lines"])
+    finally:
+        ctx.set_flood_logs(1)
+        ctx.set_flood_mode(1)
+    for name, _ in frames:
+        assert used[(name, 1, 1)]["log_rewalks"] > 0 and used[(name, 0, 1)]["log_rewalks"] == 0, (name, used[(name, 1, 1)])
+        assert used[(name, 2, 1)]["log_give_ups"] == used[(name, 2, 1)]["log_rewalks"] > 0  # (the hook: every log the slow way)
+    assert used[("bars", 1, 1)]["log_give_ups"] == 0
+    assert used[("long", 1, 1)]["second_tier_seeds"] > 0
+
+
 def test_multi_source_rewalks_change_the_time_not_the_labels(L, ctx):
     """Round 4: a seed whose walk was long leaves way-points on its footprint, and its next walk starts from the seed and
     from all of them at once on a team of wavefronts, keeping what is connected to the seed (kernels_flood.hip: team_walk,
