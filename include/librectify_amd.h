@@ -147,6 +147,12 @@ void lr_set_flood_multi_source(lr_context* ctx, int on);
  * LIBRECTIFY_FLOOD_LOGS=0 turns it off for every new context; lr_stage_counters [11], [12] count the logs worked on and
  * those that took the fall-back path. */
 void lr_set_flood_logs(lr_context* ctx, int on);
+/* Single calls enqueue the flood's first rounds blindly (what the context's last frame needed, less one) and every further
+ * round only when the host has seen -- in page-locked words the last workgroup of a round writes -- that seeds are left: no
+ * launch behind the last round with work (the blind rounds of a 4K frame were 60-120 us of empty launches); the calling
+ * thread polls while the flood runs.  On by default; the lanes of a batch call enqueue blindly as before (what
+ * lr_set_flood_blind_rounds steers).  0 = blind rounds for single calls too.  LIBRECTIFY_FLOOD_JIT=0 likewise. */
+void lr_set_flood_just_in_time(lr_context* ctx, int on);
 
 /* ---- stage API (tests, bench) --------------------------------------------------------- */
 /* Stage 1: fused 5x5 derivative filter + magnitude + direction bin + dilated-bin mask +

@@ -70,7 +70,7 @@ EXPORTS = [
     "lr_stage_counters", "lr_filter_kernel_ms", "lr_ransac_best", "lr_estimate_line_pencils",
     "lr_find_line_segment_groups_batch_host", "lr_find_line_segment_groups_batch_host_ptrs", "lr_host_alloc", "lr_host_free",
     "lr_set_seed_capacity", "lr_set_flood_blind_rounds", "lr_set_flood_staged", "lr_set_batch_streams", "lr_device_malloc", "lr_device_free", "lr_memcpy_h2d", "lr_cht_vanishing_point", "lr_refine_lines", "lr_set_estimator", "lr_ht_weights", "lr_prosac_solve", "lr_estimate_line_pencils_prosac", "lr_direct_solve", "lr_estimate_line_pencils_direct",
-    "lr_estimate_line_pencils_cht", "lr_set_stage_timing", "lr_release_thread_context", "lr_set_flood_partial_commits", "lr_set_flood_multi_source", "lr_set_flood_logs",
+    "lr_estimate_line_pencils_cht", "lr_set_stage_timing", "lr_release_thread_context", "lr_set_flood_partial_commits", "lr_set_flood_multi_source", "lr_set_flood_logs", "lr_set_flood_just_in_time",
     "lr_find_line_segment_groups_batch_host_multi",
 ]
 
@@ -152,6 +152,8 @@ def lib():
         L.lr_set_flood_multi_source.restype = None
         L.lr_set_flood_logs.argtypes = [C.c_void_p, C.c_int]
         L.lr_set_flood_logs.restype = None
+        L.lr_set_flood_just_in_time.argtypes = [C.c_void_p, C.c_int]
+        L.lr_set_flood_just_in_time.restype = None
         L.lr_release_thread_context.argtypes = []
         L.lr_release_thread_context.restype = None
         L.lr_set_stage_timing.argtypes = [C.c_void_p, C.c_int]
@@ -409,6 +411,9 @@ class Context:
 
     def set_flood_multi_source(self, on=True):
         lib().lr_set_flood_multi_source(self._h, int(bool(on)))
+
+    def set_flood_just_in_time(self, on=True):
+        lib().lr_set_flood_just_in_time(self._h, int(bool(on)))
 
     def set_flood_logs(self, on=1):
         """0 = off, 1 = on (default for single calls), 2 = on with every log through the fall-back path (test hook)."""

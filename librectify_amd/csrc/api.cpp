@@ -225,6 +225,7 @@ void lr_set_flood_staged(lr_context* ctx, int on) { ctx->flood_staged = on != 0;
 void lr_set_flood_blind_rounds(lr_context* ctx, int rounds) { ctx->flood_rounds_hint = rounds; }
 void lr_set_flood_partial_commits(lr_context* ctx, int on) { ctx->flood_partial = on != 0; }
 void lr_set_flood_multi_source(lr_context* ctx, int on) { ctx->flood_multi = on != 0; }
+void lr_set_flood_just_in_time(lr_context* ctx, int on) { ctx->flood_jit = on != 0; }
 void lr_set_flood_logs(lr_context* ctx, int on) {
     ctx->flood_logs = on != 0;
     ctx->flood_log_sweep = on == 2;

@@ -149,6 +149,8 @@ struct lr_context {
     uint32_t n_seeds = 0, n_comp = 0, n_px = 0;
     int flood_rounds = 0;
     int flood_rounds_hint = 10;  // rounds the next flood enqueues blindly
+    int flood_rounds_last = 0;   // rounds the last flood needed (0: none yet)
+    bool flood_jit = true;       // single calls enqueue the flood's later rounds just in time (kernels_flood.hip: flood_enqueue); LIBRECTIFY_FLOOD_JIT=0
     uint64_t ransac_seed = 0;
     int ransac_iters = lramd::kRansacMaxIter;
     int flood_mode = 1;

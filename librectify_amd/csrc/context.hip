@@ -804,6 +804,10 @@ FloodBuffers flood_buffers_for(lr_context* c) {
     }
     if (c->flood_staged) fbuf.win_first_shift = 3;
     fbuf.blind_rounds = c->flood_rounds_hint;
+    // rounds just in time (FloodBuffers::host_progress): what the last frame needed less one at once (three on a new context)
+    static const bool jit_off = std::getenv("LIBRECTIFY_FLOOD_JIT") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_JIT")) == 0;
+    fbuf.host_progress = c->h_counts + 48;
+    fbuf.jit_first = (c->flood_jit && !jit_off) ? (c->flood_rounds_last > 0 ? std::max(c->flood_rounds_last - 1, 2) : 3) : 0;
     return fbuf;
 }
 
@@ -910,6 +914,7 @@ int finish_flood(lr_context* c, bool* extra) {
     static const int blind_extra = std::getenv("LIBRECTIFY_BLIND_EXTRA") ? std::atoi(std::getenv("LIBRECTIFY_BLIND_EXTRA")) : 2;  // (experiment knob)
     static const int blind_min = std::getenv("LIBRECTIFY_BLIND_MIN") ? std::atoi(std::getenv("LIBRECTIFY_BLIND_MIN")) : 6;
     c->flood_rounds_hint = std::max(std::max(c->flood_rounds + blind_extra, blind_min), c->flood_rounds_hint - 1);
+    c->flood_rounds_last = c->flood_rounds;
     return 0;
 }
 
@@ -2206,6 +2211,7 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
     for (int i = 0; i < S - 1; ++i) lanes.push_back(c->workers[i]);
     const bool caller_multi = c->flood_multi;  // (lane 0 is the caller's own context: its setting comes back after the call)
     const bool caller_logs = c->flood_logs;
+    const bool caller_jit = c->flood_jit;
     for (lr_context* l : lanes) {
         l->ransac_seed = c->ransac_seed;
         l->ransac_iters = c->ransac_iters;
@@ -2223,6 +2229,7 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
         static const bool logs_lanes = std::getenv("LIBRECTIFY_FLOOD_LOGS_LANES") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_LOGS_LANES")) != 0;
         l->flood_logs = caller_logs && (S == 1 || logs_lanes);
         l->flood_log_sweep = c->flood_log_sweep;
+        l->flood_jit = caller_jit && S == 1;  // (a lane's thread has frames to stage and results to read: it does not poll)
         l->estimator = c->estimator;
         l->prosac_T_N = c->prosac_T_N;
         l->cht_d = c->cht_d;
@@ -2399,6 +2406,7 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
     for (lr_context* l : lanes) l->sleep_in_wait = false;
     c->flood_multi = caller_multi;
     c->flood_logs = caller_logs;
+    c->flood_jit = caller_jit;
     for (int si = 0; si < S; ++si)
         if (rc[si]) {
             set_error(err[si]);

@@ -214,11 +214,14 @@ def test_hough_weights_and_prosac_match_oracle(L, ctx):
 def test_second_laps_of_the_one_wait_pipeline_are_exact(L, ctx):
     """A frame is one chain of kernels with one host wait; two things make it take a second lap, both detected after
     that wait: more seeds than the seed sort was sized for, and a flood that needs more rounds than were enqueued
-    blindly.  Both forced here (and both at once), full path against the oracle; then the next frame runs in one lap."""
+    blindly.  Both forced here (and both at once), full path against the oracle; then the next frame runs in one lap.
+    (Blind rounds are what the lanes of a batch call enqueue; a single call enqueues its later rounds just in time --
+    switched off here, and checked against the same records at the end.)"""
     img = FRAMES["640x480"]
     ref, _ = O.find_line_segment_groups(img, 6.4, seed=0)
     ctx.set_seed(0)
     ctx.set_flood_mode(1)
+    ctx.set_flood_just_in_time(False)
     _assert_lines_equal(ctx.find_line_segment_groups(img, 6.4), ref)
     n_seeds = ctx.stage_counters()["seeds"]
     rounds = ctx.stage_counters()["flood_rounds"]
@@ -238,6 +241,11 @@ def test_second_laps_of_the_one_wait_pipeline_are_exact(L, ctx):
     assert ctx.stage_seeds() == n_seeds
     ctx.stage_flood()
     np.testing.assert_array_equal(ctx.download(L.BUF_LABEL), O.find_line_segments(img)["label"])
+    # just in time: however few rounds the first batch has, the frame never takes a second lap for the flood's sake
+    ctx.set_flood_just_in_time(True)
+    for _ in range(3):
+        _assert_lines_equal(ctx.find_line_segment_groups(img, 6.4), ref)
+        assert ctx.stage_counters()["frame_laps"] == 1 and ctx.stage_counters()["flood_rounds"] == rounds
 
 
 def test_seed_order_with_a_capacity_that_cuts_the_last_sort_block(L, ctx):
