@@ -205,6 +205,7 @@ struct FloodArgs {
     uint32_t* handover;                              // state of the walks handed to the second tier (FloodBuffers::handover)
     uint32_t team_tiles;                             // test hook: the team's table counts as full at this many tiles
     uint32_t hold_min_big;                           // walks in the second tier after which the hold-back engages
+    uint32_t hold_release;                           // the hold-back ends when so few seeds below the line are still active
     uint32_t t1_regional, t1_regional_min;           // ... at t1_regional tiles once the frame has had t1_regional_min walks beyond the first tier's table
     uint32_t t1_wide_tiles, t1_wide_front;           // ... or at this many tiles when its frontier holds this many records
     uint32_t* waypoints;                             // FloodBuffers::waypoints (kFloodWpWords per seed), wp_cap seeds
@@ -1903,15 +1904,23 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
 // ---- Re-walks from the log ---------------------------------------------------------------------------------------------------
 // A footprint is the connected set around the seed in {acceptable, not committed}, acceptance is static, and what borders a
 // footprint is unacceptable or committed for good: a seed's footprint can only shrink, and its next footprint is the
-// connected part around the seed of (ANY earlier footprint of it, minus the pixels committed since).  So the seeds that left
-// a log (save_log) and survive a round are listed by the survivors pass, passed over by the next round's exploration (tier
-// bit 1) and worked out here: the records' pixels are looked at once (every tile's loads in flight together: no chain of
-// dependent round trips, which is all a walk is), the components of each tile's surviving pixels become nodes (a thread a
-// tile, 64-bit masks), nodes of neighbouring tiles that touch are united (a lock-free union-find in LDS: larger root under
-// smaller, path halving), and the pixels of the nodes united with the seed's node are the footprint.  Stamps, counts and the
-// blocked marks are what a walk would have left; the log is rewritten with the new footprint.
-// More than kRwComps components in one tile, or more nodes than the table holds: the seed gives up its log and walks in the
-// next round -- in this one it counts as a walk that did not finish (nothing above it commits).
+// connected part around the seed of (ANY earlier footprint of it, minus the pixels committed since).  A walk is a chain of
+// dependent steps, one tile each, ~1.4 us a step: rounds 2-5 of the 4K bench frame lasted 134, 108, 233, 232 us for their
+// one longest re-walk (142-183 tiles) while the chip idled.  So a finished walk of log_min_tiles tiles or more leaves its
+// (tile, walked pixels) records (save_log), and in the seed's later rounds
+//  - the exploration walks log_walk_tiles tiles of it (most footprints have shrunk to a handful of tiles by their second
+//    round, and a short walk is cheaper than the records of a long one); if that is not the end of the walk the seed goes
+//    on the round's list (multi_list; a log that the last round has cut down already and is still long goes there at once),
+//  - this kernel, launched behind the exploration, works the footprint out from the records, a workgroup a seed: the
+//    records' pixels are looked at once (all tiles' loads in flight together -- no chain), the components of each tile's
+//    surviving pixels become nodes (a thread a tile, 64-bit masks), pairs of nodes of neighbouring tiles that touch are
+//    noted and then united (lock-free union-find in LDS: CAS on roots, path halving), and the pixels of the nodes united
+//    with the seed's node are the footprint.  Stamps, counts and blocked marks are what a walk would have left; the log is
+//    rewritten with the new footprint's records only.
+// Logs the tables cannot take (more than kRwComps components in a tile: noise; more nodes or pairs than there is room for)
+// go a slower way in the same launch: sweeps over the tiles' reached sets until nothing changes (see there).
+// Second-tier walks (up to 2048 tiles) leave logs too when the frame is expected to have them; a second instance of the
+// kernel with larger tables works on those.  Single 4K frames: flood 1.31 -> 0.92 ms (profiles/r04_flood_logs.txt).
 constexpr int kRwComps = 6;
 constexpr uint32_t kRwBatch = 16;  // tiles a wavefront has in flight (the pixels of a log are looked at, and stamped, with no chain between them)
 constexpr uint64_t kCol0 = 0x0101010101010101ull, kCol7 = 0x8080808080808080ull;
@@ -2393,7 +2402,7 @@ __global__ __launch_bounds__(256) void flood_commit_pixels_kernel(FloodArgs A, u
 // End of a round (one thread: the last workgroup of the survivors pass): the next list becomes the current one.  A round without progress (possible only
 // when storage ran out on the lowest active seed) stops the rounds and leaves the rest to the ordered tail.
 __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift, uint32_t regional_min, uint32_t hold_min_big,
-                              uint32_t* host_progress) {
+                              uint32_t* host_progress, uint32_t hold_release) {
     const uint32_t n_act = ld_agent(&ctrl[kCtrlNAct]);
     if (n_act == 0u) {  // (a round enqueued past the end -- or a frame without seeds: the host must not wait for more)
         if (host_progress) {
@@ -2427,7 +2436,7 @@ __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift, u
             // moved nothing (storage ran out on the lowest active seed): the full window lets the next round detect
             // the stall
             grown = window;
-            if (ld_agent(&ctrl[kCtrlBelow]) <= 64u || !moved) {
+            if (ld_agent(&ctrl[kCtrlBelow]) <= hold_release || !moved) {
                 grown = n_seeds;
                 ctrl[kCtrlPhase] = 2u;
             }
@@ -2561,7 +2570,7 @@ __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, const
         if (atomicAdd(&A.ctrl[kCtrlDone], 1u) == gridDim.x - 1u) {
             __threadfence();
             A.ctrl[kCtrlDone] = 0u;
-            flood_advance(A.ctrl, A.win_shift, A.t1_regional_min, A.hold_min_big, A.host_progress);
+            flood_advance(A.ctrl, A.win_shift, A.t1_regional_min, A.hold_min_big, A.host_progress, A.hold_release);
         }
     }
 }
@@ -2870,6 +2879,8 @@ FloodArgs flood_args(const FloodBuffers& B, const FloodFrame& F, bool use_big) {
     A.t1_regional_min = (uint32_t)std::max(t1m_env, 1);
     static const int holdmin_env = std::getenv("LIBRECTIFY_FLOOD_HOLD_MIN") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_HOLD_MIN")) : 4;
     A.hold_min_big = (uint32_t)std::max(holdmin_env, 1);
+    static const int holdrel_env = std::getenv("LIBRECTIFY_FLOOD_HOLD_RELEASE") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_HOLD_RELEASE")) : 64;
+    A.hold_release = (uint32_t)std::max(holdrel_env, 0);
     static const int t1w_env = std::getenv("LIBRECTIFY_FLOOD_T1_WIDE_TILES") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_T1_WIDE_TILES")) : 0;
     static const int t1f_env = std::getenv("LIBRECTIFY_FLOOD_T1_WIDE_FRONT") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_T1_WIDE_FRONT")) : 6;
     A.t1_wide_tiles = t1w_env > 0 ? (uint32_t)t1w_env : 0xFFFFFFFFu;
