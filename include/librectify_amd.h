@@ -207,7 +207,8 @@ int lr_filter_kernel_ms(lr_context* ctx, float* ms);
  * flood's walks were stored: [4] seeds that moved to the second LDS tier, [5] global slabs used, [6] seeds finished by
  * the ordered single-wave tail (storage exhausted); [7] laps of the frame through the pipeline (1 normally); [8] pixels
  * the flood's explorations walked in all rounds together (over [3]: the re-walk factor), [9] their 8x8-tile steps, [10] re-walks that
- * started from several way-points at once (lr_set_flood_multi_source). */
+ * started from several way-points at once (lr_set_flood_multi_source), [11] footprints worked out from a log instead of
+ * walked (lr_set_flood_logs), [12] those of them that took the fall-back path (sweeps). */
 int lr_stage_counters(lr_context* ctx, int64_t* out, int count);
 
 /* ---- RANSAC --------------------------------------------------------------------------- */

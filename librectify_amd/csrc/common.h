@@ -177,7 +177,8 @@ struct FloodBuffers {
     // -- no launch behind the last round with work (the blind rounds of a 4K frame were 60-120 us of empty launches), at
     // the price of the host's reaction time per further round.  The calling thread polls while the flood runs.
     uint32_t* host_progress = nullptr;  // page-locked, device-visible: rounds with work so far, length of the next list, stalled
-    int jit_first = 0;                  // 0: off (the lanes of a batch call: their threads have frames to stage)
+    int jit_first = 0;                  // 0: off
+    int jit_sleep_us = 0;               // the polling thread sleeps this long between looks (0: it spins -- single calls)
     uint32_t big_cap_override = 0;  // test hook: seeds per round the second tier takes (0 = the default, 8192)
     uint32_t team_tile_cap = 0;     // test hook: tiles after which the second tier's team hands a walk to a slab (0 = its table)
 };

@@ -150,6 +150,7 @@ struct lr_context {
     int flood_rounds = 0;
     int flood_rounds_hint = 10;  // rounds the next flood enqueues blindly
     int flood_rounds_last = 0;   // rounds the last flood needed (0: none yet)
+    int flood_jit_sleep_us = 0;  // (lanes of a batch call, when they enqueue just in time at all: pause between looks)
     bool flood_jit = true;       // single calls enqueue the flood's later rounds just in time (kernels_flood.hip: flood_enqueue); LIBRECTIFY_FLOOD_JIT=0
     uint64_t ransac_seed = 0;
     int ransac_iters = lramd::kRansacMaxIter;

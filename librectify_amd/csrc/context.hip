@@ -807,6 +807,7 @@ FloodBuffers flood_buffers_for(lr_context* c) {
     // rounds just in time (FloodBuffers::host_progress): what the last frame needed less one at once (three on a new context)
     static const bool jit_off = std::getenv("LIBRECTIFY_FLOOD_JIT") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_JIT")) == 0;
     fbuf.host_progress = c->h_counts + 48;
+    fbuf.jit_sleep_us = c->flood_jit_sleep_us;
     fbuf.jit_first = (c->flood_jit && !jit_off) ? (c->flood_rounds_last > 0 ? std::max(c->flood_rounds_last - 1, 2) : 3) : 0;
     return fbuf;
 }
@@ -2229,7 +2230,14 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
         static const bool logs_lanes = std::getenv("LIBRECTIFY_FLOOD_LOGS_LANES") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_LOGS_LANES")) != 0;
         l->flood_logs = caller_logs && (S == 1 || logs_lanes);
         l->flood_log_sweep = c->flood_log_sweep;
-        l->flood_jit = caller_jit && S == 1;  // (a lane's thread has frames to stage and results to read: it does not poll)
+        // (a lane's thread has nothing else to do while its frame is in flight, but the call's staging threads need the cores:
+        // a lane looks at the words every few tens of microseconds instead of spinning -- the other lanes keep the GPU busy)
+        // Measured (profiles/r04_flood_logs.txt, section 9): 9.93 -> 10.29 Gpix/s from pageable frames, 11.7 -> 12.1 from
+        // resident ones -- a frame of a lane no longer drags 3-4 rounds of empty launches through its stream.
+        // LIBRECTIFY_FLOOD_JIT_LANES = microseconds between looks (20); 0 = blind rounds.
+        static const int jit_lanes = std::getenv("LIBRECTIFY_FLOOD_JIT_LANES") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_JIT_LANES")) : 20;
+        l->flood_jit = caller_jit && (S == 1 || jit_lanes > 0);
+        l->flood_jit_sleep_us = S == 1 ? 0 : jit_lanes;
         l->estimator = c->estimator;
         l->prosac_T_N = c->prosac_T_N;
         l->cht_d = c->cht_d;
@@ -2407,6 +2415,7 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
     c->flood_multi = caller_multi;
     c->flood_logs = caller_logs;
     c->flood_jit = caller_jit;
+    c->flood_jit_sleep_us = 0;
     for (int si = 0; si < S; ++si)
         if (rc[si]) {
             set_error(err[si]);

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -2993,10 +2994,11 @@ void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& 
         (void)hipEventDestroy(dbg0);
         (void)hipEventDestroy(dbg1);
     }
-    static const int g_rounds_env = std::getenv("LIBRECTIFY_FLOOD_PARTIAL_ROUNDS") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_PARTIAL_ROUNDS")) : 1000;
-    // (with the logs the later rounds' re-walks are cheap, and what the partial commits save there no longer pays their
-    // launch: 0.970 -> 0.935 ms over the four bench frames, same rounds)
-    if (B.partial_commits && index < (logs && g_rounds_env == 1000 ? 3 : g_rounds_env))
+    static const int g_rounds_env = std::getenv("LIBRECTIFY_FLOOD_PARTIAL_ROUNDS") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_PARTIAL_ROUNDS")) : 3;
+    // (only in the first three rounds: with the logs the later rounds' re-walks are cheap, and what the partial commits save
+    // there no longer pays their launch -- 0.970 -> 0.935 ms over the four bench frames, same rounds; and the lanes of a batch
+    // are better off with a launch less per late round: 9.81 -> 9.99 Gpix/s)
+    if (B.partial_commits && index < g_rounds_env)
         hipLaunchKernelGGL(flood_partial_commit_kernel, dim3(grid), dim3(64), 0, s, A, act,
                            const_cast<uint8_t*>(F.dmask));
     hipLaunchKernelGGL(flood_commit_pixels_kernel, dim3(pix_blocks), dim3(256), 0, s, A, F.label, npix,
@@ -3081,7 +3083,8 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
                 n_left = __atomic_load_n(&B.host_progress[1], __ATOMIC_RELAXED);
                 stalled = __atomic_load_n(&B.host_progress[2], __ATOMIC_RELAXED);
                 if ((int)done_rounds + lead >= P->enqueued || (done_rounds > 0u && n_left == 0u)) break;
-                if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(1)) {
+                if (B.jit_sleep_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(B.jit_sleep_us));
+                if ((++spins & (B.jit_sleep_us > 0 ? 15 : 1023)) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(1)) {
                     timed_out = true;
                     break;
                 }
