@@ -471,8 +471,9 @@ def main(argv=None):
                     help="run only the roofline leg (the filter kernel alone): the command profiled for "
                          "profiles/*_kernel_stats_roofline_leg.csv, where rocprofv3's average must agree with kernel_ms")
     ap.add_argument("--flood-mode", type=int, default=None)
-    ap.add_argument("--streams", type=int, default=6, help="frames in flight per GPU (one context + HIP stream + host thread each); "
-                    "more than a handful only dilutes the 256 MB Infinity Cache that the flood's gathers live on")
+    ap.add_argument("--streams", type=int, default=5, help="frames in flight per GPU (one context + HIP stream + host thread each); "
+                    "more than a handful only dilutes the 256 MB Infinity Cache that the flood's gathers live on "
+                    "(round 4, with the lanes' rounds just in time: 4 / 5 / 6 / 7 lanes = 9.8 / 10.4 / 10.3 / 10.3 Gpix/s)")
     ap.add_argument("--staging-threads", type=int, default=12, help="host threads that stage pageable frames (num_threads of the batch call); "
                     "capped at this rank's share of the host cores")
     ap.add_argument("--dry-run-spawn", action="store_true", help="with --gpus N > 1 and no WORLD_SIZE: print the launch command instead of running it")

@@ -116,7 +116,7 @@ int lr_host_free(lr_context* ctx, void* p);
 int lr_device_malloc(lr_context* ctx, size_t bytes, void** out);
 int lr_device_free(lr_context* ctx, void* p);
 int lr_memcpy_h2d(lr_context* ctx, void* dst, const void* src, size_t bytes);
-/* Frames kept in flight by the batch call (one host thread + HIP stream + workspace each; default 4). */
+/* Frames kept in flight by the batch call (one host thread + HIP stream + workspace each; default 5). */
 void lr_set_batch_streams(lr_context* ctx, int n);
 /* Test hooks for the two situations in which a frame takes a second lap (lr_stage_counters [7] tells): the capacity
  * the NEXT frame's seed sort starts with (normally 1.5 x the previous frame's seed count; a frame with more seeds is

@@ -133,7 +133,7 @@ struct lr_context {
     std::vector<int> prosac_imin;    // prosac.h's Imin(2, n) by n (constants of prosac.h:62-66 only)
     std::vector<lr_context*> workers;  // extra contexts (own stream + workspace) for frames in flight in batch calls
     std::vector<lr_context*> peers;    // one context per entry of the device list of the last multi-device batch call (each with its own lanes)
-    int batch_streams = 4;
+    int batch_streams = 5;
     int estimator = 0;            // 0 = RANSAC (reference default), 1 = PROSAC, 2 = DirectEstimator, 3 = diamond space (CHT)
     int prosac_T_N = -1;
     // pinned host scalars

@@ -1954,7 +1954,7 @@ __device__ __forceinline__ void rw_union(uint32_t* par, uint32_t a, uint32_t b) 
     }
 }
 constexpr int kRewalkTiles = 256;       // records a single wavefront's tables hold (the first tier's walks: 192 tiles at most)
-constexpr uint32_t kRewalkGrid = 8192;  // workgroups of a launch: one per entry of the list (kBigCap)
+constexpr uint32_t kRewalkGrid = 2048;  // workgroups of a launch (they stride over the list: round two of a 4K frame has ~1 800 entries; empty workgroups cost the dispatcher)
 constexpr int kRewalkThreads = 256;
 constexpr int kRewalkTilesBig = 2048, kRewalkThreadsBig = 1024;  // the second tier's walks (its team's table: 1536 tiles)
 template <int kTiles>
