@@ -1959,8 +1959,9 @@ constexpr int kRewalkThreads = 256;
 constexpr int kRewalkTilesBig = 2048, kRewalkThreadsBig = 1024;  // the second tier's walks (its team's table: 1536 tiles)
 template <int kTiles>
 constexpr size_t rewalk_lds_bytes() {
+    // records 3 words, table keys 2, nodes 2 x 3, pairs 4 words a tile; table indices 2, first node 1 half-words; components 1 byte
     return (size_t)kTiles * 3 * 4 + (size_t)2 * kTiles * 4 + (size_t)2 * kTiles * 3 * 4 + (size_t)4 * kTiles * 4 + (size_t)2 * kTiles * 2 +
-           (size_t)2 * kTiles * 2 + (size_t)kTiles * 2 + (size_t)kTiles;
+           (size_t)kTiles * 2 + (size_t)kTiles;
 }
 #ifdef LR_REWALK_TIMING
 // Diagnostic build (LR_EXTRA_FLAGS=-DLR_REWALK_TIMING, printed by LIBRECTIFY_FLOOD_DEBUG): [0] seeds, [1] records, then
@@ -1990,8 +1991,7 @@ __global__ __launch_bounds__(kThreads) void flood_rewalk_kernel(FloodArgs A, con
     uint32_t* par = nhi + kNodes;    // parent
     uint32_t* edge = par + kNodes;   // pairs of touching nodes
     uint16_t* hidx = reinterpret_cast<uint16_t*>(edge + kEdges);
-    uint16_t* ntile = hidx + kHash;  // (unused but by the diagnostics: the node's record)
-    uint16_t* tfirst = ntile + kNodes;
+    uint16_t* tfirst = hidx + kHash;
     uint8_t* tcomp = reinterpret_cast<uint8_t*>(tfirst + kTiles);
     __shared__ uint32_t s_nnodes, s_over, s_blocked, s_cnt, s_seed_node, s_nout, s_nedges;
     const int lane = threadIdx.x & 63, wave = (int)uni(threadIdx.x >> 6);
@@ -2100,7 +2100,6 @@ __global__ __launch_bounds__(kThreads) void flood_rewalk_kernel(FloodArgs A, con
                 nlo[first + c] = (uint32_t)comp[c];
                 nhi[first + c] = (uint32_t)(comp[c] >> 32);
                 par[first + c] = first + (uint32_t)c;
-                ntile[first + c] = (uint16_t)t;
                 if (tid[t] == seed_tile && (comp[c] & seed_bit)) s_seed_node = first + (uint32_t)c;
             }
         }
