@@ -150,8 +150,9 @@ void lr_set_flood_logs(lr_context* ctx, int on);
 /* Single calls enqueue the flood's first rounds blindly (what the context's last frame needed, less one) and every further
  * round only when the host has seen -- in page-locked words the last workgroup of a round writes -- that seeds are left: no
  * launch behind the last round with work (the blind rounds of a 4K frame were 60-120 us of empty launches); the calling
- * thread polls while the flood runs.  On by default; the lanes of a batch call enqueue blindly as before (what
- * lr_set_flood_blind_rounds steers).  0 = blind rounds for single calls too.  LIBRECTIFY_FLOOD_JIT=0 likewise. */
+ * thread polls while the flood runs (a single call spins; a lane of a batch call looks every 20 us).  On by default.
+ * 0 = blind rounds (the previous frame's count plus two: what lr_set_flood_blind_rounds steers), and a frame whose flood
+ * needs more takes a second lap (lr_stage_counters [7]).  LIBRECTIFY_FLOOD_JIT=0 likewise. */
 void lr_set_flood_just_in_time(lr_context* ctx, int on);
 
 /* ---- stage API (tests, bench) --------------------------------------------------------- */
