@@ -142,6 +142,7 @@ struct FloodBuffers {
     // of (last footprint minus committed pixels): a finished walk leaves its (tile, pixels) records here, and the later
     // rounds label the components of those records in LDS -- no dependent chain of memory round trips.
     bool rewalk_logs = false;
+    bool giant_hold = false;   // only the lowest active seed walks on into a global slab; other walks that outgrow the second tier are held back (kernels_flood.hip: kCtrlLowest)
     bool log_sweep = false;    // test hook: the fall-back (sweeps) for every log
     bool rewalk_big = false;   // the frame is expected to have walks beyond the first tier: their logs are kept too, and a second launch per round works on them
     uint32_t log_seeds = 0, log_cap = 0;
@@ -204,7 +205,7 @@ struct FloodProgress {
     bool use_big = false;
     int win_growth = 2;
 };
-constexpr int kFloodCtrlWords = 32;
+constexpr int kFloodCtrlWords = 40;
 // Enqueues the initialisation and a first batch of rounds, then an asynchronous copy of the control block into
 // h_ctrl (kFloodCtrlWords words of pinned host memory).  Never synchronises (except in LIBRECTIFY_FLOOD_DEBUG mode).
 int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, uint32_t* h_ctrl, hipStream_t s);

@@ -158,7 +158,7 @@ struct lr_context {
     bool flood_logbig_hint = true;  // did the last frame have walks in the second tier? (their logs need a launch of their own per round: kernels_flood.hip, flood_rewalk_kernel)
     bool flood_big_hint = true;  // did the last frame's walks outgrow the first storage tier? (none yet: assume so)
     bool flood_hold_hint = false;  // did the last frame hold its weakest seeds back?
-    uint32_t flood_tiers[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // last flood: seeds in the second tier, slabs used, seeds of the ordered tail, hold-back, walked px (lo, hi), steps (lo, hi), walks beyond the first tier's table, multi-source re-walks, re-walks from logs, logs given up
+    uint32_t flood_tiers[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // last flood: seeds in the second tier, slabs used, seeds of the ordered tail, hold-back, walked px (lo, hi), steps (lo, hi), walks beyond the first tier's table, multi-source re-walks, re-walks from logs, logs given up, giants held back
     bool flood_partial = true;  // partial commits of blocked seeds (kernels_flood.hip); lr_set_flood_partial_commits
     bool flood_log_sweep = false;  // test hook (lr_set_flood_logs(ctx, 2)): every footprint worked out from a log goes the fall-back way (sweeps)
     bool flood_logs = true;     // blocked seeds work their next footprint out from the records of their last walk (kernels_flood.hip: flood_rewalk_kernel); lr_set_flood_logs, LIBRECTIFY_FLOOD_LOGS=0

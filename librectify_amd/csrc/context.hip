@@ -793,6 +793,8 @@ FloodBuffers flood_buffers_for(lr_context* c) {
     fbuf.multi_source = c->flood_multi;
     fbuf.rewalk_logs = c->flood_logs && !c->flood_multi;  // (way-points, when asked for, instead)
     fbuf.log_sweep = c->flood_log_sweep;
+    static const bool giants_off = std::getenv("LIBRECTIFY_FLOOD_GIANTS") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_GIANTS")) == 0;
+    fbuf.giant_hold = c->flood_mode == 1 && !giants_off;  // (the storage test hooks -- modes 2-7 -- keep their slabs)
     fbuf.rewalk_big = c->flood_logbig_hint;  // (the context's last frame had walks beyond the first tier)
     static const int aux_env = std::getenv("LIBRECTIFY_FLOOD_MULTI_BESIDE") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_MULTI_BESIDE")) : -1;  // (experiment: 0 = after the exploration, N = beside it in rounds 2 .. N + 1)
     if (c->flood_aux && c->flood_aux_on && aux_env != 0 && c->flood_fork.size() == c->flood_join.size()) {
@@ -806,7 +808,7 @@ FloodBuffers flood_buffers_for(lr_context* c) {
     fbuf.blind_rounds = c->flood_rounds_hint;
     // rounds just in time (FloodBuffers::host_progress): what the last frame needed less one at once (three on a new context)
     static const bool jit_off = std::getenv("LIBRECTIFY_FLOOD_JIT") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_JIT")) == 0;
-    fbuf.host_progress = c->h_counts + 48;
+    fbuf.host_progress = c->h_counts + 60;  // (the control block's copy ends at + 56)
     fbuf.jit_sleep_us = c->flood_jit_sleep_us;
     fbuf.jit_first = (c->flood_jit && !jit_off) ? (c->flood_rounds_last > 0 ? std::max(c->flood_rounds_last - 1, 2) : 3) : 0;
     return fbuf;

@@ -175,6 +175,7 @@ constexpr uint32_t kWpMaxTiles = 600u;   // the team's table holds an entry per 
 constexpr uint32_t kSrcShift = 28u, kSrcMask = 0xF0000000u, kSrcClaim = 0xF0000000u;  // table keys of a multi-source walk
 constexpr uint32_t kBigCap = 8192;  // seeds per round that can move to the second tier (FloodBuffers::big_list)
 constexpr uint32_t kFlagIncomplete = 1u, kFlagSelfFail = 2u;
+constexpr uint32_t kGiantProbes = 512u;  // marked seeds a round lets walk again (one team each: a launch's worth)
 constexpr uint32_t kLogShrunk = 0x80000000u;  // FloodArgs::log_len: the log has been cut down to a later footprint by flood_rewalk_kernel
 constexpr uint32_t kMaxSteps = 1u << 22;  // safety net of the walk loop: more records than an 8K frame has tile visits
 
@@ -221,6 +222,7 @@ struct FloodArgs {
     uint32_t log_max_len;                            // logs of at most this many records are written and used (what the launched kernels' tables hold)
     uint32_t log_sweep;                              // test hook: every footprint is worked out by sweeps (flood_rewalk_kernel)
     uint32_t* host_progress;                         // FloodBuffers::host_progress (nullptr: nobody is looking)
+    uint32_t giant_hold;                             // 1: only the lowest active seed walks on into a slab (see kCtrlLowest)
     uint32_t log_seeds;                              // seeds with per-seed words below (FloodBuffers::log_seeds)
     uint32_t* log_off;                               // first record of the seed's log ...
     uint32_t* log_len;                               // ... and their number (0: none)
@@ -267,7 +269,21 @@ enum {
     kCtrlLogTotal = 28,  // footprint-log records handed out this frame
     kCtrlLogWalks = 29,  // re-walks from logs (diagnostics: lr_stage_counters [11])
     kCtrlLogGiveUp = 30, // ... that gave their log up (tables too small) [12]
-    kCtrlWords = 32,
+    // Giants (round 4): a walk that outgrows even the second tier's table (1536 tiles: a region of ~100 000 pixels) used to
+    // move into a global slab at once -- and on a frame of smooth ramps hundreds of weak seeds share one such region, each
+    // walking all of it in every round (a 4K ramp frame: 390 M pixels walked for 3.4 M labelled, 288 ms).  Now only the
+    // LOWEST active seed may go on into a slab; any other is marked (tier bit 2), counts as a walk that did not finish, and
+    // the window closes in front of the lowest marked seed until everything below it is resolved -- then it is the lowest
+    // active seed, walks alone and commits, and takes the other marked seeds of its region with it unwalked.  Any prefix
+    // of the seed order is a valid window, so this is the hold-back with a line the frame finds for itself.
+    kCtrlLowest = 31,        // lowest active seed of the current round's list
+    kCtrlLowestNext = 32,    // ... of the next round's (survivors pass)
+    kCtrlGiantLow = 33,      // lowest active marked seed (0xFFFFFFFF: none)
+    kCtrlGiantLowNext = 34,
+    kCtrlGiantRuled = 35,    // 1: the current round's window was cut by this rule
+    kCtrlGiants = 36,        // walks held back this way over the frame (diagnostics: lr_stage_counters [13])
+    kCtrlGiantCountNext = 37,  // marked seeds among the survivors (survivors pass)
+    kCtrlWords = 40,
 };
 static_assert(kCtrlWords == kFloodCtrlWords, "control block size");
 
@@ -1720,6 +1736,17 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
         WalkState st{0u, 0u, 0u, 0u, false, 0u, 0u};
         uint32_t px = 0u;
         bool in_slab = false;
+        if (rc != 0 && A.giant_hold != 0u && k != uni(A.ctrl[kCtrlLowest])) {
+            // LDS exhausted, and this is not the lowest active seed: a giant, held back (see kCtrlLowest).  Nothing has been
+            // stamped; the seed counts as a walk that did not finish, so nothing above it commits in this round.
+            if (threadIdx.x == 0) {
+                A.tier[k] = (uint8_t)(A.tier[k] | 4u);
+                A.flags[k] = kFlagIncomplete;
+                atomicMin(&A.ctrl[kCtrlBarrier], k);
+                atomicAdd(&A.ctrl[kCtrlGiants], 1u);
+            }
+            continue;
+        }
         if (rc != 0) {
             // LDS exhausted.  The whole team moves into a global slab and goes on there (TeamGlobalStore), from the records
             // that are still unprocessed; nothing has been stamped yet, the table travels.
@@ -1883,6 +1910,8 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
         if (!did_multi && !in_slab && rc == 0 && wp_hdr == 0u && k < A.wp_cap && st.ntiles >= A.wp_min_tiles && st.ntiles <= kWpMaxTiles &&
             st.cnt <= kWpThinPx * st.ntiles)
             save_waypoints(A, k, S, st.ntiles, lane);
+        // a marked giant whose footprint fits by now is an ordinary seed again
+        if (rc == 0 && lane == 0 && (A.tier[k] & 4u)) A.tier[k] = (uint8_t)(A.tier[k] & ~4u);
         // ... and its records (save_log), for flood_rewalk_kernel
         if (!did_multi && !in_slab && rc == 0 && st.ntiles >= A.log_min_tiles && st.ntiles <= A.log_max_len && k < A.log_seeds &&
             uni(A.log_len[k]) == 0u)
@@ -2442,6 +2471,34 @@ __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift, u
             }
         }
     }
+    // giants: the window closes in front of the lowest marked seed until that seed is the lowest active one
+    {
+        const uint32_t lowest = ld_agent(&ctrl[kCtrlLowestNext]), giant = ld_agent(&ctrl[kCtrlGiantLowNext]);
+        // (a round under the rule that moved nothing -- the lowest seed's walk ran out of slabs -- is followed by one without
+        // it, so that the full window can show the stall)
+        const bool skip_rule = ld_agent(&ctrl[kCtrlGiantRuled]) != 0u && !moved;
+        bool ruled = false;
+        if (giant != 0xFFFFFFFFu && !skip_rule) {
+            // The window ends behind the lowest marked seed plus room for about kGiantProbes marked seeds more (their density
+            // over the rest of the order taken as even): those walk again up to the team's table -- most fit by now, what the
+            // seeds below them have committed is gone from their footprints -- and are ordinary seeds from then on; one that
+            // still does not fit stays marked (and is the round's barrier).  Only as the lowest active seed may it go on.
+            const uint32_t n_marked = max(ld_agent(&ctrl[kCtrlGiantCountNext]), 1u);
+            const unsigned long long rest = n_seeds > giant ? (unsigned long long)(n_seeds - giant) : 1ull;
+            const unsigned long long line = (unsigned long long)giant + 1ull + (unsigned long long)kGiantProbes * rest / n_marked;
+            (void)lowest;
+            if (line < grown) {
+                grown = line;
+                ruled = true;
+            }
+        }
+        ctrl[kCtrlGiantRuled] = ruled ? 1u : 0u;
+        ctrl[kCtrlLowest] = lowest;
+        ctrl[kCtrlGiantLow] = giant;
+        ctrl[kCtrlLowestNext] = 0xFFFFFFFFu;
+        ctrl[kCtrlGiantLowNext] = 0xFFFFFFFFu;
+        ctrl[kCtrlGiantCountNext] = 0u;
+    }
     ctrl[kCtrlWindow] = (uint32_t)grown;
     ctrl[kCtrlBelow] = 0u;
     ctrl[kCtrlRounds] = ld_agent(&ctrl[kCtrlRounds]) + 1u;
@@ -2510,7 +2567,7 @@ __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, const
                     // A survivor that left way-points on a long footprint: the coming round walks it from all of them at once
                     // (team_walk, kMulti) in a launch of its own BESIDE the round's exploration, which passes it over (tier
                     // bit 1).  (A few hundred such seeds a round at most: one atomic each.)
-                    uint8_t t = (uint8_t)(A.tier[k] & 1u);
+                    uint8_t t = (uint8_t)(A.tier[k] & 5u);  // (bit 0: outgrew the first tier; bit 2: a giant, held back)
                     if (A.multi_next != 0u && k < window && k < A.wp_cap) {
                         const uint32_t hdr = A.waypoints[(size_t)k * kFloodWpWords];
                         if (hdr != 0u && (hdr >> 8) <= kWpMaxTiles) {
@@ -2531,6 +2588,21 @@ __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, const
         for (int off = 32; off >= 1; off >>= 1) {
             wpx += (uint32_t)__shfl_xor((int)wpx, off);
             wst += (uint32_t)__shfl_xor((int)wst, off);
+        }
+        // lowest survivor, and lowest survivor that is marked as a giant (the coming round's window: flood_advance)
+        uint32_t kmin = a ? k : 0xFFFFFFFFu, gmin = (a && (A.tier[k] & 4u)) ? k : 0xFFFFFFFFu;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off));
+            gmin = min(gmin, (uint32_t)__shfl_xor((int)gmin, off));
+        }
+        const uint64_t mg = __ballot(a && (A.tier[k] & 4u));
+        if (lane == 0) {
+            if (kmin != 0xFFFFFFFFu) atomicMin(&A.ctrl[kCtrlLowestNext], kmin);
+            if (gmin != 0xFFFFFFFFu) {
+                atomicMin(&A.ctrl[kCtrlGiantLowNext], gmin);
+                atomicAdd(&A.ctrl[kCtrlGiantCountNext], (uint32_t)__popcll(mg));
+            }
         }
         if (lane == 0) {
             s_cnt[wave][0] = (uint32_t)__popcll(m);
@@ -2609,6 +2681,13 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
         ctrl[kCtrlMulti] = 0u;
         ctrl[kCtrlNMulti] = 0u;
         ctrl[kCtrlNMultiNext] = 0u;
+        ctrl[kCtrlLowest] = 0u;
+        ctrl[kCtrlLowestNext] = 0xFFFFFFFFu;
+        ctrl[kCtrlGiantLow] = 0xFFFFFFFFu;
+        ctrl[kCtrlGiantLowNext] = 0xFFFFFFFFu;
+        ctrl[kCtrlGiantRuled] = 0u;
+        ctrl[kCtrlGiantCountNext] = 0u;
+        ctrl[kCtrlGiants] = 0u;
         ctrl[kCtrlLogTotal] = 0u;
         ctrl[kCtrlLogWalks] = 0u;
         ctrl[kCtrlLogGiveUp] = 0u;
@@ -2901,6 +2980,7 @@ FloodArgs flood_args(const FloodBuffers& B, const FloodFrame& F, bool use_big) {
     static const bool log_sweep_env = std::getenv("LIBRECTIFY_FLOOD_LOG_SWEEP") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_LOG_SWEEP")) != 0;
     A.log_sweep = (log_sweep_env || B.log_sweep) ? 1u : 0u;
     A.host_progress = (B.jit_first > 0 && !g_flood_debug) ? B.host_progress : nullptr;
+    A.giant_hold = B.giant_hold ? 1u : 0u;
     A.log_max_len = (B.rewalk_big && use_big) ? (uint32_t)kRewalkTilesBig : (uint32_t)kRewalkTiles;
     A.log_seeds = logs ? B.log_seeds : 0u;
     A.log_off = B.log_off;
@@ -3167,6 +3247,7 @@ int flood_finish(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, u
         tiers_out[9] = h_ctrl[kCtrlMulti];
         tiers_out[10] = h_ctrl[kCtrlLogWalks];
         tiers_out[11] = h_ctrl[kCtrlLogGiveUp];
+        tiers_out[12] = h_ctrl[kCtrlGiants];
     }
     return 0;
 }

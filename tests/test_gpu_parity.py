@@ -359,6 +359,44 @@ def test_rewalks_from_the_logs_change_the_time_not_the_labels(L, ctx):
     assert used[("long", 1, 1)]["second_tier_seeds"] > 0
 
 
+def _ramp(W, H, seed):
+    """No edges at all: a smooth ramp with a slow wave under blurred noise.  Hundreds of weak seeds reach the same regions of
+    100 000 pixels and more, and what each of them finally gets is a few dozen pixels."""
+    from librectify_amd import synth
+
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    ramp = 0.3 + 0.3 * xx / W + 0.1 * np.sin(yy / 300.0) + rng.normal(0, 0.002, size=(H, W))
+    return synth._gauss_blur(ramp, 2.0).astype(np.float32)
+
+
+def test_giant_walks_are_held_back_until_they_are_the_lowest(L, ctx):
+    """Round 4: a walk that outgrows even the second tier's table no longer moves into a global slab unless it belongs to
+    the LOWEST active seed; any other is marked, counts as unfinished, and the window closes behind the lowest marked seed
+    plus room for some five hundred marked seeds that walk again each round (kernels_flood.hip: kCtrlLowest).  A valid
+    window is any prefix of the seed order, so the labels cannot change: ramp frames against the oracle with the rule
+    (mode 1) and without (mode 4: no second tier, slabs at once), twice each on the context (hints of the first frame);
+    the counter proves that walks were held, and that mode 1 then needs no slab."""
+    used = {}
+    try:
+        for name, img in (("ramp", _ramp(1920, 1080, 77)), ("ramp2", _ramp(1283, 717, 5)), ("regions", _regions(1920, 1080, 9))):
+            ref = O.find_line_segments(img, num_threads=8)
+            for mode in (1, 4):
+                ctx.set_flood_mode(mode)
+                for rep in range(2):
+                    ctx.stage_filter_host(img)
+                    ctx.stage_seeds()
+                    ctx.stage_flood()
+                    used[(name, mode)] = ctx.stage_counters()
+                    np.testing.assert_array_equal(ctx.download(L.BUF_LABEL), ref["label"])
+                    _assert_lines_equal(ctx.stage_fit(), ref["lines"])
+    finally:
+        ctx.set_flood_mode(1)
+    assert used[("ramp", 1)]["giants_held"] > 0 and used[("ramp", 1)]["slabs"] <= 1, used[("ramp", 1)]
+    assert used[("ramp", 4)]["giants_held"] == 0 and used[("ramp", 4)]["slabs"] > 0, used[("ramp", 4)]
+    assert used[("ramp", 1)]["walked_px"] < used[("ramp", 4)]["walked_px"]
+
+
 def test_multi_source_rewalks_change_the_time_not_the_labels(L, ctx):
     """Round 4: a seed whose walk was long leaves way-points on its footprint, and its next walk starts from the seed and
     from all of them at once on a team of wavefronts, keeping what is connected to the seed (kernels_flood.hip: team_walk,
