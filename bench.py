@@ -374,13 +374,14 @@ def natural_frame_rates(L, ctx):
 def worst_case_rates(L, ctx):
     """Frames the ordered flood likes least, one at a time through the frame call from a pageable buffer (the latency of a
     call depends on the content: INTEGRATION.md "Content-dependent latency"): a 4K frame WITHOUT strong edges (soft blobs
-    on a ramp: single floods of hundreds of thousands of pixels) and a 4K frame of sixty bars 2000-3600 px long."""
+    on a ramp: single floods of hundreds of thousands of pixels), a 4K frame of sixty bars 2000-3600 px long, and a 4K frame
+    that is nothing but a smooth ramp under blurred noise (every weak seed reaches regions of 100 000 pixels and more)."""
     from librectify_amd import synth
 
     w, h = W4K, H4K
     out = {}
     ctx.set_stage_timing(True)
-    for name, img in (("edgeless_4k", synth.region_frame(w, h, 504)), ("long_bars_4k", synth.long_bar_frame(w, h, 3))):
+    for name, img in (("edgeless_4k", synth.region_frame(w, h, 504)), ("long_bars_4k", synth.long_bar_frame(w, h, 3)), ("ramp_4k", synth.ramp_frame(w, h))):
         wall, flood = [], []
         for rep in range(4):
             t0 = time.perf_counter()
@@ -392,7 +393,7 @@ def worst_case_rates(L, ctx):
         c = ctx.stage_counters()
         out[name] = {"wall_ms": round(float(np.mean(wall)) * 1e3, 3), "max_ms": round(float(np.max(wall)) * 1e3, 3), "flood_ms": round(float(np.mean(flood)), 3),
                      "lines": int(len(lines)), "seeds": c["seeds"], "flood_rounds": c["flood_rounds"], "second_tier_walks": c["second_tier_seeds"],
-                     "slabs": c["slabs"], "ordered_tail_seeds": c["ordered_tail_seeds"]}
+                     "slabs": c["slabs"], "ordered_tail_seeds": c["ordered_tail_seeds"], "giants_held": c.get("giants_held", 0)}
     ctx.set_stage_timing(False)
     out["note"] = "the four synthetic bench frames take `single_frame`.pageable.wall_ms; these take 1.5-4x as long on the same call"
     return out

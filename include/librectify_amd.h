@@ -209,7 +209,8 @@ int lr_filter_kernel_ms(lr_context* ctx, float* ms);
  * the ordered single-wave tail (storage exhausted); [7] laps of the frame through the pipeline (1 normally); [8] pixels
  * the flood's explorations walked in all rounds together (over [3]: the re-walk factor), [9] their 8x8-tile steps, [10] re-walks that
  * started from several way-points at once (lr_set_flood_multi_source), [11] footprints worked out from a log instead of
- * walked (lr_set_flood_logs), [12] those of them that took the fall-back path (sweeps). */
+ * walked (lr_set_flood_logs), [12] those of them that took the fall-back path (sweeps), [13] walks that outgrew the second
+ * tier's table and were held back until their seed was the lowest active one (instead of moving into a global slab). */
 int lr_stage_counters(lr_context* ctx, int64_t* out, int count);
 
 /* ---- RANSAC --------------------------------------------------------------------------- */

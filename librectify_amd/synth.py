@@ -133,6 +133,16 @@ def region_frame(W, H, seed):
     return img.astype(np.float32)
 
 
+def ramp_frame(W, H, seed=77):
+    """No edges at all: a smooth ramp with a slow wave under blurred noise.  Every weak seed reaches regions of 100 000 pixels
+    and more, and what each finally gets is a few dozen pixels: before walks beyond the second tier's table were held back
+    (kernels_flood.hip: kCtrlLowest) this 4K frame took 279 ms (tools/run_edgeless.py, bench.py `worst_case`)."""
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    ramp = 0.3 + 0.3 * xx / W + 0.1 * np.sin(yy / 300.0) + rng.normal(0, 0.002, size=(H, W))
+    return _gauss_blur(ramp, 2.0).astype(np.float32)
+
+
 def long_bar_frame(W, H, seed, K=60):
     """Bars that run across most of the frame (edges of 2000-3600 px at 4K): walks of several hundred tiles each
     (tools/run_long.py, bench.py `worst_case`)."""

@@ -360,14 +360,9 @@ def test_rewalks_from_the_logs_change_the_time_not_the_labels(L, ctx):
 
 
 def _ramp(W, H, seed):
-    """No edges at all: a smooth ramp with a slow wave under blurred noise.  Hundreds of weak seeds reach the same regions of
-    100 000 pixels and more, and what each of them finally gets is a few dozen pixels."""
     from librectify_amd import synth
 
-    rng = np.random.RandomState(seed)
-    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
-    ramp = 0.3 + 0.3 * xx / W + 0.1 * np.sin(yy / 300.0) + rng.normal(0, 0.002, size=(H, W))
-    return synth._gauss_blur(ramp, 2.0).astype(np.float32)
+    return synth.ramp_frame(W, H, seed)
 
 
 def test_giant_walks_are_held_back_until_they_are_the_lowest(L, ctx):
