@@ -142,7 +142,6 @@ struct FloodBuffers {
     // of (last footprint minus committed pixels): a finished walk leaves its (tile, pixels) records here, and the later
     // rounds label the components of those records in LDS -- no dependent chain of memory round trips.
     bool rewalk_logs = false;
-    bool team_small = false;   // the second tier's launch with a small grid (the context's last frame had next to no walks there)
     bool giant_hold = false;   // only the lowest active seed walks on into a global slab; other walks that outgrow the second tier are held back (kernels_flood.hip: kCtrlLowest)
     bool log_sweep = false;    // test hook: the fall-back (sweeps) for every log
     bool rewalk_big = false;   // the frame is expected to have walks beyond the first tier: their logs are kept too, and a second launch per round works on them

@@ -155,7 +155,6 @@ struct lr_context {
     uint64_t ransac_seed = 0;
     int ransac_iters = lramd::kRansacMaxIter;
     int flood_mode = 1;
-    bool flood_team_small_hint = false;  // did the last frame have next to no walks in the second tier? (its launch then takes a small grid)
     bool flood_logbig_hint = true;  // did the last frame have walks in the second tier? (their logs need a launch of their own per round: kernels_flood.hip, flood_rewalk_kernel)
     bool flood_big_hint = true;  // did the last frame's walks outgrow the first storage tier? (none yet: assume so)
     bool flood_hold_hint = false;  // did the last frame hold its weakest seeds back?

@@ -793,7 +793,6 @@ FloodBuffers flood_buffers_for(lr_context* c) {
     fbuf.multi_source = c->flood_multi;
     fbuf.rewalk_logs = c->flood_logs && !c->flood_multi;  // (way-points, when asked for, instead)
     fbuf.log_sweep = c->flood_log_sweep;
-    fbuf.team_small = c->flood_team_small_hint;
     static const bool giants_off = std::getenv("LIBRECTIFY_FLOOD_GIANTS") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_GIANTS")) == 0;
     fbuf.giant_hold = c->flood_mode == 1 && !giants_off;  // (the storage test hooks -- modes 2-7 -- keep their slabs)
     fbuf.rewalk_big = c->flood_logbig_hint;  // (the context's last frame had walks beyond the first tier)
@@ -896,7 +895,6 @@ int finish_flood(lr_context* c, bool* extra) {
         std::fprintf(stderr, "flood: %d rounds, %u walks in the second tier, %u of them long, hold-back phase %u (started with it: %d)\n",
                      c->flood_rounds, c->flood_tiers[0], c->flood_tiers[8], c->flood_tiers[3], (int)c->flood_hold_hint);
     c->flood_logbig_hint = c->flood_tiers[0] > 0;
-    c->flood_team_small_hint = c->flood_tiers[0] <= 16;  // (second-tier walks of the frame, all rounds together)
     static const int hints_env = std::getenv("LIBRECTIFY_FLOOD_HINTS") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_HINTS")) : 1;  // (experiment knob)
     if (hints_env == 0) {  // as in round 2
         c->flood_big_hint = c->flood_tiers[0] > 0 || c->flood_tiers[1] > 0;

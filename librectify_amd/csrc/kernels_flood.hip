@@ -1256,7 +1256,6 @@ constexpr int kRingTeam = LR_TEAM_RING;
 #define LR_TEAM_GRID 512
 #endif
 constexpr uint32_t kTeamGrid = LR_TEAM_GRID;  // workgroups; each strides over the round's second-tier list
-constexpr uint32_t kTeamGridSmall = 32;     // ... when the context's last frame had next to no second-tier walks
 constexpr uint32_t kVoidTile = 0xFFFFFFFFu;
 
 struct TeamShared {
@@ -3049,14 +3048,8 @@ void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& 
     if (has_rest(index))  // entries past the guess, if any
         hipLaunchKernelGGL(flood_explore_rest_kernel, dim3(1024), dim3(64), 0, s, A, F.trig, act, B.big_list, grid);
     static const bool team = !(std::getenv("LIBRECTIFY_FLOOD_TEAM") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_TEAM")) == 0);
-    // The teams' launch is 512 workgroups of 512 threads and 41 KB of LDS that all have to find a place on the chip before they
-    // can find their list empty -- beside other lanes' kernels that takes 58 us a launch on average (10 % of a batch's kernel
-    // time, for frames that send no walk there at all).  A context whose last frame had few second-tier walks launches a
-    // small grid (the workgroups stride over the list: a frame with many such walks after one with none takes them in turns).
-    static const int team_grid_env = std::getenv("LIBRECTIFY_FLOOD_TEAM_GRID") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_TEAM_GRID")) : 0;
-    const uint32_t team_grid = team_grid_env > 0 ? (uint32_t)team_grid_env : (B.team_small ? kTeamGridSmall : kTeamGrid);
     if (use_big && team)
-        hipLaunchKernelGGL(flood_explore_team_kernel, dim3(std::min<uint32_t>(F.seed_cap, team_grid)), dim3(64 * kTeamWaves),
+        hipLaunchKernelGGL(flood_explore_team_kernel, dim3(std::min<uint32_t>(F.seed_cap, kTeamGrid)), dim3(64 * kTeamWaves),
                            kTeamLdsBytes, s, A, F.trig, B.big_list, 0u);
     else if (use_big)
         hipLaunchKernelGGL(flood_explore_big_kernel, dim3(std::min<uint32_t>(F.seed_cap, kBigCap)), dim3(64), kBigLdsBytes, s,
