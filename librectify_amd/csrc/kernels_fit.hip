@@ -379,34 +379,81 @@ __global__ __launch_bounds__(256) void fit_kernel(const uint32_t* __restrict__ p
         return;
     }
 
+    // Larger components: a lane takes the pixels lane, lane + 64, ... IN THAT ORDER (the canonical order of the sums), kU of them
+    // in flight at a time: the pixel list first, then the gathers it points to -- one round trip per kU pixels instead of one per
+    // pixel (the longest component of a frame is what this launch lasts: 3 700 px = 58 steps a pass on the 4K bench frame).
+    constexpr int kU = 8;
     float acc = 0.f;
-    for (uint32_t i = lane; i < n; i += 64) {
-        const uint32_t p = px[off + i];
-        const float wv = directional(dx[p], dy[p], s, c);
-        scratch_w[off + i] = wv;
-        acc = acc + wv;
+    for (uint32_t i0 = lane; i0 < n; i0 += 64u * kU) {
+        uint32_t p[kU];
+        float gx[kU], gy[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const uint32_t i = i0 + 64u * (uint32_t)u;
+            p[u] = i < n ? px[off + i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            gx[u] = dx[p[u]];
+            gy[u] = dy[p[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const uint32_t i = i0 + 64u * (uint32_t)u;
+            if (i < n) {
+                const float wv = directional(gx[u], gy[u], s, c);
+                scratch_w[off + i] = wv;
+                acc = acc + wv;
+            }
+        }
     }
     const float S = wave_tree(acc);
 
     float ar = 0.f, ac = 0.f;
-    for (uint32_t i = lane; i < n; i += 64) {
-        const uint32_t p = px[off + i];
-        const float r = (float)(p / uw), cc = (float)(p % uw);
-        const float wn = scratch_w[off + i] / S;
-        ar = ar + wn * r;
-        ac = ac + wn * cc;
+    for (uint32_t i0 = lane; i0 < n; i0 += 64u * kU) {
+        uint32_t p[kU];
+        float wq[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const uint32_t i = i0 + 64u * (uint32_t)u;
+            p[u] = i < n ? px[off + i] : 0u;
+            wq[u] = i < n ? scratch_w[off + i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const uint32_t i = i0 + 64u * (uint32_t)u;
+            if (i < n) {
+                const float r = (float)(p[u] / uw), cc = (float)(p[u] % uw);
+                const float wn = wq[u] / S;
+                ar = ar + wn * r;
+                ac = ac + wn * cc;
+            }
+        }
     }
     const float a_r = wave_tree(ar), a_c = wave_tree(ac);
 
     float crr = 0.f, crc = 0.f, ccc = 0.f;
-    for (uint32_t i = lane; i < n; i += 64) {
-        const uint32_t p = px[off + i];
-        const float cr = (float)(p / uw) - a_r, cc = (float)(p % uw) - a_c;
-        const float wn = scratch_w[off + i] / S;
-        const float t = cr * wn, u = cc * wn;
-        crr = crr + t * cr;
-        crc = crc + t * cc;
-        ccc = ccc + u * cc;
+    for (uint32_t i0 = lane; i0 < n; i0 += 64u * kU) {
+        uint32_t p[kU];
+        float wq[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const uint32_t i = i0 + 64u * (uint32_t)u;
+            p[u] = i < n ? px[off + i] : 0u;
+            wq[u] = i < n ? scratch_w[off + i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const uint32_t i = i0 + 64u * (uint32_t)u;
+            if (i < n) {
+                const float cr = (float)(p[u] / uw) - a_r, cc = (float)(p[u] % uw) - a_c;
+                const float wn = wq[u] / S;
+                const float t = cr * wn, u2 = cc * wn;
+                crr = crr + t * cr;
+                crc = crc + t * cc;
+                ccc = ccc + u2 * cc;
+            }
+        }
     }
     const float cov_rr = wave_tree(crr), cov_rc = wave_tree(crc), cov_cc = wave_tree(ccc);
 
@@ -415,13 +462,24 @@ __global__ __launch_bounds__(256) void fit_kernel(const uint32_t* __restrict__ p
     const float n_r = -d_c, n_c = d_r;
 
     float t0 = INFINITY, t1 = -INFINITY, es = 0.f;
-    for (uint32_t i = lane; i < n; i += 64) {
-        const uint32_t p = px[off + i];
-        const float cr = (float)(p / uw) - a_r, cc = (float)(p % uw) - a_c;
-        const float t = cr * d_r + cc * d_c;
-        t0 = fminf(t0, t);
-        t1 = fmaxf(t1, t);
-        es = es + fabsf(cr * n_r + cc * n_c);
+    for (uint32_t i0 = lane; i0 < n; i0 += 64u * kU) {
+        uint32_t p[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const uint32_t i = i0 + 64u * (uint32_t)u;
+            p[u] = i < n ? px[off + i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const uint32_t i = i0 + 64u * (uint32_t)u;
+            if (i < n) {
+                const float cr = (float)(p[u] / uw) - a_r, cc = (float)(p[u] % uw) - a_c;
+                const float t = cr * d_r + cc * d_c;
+                t0 = fminf(t0, t);
+                t1 = fmaxf(t1, t);
+                es = es + fabsf(cr * n_r + cc * n_c);
+            }
+        }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
