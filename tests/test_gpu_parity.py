@@ -645,6 +645,32 @@ def test_batch_entry_point_matches_single_calls(L, ctx):
         np.testing.assert_array_equal(tf[i].as_array(), Tr)
 
 
+def test_lanes_of_a_batch_on_frames_of_every_kind_equal_the_oracle(L, ctx):
+    """Round 4: the lanes of a batch call enqueue their flood's later rounds just in time (a look every 20 us), hold giant
+    walks back, and carry hints from frame to frame -- here over frames that could not differ more: bars, a ramp without
+    edges (held walks), regions, long bars (second tier), in an order that gives every lane a frame of another kind than its
+    last.  Every frame's records against the oracle, with two, three and five lanes, and with blind rounds."""
+    from librectify_amd import synth
+
+    w, h = 1024, 640
+    kinds = [synth.frame(w, h, 81, bars=60), synth.ramp_frame(w, h, 3), _regions(w, h, 12), synth.long_bar_frame(w, h, 5, K=14),
+             synth.frame(w, h, 82, bars=25), synth.ramp_frame(w, h, 4), _regions(w, h, 13)]
+    order = [0, 1, 2, 3, 4, 5, 6, 1, 0, 3, 2, 5, 4, 6]
+    frames = [kinds[i] for i in order]
+    refs = [O.find_line_segment_groups(f, 10.24, seed=0)[0] for f in kinds]
+    ctx.set_seed(0)
+    try:
+        for lanes, jit in ((2, True), (3, True), (5, True), (3, False)):
+            ctx.set_batch_streams(lanes)
+            ctx.set_flood_just_in_time(jit)
+            out, n, _ = ctx.find_line_segment_groups_batch_host(frames, 10.24, capacity=8192, num_threads=4)
+            for k, i in enumerate(order):
+                _assert_lines_equal(out[k][: n[k]], refs[i])
+    finally:
+        ctx.set_flood_just_in_time(True)
+        ctx.set_batch_streams(3)
+
+
 def test_host_batch_entry_point_pageable_pinned_and_strided(L, ctx):
     """lr_find_line_segment_groups_batch_host (the reference's kind of input, many frames at once): pageable frames
     through page-locked staging buffers, page-locked frames DMA-copied where they lie, both kinds mixed, row strides >
