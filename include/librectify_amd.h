@@ -141,9 +141,9 @@ void lr_set_flood_multi_source(lr_context* ctx, int on);
 /* The flood's later rounds from the logs (kernels_flood.hip: flood_rewalk_kernel): a walk of twelve tiles or more leaves
  * its footprint as (tile, pixels) records, and since a footprint only ever shrinks (filter.cpp:101-153 accepts a pixel on
  * static data and on "not claimed yet"), the seed's next footprint is the connected part around it of those records minus
- * what has been committed since -- labelled in LDS instead of walked tile after tile.  Same labels.  On by default for
- * single calls (single 4K frames: flood 1.31 -> 0.94 ms); the lanes of a batch call do not use it (no gain with several
- * frames in flight).  0 = off, 1 = on, 2 = on, every log through the fall-back path (test hook).
+ * what has been committed since -- labelled in LDS instead of walked tile after tile.  Same labels.  On by default
+ * (single 4K frames: flood 1.31 -> 0.92 ms); the lanes of a batch call keep logs only of walks of 32 tiles and more.
+ * 0 = off, 1 = on, 2 = on, every log through the fall-back path (test hook).
  * LIBRECTIFY_FLOOD_LOGS=0 turns it off for every new context; lr_stage_counters [11], [12] count the logs worked on and
  * those that took the fall-back path. */
 void lr_set_flood_logs(lr_context* ctx, int on);

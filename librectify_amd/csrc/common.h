@@ -142,6 +142,8 @@ struct FloodBuffers {
     // of (last footprint minus committed pixels): a finished walk leaves its (tile, pixels) records here, and the later
     // rounds label the components of those records in LDS -- no dependent chain of memory round trips.
     bool rewalk_logs = false;
+    int log_min_tiles = 0, log_walk_tiles = 0;  // 0: the defaults (16 and 12, LIBRECTIFY_FLOOD_LOG_MIN / _WALK); the lanes of a batch bring their own
+    int log_from_round = 1;    // first round (from 0) whose seeds turn to their logs (walks leave logs from the first round on)
     bool giant_hold = false;   // only the lowest active seed walks on into a global slab; other walks that outgrow the second tier are held back (kernels_flood.hip: kCtrlLowest)
     bool log_sweep = false;    // test hook: the fall-back (sweeps) for every log
     bool rewalk_big = false;   // the frame is expected to have walks beyond the first tier: their logs are kept too, and a second launch per round works on them

@@ -160,6 +160,8 @@ struct lr_context {
     bool flood_hold_hint = false;  // did the last frame hold its weakest seeds back?
     uint32_t flood_tiers[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // last flood: seeds in the second tier, slabs used, seeds of the ordered tail, hold-back, walked px (lo, hi), steps (lo, hi), walks beyond the first tier's table, multi-source re-walks, re-walks from logs, logs given up, giants held back
     bool flood_partial = true;  // partial commits of blocked seeds (kernels_flood.hip); lr_set_flood_partial_commits
+    int flood_log_min = 0, flood_log_walk = 0;  // thresholds of the logs (0: the defaults; the lanes of a batch call get 32 and 24)
+    int flood_log_from = 1;        // first round (from 0) whose seeds turn to their logs (lanes of a batch: experiment knob LIBRECTIFY_FLOOD_LOGS_LANES_FROM)
     bool flood_log_sweep = false;  // test hook (lr_set_flood_logs(ctx, 2)): every footprint worked out from a log goes the fall-back way (sweeps)
     bool flood_logs = true;     // blocked seeds work their next footprint out from the records of their last walk (kernels_flood.hip: flood_rewalk_kernel); lr_set_flood_logs, LIBRECTIFY_FLOOD_LOGS=0
     bool flood_multi = false;   // re-walks of long footprints from several way-points at once (kernels_flood.hip): opt-in, lr_set_flood_multi_source / LIBRECTIFY_FLOOD_MULTI=1

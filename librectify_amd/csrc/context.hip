@@ -793,6 +793,9 @@ FloodBuffers flood_buffers_for(lr_context* c) {
     fbuf.multi_source = c->flood_multi;
     fbuf.rewalk_logs = c->flood_logs && !c->flood_multi;  // (way-points, when asked for, instead)
     fbuf.log_sweep = c->flood_log_sweep;
+    fbuf.log_from_round = c->flood_log_from;
+    fbuf.log_min_tiles = c->flood_log_min;
+    fbuf.log_walk_tiles = c->flood_log_walk;
     static const bool giants_off = std::getenv("LIBRECTIFY_FLOOD_GIANTS") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_GIANTS")) == 0;
     fbuf.giant_hold = c->flood_mode == 1 && !giants_off;  // (the storage test hooks -- modes 2-7 -- keep their slabs)
     fbuf.rewalk_big = c->flood_logbig_hint;  // (the context's last frame had walks beyond the first tier)
@@ -2226,11 +2229,18 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
         // rounds overlap each other anyway (profiles/r04_flood_multi_sweep.txt).  LIBRECTIFY_FLOOD_MULTI_LANES=1 keeps them.
         static const bool multi_lanes = std::getenv("LIBRECTIFY_FLOOD_MULTI_LANES") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_MULTI_LANES")) != 0;
         l->flood_multi = caller_multi && (S == 1 || multi_lanes);
-        // Re-walks from the logs likewise: they shorten a frame's later rounds (single 4K frames: flood 1.31 -> 0.94 ms) by
-        // work of their own in round two, and S frames in flight gain nothing from shorter rounds: 9.8 -> 9.3 Gpix/s with
-        // them (profiles/r04_flood_logs.txt).  LIBRECTIFY_FLOOD_LOGS_LANES=1 keeps them.
-        static const bool logs_lanes = std::getenv("LIBRECTIFY_FLOOD_LOGS_LANES") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_LOGS_LANES")) != 0;
+        // Re-walks from the logs: in the lanes only for walks of 32 tiles and more, behind a walk of 24 tiles.  With the
+        // thresholds of a single call (16 / 12) round two's work on thousands of small logs is work on top, and S frames in
+        // flight gain nothing from shorter rounds: 10.34 -> 10.2 Gpix/s; with these the long re-walks go and little is added:
+        // 10.34 -> 10.55 (profiles/r04_flood_logs.txt section 14).  LIBRECTIFY_FLOOD_LOGS_LANES=0 keeps the lanes without.
+        static const bool logs_lanes = !(std::getenv("LIBRECTIFY_FLOOD_LOGS_LANES") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_LOGS_LANES")) == 0);
         l->flood_logs = caller_logs && (S == 1 || logs_lanes);
+        static const int lanes_min = std::getenv("LIBRECTIFY_FLOOD_LOG_MIN_LANES") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_LOG_MIN_LANES")) : 32;
+        static const int lanes_walk = std::getenv("LIBRECTIFY_FLOOD_LOG_WALK_LANES") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_LOG_WALK_LANES")) : 24;
+        l->flood_log_min = S == 1 ? 0 : lanes_min;
+        l->flood_log_walk = S == 1 ? 0 : lanes_walk;
+        static const int logs_lanes_from = std::getenv("LIBRECTIFY_FLOOD_LOGS_LANES_FROM") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_LOGS_LANES_FROM")) : 1;
+        l->flood_log_from = S == 1 ? 1 : std::max(logs_lanes_from, 1);
         l->flood_log_sweep = c->flood_log_sweep;
         // (a lane's thread has nothing else to do while its frame is in flight, but the call's staging threads need the cores:
         // a lane looks at the words every few tens of microseconds instead of spinning -- the other lanes keep the GPU busy)
@@ -2416,6 +2426,8 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
     for (lr_context* l : lanes) l->sleep_in_wait = false;
     c->flood_multi = caller_multi;
     c->flood_logs = caller_logs;
+    c->flood_log_from = 1;
+    c->flood_log_min = c->flood_log_walk = 0;
     c->flood_jit = caller_jit;
     c->flood_jit_sleep_us = 0;
     for (int si = 0; si < S; ++si)

@@ -219,6 +219,7 @@ struct FloodArgs {
     // as (tile, walked pixels) records; the seed's later rounds work on those records instead of walking the image again
     uint32_t log_min_tiles;                          // 0xFFFFFFFF: no logs
     uint32_t log_walk_tiles;                         // a seed with a log walks this many tiles before it turns to the log
+    uint32_t log_use;                                // 0: this round's walks leave logs but none is used yet (FloodBuffers::log_from_round)
     uint32_t log_max_len;                            // logs of at most this many records are written and used (what the launched kernels' tables hold)
     uint32_t log_sweep;                              // test hook: every footprint is worked out by sweeps (flood_rewalk_kernel)
     uint32_t* host_progress;                         // FloodBuffers::host_progress (nullptr: nobody is looking)
@@ -994,7 +995,7 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
     // on this round's list of flood_rewalk_kernel, which runs behind the exploration (nothing is stamped yet).
     const uint32_t log_w = (kFirstTier && A.log_min_tiles != 0xFFFFFFFFu && k < A.log_seeds) ? uni(A.log_len[k]) : 0u;
     const uint32_t log_n = log_w & ~kLogShrunk;
-    const bool has_log = log_n != 0u && log_n <= A.log_max_len;
+    const bool has_log = log_n != 0u && log_n <= A.log_max_len && A.log_use != 0u;
     const bool skip_first = (outgrown || wp_seed) && !has_log;
     if (!skip_first) {
         for (int i = lane; i < Lds::kHashN; i += 64) L.hk[i] = 0u;
@@ -2974,9 +2975,9 @@ FloodArgs flood_args(const FloodBuffers& B, const FloodFrame& F, bool use_big) {
     // logs: walks of this many tiles leave one (LIBRECTIFY_FLOOD_LOG_MIN); with logs there are no way-points
     static const int log_min_env = std::getenv("LIBRECTIFY_FLOOD_LOG_MIN") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_LOG_MIN")) : 16;
     const bool logs = B.rewalk_logs && B.log_buf && B.log_off && B.log_len && B.multi_list;
-    A.log_min_tiles = logs ? (uint32_t)std::max(log_min_env, 1) : 0xFFFFFFFFu;
+    A.log_min_tiles = logs ? (uint32_t)std::max(B.log_min_tiles > 0 ? B.log_min_tiles : log_min_env, 1) : 0xFFFFFFFFu;
     static const int log_walk_env = std::getenv("LIBRECTIFY_FLOOD_LOG_WALK") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_LOG_WALK")) : 12;
-    A.log_walk_tiles = (uint32_t)std::max(log_walk_env, 3);
+    A.log_walk_tiles = (uint32_t)std::max(B.log_walk_tiles > 0 ? B.log_walk_tiles : log_walk_env, 3);
     static const bool log_sweep_env = std::getenv("LIBRECTIFY_FLOOD_LOG_SWEEP") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_LOG_SWEEP")) != 0;
     A.log_sweep = (log_sweep_env || B.log_sweep) ? 1u : 0u;
     A.host_progress = (B.jit_first > 0 && !g_flood_debug) ? B.host_progress : nullptr;
@@ -3037,6 +3038,7 @@ void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& 
     A.multi_next = (B.aux_stream != nullptr && A.wp_min_tiles != 0xFFFFFFFFu && use_big && index + 1 >= 1 && index + 1 <= B.multi_round_last &&
                     index + 1 < B.n_fork_events && !g_flood_debug) ? 1u : 0u;
     const bool logs = A.log_min_tiles != 0xFFFFFFFFu;
+    A.log_use = (logs && index >= B.log_from_round) ? 1u : 0u;
     if (multi_now) {
         (void)hipEventRecord(B.fork_events[index], s);
         (void)hipStreamWaitEvent(B.aux_stream, B.fork_events[index], 0);
@@ -3055,10 +3057,10 @@ void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& 
         hipLaunchKernelGGL(flood_explore_big_kernel, dim3(std::min<uint32_t>(F.seed_cap, kBigCap)), dim3(64), kBigLdsBytes, s,
                            A, F.trig, B.big_list);
     if (multi_now) (void)hipStreamWaitEvent(s, B.join_events[index], 0);
-    if (logs && index >= 1)
+    if (logs && index >= std::max(B.log_from_round, 1))
         hipLaunchKernelGGL((flood_rewalk_kernel<kRewalkThreads, kRewalkTiles>), dim3(std::min<uint32_t>(F.seed_cap, kRewalkGrid)), dim3(kRewalkThreads),
                            rewalk_lds_bytes<kRewalkTiles>(), s, A, B.multi_list, 1u);
-    if (logs && index >= 1 && A.log_max_len > (uint32_t)kRewalkTiles)
+    if (logs && index >= std::max(B.log_from_round, 1) && A.log_max_len > (uint32_t)kRewalkTiles)
         hipLaunchKernelGGL((flood_rewalk_kernel<kRewalkThreadsBig, kRewalkTilesBig>), dim3(std::min<uint32_t>(F.seed_cap, 1024u)),
                            dim3(kRewalkThreadsBig), rewalk_lds_bytes<kRewalkTilesBig>(), s, A, B.multi_list, (uint32_t)kRewalkTiles + 1u);
     if (g_flood_debug) (void)hipEventRecord(dbg1, s);
