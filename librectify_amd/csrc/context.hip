@@ -813,7 +813,12 @@ FloodBuffers flood_buffers_for(lr_context* c) {
     static const bool jit_off = std::getenv("LIBRECTIFY_FLOOD_JIT") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_JIT")) == 0;
     fbuf.host_progress = c->h_counts + 60;  // (the control block's copy ends at + 56)
     fbuf.jit_sleep_us = c->flood_jit_sleep_us;
-    fbuf.jit_first = (c->flood_jit && !jit_off) ? (c->flood_rounds_last > 0 ? std::max(c->flood_rounds_last - 1, 2) : 3) : 0;
+    // (at most four rounds blindly -- the rounds that always bring their `rest` launch, kernels_flood.hip kRestRounds: a later
+    // blind round whose list is longer than its grid walks only a part of it, and lists stay long while a window is closed in
+    // front of waiting seeds (a frame of soft blobs went to the ordered tail that way now and then: 42 -> 200 ms); a round
+    // enqueued just in time knows its list's length and brings the launch when it needs it.  LIBRECTIFY_FLOOD_JIT_FIRST_MAX)
+    static const int jit_first_max = std::getenv("LIBRECTIFY_FLOOD_JIT_FIRST_MAX") ? std::max(1, std::atoi(std::getenv("LIBRECTIFY_FLOOD_JIT_FIRST_MAX"))) : 4;
+    fbuf.jit_first = (c->flood_jit && !jit_off) ? std::min(c->flood_rounds_last > 0 ? std::max(c->flood_rounds_last - 1, 2) : 3, jit_first_max) : 0;
     return fbuf;
 }
 

@@ -2996,7 +2996,15 @@ FloodArgs flood_args(const FloodBuffers& B, const FloodFrame& F, bool use_big) {
 
 
 // one round: explore (main launch, the entries past its grid, second LDS tier), commit pass, survivors pass
-void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& A0, bool use_big, int index, hipStream_t s) {
+// `known_len`: the length of this round's list when the host has seen it (rounds enqueued just in time), 0xFFFFFFFF when the
+// round is enqueued blindly; `next_known`: the NEXT round will be enqueued with its length known.  A round whose list is
+// known to be longer than its grid gets the `rest` launch whatever its index, and a round whose successor will know needs
+// no barrier for entries the successor "will not reach".  (Lists stay long into the late rounds when a window is closed in
+// front of waiting seeds -- the hold-back, the giants' line: a late round that walked only its first grid's worth of an
+// unordered list could leave the lowest active seed unwalked, move nothing, and send the frame to the ordered tail.)
+constexpr int kRestRounds = 4;  // rounds 0 .. kRestRounds - 1 always bring their `rest` launch: the rounds a frame may enqueue blindly (context.hip: jit_first_max)
+void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& A0, bool use_big, int index, hipStream_t s,
+                   uint32_t known_len = 0xFFFFFFFFu, bool next_known = false) {
     uint32_t* lists[2] = {B.act_a, B.act_b};
     uint32_t* act = lists[index & 1];
     uint32_t* act_next = lists[(index + 1) & 1];
@@ -3011,7 +3019,7 @@ void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& 
     }
     // grid: see flood_explore_kernel.  A staged start keeps the list long for a round more.
     // (not below a quarter: while the weakest fifth of the seeds is held back, the list stays that long)
-    // From the fourth round on the lists are a tenth of the grid (a quarter of the capacity) and the `rest` launch -- the
+    // From the fifth round on (kRestRounds) the lists are a tenth of the grid (a quarter of the capacity) and the `rest` launch -- the
     // entries past the guess -- was one empty launch per round, blind rounds included.  It is gone there; should such a list
     // ever be longer than its grid, the round walks its first entries and the survivors pass that wrote the list has set
     // the round's barrier at the lowest seed behind them (next_reach): nothing above an unwalked seed commits, exact as
@@ -3020,14 +3028,15 @@ void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& 
     auto grid_of = [&](int idx) {
         const int shift = std::min(std::max(idx - (B.win_first_shift > 0 ? 1 : 0), 0), 2);
         uint32_t g = std::max<uint32_t>(std::min<uint32_t>(F.seed_cap, 2048u), F.seed_cap >> shift);
-        if (test_grid > 0 && idx >= 3) g = std::min<uint32_t>(g, (uint32_t)test_grid);
+        if (test_grid > 0 && idx >= kRestRounds) g = std::min<uint32_t>(g, (uint32_t)test_grid);
         return g;
     };
-    auto has_rest = [&](int idx) { return idx < 3 && grid_of(idx) < F.seed_cap; };
+    auto has_rest = [&](int idx) { return idx < kRestRounds && grid_of(idx) < F.seed_cap; };
     const uint32_t grid = grid_of(index);
+    const bool rest_now = has_rest(index) || (known_len != 0xFFFFFFFFu && known_len > grid);
     FloodArgs A = A0;
-    A.no_rest = (grid < F.seed_cap && !has_rest(index)) ? 1u : 0u;
-    A.next_reach = (grid_of(index + 1) < F.seed_cap && !has_rest(index + 1)) ? grid_of(index + 1) : 0xFFFFFFFFu;
+    A.no_rest = (grid < F.seed_cap && !rest_now) ? 1u : 0u;
+    A.next_reach = (grid_of(index + 1) < F.seed_cap && !has_rest(index + 1) && !next_known) ? grid_of(index + 1) : 0xFFFFFFFFu;
     // Way-point seeds listed by the last survivors pass are walked by teams in a launch of their own on the context's second
     // stream, BESIDE this round's exploration (one stream runs its kernels one after the other, and hipExtAnyOrderLaunch is
     // not honoured on gfx950: tools/ubench/anyorder.hip): fork behind the last round, join in front of the commit passes.
@@ -3047,7 +3056,7 @@ void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& 
         (void)hipEventRecord(B.join_events[index], B.aux_stream);
     }
     hipLaunchKernelGGL(flood_explore_kernel, dim3(grid), dim3(64), 0, s, A, F.trig, act, B.big_list);
-    if (has_rest(index))  // entries past the guess, if any
+    if (rest_now)  // entries past the guess, if any
         hipLaunchKernelGGL(flood_explore_rest_kernel, dim3(1024), dim3(64), 0, s, A, F.trig, act, B.big_list, grid);
     static const bool team = !(std::getenv("LIBRECTIFY_FLOOD_TEAM") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_TEAM")) == 0);
     if (use_big && team)
@@ -3153,7 +3162,7 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
         // over and left seeds, the host's reaction hides behind that last round, at most one round is enqueued in vain:
         // measured the same as none ahead, 0.921 against 0.923 ms over eight 4K frames, blind rounds 0.937)
         static const int lead = std::getenv("LIBRECTIFY_FLOOD_JIT_LEAD") ? std::max(0, std::atoi(std::getenv("LIBRECTIFY_FLOOD_JIT_LEAD"))) : 0;
-        for (int r = 0; r < first; ++r, ++P->enqueued) enqueue_round(B, F, A, P->use_big, P->enqueued, s);
+        for (int r = 0; r < first; ++r, ++P->enqueued) enqueue_round(B, F, A, P->use_big, P->enqueued, s, 0xFFFFFFFFu, r == first - 1);
         const auto t0 = std::chrono::steady_clock::now();
         for (;;) {
             uint32_t done_rounds, n_left, stalled;
@@ -3171,11 +3180,12 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
                 }
             }
             if (timed_out) {
-                for (int r = 0; r < 2; ++r, ++P->enqueued) enqueue_round(B, F, A, P->use_big, P->enqueued, s);
+                // (with the `rest` launch whatever the list's length: the round before them was told its successor would know)
+                for (int r = 0; r < 2; ++r, ++P->enqueued) enqueue_round(B, F, A, P->use_big, P->enqueued, s, 0xFFFFFFFEu, true);
                 break;
             }
             if (n_left == 0u || stalled != 0u || P->enqueued >= 64) break;
-            enqueue_round(B, F, A, P->use_big, P->enqueued, s);
+            enqueue_round(B, F, A, P->use_big, P->enqueued, s, n_left, true);
             ++P->enqueued;
         }
     } else {
@@ -3209,7 +3219,9 @@ int flood_finish(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, u
             A.big_cap = big_cap;
         }
         const int batch = g_flood_debug ? 1 : 3;
-        for (int r = 0; r < batch; ++r, ++P->enqueued) enqueue_round(B, F, A, P->use_big, P->enqueued, s);
+        // (these rounds always bring their `rest` launch: the rounds before them may have been told that their successor would
+        // know its list's length, and a flood that is still going after its first laps has long lists to walk)
+        for (int r = 0; r < batch; ++r, ++P->enqueued) enqueue_round(B, F, A, P->use_big, P->enqueued, s, 0xFFFFFFFEu, true);
         LR_HIP(hipMemcpyAsync(h_ctrl, B.ctrl, kCtrlWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         LR_HIP(hipStreamSynchronize(s));
     }

@@ -939,10 +939,12 @@ def test_what_a_context_carries_from_frame_to_frame_never_changes_a_result(L):
 
 
 def test_a_round_whose_list_outgrows_its_grid_is_exact(L):
-    """From the fourth round on the exploration has no `rest` launch behind it: a list longer than the grid is walked in its
+    """From the fifth round on the exploration has no `rest` launch behind it: a list longer than the grid is walked in its
     first entries only, and the survivors pass before it has put the round's barrier at the lowest seed behind them.
-    LIBRECTIFY_FLOOD_TEST_GRID=4 makes every such round outgrow its grid (the flood then stalls and the ordered tail
-    finishes it: slow, and exact).  The knob is read once per process: one child process, three frames against the oracle."""
+    LIBRECTIFY_FLOOD_TEST_GRID=1 makes every such round with more than one seed left outgrow its grid (more rounds, or the
+    flood stalls and the ordered tail finishes it: slow, and exact).  That is the life of rounds enqueued BLINDLY (LIBRECTIFY_FLOOD_JIT=0 here); a round
+    enqueued just in time knows its list's length and brings the `rest` launch when the grid is too small (round 4: second
+    child -- same frames, same records, and no seed left to the ordered tail).  The knobs are read once per process."""
     import subprocess
     import sys
 
@@ -955,17 +957,25 @@ import librectify_amd as L
 from librectify_amd import synth
 ctx = L.Context(0); ctx.set_seed(0)
 tails = 0
+rounds = 0
 for img in (synth.frame(3840, 2160, 1), synth.frame(1920, 1080, 9), synth.frame(960, 540, 4, bars=40)):
     ref, _ = O.find_line_segment_groups(img, max(img.shape) / 100.0, seed=0)
     got = ctx.find_line_segment_groups(img, max(img.shape) / 100.0)
     assert got.tobytes() == ref.tobytes(), "mismatch"
     tails += ctx.stage_counters()["ordered_tail_seeds"]
-assert tails > 0, "the knob did not bite"
-print("ok", tails)
+    rounds += ctx.stage_counters()["flood_rounds"]
+print("ok", tails, rounds)
 """ % (ROOT, ROOT)
-    env = dict(os.environ, LIBRECTIFY_FLOOD_TEST_GRID="4")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and r.stdout.strip().startswith("ok"), (r.stdout[-500:], r.stderr[-1500:])
+    tails, rounds = {}, {}
+    for jit in ("0", "1"):
+        env = dict(os.environ, LIBRECTIFY_FLOOD_TEST_GRID="1", LIBRECTIFY_FLOOD_JIT=jit)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and r.stdout.strip().startswith("ok"), (jit, r.stdout[-500:], r.stderr[-1500:])
+        tails[jit], rounds[jit] = int(r.stdout.split()[1]), int(r.stdout.split()[2])
+    # blind: one entry a round is walked from the fifth round on, the rest waits behind the barrier (or the flood stalls
+    # and the ordered tail finishes it); just in time: the launch for the rest is there, no round more than without the knob
+    assert tails["0"] > 0 or rounds["0"] > rounds["1"], ("the knob did not bite", tails, rounds)
+    assert tails["1"] == 0, tails  # (a frame enqueues at most four rounds blindly: those that have the launch anyway)
 
 
 def test_component_sort_classes_up_to_a_flood_of_20000_pixels(L, ctx):
