@@ -147,7 +147,7 @@ void lr_set_flood_multi_source(lr_context* ctx, int on);
  * LIBRECTIFY_FLOOD_LOGS=0 turns it off for every new context; lr_stage_counters [11], [12] count the logs worked on and
  * those that took the fall-back path. */
 void lr_set_flood_logs(lr_context* ctx, int on);
-/* Single calls enqueue the flood's first rounds blindly (what the context's last frame needed, less one) and every further
+/* Single calls enqueue the flood's first rounds blindly (what the context's last frame needed, less one; four at most) and every further
  * round only when the host has seen -- in page-locked words the last workgroup of a round writes -- that seeds are left: no
  * launch behind the last round with work (the blind rounds of a 4K frame were 60-120 us of empty launches); the calling
  * thread polls while the flood runs (a single call spins; a lane of a batch call looks every 20 us).  On by default.
