@@ -155,6 +155,7 @@ struct lr_context {
     uint64_t ransac_seed = 0;
     int ransac_iters = lramd::kRansacMaxIter;
     int flood_mode = 1;
+    bool flood_logbig_off = false;  // lanes of a batch call keep no logs of second-tier walks (context.hip: find_groups_batch)
     bool flood_logbig_hint = true;  // did the last frame have walks in the second tier? (their logs need a launch of their own per round: kernels_flood.hip, flood_rewalk_kernel)
     bool flood_big_hint = true;  // did the last frame's walks outgrow the first storage tier? (none yet: assume so)
     bool flood_hold_hint = false;  // did the last frame hold its weakest seeds back?

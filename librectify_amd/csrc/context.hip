@@ -798,7 +798,7 @@ FloodBuffers flood_buffers_for(lr_context* c) {
     fbuf.log_walk_tiles = c->flood_log_walk;
     static const bool giants_off = std::getenv("LIBRECTIFY_FLOOD_GIANTS") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_GIANTS")) == 0;
     fbuf.giant_hold = c->flood_mode == 1 && !giants_off;  // (the storage test hooks -- modes 2-7 -- keep their slabs)
-    fbuf.rewalk_big = c->flood_logbig_hint;  // (the context's last frame had walks beyond the first tier)
+    fbuf.rewalk_big = c->flood_logbig_hint && !c->flood_logbig_off;  // (the context's last frame had walks beyond the first tier)
     static const int aux_env = std::getenv("LIBRECTIFY_FLOOD_MULTI_BESIDE") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_MULTI_BESIDE")) : -1;  // (experiment: 0 = after the exploration, N = beside it in rounds 2 .. N + 1)
     if (c->flood_aux && c->flood_aux_on && aux_env != 0 && c->flood_fork.size() == c->flood_join.size()) {
         fbuf.aux_stream = c->flood_aux;
@@ -2246,6 +2246,11 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
         l->flood_log_walk = S == 1 ? 0 : lanes_walk;
         static const int logs_lanes_from = std::getenv("LIBRECTIFY_FLOOD_LOGS_LANES_FROM") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_LOGS_LANES_FROM")) : 1;
         l->flood_log_from = S == 1 ? 1 : std::max(logs_lanes_from, 1);
+        // ... and without the logs of second-tier walks: their kernel is a launch of 1 024 threads and 142 KB of LDS a
+        // workgroup that has to find whole CUs beside the other lanes' kernels (2.7 launches a frame x 52 us in
+        // profiles/r04_kernel_stats.csv): 10.67 -> 10.76 Gpix/s without (three repetitions each).  LIBRECTIFY_FLOOD_LOGBIG_LANES=1
+        static const bool logbig_lanes = std::getenv("LIBRECTIFY_FLOOD_LOGBIG_LANES") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_LOGBIG_LANES")) != 0;
+        l->flood_logbig_off = S > 1 && !logbig_lanes;
         l->flood_log_sweep = c->flood_log_sweep;
         // (a lane's thread has nothing else to do while its frame is in flight, but the call's staging threads need the cores:
         // a lane looks at the words every few tens of microseconds instead of spinning -- the other lanes keep the GPU busy)
@@ -2432,6 +2437,7 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
     c->flood_multi = caller_multi;
     c->flood_logs = caller_logs;
     c->flood_log_from = 1;
+    c->flood_logbig_off = false;
     c->flood_log_min = c->flood_log_walk = 0;
     c->flood_jit = caller_jit;
     c->flood_jit_sleep_us = 0;
