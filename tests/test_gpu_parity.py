@@ -645,6 +645,51 @@ def test_batch_entry_point_matches_single_calls(L, ctx):
         np.testing.assert_array_equal(tf[i].as_array(), Tr)
 
 
+def _unusual_frames(W, H):
+    """Content of the kinds tools/latency_fuzz.py times: noise of several scales, periodic patterns WITHOUT noise (exact ties:
+    every pixel of a flank is a seed of the same magnitude), analytic gradients, single edges, glyph-like blocks."""
+    from librectify_amd import synth
+
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    rng = np.random.RandomState(11)
+    blur = synth._gauss_blur
+    return {
+        "white noise": (0.5 + rng.normal(0, 0.05, (H, W))).astype(np.float32),
+        "blurred noise": blur(0.5 + rng.normal(0, 0.2, (H, W)), 3.0).astype(np.float32),
+        "checkerboard 16": ((((xx // 16) + (yy // 16)) % 2) * 0.6 + 0.2).astype(np.float32),
+        "checkerboard 32 blurred": blur((((xx // 32) + (yy // 32)) % 2) * 0.6 + 0.2, 1.5).astype(np.float32),
+        "stripes period 6": (0.5 + 0.4 * np.sin(xx * 2 * np.pi / 6)).astype(np.float32),
+        "diagonal stripes": (0.5 + 0.4 * np.sin((xx + 0.5 * yy) * 2 * np.pi / 40)).astype(np.float32),
+        "concentric circles": (0.5 + 0.4 * np.sin(np.hypot(xx - W / 2, yy - H / 2) / 12)).astype(np.float32),
+        "one vertical edge": blur(np.where(xx > W / 2, 0.8, 0.2), 1.0).astype(np.float32),
+        "one slanted edge + noise": (blur(np.where(xx > W / 2 + 0.1 * yy, 0.8, 0.2), 1.0) + rng.normal(0, 0.01, (H, W))).astype(np.float32),
+        "radial gradient": (1.0 - np.hypot(xx - W / 2, yy - H / 2) / np.hypot(W / 2, H / 2)).astype(np.float32),
+        "radial gradient + noise": (1.0 - np.hypot(xx - W / 2, yy - H / 2) / np.hypot(W / 2, H / 2) + rng.normal(0, 0.003, (H, W))).astype(np.float32),
+        "glyph-like blocks": blur((rng.rand(H // 8 + 1, W // 8 + 1) > 0.7).astype(np.float64).repeat(8, 0).repeat(8, 1)[:H, :W] * 0.7 + 0.15, 0.8).astype(np.float32),
+        "grid of thin lines": blur(np.where(((xx % 48) < 2) | ((yy % 48) < 2), 0.9, 0.2), 0.7).astype(np.float32),
+    }
+
+
+def test_unusual_content_matches_the_oracle(L, ctx):
+    """Round 4: the kinds of content the latency fuzz runs, at 416x304 (tiles ragged on both sides): label image, segment
+    records and the grouped result against the oracle -- among them patterns without any noise, where every pixel of a flank
+    is a seed with the same magnitude (ties in the seed order, hundreds of seeds per edge with one footprint) and analytic
+    gradients whose floods are rings that exhaust the storage tiers (the ordered tail finishes those)."""
+    W, H = 416, 304
+    ctx.set_seed(0)
+    ctx.set_flood_mode(1)
+    for name, img in _unusual_frames(W, H).items():
+        img = np.ascontiguousarray(img)
+        ref = O.find_line_segments(img)
+        ctx.stage_filter_host(img)
+        assert ctx.stage_seeds() == ref["n_seeds"], name
+        ctx.stage_flood()
+        np.testing.assert_array_equal(ctx.download(L.BUF_LABEL), ref["label"], err_msg=name)
+        _assert_lines_equal(ctx.stage_fit(), ref["lines"])
+        full, _ = O.find_line_segment_groups(img, 4.16, seed=0)
+        _assert_lines_equal(ctx.find_line_segment_groups(img, 4.16), full)
+
+
 def test_lanes_of_a_batch_on_frames_of_every_kind_equal_the_oracle(L, ctx):
     """Round 4: the lanes of a batch call enqueue their flood's later rounds just in time (a look every 20 us), hold giant
     walks back, and carry hints from frame to frame -- here over frames that could not differ more: bars, a ramp without
