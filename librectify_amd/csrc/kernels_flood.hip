@@ -1067,7 +1067,19 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
             L.put(0u, ((uint32_t)(sr >> 3) << 16) | (uint32_t)(sc >> 3), 1ull << ((sr & 7) * 8 + (sc & 7)));
             rc = walk(A, k, b, thr, sn, cs, L, P, st, lane, own);
         }
-        // second tier full this round: carry on in a slab from the state reached
+        // second tier full this round: carry on in a slab from the state reached -- if this is the lowest active seed; any
+        // other is held back like a walk that outgrows the second tier's table (see kCtrlLowest): with eight thousand walks in
+        // the second tier the frame is one of overlapping giants (a noiseless radial gradient: 35 837 seeds, all of one
+        // magnitude, sixteen rings), and the slabs are for the one walk that is sure to commit
+        if (rc != 0 && A.giant_hold != 0u && k != uni(A.ctrl[kCtrlLowest])) {
+            if (lane == 0) {
+                A.tier[k] = (uint8_t)(A.tier[k] | 5u);  // (outgrew the first tier; a giant)
+                A.flags[k] = kFlagIncomplete;
+                atomicMin(&A.ctrl[kCtrlBarrier], k);
+                atomicAdd(&A.ctrl[kCtrlGiants], 1u);
+            }
+            return;
+        }
     }
     stamp_footprint(A, k, L, st, lane);
     // (only THIN footprints: a region's frontier is wide, the team's level-synchronous walk takes it eight tiles at a time as
