@@ -2669,7 +2669,7 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
                                                                int win_first_shift, int hold_pct, uint32_t hold_from_start,
                                                                uint32_t* __restrict__ label, size_t npix,
                                                                uint32_t* __restrict__ waypoints, uint32_t wp_cap,
-                                                               uint32_t* __restrict__ log_len, uint32_t log_seeds) {
+                                                               uint32_t* __restrict__ log_len, uint32_t log_seeds, uint32_t dense_div) {
     // (the label image is set to "free" here as well: one launch less in front of the first round)
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) label[i] = kLabelFree;
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
@@ -2677,6 +2677,10 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
     if (k == 0u) {
         // staged start and hold-back line (see kCtrlWindow, flood_advance)
         uint32_t win_first = win_first_shift > 0 ? max(1024u, n_seeds >> win_first_shift) : n_seeds;
+        // A frame where every twelfth pixel or more is a seed is one of exact ties (a periodic pattern without noise: every
+        // pixel of a flank a seed of the same magnitude, hundreds of seeds with ONE footprint): the strongest eighth walks
+        // first, commits the flanks, and the others die unwalked (stripes of period 6 at 1080p: 687 564 seeds, 639 components).
+        if (dense_div != 0u && win_first_shift <= 0 && n_seeds > (uint32_t)(npix / dense_div)) win_first = max(1024u, n_seeds >> 3);
         if (win_first > n_seeds) win_first = n_seeds;
         uint32_t win_hold = (hold_pct > 0 && hold_pct < 100) ? (uint32_t)((unsigned long long)n_seeds * (uint32_t)hold_pct / 100u) : n_seeds;
         if (win_hold < 1024u) win_hold = n_seeds;  // not worth another phase
@@ -3150,13 +3154,15 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
         }
     }
     {
+        static const int dense_env = std::getenv("LIBRECTIFY_FLOOD_DENSE_DIV") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_DENSE_DIV")) : 12;
+        const uint32_t dense_div = (uint32_t)std::max(dense_env, 0);
         const size_t npix = (size_t)F.w * F.h;
         const uint32_t seed_blocks = (F.seed_cap + 255) / 256;
         const uint32_t blocks = std::max<uint32_t>(seed_blocks, (uint32_t)std::min<size_t>((npix + 255) / 256, 4096));
         hipLaunchKernelGGL(flood_init_seeds_kernel, dim3(blocks), dim3(256), 0, s, F.d_n_seeds, F.seed_cap, B.act_a, B.state,
                            B.tier, B.blocked, B.count, B.flags, F.seed_size, B.ctrl, B.dirty,
                            (uint32_t)((npix + 255) >> 8), win_first_shift, hold_pct, hold_start ? 1u : 0u, F.label, npix,
-                           B.waypoints, B.wp_cap, B.log_len, B.log_len ? B.log_seeds : 0u);
+                           B.waypoints, B.wp_cap, B.log_len, B.log_len ? B.log_seeds : 0u, dense_div);
     }
     FloodArgs A = flood_args(B, F, P->use_big);
     A.win_shift = (uint32_t)win_growth;
