@@ -2929,6 +2929,15 @@ static void flood_debug_round(const FloodBuffers& B, const FloodFrame& F, uint32
                  "blocked %u, barrier %u, slabs %u\n",
                  ctrl[kCtrlRounds] + 1, n_act, tpx, tsteps, mxs, cnt[mxk], mxk, nb, ctrl[kCtrlBarrier],
                  ctrl[kCtrlSlabs]);
+    {  // the longest walk's seed: storage tier marks and log
+        uint8_t t = 0;
+        uint32_t ll = 0, full[kCtrlWords];
+        (void)hipMemcpy(&t, B.tier + mxk, 1, hipMemcpyDeviceToHost);
+        if (B.log_len && mxk < B.log_seeds) (void)hipMemcpy(&ll, B.log_len + mxk, 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(full, B.ctrl, sizeof(full), hipMemcpyDeviceToHost);
+        std::fprintf(stderr, "  ... that seed: tier marks %u (1 outgrew the first tier, 4 held as a giant), log %u records%s; window %u, lowest active %u, lowest held %u, log records handed out %u of %u\n",
+                     (unsigned)t, ll & 0x7FFFFFFFu, (ll >> 31) ? " (cut down)" : "", full[kCtrlWindow], full[kCtrlLowest], full[kCtrlGiantLow], full[kCtrlLogTotal], B.log_cap);
+    }
 }
 
 namespace {
