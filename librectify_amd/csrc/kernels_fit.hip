@@ -152,22 +152,33 @@ __global__ __launch_bounds__(256) void component_scatter_kernel(const uint32_t* 
     const int lane = threadIdx.x & 63;
     const size_t step = (size_t)gridDim.x * 256;
     const size_t n_pad = (npix + 255) / 256 * 256;  // whole wavefronts take part in the ballots
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_pad; i += step) {
-        uint32_t r = kNoComp;
-        if (i < npix) {
-            const uint32_t l = label[i];
-            if (l != kLabelFree) r = comp_rank[l];
+    // (four of a thread's pixels at a time: their labels, then the ranks those point to, are in flight together -- the pass is
+    // two dependent loads and an atomic with a returned value per wavefront and component, and nearly all latency)
+    constexpr int kU = 4;
+    for (size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x; i0 < n_pad; i0 += step * kU) {
+        uint32_t l[kU], r[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const size_t i = i0 + step * (size_t)u;
+            l[u] = i < npix ? label[i] : kLabelFree;
         }
-        uint64_t todo = __ballot(r != kNoComp);
-        while (todo != 0ull) {
-            const int leader = __builtin_ctzll(todo);
-            const uint32_t rl = (uint32_t)__builtin_amdgcn_readlane((int)r, leader);
-            const uint64_t same = __ballot(r == rl) & todo;
-            uint32_t base = 0;
-            if (lane == leader) base = comp_off[rl] + atomicAdd(&cursor[rl], (uint32_t)__popcll(same));
-            base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-            if ((same >> lane) & 1ull) px[base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = (uint32_t)i;
-            todo &= ~same;
+#pragma unroll
+        for (int u = 0; u < kU; ++u) r[u] = l[u] != kLabelFree ? comp_rank[l[u]] : kNoComp;
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const size_t i = i0 + step * (size_t)u;
+            if (i >= n_pad) break;  // (uniform: i0 and step are multiples of the wavefront within a workgroup's stride)
+            uint64_t todo = __ballot(r[u] != kNoComp);
+            while (todo != 0ull) {
+                const int leader = __builtin_ctzll(todo);
+                const uint32_t rl = (uint32_t)__builtin_amdgcn_readlane((int)r[u], leader);
+                const uint64_t same = __ballot(r[u] == rl) & todo;
+                uint32_t base = 0;
+                if (lane == leader) base = comp_off[rl] + atomicAdd(&cursor[rl], (uint32_t)__popcll(same));
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+                if ((same >> lane) & 1ull) px[base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = (uint32_t)i;
+                todo &= ~same;
+            }
         }
     }
 }
