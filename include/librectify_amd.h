@@ -154,6 +154,13 @@ void lr_set_flood_logs(lr_context* ctx, int on);
  * 0 = blind rounds (the previous frame's count plus two: what lr_set_flood_blind_rounds steers), and a frame whose flood
  * needs more takes a second lap (lr_stage_counters [7]).  LIBRECTIFY_FLOOD_JIT=0 likewise. */
 void lr_set_flood_just_in_time(lr_context* ctx, int on);
+/* The giant step (kernels_flood.hip: kCtrlGiantStep).  The lowest active seed's flood is what the reference's loop
+ * (line_detector.cpp:98-119 over filter.cpp:110-153) does next and nothing about it is speculative: when its walk outgrows
+ * the LDS tiers (a smooth region of 100 000 pixels, a ring of a noiseless gradient) the whole device labels it between two
+ * rounds -- the seed's acceptance test as a 64-bit mask per 8x8 tile, a union-find over the tiles' components, labels --
+ * instead of one team of wavefronts walking it tile after tile through a global slab.  Same labels.  On by default;
+ * 0 = the slab walk (comparison), LIBRECTIFY_FLOOD_GIANT_STEP=0 likewise; lr_stage_counters [14] counts the steps. */
+void lr_set_flood_giant_step(lr_context* ctx, int on);
 
 /* ---- stage API (tests, bench) --------------------------------------------------------- */
 /* Stage 1: fused 5x5 derivative filter + magnitude + direction bin + dilated-bin mask +
@@ -210,7 +217,8 @@ int lr_filter_kernel_ms(lr_context* ctx, float* ms);
  * the flood's explorations walked in all rounds together (over [3]: the re-walk factor), [9] their 8x8-tile steps, [10] re-walks that
  * started from several way-points at once (lr_set_flood_multi_source), [11] footprints worked out from a log instead of
  * walked (lr_set_flood_logs), [12] those of them that took the fall-back path (sweeps), [13] walks that outgrew the second
- * tier's table and were held back until their seed was the lowest active one (instead of moving into a global slab). */
+ * tier's table and were held back until their seed was the lowest active one (instead of moving into a global slab),
+ * [14] giant steps: floods of the lowest active seed labelled by the whole device (lr_set_flood_giant_step). */
 int lr_stage_counters(lr_context* ctx, int64_t* out, int count);
 
 /* ---- RANSAC --------------------------------------------------------------------------- */

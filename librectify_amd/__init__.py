@@ -70,7 +70,7 @@ EXPORTS = [
     "lr_stage_counters", "lr_filter_kernel_ms", "lr_ransac_best", "lr_estimate_line_pencils",
     "lr_find_line_segment_groups_batch_host", "lr_find_line_segment_groups_batch_host_ptrs", "lr_host_alloc", "lr_host_free",
     "lr_set_seed_capacity", "lr_set_flood_blind_rounds", "lr_set_flood_staged", "lr_set_batch_streams", "lr_device_malloc", "lr_device_free", "lr_memcpy_h2d", "lr_cht_vanishing_point", "lr_refine_lines", "lr_set_estimator", "lr_ht_weights", "lr_prosac_solve", "lr_estimate_line_pencils_prosac", "lr_direct_solve", "lr_estimate_line_pencils_direct",
-    "lr_estimate_line_pencils_cht", "lr_set_stage_timing", "lr_release_thread_context", "lr_set_flood_partial_commits", "lr_set_flood_multi_source", "lr_set_flood_logs", "lr_set_flood_just_in_time",
+    "lr_estimate_line_pencils_cht", "lr_set_stage_timing", "lr_release_thread_context", "lr_set_flood_partial_commits", "lr_set_flood_multi_source", "lr_set_flood_logs", "lr_set_flood_just_in_time", "lr_set_flood_giant_step",
     "lr_find_line_segment_groups_batch_host_multi",
 ]
 
@@ -152,6 +152,8 @@ def lib():
         L.lr_set_flood_multi_source.restype = None
         L.lr_set_flood_logs.argtypes = [C.c_void_p, C.c_int]
         L.lr_set_flood_logs.restype = None
+        L.lr_set_flood_giant_step.argtypes = [C.c_void_p, C.c_int]
+        L.lr_set_flood_giant_step.restype = None
         L.lr_set_flood_just_in_time.argtypes = [C.c_void_p, C.c_int]
         L.lr_set_flood_just_in_time.restype = None
         L.lr_release_thread_context.argtypes = []
@@ -276,11 +278,11 @@ class Context:
         return ms.value
 
     def stage_counters(self):
-        c = np.zeros(14, np.int64)
-        _check(lib().lr_stage_counters(self._h, _ptr(c), 14))
+        c = np.zeros(15, np.int64)
+        _check(lib().lr_stage_counters(self._h, _ptr(c), 15))
         return dict(seeds=int(c[0]), components=int(c[1]), flood_rounds=int(c[2]), labelled_px=int(c[3]),
                     second_tier_seeds=int(c[4]), slabs=int(c[5]), ordered_tail_seeds=int(c[6]), frame_laps=int(c[7]),
-                    walked_px=int(c[8]), walk_steps=int(c[9]), multi_source_walks=int(c[10]), log_rewalks=int(c[11]), log_give_ups=int(c[12]), giants_held=int(c[13]))
+                    walked_px=int(c[8]), walk_steps=int(c[9]), multi_source_walks=int(c[10]), log_rewalks=int(c[11]), log_give_ups=int(c[12]), giants_held=int(c[13]), giant_steps=int(c[14]))
 
     # ---- full path ----
     def find_line_segment_groups(self, img, min_length, refine=False, num_threads=-1, capacity=None):
@@ -414,6 +416,10 @@ class Context:
 
     def set_flood_just_in_time(self, on=True):
         lib().lr_set_flood_just_in_time(self._h, int(bool(on)))
+
+    def set_flood_giant_step(self, on=True):
+        """the lowest active seed's flood by the whole device when it outgrows the LDS tiers (default); False = the slab walk"""
+        lib().lr_set_flood_giant_step(self._h, int(bool(on)))
 
     def set_flood_logs(self, on=1):
         """0 = off, 1 = on (default for single calls), 2 = on with every log through the fall-back path (test hook)."""

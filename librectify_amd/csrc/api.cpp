@@ -226,6 +226,7 @@ void lr_set_flood_blind_rounds(lr_context* ctx, int rounds) { ctx->flood_rounds_
 void lr_set_flood_partial_commits(lr_context* ctx, int on) { ctx->flood_partial = on != 0; }
 void lr_set_flood_multi_source(lr_context* ctx, int on) { ctx->flood_multi = on != 0; }
 void lr_set_flood_just_in_time(lr_context* ctx, int on) { ctx->flood_jit = on != 0; }
+void lr_set_flood_giant_step(lr_context* ctx, int on) { ctx->flood_giant_step = on != 0; }
 void lr_set_flood_logs(lr_context* ctx, int on) {
     ctx->flood_logs = on != 0;
     ctx->flood_log_sweep = on == 2;
@@ -301,13 +302,14 @@ int lr_stage_times(lr_context* ctx, float* ms, int count) {
 }
 
 int lr_stage_counters(lr_context* ctx, int64_t* out, int count) {
-    const int64_t v[14] = {(int64_t)ctx->n_seeds,        (int64_t)ctx->n_comp,         (int64_t)ctx->flood_rounds,
+    const int64_t v[15] = {(int64_t)ctx->n_seeds,        (int64_t)ctx->n_comp,         (int64_t)ctx->flood_rounds,
                            (int64_t)ctx->n_px,           (int64_t)ctx->flood_tiers[0], (int64_t)ctx->flood_tiers[1],
                            (int64_t)ctx->flood_tiers[2], (int64_t)ctx->frame_laps,
                            (int64_t)(((uint64_t)ctx->flood_tiers[5] << 32) | ctx->flood_tiers[4]),
                            (int64_t)(((uint64_t)ctx->flood_tiers[7] << 32) | ctx->flood_tiers[6]),
-                           (int64_t)ctx->flood_tiers[9], (int64_t)ctx->flood_tiers[10], (int64_t)ctx->flood_tiers[11], (int64_t)ctx->flood_tiers[12]};
-    for (int i = 0; i < count && i < 14; ++i) out[i] = v[i];
+                           (int64_t)ctx->flood_tiers[9], (int64_t)ctx->flood_tiers[10], (int64_t)ctx->flood_tiers[11], (int64_t)ctx->flood_tiers[12],
+                           (int64_t)ctx->flood_tiers[13]};
+    for (int i = 0; i < count && i < 15; ++i) out[i] = v[i];
     return 0;
 }
 

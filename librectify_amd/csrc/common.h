@@ -145,6 +145,12 @@ struct FloodBuffers {
     int log_min_tiles = 0, log_walk_tiles = 0;  // 0: the defaults (16 and 12, LIBRECTIFY_FLOOD_LOG_MIN / _WALK); the lanes of a batch bring their own
     int log_from_round = 1;    // first round (from 0) whose seeds turn to their logs (walks leave logs from the first round on)
     bool giant_hold = false;   // only the lowest active seed walks on into a global slab; other walks that outgrow the second tier are held back (kernels_flood.hip: kCtrlLowest)
+    // The giant step (round 5; kernels_flood.hip: kCtrlGiantStep): when the lowest active seed's walk outgrows the LDS tiers, its
+    // flood -- a plain connected component, nothing speculative about it -- is labelled by the whole device between two
+    // rounds (tile masks + union-find) instead of being walked by one team of wavefronts through a slab.
+    bool giant_step = true;          // LIBRECTIFY_FLOOD_GIANT_STEP=0: the slab walk, as before (comparison)
+    void* giant_mask = nullptr;      // one 64-bit mask per 8x8 tile of the frame
+    uint32_t* giant_parent = nullptr;  // one word per pixel (the ordered kernels' queue: never in use at the same time)
     bool log_sweep = false;    // test hook: the fall-back (sweeps) for every log
     bool rewalk_big = false;   // the frame is expected to have walks beyond the first tier: their logs are kept too, and a second launch per round works on them
     uint32_t log_seeds = 0, log_cap = 0;
@@ -179,7 +185,7 @@ struct FloodBuffers {
     // when the host has SEEN, in page-locked words the last workgroup of a round writes, that the rounds so far left seeds
     // -- no launch behind the last round with work (the blind rounds of a 4K frame were 60-120 us of empty launches), at
     // the price of the host's reaction time per further round.  The calling thread polls while the flood runs.
-    uint32_t* host_progress = nullptr;  // page-locked, device-visible: rounds with work so far, length of the next list, stalled
+    uint32_t* host_progress = nullptr;  // page-locked, device-visible: rounds with work so far, length of the next list, stalled, giant step asked for, giant steps done
     int jit_first = 0;                  // 0: off
     int jit_sleep_us = 0;               // the polling thread sleeps this long between looks (0: it spins -- single calls)
     uint32_t big_cap_override = 0;  // test hook: seeds per round the second tier takes (0 = the default, 8192)
@@ -207,15 +213,15 @@ struct FloodProgress {
     bool use_big = false;
     int win_growth = 2;
 };
-constexpr int kFloodCtrlWords = 40;
+constexpr int kFloodCtrlWords = 48;
 // Enqueues the initialisation and a first batch of rounds, then an asynchronous copy of the control block into
 // h_ctrl (kFloodCtrlWords words of pinned host memory).  Never synchronises (except in LIBRECTIFY_FLOOD_DEBUG mode).
 int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, uint32_t* h_ctrl, hipStream_t s);
 // After the stream has been synchronised: completes the flood if the first batch did not (more rounds, ordered tail;
 // synchronises).  *extra = the label image changed after flood_enqueue's rounds, so later stages must run again.
 int flood_finish(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, uint32_t* h_ctrl, int* rounds_out,
-                 uint32_t* tiers_out /* [8]: seeds moved to the second tier, slabs used, seeds left to the ordered tail,
-                                        hold-back engaged, pixels walked (lo, hi), tile steps (lo, hi) */,
+                 uint32_t* tiers_out /* [14]: seeds moved to the second tier, slabs used, seeds left to the ordered tail,
+                                        hold-back engaged, pixels walked (lo, hi), tile steps (lo, hi), ... giant steps */,
                  bool* extra, hipStream_t s);
 
 // kernels_fit.hip (all counts stay on the device: launches cover seed_cap / comp_cap)

@@ -137,7 +137,7 @@ struct lr_context {
     int estimator = 0;            // 0 = RANSAC (reference default), 1 = PROSAC, 2 = DirectEstimator, 3 = diamond space (CHT)
     int prosac_T_N = -1;
     // pinned host scalars
-    uint32_t* h_counts = nullptr;  // 8 words
+    uint32_t* h_counts = nullptr;  // 8 words of counts; + 16: the flood's control block; + 72: the words the flood's rounds report in
     float* h_best = nullptr;       // [0] score, [1] iter (as int bits)
 
     // constants
@@ -151,6 +151,7 @@ struct lr_context {
     int flood_rounds_hint = 10;  // rounds the next flood enqueues blindly
     int flood_rounds_last = 0;   // rounds the last flood needed (0: none yet)
     int flood_jit_sleep_us = 0;  // (lanes of a batch call, when they enqueue just in time at all: pause between looks)
+    bool flood_giant_step = true;  // the lowest active seed's flood by the whole device when it outgrows the LDS tiers (kernels_flood.hip: kCtrlGiantStep); lr_set_flood_giant_step, LIBRECTIFY_FLOOD_GIANT_STEP=0
     bool flood_jit = true;       // single calls enqueue the flood's later rounds just in time (kernels_flood.hip: flood_enqueue); LIBRECTIFY_FLOOD_JIT=0
     uint64_t ransac_seed = 0;
     int ransac_iters = lramd::kRansacMaxIter;
@@ -159,7 +160,7 @@ struct lr_context {
     bool flood_logbig_hint = true;  // did the last frame have walks in the second tier? (their logs need a launch of their own per round: kernels_flood.hip, flood_rewalk_kernel)
     bool flood_big_hint = true;  // did the last frame's walks outgrow the first storage tier? (none yet: assume so)
     bool flood_hold_hint = false;  // did the last frame hold its weakest seeds back?
-    uint32_t flood_tiers[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // last flood: seeds in the second tier, slabs used, seeds of the ordered tail, hold-back, walked px (lo, hi), steps (lo, hi), walks beyond the first tier's table, multi-source re-walks, re-walks from logs, logs given up, giants held back
+    uint32_t flood_tiers[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // last flood: seeds in the second tier, slabs used, seeds of the ordered tail, hold-back, walked px (lo, hi), steps (lo, hi), walks beyond the first tier's table, multi-source re-walks, re-walks from logs, logs given up, giants held back
     bool flood_partial = true;  // partial commits of blocked seeds (kernels_flood.hip); lr_set_flood_partial_commits
     int flood_log_min = 0, flood_log_walk = 0;  // thresholds of the logs (0: the defaults; the lanes of a batch call get 32 and 24)
     int flood_log_from = 1;        // first round (from 0) whose seeds turn to their logs (lanes of a batch: experiment knob LIBRECTIFY_FLOOD_LOGS_LANES_FROM)

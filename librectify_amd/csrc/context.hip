@@ -157,6 +157,11 @@ static int ensure_flood_buffers(lr_context* c) {
         dev_alloc(f.act_a, cs) || dev_alloc(f.act_b, cs) || dev_alloc(f.ctrl, kFloodCtrlWords) || dev_alloc(f.big_list, 8192) || dev_alloc(f.handover, 8192 * kFloodHandWords) ||
         dev_alloc(f.dirty, cs / 256 + 16))
         return 1;
+    {   // the giant step's tile masks: (w + 7) / 8 x (h + 7) / 8 tiles <= cs / 16 + 64 for frames of 5 x 5 and more
+        uint64_t* gm = (uint64_t*)f.giant_mask;
+        if (dev_alloc(gm, cs / 16 + 64)) return 1;
+        f.giant_mask = gm;
+    }
     f.wp_cap = (uint32_t)std::min<size_t>(std::max<size_t>(cs / 16, 4096), cs);  // (one seed per 16 pixels: the 4K bench frame has one per 200)
     if (dev_alloc(f.waypoints, (size_t)f.wp_cap * kFloodWpWords) || dev_alloc(f.multi_list, 8192)) return 1;
     // footprint logs (FloodBuffers::rewalk_logs): per-seed words for one seed per 16 pixels, a record per 8 pixels
@@ -624,7 +629,7 @@ int ctx_create(int device, lr_context** out) {
         check(hipMalloc((void**)&c->d_gnorm, 4 * sizeof(float)), "hipMalloc(normalisation)");
         check(hipMalloc((void**)&c->d_models, 64 * sizeof(float)), "hipMalloc(models)");
         check(hipMalloc((void**)&c->d_best_slots, kRansacBestSlots * sizeof(unsigned long long)), "hipMalloc(best slots)");
-        check(hipHostMalloc((void**)&c->h_counts, 64 * sizeof(uint32_t)), "hipHostMalloc(counts)");
+        check(hipHostMalloc((void**)&c->h_counts, 128 * sizeof(uint32_t)), "hipHostMalloc(counts)");
         check(hipHostMalloc((void**)&c->h_best, 2 * sizeof(float)), "hipHostMalloc(best)");
         if (bad == hipSuccess) check(hipMemset(c->d_models, 0, 64 * sizeof(float)), "hipMemset(models)");
         if (bad == hipSuccess) check(hipMemset(c->d_counts, 0, 64 * sizeof(uint32_t)), "hipMemset(counts)");
@@ -662,7 +667,7 @@ void ctx_destroy(lr_context* c) {
                     c->label, c->queue, c->comp_rank, c->comp_seed, c->comp_off, c->cursor, c->px_a, c->px_b,
                     c->scratch_w, c->d_lines, c->temp, c->d_model, c->d_best_slots,
                     c->fb.blocked, c->fb.count, c->fb.flags, c->fb.state, c->fb.tier, c->fb.act_a, c->fb.act_b,
-                    c->fb.ctrl, c->fb.big_list, c->fb.handover, c->fb.waypoints, c->fb.multi_list, c->fb.log_off, c->fb.log_len, c->fb.log_buf, c->fb.dirty, c->fb.slab_ring, c->fb.slab_hash, c->d_pairs, c->d_peak, c->d_weights,
+                    c->fb.ctrl, c->fb.big_list, c->fb.handover, c->fb.waypoints, c->fb.multi_list, c->fb.log_off, c->fb.log_len, c->fb.log_buf, c->fb.dirty, c->fb.giant_mask, c->fb.slab_ring, c->fb.slab_hash, c->d_pairs, c->d_peak, c->d_weights,
                     c->d_samples, c->d_hcounts, c->comp_large, c->d_tables, c->d_orig, c->d_inl, c->d_flines, c->d_gctl,
                     c->d_gnorm, c->d_models, c->d_refine_table, c->d_refine_edges, c->d_cht_acc, c->d_cht_idx, c->d_cht_peak, c->d_rec, c->d_recflags};
     for (void* p : ptrs)
@@ -798,6 +803,9 @@ FloodBuffers flood_buffers_for(lr_context* c) {
     fbuf.log_walk_tiles = c->flood_log_walk;
     static const bool giants_off = std::getenv("LIBRECTIFY_FLOOD_GIANTS") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_GIANTS")) == 0;
     fbuf.giant_hold = c->flood_mode == 1 && !giants_off;  // (the storage test hooks -- modes 2-7 -- keep their slabs)
+    static const bool giant_step_off = std::getenv("LIBRECTIFY_FLOOD_GIANT_STEP") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_GIANT_STEP")) == 0;
+    fbuf.giant_step = !giant_step_off && c->flood_giant_step;
+    fbuf.giant_parent = reinterpret_cast<uint32_t*>(c->queue);
     fbuf.rewalk_big = c->flood_logbig_hint && !c->flood_logbig_off;  // (the context's last frame had walks beyond the first tier)
     static const int aux_env = std::getenv("LIBRECTIFY_FLOOD_MULTI_BESIDE") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_MULTI_BESIDE")) : -1;  // (experiment: 0 = after the exploration, N = beside it in rounds 2 .. N + 1)
     if (c->flood_aux && c->flood_aux_on && aux_env != 0 && c->flood_fork.size() == c->flood_join.size()) {
@@ -811,7 +819,7 @@ FloodBuffers flood_buffers_for(lr_context* c) {
     fbuf.blind_rounds = c->flood_rounds_hint;
     // rounds just in time (FloodBuffers::host_progress): what the last frame needed less one at once (three on a new context)
     static const bool jit_off = std::getenv("LIBRECTIFY_FLOOD_JIT") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_JIT")) == 0;
-    fbuf.host_progress = c->h_counts + 60;  // (the control block's copy ends at + 56)
+    fbuf.host_progress = c->h_counts + 72;  // (the control block's copy ends at + 64)
     fbuf.jit_sleep_us = c->flood_jit_sleep_us;
     // (at most four rounds blindly -- the rounds that always bring their `rest` launch, kernels_flood.hip kRestRounds: a later
     // blind round whose list is longer than its grid walks only a part of it, and lists stay long while a window is closed in
@@ -2229,6 +2237,7 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
         l->flood_mode = c->flood_mode;
         l->flood_staged = c->flood_staged;  // (off unless lr_set_flood_staged: +6 % in round 1, -3 % now)
         l->flood_partial = c->flood_partial;
+        l->flood_giant_step = c->flood_giant_step;
         // Multi-source re-walks shorten a frame's rounds at the price of more work per long walk (eight wavefronts and a
         // second table entry per tile): worth it when the frame has the GPU to itself, not when S frames share it -- their
         // rounds overlap each other anyway (profiles/r04_flood_multi_sweep.txt).  LIBRECTIFY_FLOOD_MULTI_LANES=1 keeps them.
@@ -2510,6 +2519,7 @@ int ctx_find_groups_batch_host_multi(lr_context* c, const int* devices, int n_de
         p->flood_multi = c->flood_multi;
         p->flood_logs = c->flood_logs;
         p->flood_log_sweep = c->flood_log_sweep;
+        p->flood_giant_step = c->flood_giant_step;
         p->estimator = c->estimator;
         p->prosac_T_N = c->prosac_T_N;
         p->cht_d = c->cht_d;

@@ -175,6 +175,7 @@ constexpr uint32_t kWpMaxTiles = 600u;   // the team's table holds an entry per 
 constexpr uint32_t kSrcShift = 28u, kSrcMask = 0xF0000000u, kSrcClaim = 0xF0000000u;  // table keys of a multi-source walk
 constexpr uint32_t kBigCap = 8192;  // seeds per round that can move to the second tier (FloodBuffers::big_list)
 constexpr uint32_t kFlagIncomplete = 1u, kFlagSelfFail = 2u;
+constexpr uint32_t kFullTiles = 48u;     // a first-tier walk is held at this many tiles once the round's second-tier list is full (explore_seed)
 constexpr uint32_t kGiantProbes = 512u;  // marked seeds a round lets walk again (one team each: a launch's worth)
 constexpr uint32_t kLogShrunk = 0x80000000u;  // FloodArgs::log_len: the log has been cut down to a later footprint by flood_rewalk_kernel
 constexpr uint32_t kMaxSteps = 1u << 22;  // safety net of the walk loop: more records than an 8K frame has tile visits
@@ -229,6 +230,12 @@ struct FloodArgs {
     uint32_t* log_len;                               // ... and their number (0: none)
     uint32_t* log_buf;                               // records: tile, walked lo, walked hi
     uint32_t log_cap;                                // records the buffer holds
+    // ---- the giant step (see kCtrlGiantStep): the lowest active seed's flood by the whole device
+    uint32_t giant_step;                             // 1: a walk of the LOWEST active seed that outgrows the LDS tiers asks for it instead of moving into a slab
+    uint32_t* act_a;                                 // the two active lists: a round with work reads the one its index (kCtrlRounds) selects and
+    uint32_t* act_b;                                 // appends to the other (rounds enqueued behind a request for a giant step do nothing and do not count)
+    unsigned long long* giant_mask;                  // per 8x8 tile: the seed's acceptable pixels, then its flood's (FloodBuffers::giant_mask)
+    uint32_t* giant_parent;                          // per pixel: union-find parent of the in-tile components' first pixels (FloodBuffers::giant_parent)
 };
 // All words but kCtrlGen are set up by flood_init_seeds_kernel every frame; kCtrlGen lives on for the lifetime of
 // the slab memory (hash entries are tagged with it, so a generation must never be reused while old entries are
@@ -284,7 +291,18 @@ enum {
     kCtrlGiantRuled = 35,    // 1: the current round's window was cut by this rule
     kCtrlGiants = 36,        // walks held back this way over the frame (diagnostics: lr_stage_counters [13])
     kCtrlGiantCountNext = 37,  // marked seeds among the survivors (survivors pass)
-    kCtrlWords = 40,
+    // The giant step (round 5).  The lowest active seed is never blocked and always commits: its flood is a plain connected
+    // component of a static predicate (acceptable for this seed and not committed), the one flood the WHOLE device can work on
+    // without touching exactness.  When the lowest active seed is a marked giant -- at the end of a round (flood_advance), or
+    // after a giant step (giant_finish_kernel) -- this word holds seed + 1: every kernel of a round leaves at once while it is
+    // set (rounds enqueued blindly behind the request do nothing and do not count), the host sees the request in
+    // host_progress[3] and enqueues the step (giant_*_kernel: tile masks, union-find over the tiles' components, labels).
+    kCtrlGiantStep = 38,
+    kCtrlGiantDone = 39,       // giant steps of the frame (diagnostics: lr_stage_counters [14]; the host waits for its count)
+    kCtrlGiantPx = 40,         // pixels of the step in progress
+    kCtrlGiantBlocks = 41,     // workgroups of giant_finish_kernel that have finished
+    kCtrlWindowFree = 42,      // the coming round's window before the giants' rule cut it (giant_finish_kernel applies the rule again)
+    kCtrlWords = 48,
 };
 static_assert(kCtrlWords == kFloodCtrlWords, "control block size");
 
@@ -304,6 +322,12 @@ __device__ __forceinline__ uint64_t m_gt_s(int a, int b) { return __builtin_amdg
 __device__ __forceinline__ uint64_t m_gt_f(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 2); }
 __device__ __forceinline__ bool lane_of(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
 __device__ __forceinline__ uint64_t uni64(uint64_t v) { return uni64((uint32_t)v, (uint32_t)(v >> 32)); }
+
+// the active list a round with work reads, and the one it appends to (see FloodArgs::act_a)
+__device__ __forceinline__ const uint32_t* act_now(const FloodArgs& A) { return (uni(A.ctrl[kCtrlRounds]) & 1u) ? A.act_b : A.act_a; }
+__device__ __forceinline__ uint32_t* act_other(const FloodArgs& A) { return (uni(A.ctrl[kCtrlRounds]) & 1u) ? A.act_a : A.act_b; }
+// a giant step has been asked for: the round's kernels leave at once
+__device__ __forceinline__ bool giant_pending(const FloodArgs& A) { return uni(A.ctrl[kCtrlGiantStep]) != 0u; }
 
 struct WalkState {
     uint32_t head, tail, cnt, ntiles;
@@ -976,7 +1000,8 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
     const bool own = seed_label == k;
     if (seed_label < kMarkBit && !own) return;  // claimed by an earlier flood: dead (the survivors pass takes it off the list)
     // on this round's list of way-point seeds: a team walks it right now, in a launch beside this one (enqueue_round)
-    if (kFirstTier && (uni((uint32_t)A.tier[k]) & 2u) != 0u) return;
+    // (bit 3: finished by a giant step between the rounds -- the survivors pass of this round takes it off the list)
+    if (kFirstTier && (uni((uint32_t)A.tier[k]) & 10u) != 0u) return;
     if (!own && !(((seed_mask >> b) & 1) && directional(seed_dx, seed_dy, sn, cs) > thr)) {
         if (lane == 0) A.flags[k] = kFlagSelfFail;  // flood() accepts nothing, not even the seed
         return;
@@ -1020,8 +1045,14 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
                 }
             }
         }
+        // (The second tier's list is full already -- eight thousand long walks in this round: a frame of overlapping giants, a
+        // noiseless gradient whose every pixel is a seed -- so a walk that outgrows this tier will be held back whatever its
+        // length, see below: it is held at kFullTiles tiles instead of walking on to the table's 190.  Radial gradient at
+        // 1080p, 78 704 seeds: first round 45 ms before.)
+        const bool tier2_full = hand_over && A.giant_hold != 0u && uni(ld_agent(&A.ctrl[kCtrlNBig])) >= A.big_cap &&
+                                k != uni(A.ctrl[kCtrlLowest]);
         if (rc != 0)  // (from the start, or from where the budgeted walk stands: the list was full)
-            rc = walk(A, k, b, thr, sn, cs, L, P, st, lane, own, nullptr, hand_over ? t1_tiles : 0xFFFFFFFFu,
+            rc = walk(A, k, b, thr, sn, cs, L, P, st, lane, own, nullptr, hand_over ? (tier2_full ? min(t1_tiles, kFullTiles) : t1_tiles) : 0xFFFFFFFFu,
                       hand_over ? A.t1_wide_tiles : 0xFFFFFFFFu, hand_over ? A.t1_wide_front : 0xFFFFFFFFu);
     }
     if (kFirstTier && rc != 0 && A.big_cap != 0u) {
@@ -1071,7 +1102,9 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
         // other is held back like a walk that outgrows the second tier's table (see kCtrlLowest): with eight thousand walks in
         // the second tier the frame is one of overlapping giants (a noiseless radial gradient: 35 837 seeds, all of one
         // magnitude, sixteen rings), and the slabs are for the one walk that is sure to commit
-        if (rc != 0 && A.giant_hold != 0u && k != uni(A.ctrl[kCtrlLowest])) {
+        // (with the giant step the lowest active seed is marked as well: the end of the round finds the lowest survivor marked
+        // and asks for the step -- flood_advance)
+        if (rc != 0 && A.giant_hold != 0u && (A.giant_step != 0u || k != uni(A.ctrl[kCtrlLowest]))) {
             if (lane == 0) {
                 A.tier[k] = (uint8_t)(A.tier[k] | 5u);  // (outgrew the first tier; a giant)
                 A.flags[k] = kFlagIncomplete;
@@ -1169,8 +1202,7 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
 //    that the compiler's s_waitcnt vmcnt(0) does not wait for them too): 385, 304, 238, 207, 142 us.  The same with
 //    throw-away loads that only warm the cache: 446, 370, 270, 240, 160 us.
 template <bool kRest>
-__device__ __forceinline__ void explore_body(const FloodArgs& A, const BinTrig& trig, const uint32_t* __restrict__ act,
-                                             uint32_t* __restrict__ big_list, uint32_t first) {
+__device__ __forceinline__ void explore_body(const FloodArgs& A, const BinTrig& trig, uint32_t* __restrict__ big_list, uint32_t first) {
     __shared__ uint32_t s_ring[3][kRingT];
     __shared__ uint32_t s_hash[3][kHashT];
     __shared__ uint32_t s_pend[2][kPend];
@@ -1180,6 +1212,8 @@ __device__ __forceinline__ void explore_body(const FloodArgs& A, const BinTrig& 
     asm volatile("" ::"v"(&s_pad[threadIdx.x]) : "memory");
 #endif
     const int lane = threadIdx.x & 63;
+    if (giant_pending(A)) return;
+    const uint32_t* __restrict__ act = act_now(A);
     const uint32_t n_act = uni(A.ctrl[kCtrlNAct]), window = uni(A.ctrl[kCtrlWindow]);
     // A frame with many LONG walks (sixteen beyond what the first tier's table holds: natural images, frames of long bars)
     // hands its walks over earlier from the next round on -- at 32 tiles instead of 190: the first tier's rounds last as
@@ -1215,12 +1249,12 @@ __device__ __forceinline__ void explore_body(const FloodArgs& A, const BinTrig& 
 // half the walks per CU -- LDS padded to 18.9 KB -- round one takes 600 us instead of 374 and the batch rate drops by a
 // quarter, so occupancy is what the bulk rounds live on up to about this point.)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void flood_explore_kernel(
-    FloodArgs A, BinTrig trig, const uint32_t* __restrict__ act, uint32_t* __restrict__ big_list) {
-    explore_body<false>(A, trig, act, big_list, 0u);
+    FloodArgs A, BinTrig trig, uint32_t* __restrict__ big_list) {
+    explore_body<false>(A, trig, big_list, 0u);
 }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void flood_explore_rest_kernel(
-    FloodArgs A, BinTrig trig, const uint32_t* __restrict__ act, uint32_t* __restrict__ big_list, uint32_t first) {
-    explore_body<true>(A, trig, act, big_list, first);
+    FloodArgs A, BinTrig trig, uint32_t* __restrict__ big_list, uint32_t first) {
+    explore_body<true>(A, trig, big_list, first);
 }
 
 // Second storage tier: the same walk from the start with a 1024-record ring and a 2048-tile table (dynamic LDS,
@@ -1230,6 +1264,7 @@ __global__ __launch_bounds__(64) void flood_explore_big_kernel(FloodArgs A, BinT
                                                                uint32_t* __restrict__ big_list) {
     extern __shared__ uint32_t s_big[];
     const int lane = threadIdx.x & 63;
+    if (giant_pending(A)) return;
     const uint32_t ai = uni(blockIdx.x);
     const uint32_t n_big = uni(A.ctrl[kCtrlNBig]);
     if (ai >= (n_big < A.big_cap ? n_big : A.big_cap)) return;
@@ -1626,7 +1661,7 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
                                                                              uint32_t from_multi_list) {
     extern __shared__ uint32_t s_team[];
     const int lane = threadIdx.x & 63, wave = (int)uni(threadIdx.x >> 6);
-    if (uni(A.ctrl[kCtrlNAct]) == 0u) return;  // a round enqueued past the end (or past a stall: the listed seeds are the ordered tail's)
+    if (uni(A.ctrl[kCtrlNAct]) == 0u || giant_pending(A)) return;  // a round enqueued past the end (or past a stall: the listed seeds are the ordered tail's)
     const uint32_t n_big_raw = uni(A.ctrl[from_multi_list ? kCtrlNMulti : kCtrlNBig]);
     const uint32_t n_big = from_multi_list ? min(n_big_raw, kBigCap) : (n_big_raw < A.big_cap ? n_big_raw : A.big_cap);
     uint32_t* ring = s_team;
@@ -1749,9 +1784,10 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
         WalkState st{0u, 0u, 0u, 0u, false, 0u, 0u};
         uint32_t px = 0u;
         bool in_slab = false;
-        if (rc != 0 && A.giant_hold != 0u && k != uni(A.ctrl[kCtrlLowest])) {
+        if (rc != 0 && A.giant_hold != 0u && (A.giant_step != 0u || k != uni(A.ctrl[kCtrlLowest]))) {
             // LDS exhausted, and this is not the lowest active seed: a giant, held back (see kCtrlLowest).  Nothing has been
-            // stamped; the seed counts as a walk that did not finish, so nothing above it commits in this round.
+            // stamped; the seed counts as a walk that did not finish, so nothing above it commits in this round.  (With the
+            // giant step the lowest active seed is marked as well, and the end of the round asks for the step: flood_advance.)
             if (threadIdx.x == 0) {
                 A.tier[k] = (uint8_t)(A.tier[k] | 4u);
                 A.flags[k] = kFlagIncomplete;
@@ -2038,7 +2074,7 @@ __global__ __launch_bounds__(kThreads) void flood_rewalk_kernel(FloodArgs A, con
     __shared__ uint32_t s_nnodes, s_over, s_blocked, s_cnt, s_seed_node, s_nout, s_nedges;
     const int lane = threadIdx.x & 63, wave = (int)uni(threadIdx.x >> 6);
     const int lr = lane >> 3, lc = lane & 7;
-    if (uni(A.ctrl[kCtrlNAct]) == 0u) return;  // a round enqueued past the end, or past a stall
+    if (uni(A.ctrl[kCtrlNAct]) == 0u || giant_pending(A)) return;  // a round enqueued past the end, or past a stall
     const uint32_t n_list = min(uni(A.ctrl[kCtrlNMulti]), kBigCap);
     const uint32_t window = uni(A.ctrl[kCtrlWindow]);
     for (uint32_t ai = uni(blockIdx.x); ai < n_list; ai += gridDim.x) {
@@ -2369,13 +2405,14 @@ __global__ __launch_bounds__(kThreads) void flood_rewalk_kernel(FloodArgs A, con
 //   - the seed's later explorations start from what it owns and meet fewer foreign stamps.
 // Only for seeds below the round's barrier (all lower seeds have stamped completely) whose exploration finished.  A
 // walk that outgrows the first storage tier simply stops: any connected part is as safe as the whole.
-__global__ __launch_bounds__(64) void flood_partial_commit_kernel(FloodArgs A, const uint32_t* __restrict__ act,
-                                                                  uint8_t* __restrict__ dmask_rw) {
+__global__ __launch_bounds__(64) void flood_partial_commit_kernel(FloodArgs A, uint8_t* __restrict__ dmask_rw) {
     __shared__ uint32_t s_ring[3][kRingT];
     __shared__ uint32_t s_hash[3][kHashT];
     __shared__ uint32_t s_pend[2][kPend];
     __shared__ uint8_t s_ord[kHashT];
     const int lane = threadIdx.x & 63;
+    if (giant_pending(A)) return;
+    const uint32_t* __restrict__ act = act_now(A);
     const uint32_t n_act = uni(A.ctrl[kCtrlNAct]), window = uni(A.ctrl[kCtrlWindow]), barrier = uni(A.ctrl[kCtrlBarrier]);
     LdsStore L{s_ring[0], s_ring[1], s_ring[2], s_hash[0], s_hash[1], s_hash[2], s_ord};
     Pending P{s_pend[0], s_pend[1]};
@@ -2413,7 +2450,7 @@ __device__ __forceinline__ bool seed_commits(const FloodArgs& A, uint32_t k, uin
 __global__ __launch_bounds__(256) void flood_commit_pixels_kernel(FloodArgs A, uint32_t* __restrict__ label, size_t npix,
                                                                   uint8_t* __restrict__ dmask) {
     const uint32_t* __restrict__ ctrl = A.ctrl;
-    if (ctrl[kCtrlNAct] == 0u) return;  // a round enqueued past the end
+    if (ctrl[kCtrlNAct] == 0u || ctrl[kCtrlGiantStep] != 0u) return;  // a round enqueued past the end, or behind a request for a giant step
     const uint32_t barrier = ctrl[kCtrlBarrier];
     const int lane = threadIdx.x & 63;
     const uint32_t n_runs = (uint32_t)((npix + 255) >> 8);
@@ -2444,7 +2481,7 @@ __global__ __launch_bounds__(256) void flood_commit_pixels_kernel(FloodArgs A, u
 // End of a round (one thread: the last workgroup of the survivors pass): the next list becomes the current one.  A round without progress (possible only
 // when storage ran out on the lowest active seed) stops the rounds and leaves the rest to the ordered tail.
 __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift, uint32_t regional_min, uint32_t hold_min_big,
-                              uint32_t* host_progress, uint32_t hold_release) {
+                              uint32_t* host_progress, uint32_t hold_release, uint32_t giant_step) {
     const uint32_t n_act = ld_agent(&ctrl[kCtrlNAct]);
     if (n_act == 0u) {  // (a round enqueued past the end -- or a frame without seeds: the host must not wait for more)
         if (host_progress) {
@@ -2457,7 +2494,11 @@ __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift, u
     const uint32_t n_next = ld_agent(&ctrl[kCtrlNNext]);
     const uint32_t window = ld_agent(&ctrl[kCtrlWindow]);
     const bool moved = ld_agent(&ctrl[kCtrlNCommit]) > 0u || n_next < n_act;
-    const bool progress = moved || window < n_seeds;
+    // the lowest survivor is a marked giant: its flood is the next thing the ordered algorithm does, and the whole device
+    // does it (giant step) before the next round with work
+    const bool want_giant = giant_step != 0u && n_next > 0u && ld_agent(&ctrl[kCtrlGiantLowNext]) != 0xFFFFFFFFu &&
+                            ld_agent(&ctrl[kCtrlGiantLowNext]) == ld_agent(&ctrl[kCtrlLowestNext]);
+    const bool progress = moved || window < n_seeds || want_giant;
     // Window of the next round.  Staged start: it grows by << win_shift up to the seed count.  Hold-back: once a
     // full round has shown walks that outgrow the first storage tier (a frame with long edges or large smooth
     // regions: the weakest seeds, with the lowest thresholds, own the largest footprints and stay blocked for most
@@ -2489,8 +2530,9 @@ __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift, u
         const uint32_t lowest = ld_agent(&ctrl[kCtrlLowestNext]), giant = ld_agent(&ctrl[kCtrlGiantLowNext]);
         // (a round under the rule that moved nothing -- the lowest seed's walk ran out of slabs -- is followed by one without
         // it, so that the full window can show the stall)
-        const bool skip_rule = ld_agent(&ctrl[kCtrlGiantRuled]) != 0u && !moved;
+        const bool skip_rule = ld_agent(&ctrl[kCtrlGiantRuled]) != 0u && !moved && !want_giant;
         bool ruled = false;
+        unsigned long long grown_free = grown;
         if (giant != 0xFFFFFFFFu && !skip_rule) {
             // The window ends behind the lowest marked seed plus room for about kGiantProbes marked seeds more (their density
             // over the rest of the order taken as even): those walk again up to the team's table -- most fit by now, what the
@@ -2501,10 +2543,12 @@ __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift, u
             const unsigned long long line = (unsigned long long)giant + 1ull + (unsigned long long)kGiantProbes * rest / n_marked;
             (void)lowest;
             if (line < grown) {
+                grown_free = grown;
                 grown = line;
                 ruled = true;
             }
         }
+        ctrl[kCtrlWindowFree] = (uint32_t)(ruled ? grown_free : grown);
         ctrl[kCtrlGiantRuled] = ruled ? 1u : 0u;
         ctrl[kCtrlLowest] = lowest;
         ctrl[kCtrlGiantLow] = giant;
@@ -2527,9 +2571,11 @@ __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift, u
     ctrl[kCtrlNMulti] = progress ? ld_agent(&ctrl[kCtrlNMultiNext]) : 0u;
     ctrl[kCtrlNMultiNext] = 0u;
     ctrl[kCtrlBigSeen] = ld_agent(&ctrl[kCtrlBigLong]) >= regional_min ? 1u : 0u;
+    ctrl[kCtrlGiantStep] = (progress && want_giant) ? ld_agent(&ctrl[kCtrlLowest]) + 1u : 0u;  // (kCtrlLowest: the lowest survivor, set above)
     if (host_progress) {  // the host enqueues the next round when it sees this one over and seeds left (flood_enqueue)
         __hip_atomic_store(&host_progress[1], progress ? n_next : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&host_progress[2], progress ? 0u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host_progress[3], (progress && want_giant) ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&host_progress[0], ld_agent(&ctrl[kCtrlRounds]), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
@@ -2540,10 +2586,11 @@ __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift, u
 // round against 16 + 13, 14 + 10, 9 + 9, ... for the two launches, single frames and batches unchanged.  With one
 // __threadfence per workgroup of the 4336 it took 65-140 us per round: the fence, not the atomics.)
 // After the commit: which seeds go on to the next round?
-__global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, const uint32_t* __restrict__ act,
-                                                              uint8_t* __restrict__ state,
-                                                              int32_t* __restrict__ seed_size,
-                                                              uint32_t* __restrict__ act_next) {
+__global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, uint8_t* __restrict__ state,
+                                                              int32_t* __restrict__ seed_size) {
+    if (giant_pending(A)) return;  // (nothing of this round ran: not counted, nothing reported)
+    const uint32_t* __restrict__ act = act_now(A);
+    uint32_t* __restrict__ act_next = act_other(A);
     const uint32_t n_act = A.ctrl[kCtrlNAct];
     const uint32_t n_pad = (n_act + 255u) & ~255u;  // whole workgroups take part in the ballots and barriers
     const uint32_t window = A.ctrl[kCtrlWindow];
@@ -2655,7 +2702,7 @@ __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, const
         if (atomicAdd(&A.ctrl[kCtrlDone], 1u) == gridDim.x - 1u) {
             __threadfence();
             A.ctrl[kCtrlDone] = 0u;
-            flood_advance(A.ctrl, A.win_shift, A.t1_regional_min, A.hold_min_big, A.host_progress, A.hold_release);
+            flood_advance(A.ctrl, A.win_shift, A.t1_regional_min, A.hold_min_big, A.host_progress, A.hold_release, A.giant_step);
         }
     }
 }
@@ -2705,6 +2752,10 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
         ctrl[kCtrlGiantRuled] = 0u;
         ctrl[kCtrlGiantCountNext] = 0u;
         ctrl[kCtrlGiants] = 0u;
+        ctrl[kCtrlGiantStep] = 0u;
+        ctrl[kCtrlGiantDone] = 0u;
+        ctrl[kCtrlGiantPx] = 0u;
+        ctrl[kCtrlGiantBlocks] = 0u;
         ctrl[kCtrlLogTotal] = 0u;
         ctrl[kCtrlLogWalks] = 0u;
         ctrl[kCtrlLogGiveUp] = 0u;
@@ -2733,6 +2784,315 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
     count[k] = 0u;
     flags[k] = 0u;
     seed_size[k] = 0;
+}
+
+// ---- The giant step: the lowest active seed's flood by the whole device -----------------------------------------------------
+// (see kCtrlGiantStep.)  The lowest active seed is never blocked: what it reaches is what the ordered flood (filter.cpp:110-153
+// under line_detector.cpp:98-119) gives it, the connected component around its pixel of {acceptable for this seed, not
+// committed} -- and nothing about that set is speculative.  A team of eight wavefronts used to walk it tile after tile
+// through a global slab (a region of 140 000 pixels: 11.7 ms of a 1080p frame; a ring of a noiseless radial gradient: 3-9 ms,
+// sixteen of them).  Here the component is LABELLED instead of walked, by as many workgroups as the frame has tiles:
+//   giant_mask_kernel    the seed's acceptance test on every pixel, as one 64-bit mask per 8x8 tile (a wavefront takes a strip
+//                        of eight tiles: 256-byte rows); the in-tile components of each mask (8-neighbour closure on the mask)
+//                        become the nodes of a union-find, a node's name the index of its first pixel;
+//   giant_merge_kernel   a thread a tile: components of neighbouring tiles that touch across the border (east, south,
+//                        south-east, south-west) are united -- compare-and-swap on roots, path halving, every access at L2;
+//   giant_commit_kernel  the components united with the seed's become its flood: label = seed, direction mask cleared (the
+//                        form a commit leaves), pixels counted;
+//   giant_finish_kernel  the seed is retired (tier bit 3: explorations pass it over; count, blocked and flags as a finished,
+//                        unblocked walk leaves them: the next round's survivors pass books it as committed), the lowest
+//                        seed of the list that is still alive becomes kCtrlLowest, the giants' line is drawn again -- and
+//                        if that seed is a marked giant too, the next step is asked for at once (a ring of equal seeds
+//                        after another: no round in between).
+// The cost does not depend on the component's shape or size: 9 bytes a pixel read once, a word a tile, a handful of atomics
+// a tile border.  Exact because the step does what the reference's loop does next: every lower seed is resolved.
+__device__ __forceinline__ uint64_t giant_closure(uint64_t c, uint64_t M) {
+    uint64_t prev;
+    do {
+        prev = c;
+        c = dilate8(c) & M;
+        c = dilate8(c) & M;
+    } while (c != prev);
+    return c;
+}
+__device__ __forceinline__ uint32_t gu_find(uint32_t* par, uint32_t x) {
+    for (;;) {
+        const uint32_t p = ld_agent(&par[x]);
+        if (p == x) return x;
+        const uint32_t g = ld_agent(&par[p]);
+        if (g != p) __hip_atomic_store(&par[x], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (any ancestor is a valid parent)
+        x = g;
+    }
+}
+__device__ __forceinline__ void gu_union(uint32_t* par, uint32_t a, uint32_t b) {
+    for (;;) {
+        uint32_t ra = gu_find(par, a), rb = gu_find(par, b);
+        if (ra == rb) return;
+        if (rw_order(ra) < rw_order(rb)) {  // (a scrambled order of the names: see rw_order)
+            const uint32_t t = ra;
+            ra = rb;
+            rb = t;
+        }
+        if (atomicCAS(&par[ra], ra, rb) == ra) return;  // (a root only ever changes through this exchange)
+    }
+}
+__device__ __forceinline__ uint32_t giant_pixel(uint32_t tx, uint32_t ty, uint32_t bit, uint32_t w) {
+    return (ty * 8u + (bit >> 3)) * w + tx * 8u + (bit & 7u);
+}
+
+__global__ __launch_bounds__(256) void giant_mask_kernel(FloodArgs A, BinTrig trig) {
+    const uint32_t gs = uni(A.ctrl[kCtrlGiantStep]);
+    if (gs == 0u) return;
+    const uint32_t g = gs - 1u;
+    const int lane = threadIdx.x & 63;
+    const int s = (int)uni((uint32_t)A.seed_idx[g]);
+    const int b = (int)uni((uint32_t)A.seed_bin[g]);
+    const float thr = __uint_as_float(uni(__float_as_uint(A.seed_thr[g])));
+    const float sn = trig.st[b], cs = trig.ct[b];
+    const bool own = uni(A.label[s]) == g;  // it has committed a part of its flood in the rounds: its own ground
+    const uint32_t bin_bit = 1u << b;
+    const uint32_t tiles_x = (uint32_t)A.tiles_x, tiles_y = (uint32_t)(A.h + 7) >> 3;
+    const uint32_t strips_x = (tiles_x + 7u) >> 3, n_strips = strips_x * tiles_y;
+    const uint32_t uw = (uint32_t)A.w;
+    for (uint32_t si = blockIdx.x * 4u + (threadIdx.x >> 6); si < n_strips; si += gridDim.x * 4u) {
+        const uint32_t sy = uni(si / strips_x), sx = uni(si - sy * strips_x);
+        const uint32_t x = sx * 64u + (uint32_t)lane;
+        uint32_t dm[8], lab[8];
+        float gx[8], gy[8];
+        bool in[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const uint32_t y = sy * 8u + (uint32_t)r;
+            in[r] = x < uw && y < (uint32_t)A.h;
+            const uint32_t q = in[r] ? y * uw + x : 0u;
+            dm[r] = ld8(A.dmask, q);
+            gx[r] = ldf(A.dx, q);
+            gy[r] = ldf(A.dy, q);
+            lab[r] = own ? ld32(A.label, q) : kLabelFree;
+        }
+        uint64_t rows[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            bool ok = in[r] && (dm[r] & bin_bit) != 0u && directional(gx[r], gy[r], sn, cs) > thr;
+            if (own) ok = ok || (in[r] && lab[r] == g);
+            rows[r] = __ballot(ok);
+        }
+        // lanes 0..7: a tile each -- its mask out of the eight row ballots, its components' first pixels into the union-find
+        if (lane < 8) {
+            const uint32_t tx = sx * 8u + (uint32_t)lane;
+            if (tx < tiles_x) {
+                uint64_t M = 0ull;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) M |= ((rows[r] >> (8 * lane)) & 0xFFull) << (8 * r);
+                A.giant_mask[(size_t)sy * tiles_x + tx] = M;
+                uint64_t rem = M;
+                while (rem != 0ull) {
+                    const uint64_t c = giant_closure(rem & (~rem + 1ull), M);
+                    rem &= ~c;
+                    const uint32_t p = giant_pixel(tx, sy, (uint32_t)__builtin_ctzll(c), uw);
+                    A.giant_parent[p] = p;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void giant_merge_kernel(FloodArgs A) {
+    if (A.ctrl[kCtrlGiantStep] == 0u) return;
+    const uint32_t tiles_x = (uint32_t)A.tiles_x, tiles_y = (uint32_t)(A.h + 7) >> 3, n_tiles = tiles_x * tiles_y;
+    const uint32_t uw = (uint32_t)A.w;
+    uint32_t* par = A.giant_parent;
+    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n_tiles; t += gridDim.x * 256u) {
+        const uint64_t M = A.giant_mask[t];
+        if (M == 0ull) continue;
+        const uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
+        const bool east = tx + 1u < tiles_x, south = ty + 1u < tiles_y, west = tx > 0u;
+        const uint64_t Me = east ? A.giant_mask[t + 1u] : 0ull;
+        const uint64_t Ms = south ? A.giant_mask[t + tiles_x] : 0ull;
+        const uint64_t Mse = (south && east) ? A.giant_mask[t + tiles_x + 1u] : 0ull;
+        const uint64_t Msw = (south && west) ? A.giant_mask[t + tiles_x - 1u] : 0ull;
+        if (((M & kCol7) == 0ull || (Me & kCol0) == 0ull) && ((M >> 56) == 0ull || (Ms & 0xFFull) == 0ull) &&
+            ((M >> 63) == 0ull || (Mse & 1ull) == 0ull) && (((M >> 56) & 1ull) == 0ull || ((Msw >> 7) & 1ull) == 0ull))
+            continue;  // nothing of this tile touches a tile to the east or south of it
+        uint64_t rem = M;
+        while (rem != 0ull) {
+            const uint64_t c = giant_closure(rem & (~rem + 1ull), M);
+            rem &= ~c;
+            const uint32_t pc = giant_pixel(tx, ty, (uint32_t)__builtin_ctzll(c), uw);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                uint64_t e, Mu;
+                uint32_t ux, uy;
+                if (d == 0) {  // east: this component's column 7 against the neighbour's column 0
+                    e = (c >> 7) & kCol0;
+                    e |= (e << 8) | (e >> 8);
+                    Mu = Me, ux = tx + 1u, uy = ty;
+                } else if (d == 1) {  // south: its row 7 against the neighbour's row 0
+                    e = c >> 56;
+                    e = (e | (e << 1) | (e >> 1)) & 0xFFull;
+                    Mu = Ms, ux = tx, uy = ty + 1u;
+                } else if (d == 2) {  // south-east: corner against corner
+                    e = c >> 63;
+                    Mu = Mse, ux = tx + 1u, uy = ty + 1u;
+                } else {  // south-west
+                    e = ((c >> 56) & 1ull) << 7;
+                    Mu = Msw, ux = tx - 1u, uy = ty + 1u;
+                }
+                e &= Mu;
+                while (e != 0ull) {
+                    const uint64_t cu = giant_closure(e & (~e + 1ull), Mu);
+                    e &= ~cu;
+                    gu_union(par, pc, giant_pixel(ux, uy, (uint32_t)__builtin_ctzll(cu), uw));
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void giant_commit_kernel(FloodArgs A, uint8_t* __restrict__ dmask_rw) {
+    const uint32_t gs = uni(A.ctrl[kCtrlGiantStep]);
+    if (gs == 0u) return;
+    const uint32_t g = gs - 1u;
+    __shared__ uint32_t s_root;
+    const uint32_t tiles_x = (uint32_t)A.tiles_x, tiles_y = (uint32_t)(A.h + 7) >> 3;
+    const uint32_t uw = (uint32_t)A.w;
+    uint32_t* par = A.giant_parent;
+    if (threadIdx.x == 0) {
+        const uint32_t s = (uint32_t)A.seed_idx[g];
+        const uint32_t sr = s / uw, sc = s - sr * uw;
+        const uint64_t M = A.giant_mask[(size_t)(sr >> 3) * tiles_x + (sc >> 3)];
+        const uint64_t bit = 1ull << ((sr & 7u) * 8u + (sc & 7u));
+        uint32_t root = 0xFFFFFFFFu;  // (the seed's own pixel is not acceptable: flood() accepts nothing)
+        if (M & bit) root = gu_find(par, giant_pixel(sc >> 3, sr >> 3, (uint32_t)__builtin_ctzll(giant_closure(bit, M)), uw));
+        s_root = root;
+    }
+    __syncthreads();
+    const uint32_t root = s_root;
+    if (root == 0xFFFFFFFFu) return;
+    const int lane = threadIdx.x & 63;
+    // a wavefront takes 64 consecutive tiles of a tile row, a lane a tile; then the flood's pixels of those tiles are written
+    // eight tiles (64 pixels a row) at a time
+    const uint32_t runs_x = (tiles_x + 63u) >> 6, n_runs = runs_x * tiles_y;
+    uint32_t cnt = 0u;
+    for (uint32_t ri = blockIdx.x * 4u + (threadIdx.x >> 6); ri < n_runs; ri += gridDim.x * 4u) {
+        const uint32_t ty = uni(ri / runs_x), rx = uni(ri - ty * runs_x);
+        const uint32_t tx = rx * 64u + (uint32_t)lane;
+        uint64_t F = 0ull;
+        if (tx < tiles_x) {
+            const uint64_t M = A.giant_mask[(size_t)ty * tiles_x + tx];
+            uint64_t rem = M;
+            while (rem != 0ull) {
+                const uint64_t c = giant_closure(rem & (~rem + 1ull), M);
+                rem &= ~c;
+                if (gu_find(par, giant_pixel(tx, ty, (uint32_t)__builtin_ctzll(c), uw)) == root) F |= c;
+            }
+        }
+        cnt += (uint32_t)__popcll(F);
+        const uint64_t any = __ballot(F != 0ull);
+        if (any == 0ull) continue;
+        for (int sub = 0; sub < 8; ++sub) {
+            if (((any >> (8 * sub)) & 0xFFull) == 0ull) continue;
+            const int src = sub * 8 + (lane >> 3);
+            const uint64_t Fs = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(F >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)F, src);
+            const uint32_t x = rx * 512u + (uint32_t)sub * 64u + (uint32_t)lane;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                if ((Fs >> (8 * r + (lane & 7))) & 1ull) {
+                    const uint32_t q = (ty * 8u + (uint32_t)r) * uw + x;
+                    A.label[q] = g;
+                    dmask_rw[q] = 0;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, off);
+    if (lane == 0 && cnt != 0u) atomicAdd(&A.ctrl[kCtrlGiantPx], cnt);
+}
+
+__global__ __launch_bounds__(256) void giant_finish_kernel(FloodArgs A) {
+    const uint32_t gs = A.ctrl[kCtrlGiantStep];
+    if (gs == 0u) return;
+    const uint32_t g = gs - 1u;
+    const uint32_t* __restrict__ act = act_now(A);
+    const uint32_t n_act = A.ctrl[kCtrlNAct];
+    const uint32_t n_pad = (n_act + 63u) & ~63u;
+    const int lane = threadIdx.x & 63;
+    // the lowest seed of the list that is still alive, and the lowest marked one (what flood_advance takes from the survivors pass)
+    for (uint32_t ai = blockIdx.x * 256u + threadIdx.x; ai < n_pad; ai += gridDim.x * 256u) {
+        uint32_t kmin = 0xFFFFFFFFu, gmin = 0xFFFFFFFFu;
+        if (ai < n_act) {
+            const uint32_t k = act[ai];
+            const uint8_t t = A.tier[k];
+            if (k != g && (t & 8u) == 0u) {
+                const uint32_t own_label = A.label[A.seed_idx[k]];
+                if (own_label >= kMarkBit || own_label == k) {  // (between rounds: free, or its own ground)
+                    kmin = k;
+                    if (t & 4u) gmin = k;
+                }
+            }
+        }
+        const uint64_t mg = __ballot(gmin != 0xFFFFFFFFu);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off));
+            gmin = min(gmin, (uint32_t)__shfl_xor((int)gmin, off));
+        }
+        if (lane == 0) {
+            if (kmin != 0xFFFFFFFFu) atomicMin(&A.ctrl[kCtrlLowestNext], kmin);
+            if (gmin != 0xFFFFFFFFu) {
+                atomicMin(&A.ctrl[kCtrlGiantLowNext], gmin);
+                atomicAdd(&A.ctrl[kCtrlGiantCountNext], (uint32_t)__popcll(mg));
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    __threadfence();
+    if (atomicAdd(&A.ctrl[kCtrlGiantBlocks], 1u) != gridDim.x - 1u) return;
+    __threadfence();
+    uint32_t* ctrl = A.ctrl;
+    const uint32_t total = ld_agent(&ctrl[kCtrlGiantPx]);
+    // the seed leaves the rounds as a finished, unblocked walk: the coming round's survivors pass books it as committed
+    A.count[g] = total;
+    A.blocked[g] = 0u;
+    A.flags[g] = total != 0u ? 0u : kFlagSelfFail;
+    A.tier[g] = (uint8_t)((A.tier[g] & ~4u) | 8u);
+    const uint32_t lowest = ld_agent(&ctrl[kCtrlLowestNext]), giant = ld_agent(&ctrl[kCtrlGiantLowNext]);
+    const uint32_t n_seeds = ld_agent(&ctrl[kCtrlNSeeds]);
+    // the coming round's window: the giants' rule again, with the lowest marked seed that is left (flood_advance)
+    unsigned long long grown = ld_agent(&ctrl[kCtrlWindowFree]);
+    bool ruled = false;
+    if (giant != 0xFFFFFFFFu) {
+        const uint32_t n_marked = max(ld_agent(&ctrl[kCtrlGiantCountNext]), 1u);
+        const unsigned long long rest = n_seeds > giant ? (unsigned long long)(n_seeds - giant) : 1ull;
+        const unsigned long long line = (unsigned long long)giant + 1ull + (unsigned long long)kGiantProbes * rest / n_marked;
+        if (line < grown) {
+            grown = line;
+            ruled = true;
+        }
+    }
+    ctrl[kCtrlWindow] = (uint32_t)grown;
+    ctrl[kCtrlGiantRuled] = ruled ? 1u : 0u;
+    ctrl[kCtrlLowest] = lowest;
+    ctrl[kCtrlGiantLow] = giant;
+    ctrl[kCtrlLowestNext] = 0xFFFFFFFFu;
+    ctrl[kCtrlGiantLowNext] = 0xFFFFFFFFu;
+    ctrl[kCtrlGiantCountNext] = 0u;
+    ctrl[kCtrlBarrier] = 0xFFFFFFFFu;  // (the round that follows is enqueued with its list's length known: it reaches every entry)
+    ctrl[kCtrlGiantPx] = 0u;
+    ctrl[kCtrlGiantBlocks] = 0u;
+    const uint32_t done = ld_agent(&ctrl[kCtrlGiantDone]) + 1u;
+    ctrl[kCtrlGiantDone] = done;
+    const bool again = giant != 0xFFFFFFFFu && giant == lowest;
+    ctrl[kCtrlGiantStep] = again ? giant + 1u : 0u;
+    if (A.host_progress) {
+        __hip_atomic_store(&A.host_progress[0], ld_agent(&ctrl[kCtrlRounds]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&A.host_progress[1], n_act, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&A.host_progress[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&A.host_progress[3], again ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&A.host_progress[4], done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // Ordered tail: the reference's loop over an (ascending) list of remaining seeds, starting from
@@ -2811,12 +3171,13 @@ __global__ __launch_bounds__(64) void flood_ordered_tail_kernel(const float* __r
 // ---- host side of the rounds ------------------------------------------------------------------
 
 // LIBRECTIFY_FLOOD_DEBUG: what the round's exploration did (synchronises; rounds are then enqueued one at a time)
-static void flood_debug_round(const FloodBuffers& B, const FloodFrame& F, uint32_t n_seeds, const uint32_t* act, hipStream_t s) {
-    uint32_t ctrl[16];
+static void flood_debug_round(const FloodBuffers& B, const FloodFrame& F, uint32_t n_seeds, hipStream_t s) {
+    uint32_t ctrl[kFloodCtrlWords];
     (void)hipStreamSynchronize(s);
     (void)hipMemcpy(ctrl, B.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost);
     const uint32_t n_act = ctrl[kCtrlNAct];
-    if (n_act == 0) return;
+    if (n_act == 0 || ctrl[kCtrlGiantStep] != 0u) return;  // (nothing left, or a giant step is asked for: the round did nothing)
+    const uint32_t* act = (ctrl[kCtrlRounds] & 1u) ? B.act_b : B.act_a;
     std::vector<uint32_t> cnt(n_seeds), blk(n_seeds), flg(n_seeds), actv(n_act);
     (void)hipMemcpy(flg.data(), B.flags, n_seeds * sizeof(uint32_t), hipMemcpyDeviceToHost);
     (void)hipMemcpy(actv.data(), act, n_act * sizeof(uint32_t), hipMemcpyDeviceToHost);
@@ -3020,6 +3381,11 @@ FloodArgs flood_args(const FloodBuffers& B, const FloodFrame& F, bool use_big) {
     if (logs) A.wp_min_tiles = 0xFFFFFFFFu;
     static const int g_cap_env = std::getenv("LIBRECTIFY_FLOOD_PARTIAL_STEPS") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_PARTIAL_STEPS")) : 16;
     A.g_cap = g_cap_env > 0 ? (uint32_t)g_cap_env : kMaxSteps;
+    A.act_a = B.act_a;
+    A.act_b = B.act_b;
+    A.giant_mask = reinterpret_cast<unsigned long long*>(B.giant_mask);
+    A.giant_parent = B.giant_parent;
+    A.giant_step = (B.giant_hold && B.giant_step && B.giant_mask && B.giant_parent && use_big) ? 1u : 0u;
     return A;
 }
 
@@ -3034,9 +3400,8 @@ FloodArgs flood_args(const FloodBuffers& B, const FloodFrame& F, bool use_big) {
 constexpr int kRestRounds = 4;  // rounds 0 .. kRestRounds - 1 always bring their `rest` launch: the rounds a frame may enqueue blindly (context.hip: jit_first_max)
 void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& A0, bool use_big, int index, hipStream_t s,
                    uint32_t known_len = 0xFFFFFFFFu, bool next_known = false) {
-    uint32_t* lists[2] = {B.act_a, B.act_b};
-    uint32_t* act = lists[index & 1];
-    uint32_t* act_next = lists[(index + 1) & 1];
+    // (which of the two active lists a round reads is the device's business -- kCtrlRounds, act_now: rounds enqueued behind a
+    // request for a giant step do nothing and do not count; `index` only sizes grids and picks the launches of a round)
     const size_t npix = (size_t)F.w * F.h;
     const int pix_blocks = (int)std::min<size_t>((npix + 255) / 256, 4096);
     const int seed_blocks = (int)std::min<uint32_t>((F.seed_cap + 255) / 256, 256);
@@ -3084,9 +3449,9 @@ void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& 
                            kTeamLdsBytes, B.aux_stream, A, F.trig, B.multi_list, 1u);
         (void)hipEventRecord(B.join_events[index], B.aux_stream);
     }
-    hipLaunchKernelGGL(flood_explore_kernel, dim3(grid), dim3(64), 0, s, A, F.trig, act, B.big_list);
+    hipLaunchKernelGGL(flood_explore_kernel, dim3(grid), dim3(64), 0, s, A, F.trig, B.big_list);
     if (rest_now)  // entries past the guess, if any
-        hipLaunchKernelGGL(flood_explore_rest_kernel, dim3(1024), dim3(64), 0, s, A, F.trig, act, B.big_list, grid);
+        hipLaunchKernelGGL(flood_explore_rest_kernel, dim3(1024), dim3(64), 0, s, A, F.trig, B.big_list, grid);
     static const bool team = !(std::getenv("LIBRECTIFY_FLOOD_TEAM") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_TEAM")) == 0);
     if (use_big && team)
         hipLaunchKernelGGL(flood_explore_team_kernel, dim3(std::min<uint32_t>(F.seed_cap, kTeamGrid)), dim3(64 * kTeamWaves),
@@ -3106,7 +3471,7 @@ void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& 
         uint32_t n = 0;
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(&n, F.d_n_seeds, sizeof(n), hipMemcpyDeviceToHost);
-        flood_debug_round(B, F, std::min(n, F.seed_cap), act, s);
+        flood_debug_round(B, F, std::min(n, F.seed_cap), s);
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, dbg0, dbg1);
         std::fprintf(stderr, "  explore kernels of this round: %.1f us\n", ms * 1e3f);
@@ -3118,11 +3483,38 @@ void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& 
     // there no longer pays their launch -- 0.970 -> 0.935 ms over the four bench frames, same rounds; and the lanes of a batch
     // are better off with a launch less per late round: 9.81 -> 9.99 Gpix/s)
     if (B.partial_commits && index < g_rounds_env)
-        hipLaunchKernelGGL(flood_partial_commit_kernel, dim3(grid), dim3(64), 0, s, A, act,
-                           const_cast<uint8_t*>(F.dmask));
+        hipLaunchKernelGGL(flood_partial_commit_kernel, dim3(grid), dim3(64), 0, s, A, const_cast<uint8_t*>(F.dmask));
     hipLaunchKernelGGL(flood_commit_pixels_kernel, dim3(pix_blocks), dim3(256), 0, s, A, F.label, npix,
                        const_cast<uint8_t*>(F.dmask));
-    hipLaunchKernelGGL(flood_survivors_kernel, dim3(seed_blocks), dim3(256), 0, s, A, act, B.state, F.seed_size, act_next);
+    hipLaunchKernelGGL(flood_survivors_kernel, dim3(seed_blocks), dim3(256), 0, s, A, B.state, F.seed_size);
+}
+
+// The giant step (kCtrlGiantStep): four launches sized by the frame's tiles; each leaves at once when no step is asked for.
+void enqueue_giant_step(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& A, hipStream_t s) {
+    const uint32_t tiles_x = (uint32_t)(F.w + 7) / 8, tiles_y = (uint32_t)(F.h + 7) / 8;
+    const uint32_t strips = ((tiles_x + 7) / 8) * tiles_y, runs = ((tiles_x + 63) / 64) * tiles_y, n_tiles = tiles_x * tiles_y;
+    hipEvent_t dbg0 = nullptr, dbg1 = nullptr;
+    if (g_flood_debug) {
+        (void)hipEventCreate(&dbg0);
+        (void)hipEventCreate(&dbg1);
+        (void)hipEventRecord(dbg0, s);
+    }
+    hipLaunchKernelGGL(giant_mask_kernel, dim3(std::min<uint32_t>((strips + 3) / 4, 8192u)), dim3(256), 0, s, A, F.trig);
+    hipLaunchKernelGGL(giant_merge_kernel, dim3(std::min<uint32_t>((n_tiles + 255) / 256, 4096u)), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(giant_commit_kernel, dim3(std::min<uint32_t>((runs + 3) / 4, 4096u)), dim3(256), 0, s, A, const_cast<uint8_t*>(F.dmask));
+    hipLaunchKernelGGL(giant_finish_kernel, dim3(std::min<uint32_t>((F.seed_cap + 255) / 256, 256u)), dim3(256), 0, s, A);
+    if (g_flood_debug) {
+        uint32_t ctrl[kCtrlWords];
+        (void)hipEventRecord(dbg1, s);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(ctrl, B.ctrl, sizeof(ctrl), hipMemcpyDeviceToHost);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, dbg0, dbg1);
+        std::fprintf(stderr, "giant step %u: %.1f us; lowest active seed now %u, lowest held %u, window %u, next step for seed %d\n", ctrl[kCtrlGiantDone],
+                     ms * 1e3f, ctrl[kCtrlLowest], ctrl[kCtrlGiantLow], ctrl[kCtrlWindow], (int)ctrl[kCtrlGiantStep] - 1);
+        (void)hipEventDestroy(dbg0);
+        (void)hipEventDestroy(dbg1);
+    }
 }
 
 }  // namespace
@@ -3186,7 +3578,7 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
         // the host has seen the rounds so far leave seeds.  A round that never reports (nothing should keep it) ends the
         // watch after a second: the rest goes the blind way, flood_finish picks up whatever is left.
         volatile uint32_t* hp = B.host_progress;
-        hp[0] = hp[1] = hp[2] = 0u;
+        hp[0] = hp[1] = hp[2] = hp[3] = hp[4] = 0u;
         std::atomic_thread_fence(std::memory_order_seq_cst);
         const int first = std::min(std::max(B.jit_first, 1), 16);
         // (LIBRECTIFY_FLOOD_JIT_LEAD=1 keeps one round ahead -- the next round goes in when all but the last one enqueued are
@@ -3194,30 +3586,57 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
         // measured the same as none ahead, 0.921 against 0.923 ms over eight 4K frames, blind rounds 0.937)
         static const int lead = std::getenv("LIBRECTIFY_FLOOD_JIT_LEAD") ? std::max(0, std::atoi(std::getenv("LIBRECTIFY_FLOOD_JIT_LEAD"))) : 0;
         for (int r = 0; r < first; ++r, ++P->enqueued) enqueue_round(B, F, A, P->use_big, P->enqueued, s, 0xFFFFFFFFu, r == first - 1);
+        // Rounds that count on the device (kCtrlRounds) against rounds enqueued that can still count: a round enqueued behind a
+        // request for a giant step does nothing, so once a request is seen every round enqueued so far is accounted for.
+        int counting = P->enqueued;
+        uint32_t giants = 0;  // giant steps enqueued
         const auto t0 = std::chrono::steady_clock::now();
+        auto deadline_passed = [&](int& spins) {
+            if (B.jit_sleep_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(B.jit_sleep_us));
+            return (++spins & (B.jit_sleep_us > 0 ? 15 : 1023)) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(1);
+        };
         for (;;) {
-            uint32_t done_rounds, n_left, stalled;
+            uint32_t done_rounds, n_left, stalled, want_giant;
             int spins = 0;
             bool timed_out = false;
             for (;;) {
                 done_rounds = __atomic_load_n(&B.host_progress[0], __ATOMIC_ACQUIRE);
                 n_left = __atomic_load_n(&B.host_progress[1], __ATOMIC_RELAXED);
                 stalled = __atomic_load_n(&B.host_progress[2], __ATOMIC_RELAXED);
-                if ((int)done_rounds + lead >= P->enqueued || (done_rounds > 0u && n_left == 0u)) break;
-                if (B.jit_sleep_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(B.jit_sleep_us));
-                if ((++spins & (B.jit_sleep_us > 0 ? 15 : 1023)) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(1)) {
+                want_giant = __atomic_load_n(&B.host_progress[3], __ATOMIC_RELAXED);
+                if ((int)done_rounds + lead >= counting || (done_rounds > 0u && n_left == 0u) || want_giant != 0u) break;
+                if (deadline_passed(spins)) {
                     timed_out = true;
                     break;
                 }
+            }
+            // The lowest active seed is a marked giant: the whole device floods it (giant_*_kernel), and the next one if the
+            // step's last kernel asks for it, before the next round with work goes in.
+            while (!timed_out && want_giant != 0u && n_left != 0u && stalled == 0u) {
+                enqueue_giant_step(B, F, A, s);
+                ++giants;
+                while (__atomic_load_n(&B.host_progress[4], __ATOMIC_ACQUIRE) < giants) {
+                    if (deadline_passed(spins)) {
+                        timed_out = true;
+                        break;
+                    }
+                }
+                if (timed_out) break;
+                done_rounds = __atomic_load_n(&B.host_progress[0], __ATOMIC_RELAXED);
+                n_left = __atomic_load_n(&B.host_progress[1], __ATOMIC_RELAXED);
+                want_giant = __atomic_load_n(&B.host_progress[3], __ATOMIC_RELAXED);
+                counting = (int)done_rounds;
+                if (giants >= 4096u) break;  // (never: a step retires a seed)
             }
             if (timed_out) {
                 // (with the `rest` launch whatever the list's length: the round before them was told its successor would know)
                 for (int r = 0; r < 2; ++r, ++P->enqueued) enqueue_round(B, F, A, P->use_big, P->enqueued, s, 0xFFFFFFFEu, true);
                 break;
             }
-            if (n_left == 0u || stalled != 0u || P->enqueued >= 64) break;
+            if (n_left == 0u || stalled != 0u || P->enqueued >= 256) break;
             enqueue_round(B, F, A, P->use_big, P->enqueued, s, n_left, true);
             ++P->enqueued;
+            ++counting;
         }
     } else {
     const int batch = g_flood_debug ? 1 : std::min(std::max(B.blind_rounds, 1), 16);
@@ -3250,6 +3669,10 @@ int flood_finish(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, u
             A.big_cap = big_cap;
         }
         const int batch = g_flood_debug ? 1 : 3;
+        // (a giant step was asked for and nobody was looking: the rounds behind the request did nothing.  Steps that follow
+        // each other -- a step's last kernel asks for the next -- take a lap each here: this is the path of the debug mode,
+        // of blind rounds and of a watch that timed out)
+        if (h_ctrl[kCtrlGiantStep] != 0u && A.giant_step != 0u) enqueue_giant_step(B, F, A, s);
         // (these rounds always bring their `rest` launch: the rounds before them may have been told that their successor would
         // know its list's length, and a flood that is still going after its first laps has long lists to walk)
         for (int r = 0; r < batch; ++r, ++P->enqueued) enqueue_round(B, F, A, P->use_big, P->enqueued, s, 0xFFFFFFFEu, true);
@@ -3293,6 +3716,7 @@ int flood_finish(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, u
         tiers_out[10] = h_ctrl[kCtrlLogWalks];
         tiers_out[11] = h_ctrl[kCtrlLogGiveUp];
         tiers_out[12] = h_ctrl[kCtrlGiants];
+        tiers_out[13] = h_ctrl[kCtrlGiantDone];
     }
     return 0;
 }
