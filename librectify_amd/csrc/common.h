@@ -185,7 +185,7 @@ struct FloodBuffers {
     // when the host has SEEN, in page-locked words the last workgroup of a round writes, that the rounds so far left seeds
     // -- no launch behind the last round with work (the blind rounds of a 4K frame were 60-120 us of empty launches), at
     // the price of the host's reaction time per further round.  The calling thread polls while the flood runs.
-    uint32_t* host_progress = nullptr;  // page-locked, device-visible: rounds with work so far, length of the next list, stalled, giant step asked for, giant steps done
+    uint32_t* host_progress = nullptr;  // page-locked, device-visible, 8-byte aligned: one 64-bit report (kernels_flood.hip: flood_report)
     int jit_first = 0;                  // 0: off
     int jit_sleep_us = 0;               // the polling thread sleeps this long between looks (0: it spins -- single calls)
     uint32_t big_cap_override = 0;  // test hook: seeds per round the second tier takes (0 = the default, 8192)
@@ -212,6 +212,10 @@ struct FloodProgress {
     int enqueued = 0;  // rounds enqueued so far
     bool use_big = false;
     int win_growth = 2;
+    // what the host that enqueued the rounds just in time has seen when the flood is over: the largest flood committed
+    // (sizes_known = false: blind rounds, or a flood that flood_finish had to complete; max_flood: 0 or "more than 2^14 pixels")
+    bool sizes_known = false;
+    uint32_t max_flood = 0;
 };
 constexpr int kFloodCtrlWords = 48;
 // Enqueues the initialisation and a first batch of rounds, then an asynchronous copy of the control block into
@@ -226,16 +230,27 @@ int flood_finish(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, u
 
 // kernels_fit.hip (all counts stay on the device: launches cover seed_cap / comp_cap)
 size_t fit_temp_bytes(size_t max_pixels, uint32_t max_segments);
+// Pixel lists of more than 2^14 pixels ("huge" components) are dealt into buckets of 2^14 consecutive pixel indices and
+// sorted bucket by bucket (kernels_fit.hip: huge_count_kernel, huge_sort_kernel).  tab: max x ceil(pixels / 2^14) words,
+// ZERO between frames (the sort leaves them so); list: max words; jobs: four words per word of tab.
+struct HugeSort {
+    uint32_t* tab = nullptr;
+    uint32_t* list = nullptr;
+    uint32_t* jobs = nullptr;
+    uint32_t max = 0;
+};
+// n_large: seven words (kernels_fit.hip); cursor: one word per component, zeroed BEFORE launch_component_offsets
 int launch_component_offsets(const int32_t* seed_size, const uint32_t* d_n_seeds, uint32_t seed_cap, int min_size,
                              uint32_t* comp_rank, uint32_t* comp_seed, uint32_t* comp_off,
                              uint32_t* totals /*[0]=n_comp,[1]=n_px*/, uint32_t* large_list, uint32_t large_cap,
-                             uint32_t* n_large /*[2]*/, void* temp, size_t temp_bytes, hipStream_t s);
+                             uint32_t* n_large, void* temp, size_t temp_bytes, uint32_t* cursor, const HugeSort& hs, hipStream_t s);
+// with_huge = false: the caller knows that no flood of the frame has more than 2^14 pixels (the launches for those are left out)
 int launch_component_scatter(const uint32_t* label, size_t npix, const uint32_t* comp_rank, const uint32_t* comp_off,
-                             uint32_t* cursor, uint32_t* px, hipStream_t s);
-// scratch: >= 2 x (pixels of the frame) words, used by lists of more than 4096 pixels only
+                             uint32_t* cursor, uint32_t* px, const HugeSort& hs, uint32_t* n_large, bool with_huge, hipStream_t s);
+// scratch: >= 2 x (pixels of the frame) words, used by lists of more than 2^14 pixels that found no row in the huge table only
 int launch_component_sort(const uint32_t* px_in, uint32_t* px_out, const uint32_t* comp_off, const uint32_t* d_n_comp,
                           uint32_t comp_cap, const uint32_t* large_list, uint32_t large_cap, const uint32_t* n_large,
-                          uint32_t* scratch, hipStream_t s);
+                          uint32_t* scratch, const uint32_t* cursor, const HugeSort& hs, bool with_huge, hipStream_t s);
 int launch_fit(const uint32_t* px_sorted, const uint32_t* px_unsorted, const uint32_t* comp_off, const uint32_t* comp_seed, const uint32_t* d_n_comp,
                uint32_t comp_cap, const int32_t* seed_bin, const float* dx, const float* dy, int w, BinTrig trig,
                float* scratch_w, LineSegment* out, hipStream_t s);

@@ -78,6 +78,7 @@ struct lr_context {
     void* temp = nullptr;
     size_t temp_bytes = 0;
     uint32_t* comp_large = nullptr;  // components of more than 64 pixels (sorted by a workgroup each)
+    lramd::HugeSort huge;                   // ... of more than 2^14: buckets (kernels_fit.hip: huge_count_kernel)
     uint32_t seed_cap = 0;           // capacity the seed sort runs with (the seed count is not known when it is enqueued)
     uint32_t seed_cap_once = 0;      // test hook: capacity of the next frame's seed sort
     int frame_laps = 0;              // laps the last frame took (1; 2 if the seed sort overflowed or the flood needed more rounds)

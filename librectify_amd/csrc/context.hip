@@ -138,6 +138,12 @@ int ctx_ensure_image_capacity(lr_context* c, int w, int h) {
         dev_alloc(c->px_b, cp) || dev_alloc(c->scratch_w, cp) || dev_alloc(c->d_lines, cp / 6 + 16) ||
         dev_alloc(c->comp_large, cp / 64 + 16))
         return 1;
+    {   // huge components: a row of buckets (2^14 pixel indices each) for up to 256 of them; the table is zero between frames
+        const size_t nb = (cp + 16383) >> 14;
+        c->huge.max = 256;
+        if (dev_alloc(c->huge.tab, c->huge.max * nb) || dev_alloc(c->huge.jobs, 4 * c->huge.max * nb) || dev_alloc(c->huge.list, c->huge.max)) return 1;
+        LR_HIP(hipMemsetAsync(c->huge.tab, 0, c->huge.max * nb * sizeof(uint32_t), c->stream));
+    }
     const size_t tb = std::max(seeds_temp_bytes(ct, cp), fit_temp_bytes(cp, (uint32_t)std::min<size_t>(cp / 6 + 16, 0xFFFFFFFFu)));
     if (c->temp) (void)hipFree(c->temp);
     c->temp = nullptr;
@@ -668,7 +674,7 @@ void ctx_destroy(lr_context* c) {
                     c->scratch_w, c->d_lines, c->temp, c->d_model, c->d_best_slots,
                     c->fb.blocked, c->fb.count, c->fb.flags, c->fb.state, c->fb.tier, c->fb.act_a, c->fb.act_b,
                     c->fb.ctrl, c->fb.big_list, c->fb.handover, c->fb.waypoints, c->fb.multi_list, c->fb.log_off, c->fb.log_len, c->fb.log_buf, c->fb.dirty, c->fb.giant_mask, c->fb.slab_ring, c->fb.slab_hash, c->d_pairs, c->d_peak, c->d_weights,
-                    c->d_samples, c->d_hcounts, c->comp_large, c->d_tables, c->d_orig, c->d_inl, c->d_flines, c->d_gctl,
+                    c->d_samples, c->d_hcounts, c->comp_large, c->huge.tab, c->huge.jobs, c->huge.list, c->d_tables, c->d_orig, c->d_inl, c->d_flines, c->d_gctl,
                     c->d_gnorm, c->d_models, c->d_refine_table, c->d_refine_edges, c->d_cht_acc, c->d_cht_idx, c->d_cht_peak, c->d_rec, c->d_recflags};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -940,17 +946,35 @@ int finish_flood(lr_context* c, bool* extra) {
 int enqueue_fit(lr_context* c) {
     const size_t npix = (size_t)c->w * c->h;
     const uint32_t comp_cap = line_cap_for(c);
+    // Floods of more than 2^14 pixels have launches of their own (kernels_fit.hip: huge_count_kernel, huge_sort_kernel), left
+    // out when the host KNOWS that the frame has none: the flood's rounds, enqueued just in time, report their largest commit.
+    const bool with_huge = !(c->flood_mode != 0 && c->flood_prog.sizes_known && c->flood_prog.max_flood <= (1u << 14));
+    LR_HIP(hipMemsetAsync(c->cursor, 0, (size_t)comp_cap * sizeof(uint32_t), c->stream));
     if (launch_component_offsets(c->seed_size, c->d_counts + kCntSeeds, c->seed_cap, kComponentMinSize, c->comp_rank,
                                  c->comp_seed, c->comp_off, c->d_counts + kCntComp, c->comp_large,
-                                 (uint32_t)(c->cap_pix / 64 + 16), c->d_counts + kCntLarge, c->temp, c->temp_bytes, c->stream))
+                                 (uint32_t)(c->cap_pix / 64 + 16), c->d_counts + kCntLarge, c->temp, c->temp_bytes, c->cursor,
+                                 with_huge ? c->huge : HugeSort{}, c->stream))
         return 1;
-    LR_HIP(hipMemsetAsync(c->cursor, 0, (size_t)comp_cap * sizeof(uint32_t), c->stream));
-    if (launch_component_scatter(c->label, npix, c->comp_rank, c->comp_off, c->cursor, c->px_a, c->stream)) return 1;
+    if (launch_component_scatter(c->label, npix, c->comp_rank, c->comp_off, c->cursor, c->px_a, c->huge, c->d_counts + kCntLarge, with_huge,
+                                 c->stream))
+        return 1;
     // (the sorted seed keys are dead once the seeds are set up: their buffer is the large lists' sorting scratch)
     if (launch_component_sort(c->px_a, c->px_b, c->comp_off, c->d_counts + kCntComp, comp_cap, c->comp_large,
                               (uint32_t)(c->cap_pix / 64 + 16), c->d_counts + kCntLarge, reinterpret_cast<uint32_t*>(c->keys_b),
-                              c->stream))
+                              c->cursor, c->huge, with_huge, c->stream))
         return 1;
+    static const bool fit_debug = std::getenv("LIBRECTIFY_FIT_DEBUG") != nullptr;
+    if (fit_debug) {
+        uint32_t cnt[16];
+        LR_HIP(hipStreamSynchronize(c->stream));
+        LR_HIP(hipMemcpy(cnt, c->d_counts, sizeof(cnt), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "fit: with_huge %d (sizes known %d, largest flood %u); seeds %u comps %u px %u; lists: %u of 65..1024 px, %u longer, %u huge in %u buckets; counter %u\n",
+                     (int)with_huge, (int)c->flood_prog.sizes_known, c->flood_prog.max_flood, cnt[0], cnt[1], cnt[2], cnt[4], cnt[5], cnt[6], cnt[7], cnt[10]);
+        const uint32_t nj = std::min<uint32_t>(cnt[7], 6);
+        std::vector<uint32_t> jobs(4 * nj + 4);
+        if (nj) LR_HIP(hipMemcpy(jobs.data(), c->huge.jobs, nj * 16, hipMemcpyDeviceToHost));
+        for (uint32_t j = 0; j < nj; ++j) std::fprintf(stderr, "   bucket job %u: start %u, %u px, table word %u\n", j, jobs[4 * j], jobs[4 * j + 1], jobs[4 * j + 2]);
+    }
     if (launch_fit(c->px_b, c->px_a, c->comp_off, c->comp_seed, c->d_counts + kCntComp, comp_cap, c->seed_bin, c->dx, c->dy, c->w,
                    c->trig, c->scratch_w, c->d_lines, c->stream))
         return 1;

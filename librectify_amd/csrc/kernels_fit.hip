@@ -10,6 +10,7 @@
 // No size in this stage is known to the host when it enqueues the kernels (seed, component and
 // pixel counts stay on the device until the frame's single synchronisation): launches cover the
 // capacity the seed sort ran with and every kernel reads the real counts from memory.
+#include <algorithm>
 #include <cstring>
 
 #include "common.h"
@@ -23,6 +24,16 @@ constexpr uint32_t kNoComp = 0xFFFFFFFFu;
 // [b * kOffChunk, (b + 1) * kOffChunk), eight consecutive seeds per thread.  First kernel: per-chunk totals.
 // Second kernel: every workgroup adds up the totals of the chunks before it and scans its own chunk.
 constexpr uint32_t kSortLds = 1024;  // longest pixel list sorted by a 256-thread workgroup (4 KB of LDS); longer ones take 1024 threads
+constexpr uint32_t kSortLdsBig = 16384;  // ... in 64 KB of LDS
+// Lists beyond that ("huge": a flood of a smooth region, a ring of a noiseless gradient -- hundreds of thousands of pixels)
+// were sorted in place in global memory by ONE workgroup: 7.7 ms for a 140 000-pixel flood, 53 ms for sixteen rings at
+// 1080p.  The keys are distinct pixel indices, so a run of 2^14 consecutive indices holds at most 2^14 of them whatever
+// the component looks like: the pixels of a huge component are dealt into buckets by index >> 14 (counted first, so that
+// every bucket has its place in the component's slice), and the buckets are sorted in LDS by as many workgroups as there
+// are.  Words of `n_large` (the frame's d_counts + 4): [0] lists of 65..1024 pixels, [1] longer ones, [2] huge
+// components, [3] their non-empty buckets, [6] workgroups of huge_count_kernel that have finished.
+constexpr uint32_t kHugeShift = 14;
+constexpr uint32_t kHugeFlag = 0x80000000u;  // cursor[component]: the component's number among the huge ones, flagged
 constexpr int kOffPer = 8;
 constexpr uint32_t kOffChunk = 256 * kOffPer;
 
@@ -45,7 +56,7 @@ __global__ __launch_bounds__(256) void component_sums_kernel(const int32_t* __re
                                                              uint32_t* __restrict__ n_large) {
     __shared__ uint32_t s_c[4], s_p[4];
     const uint32_t n_seeds = min(*n_ptr, cap);
-    if (blockIdx.x == 0 && threadIdx.x == 0) n_large[0] = n_large[1] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) n_large[0] = n_large[1] = n_large[2] = n_large[3] = 0u;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int sz[kOffPer];
     uint32_t c, p;
@@ -71,7 +82,9 @@ __global__ __launch_bounds__(256) void component_offsets_kernel(const int32_t* _
                                                                 uint32_t* __restrict__ comp_off,
                                                                 uint32_t* __restrict__ totals,
                                                                 uint32_t* __restrict__ large_list,
-                                                                uint32_t large_cap, uint32_t* __restrict__ n_large) {
+                                                                uint32_t large_cap, uint32_t* __restrict__ n_large,
+                                                                uint32_t* __restrict__ cursor, uint32_t* __restrict__ huge_list,
+                                                                uint32_t huge_max) {
     __shared__ uint32_t s_c[4], s_p[4], s_cc[4], s_cp[4];
     const uint32_t n_seeds = min(*n_ptr, cap);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -129,6 +142,13 @@ __global__ __launch_bounds__(256) void component_offsets_kernel(const int32_t* _
                 // 1024 pixels (list filled from the front), through global memory beyond (filled from the back)
                 if (sz[j] > (int)kSortLds) large_list[large_cap - 1u - atomicAdd(n_large + 1, 1u)] = rank;
                 else if (sz[j] > 64) large_list[atomicAdd(n_large, 1u)] = rank;
+                if (sz[j] > (int)kSortLdsBig && huge_max != 0u) {  // (beyond huge_max -- never: the old way, component_sort_big_kernel<true>)
+                    const uint32_t hi = atomicAdd(n_large + 2, 1u);
+                    if (hi < huge_max) {
+                        cursor[rank] = hi | kHugeFlag;  // (zeroed before this launch; the scatter pass finds the buckets through it)
+                        huge_list[hi] = rank;
+                    }
+                }
                 rank += 1u;
                 off_px += (uint32_t)sz[j];
             }
@@ -148,7 +168,8 @@ __global__ __launch_bounds__(256) void component_scatter_kernel(const uint32_t* 
                                                                 const uint32_t* __restrict__ comp_rank,
                                                                 const uint32_t* __restrict__ comp_off,
                                                                 uint32_t* __restrict__ cursor,
-                                                                uint32_t* __restrict__ px) {
+                                                                uint32_t* __restrict__ px, uint32_t* __restrict__ huge_tab,
+                                                                uint32_t nb) {
     const int lane = threadIdx.x & 63;
     const size_t step = (size_t)gridDim.x * 256;
     const size_t n_pad = (npix + 255) / 256 * 256;  // whole wavefronts take part in the ballots
@@ -174,7 +195,14 @@ __global__ __launch_bounds__(256) void component_scatter_kernel(const uint32_t* 
                 const uint32_t rl = (uint32_t)__builtin_amdgcn_readlane((int)r[u], leader);
                 const uint64_t same = __ballot(r[u] == rl) & todo;
                 uint32_t base = 0;
-                if (lane == leader) base = comp_off[rl] + atomicAdd(&cursor[rl], (uint32_t)__popcll(same));
+                if (lane == leader) {
+                    const uint32_t o0 = comp_off[rl], o1 = comp_off[rl + 1u];
+                    uint32_t hi = 0u;
+                    if (o1 - o0 > kSortLdsBig) hi = cursor[rl];  // (a huge component's word is its number, never counted on)
+                    // (a wavefront's 64 consecutive pixels lie in one bucket: 2^14 is a multiple of 64)
+                    if (hi & kHugeFlag) base = atomicAdd(&huge_tab[(size_t)(hi & ~kHugeFlag) * nb + (uint32_t)(i >> kHugeShift)], (uint32_t)__popcll(same));
+                    else base = o0 + atomicAdd(&cursor[rl], (uint32_t)__popcll(same));
+                }
                 base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
                 if ((same >> lane) & 1ull) px[base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = (uint32_t)i;
                 todo &= ~same;
@@ -272,7 +300,6 @@ __global__ __launch_bounds__(256) void component_sort_large_kernel(const uint32_
     }
 }
 
-constexpr uint32_t kSortLdsBig = 16384;  // 64 KB
 // kGlobal = false: lists of 4097..16384 pixels, in LDS; true: longer ones, in `scratch` (>= 2 x the frame's pixels;
 // launched with ONE workgroup, which takes them one after the other)
 template <bool kGlobal>
@@ -282,7 +309,8 @@ __global__ __launch_bounds__(1024) void component_sort_big_kernel(const uint32_t
                                                                   const uint32_t* __restrict__ large_list,
                                                                   uint32_t large_cap,
                                                                   const uint32_t* __restrict__ n_large,
-                                                                  uint32_t* __restrict__ scratch) {
+                                                                  uint32_t* __restrict__ scratch,
+                                                                  const uint32_t* __restrict__ cursor) {
     __shared__ uint32_t s_key[kGlobal ? 1 : kSortLdsBig];
     const uint32_t n_list = n_large[1];
     for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
@@ -290,6 +318,7 @@ __global__ __launch_bounds__(1024) void component_sort_big_kernel(const uint32_t
         const uint32_t off = comp_off[comp];
         const uint32_t n = comp_off[comp + 1] - off;
         if ((n > kSortLdsBig) != kGlobal) continue;  // the other launch's
+        if (kGlobal && cursor != nullptr && (cursor[comp] & kHugeFlag)) continue;  // dealt into buckets: huge_sort_kernel
         uint32_t P = 2048;
         while (P < n) P <<= 1;
         if (!kGlobal) {
@@ -305,6 +334,89 @@ __global__ __launch_bounds__(1024) void component_sort_big_kernel(const uint32_t
             for (uint32_t i = threadIdx.x; i < n; i += 1024) px_out[off + i] = scratch[i];
             __syncthreads();
         }
+    }
+}
+
+// Pixels of huge components per bucket, then (the last workgroup to finish) every component's buckets in place: a
+// bucket's word becomes the position of its first pixel in the sorted list -- the scatter pass takes the pixels' places from
+// there -- and every non-empty bucket is a job of huge_sort_kernel.  Leaves at once on a frame without huge components.
+__global__ __launch_bounds__(256) void huge_count_kernel(const uint32_t* __restrict__ label, size_t npix,
+                                                         const uint32_t* __restrict__ comp_rank,
+                                                         const uint32_t* __restrict__ comp_off,
+                                                         const uint32_t* __restrict__ cursor, uint32_t* __restrict__ huge_tab,
+                                                         uint32_t nb, const uint32_t* __restrict__ huge_list, uint32_t huge_max,
+                                                         uint4* __restrict__ jobs, uint32_t* __restrict__ n_large) {
+    const uint32_t n_huge = min(n_large[2], huge_max);
+    if (n_huge == 0u) return;
+    const int lane = threadIdx.x & 63;
+    const size_t step = (size_t)gridDim.x * 256;
+    const size_t n_pad = (npix + 255) / 256 * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_pad; i += step) {
+        const uint32_t l = i < npix ? label[i] : kLabelFree;
+        const uint32_t r = l != kLabelFree ? comp_rank[l] : kNoComp;
+        uint32_t hi = 0u;
+        if (r != kNoComp && comp_off[r + 1u] - comp_off[r] > kSortLdsBig) hi = cursor[r];
+        uint64_t todo = __ballot((hi & kHugeFlag) != 0u);
+        while (todo != 0ull) {
+            const int leader = __builtin_ctzll(todo);
+            const uint32_t hl = (uint32_t)__builtin_amdgcn_readlane((int)hi, leader);
+            const uint64_t same = __ballot(hi == hl) & todo;
+            if (lane == leader) atomicAdd(&huge_tab[(size_t)(hl & ~kHugeFlag) * nb + (uint32_t)(i >> kHugeShift)], (uint32_t)__popcll(same));
+            todo &= ~same;
+        }
+    }
+    __shared__ uint32_t s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(n_large + 6, 1u) == gridDim.x - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last == 0u) return;
+    __threadfence();
+    if (threadIdx.x == 0) n_large[6] = 0u;
+    // a wavefront a component, 64 buckets at a time
+    for (uint32_t h = threadIdx.x >> 6; h < n_huge; h += 4u) {
+        const uint32_t rank = huge_list[h];
+        uint32_t run = comp_off[rank];
+        for (uint32_t b0 = 0; b0 < nb; b0 += 64u) {
+            const uint32_t b = b0 + (uint32_t)lane;
+            uint32_t* e = &huge_tab[(size_t)h * nb + b];
+            const uint32_t cnt = b < nb ? __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            uint32_t inc = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t t = (uint32_t)__shfl_up((int)inc, off);
+                if (lane >= off) inc += t;
+            }
+            const uint32_t start = run + inc - cnt;
+            if (cnt != 0u) {
+                *e = start;
+                jobs[atomicAdd(n_large + 3, 1u)] = make_uint4(start, cnt, h * nb + b, 0u);
+            }
+            run += (uint32_t)__shfl((int)inc, 63);
+        }
+    }
+}
+
+// A bucket of a huge component (at most 2^14 pixels: the indices of a run of 2^14 consecutive pixels) per workgroup at a
+// time, sorted in LDS; the bucket's word in the table goes back to zero for the next frame.
+__global__ __launch_bounds__(1024) void huge_sort_kernel(const uint32_t* __restrict__ px_in, uint32_t* __restrict__ px_out,
+                                                         const uint4* __restrict__ jobs, uint32_t* __restrict__ huge_tab,
+                                                         const uint32_t* __restrict__ n_large) {
+    __shared__ uint32_t s_key[kSortLdsBig];
+    const uint32_t n_jobs = n_large[3];
+    for (uint32_t j = blockIdx.x; j < n_jobs; j += gridDim.x) {
+        const uint4 job = jobs[j];
+        const uint32_t off = job.x, n = job.y;
+        uint32_t P = 64;
+        while (P < n) P <<= 1;
+        for (uint32_t i = threadIdx.x; i < P; i += 1024) s_key[i] = i < n ? px_in[off + i] : 0xFFFFFFFFu;
+        __syncthreads();
+        bitonic_sort<1024>(s_key, P);
+        for (uint32_t i = threadIdx.x; i < n; i += 1024) px_out[off + i] = s_key[i];
+        if (threadIdx.x == 0) huge_tab[job.z] = 0u;
+        __syncthreads();
     }
 }
 
@@ -522,7 +634,7 @@ size_t fit_temp_bytes(size_t max_pixels, uint32_t max_segments) {
 int launch_component_offsets(const int32_t* seed_size, const uint32_t* d_n_seeds, uint32_t seed_cap, int min_size,
                              uint32_t* comp_rank, uint32_t* comp_seed, uint32_t* comp_off, uint32_t* totals,
                              uint32_t* large_list, uint32_t large_cap, uint32_t* n_large, void* temp, size_t temp_bytes,
-                             hipStream_t s) {
+                             uint32_t* cursor, const HugeSort& hs, hipStream_t s) {
     const uint32_t chunks = (seed_cap + kOffChunk - 1) / kOffChunk;
     if (chunks == 0 || temp_bytes < chunks * sizeof(uint2)) {
         set_error("launch_component_offsets: workspace too small");
@@ -532,31 +644,42 @@ int launch_component_offsets(const int32_t* seed_size, const uint32_t* d_n_seeds
     hipLaunchKernelGGL(component_sums_kernel, dim3(chunks), dim3(256), 0, s, seed_size, d_n_seeds, seed_cap, min_size,
                        chunk_tot, n_large);
     hipLaunchKernelGGL(component_offsets_kernel, dim3(chunks), dim3(256), 0, s, seed_size, d_n_seeds, seed_cap, min_size,
-                       chunk_tot, comp_rank, comp_seed, comp_off, totals, large_list, large_cap, n_large);
+                       chunk_tot, comp_rank, comp_seed, comp_off, totals, large_list, large_cap, n_large, cursor, hs.list,
+                       hs.tab ? hs.max : 0u);
     LR_HIP(hipGetLastError());
     return 0;
 }
 
+// `with_huge`: false when the caller KNOWS that the frame has no flood of more than 2^14 pixels (the flood's rounds report
+// their largest commit to the host that enqueues them just in time): the counting launch is left out.
 int launch_component_scatter(const uint32_t* label, size_t npix, const uint32_t* comp_rank, const uint32_t* comp_off,
-                             uint32_t* cursor, uint32_t* px, hipStream_t s) {
+                             uint32_t* cursor, uint32_t* px, const HugeSort& hs, uint32_t* n_large, bool with_huge, hipStream_t s) {
+    const uint32_t nb = (uint32_t)((npix + ((size_t)1 << kHugeShift) - 1) >> kHugeShift);
     const size_t want = (npix + 255) / 256;
+    if (with_huge && hs.tab)
+        hipLaunchKernelGGL(huge_count_kernel, dim3((unsigned)std::min<size_t>(want, 2048)), dim3(256), 0, s, label, npix, comp_rank, comp_off,
+                           cursor, hs.tab, nb, hs.list, hs.max, reinterpret_cast<uint4*>(hs.jobs), n_large);
     const int blocks = (int)(want < 8192 ? want : 8192);
     hipLaunchKernelGGL(component_scatter_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, label, npix, comp_rank,
-                       comp_off, cursor, px);
+                       comp_off, cursor, px, hs.tab, nb);
     LR_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_component_sort(const uint32_t* px_in, uint32_t* px_out, const uint32_t* comp_off, const uint32_t* d_n_comp,
                           uint32_t comp_cap, const uint32_t* large_list, uint32_t large_cap, const uint32_t* n_large,
-                          uint32_t* scratch, hipStream_t s) {
+                          uint32_t* scratch, const uint32_t* cursor, const HugeSort& hs, bool with_huge, hipStream_t s) {
     if (comp_cap == 0) return 0;
     (void)d_n_comp;  // (lists of up to 64 pixels: fit_kernel)
     hipLaunchKernelGGL(component_sort_large_kernel, dim3(4096), dim3(256), 0, s, px_in, px_out, comp_off, large_list, n_large);
     hipLaunchKernelGGL(component_sort_big_kernel<false>, dim3(128), dim3(1024), 0, s, px_in, px_out, comp_off, large_list,
-                       large_cap, n_large, scratch);
-    hipLaunchKernelGGL(component_sort_big_kernel<true>, dim3(1), dim3(1024), 0, s, px_in, px_out, comp_off, large_list,
-                       large_cap, n_large, scratch);
+                       large_cap, n_large, scratch, cursor);
+    if (with_huge && hs.tab) {
+        hipLaunchKernelGGL(huge_sort_kernel, dim3(512), dim3(1024), 0, s, px_in, px_out, reinterpret_cast<const uint4*>(hs.jobs), hs.tab, n_large);
+        // (more huge components than the table has rows for -- never: the old way, one workgroup through global memory)
+        hipLaunchKernelGGL(component_sort_big_kernel<true>, dim3(1), dim3(1024), 0, s, px_in, px_out, comp_off, large_list,
+                           large_cap, n_large, scratch, cursor);
+    }
     LR_HIP(hipGetLastError());
     return 0;
 }

@@ -175,6 +175,7 @@ constexpr uint32_t kWpMaxTiles = 600u;   // the team's table holds an entry per 
 constexpr uint32_t kSrcShift = 28u, kSrcMask = 0xF0000000u, kSrcClaim = 0xF0000000u;  // table keys of a multi-source walk
 constexpr uint32_t kBigCap = 8192;  // seeds per round that can move to the second tier (FloodBuffers::big_list)
 constexpr uint32_t kFlagIncomplete = 1u, kFlagSelfFail = 2u;
+constexpr uint32_t kHugeFlood = 1u << 14;  // (kernels_fit.hip: kSortLdsBig)
 constexpr uint32_t kFullTiles = 48u;     // a first-tier walk is held at this many tiles once the round's second-tier list is full (explore_seed)
 constexpr uint32_t kGiantProbes = 512u;  // marked seeds a round lets walk again (one team each: a launch's worth)
 constexpr uint32_t kLogShrunk = 0x80000000u;  // FloodArgs::log_len: the log has been cut down to a later footprint by flood_rewalk_kernel
@@ -296,11 +297,12 @@ enum {
     // without touching exactness.  When the lowest active seed is a marked giant -- at the end of a round (flood_advance), or
     // after a giant step (giant_finish_kernel) -- this word holds seed + 1: every kernel of a round leaves at once while it is
     // set (rounds enqueued blindly behind the request do nothing and do not count), the host sees the request in
-    // host_progress[3] and enqueues the step (giant_*_kernel: tile masks, union-find over the tiles' components, labels).
+    // report (flood_report) and enqueues the step (giant_*_kernel: tile masks, union-find over the tiles' components, labels).
     kCtrlGiantStep = 38,
     kCtrlGiantDone = 39,       // giant steps of the frame (diagnostics: lr_stage_counters [14]; the host waits for its count)
     kCtrlGiantPx = 40,         // pixels of the step in progress
     kCtrlGiantBlocks = 41,     // workgroups of giant_finish_kernel that have finished
+    kCtrlMaxFlood = 43,        // pixels of the largest flood committed so far, if more than kHugeFlood (the fit's launches for huge components: a bit of flood_report)
     kCtrlWindowFree = 42,      // the coming round's window before the giants' rule cut it (giant_finish_kernel applies the rule again)
     kCtrlWords = 48,
 };
@@ -2478,16 +2480,28 @@ __global__ __launch_bounds__(256) void flood_commit_pixels_kernel(FloodArgs A, u
     }
 }
 
+// What the device tells the host that enqueues rounds just in time (FloodBuffers::host_progress): ONE 64-bit word, so that
+// every look is a consistent report -- n_left (29 bits) | stalled << 29 | giant step asked for << 30 | a flood of more than
+// kHugeFlood pixels has been committed << 31 | rounds with work so far << 32 (12 bits) | giant steps done << 44 (16 bits) |
+// 1 << 63 (a report: the host zeroes the word before the frame).  (Six separate words, the count of rounds stored last,
+// let the host see "giant step asked for" beside a stale "no seeds left" and take the flood for finished.)
+__device__ __forceinline__ void flood_report(uint32_t* host_progress, uint32_t rounds, uint32_t n_left, bool stalled, bool want_giant,
+                                             uint32_t giants_done, bool huge) {
+    const unsigned long long w = (unsigned long long)(n_left & 0x1FFFFFFFu) | ((unsigned long long)(stalled ? 1u : 0u) << 29) |
+                                 ((unsigned long long)(want_giant ? 1u : 0u) << 30) | ((unsigned long long)(huge ? 1u : 0u) << 31) |
+                                 ((unsigned long long)min(rounds, 0xFFFu) << 32) | ((unsigned long long)min(giants_done, 0xFFFFu) << 44) | (1ull << 63);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_progress), w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // End of a round (one thread: the last workgroup of the survivors pass): the next list becomes the current one.  A round without progress (possible only
 // when storage ran out on the lowest active seed) stops the rounds and leaves the rest to the ordered tail.
 __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift, uint32_t regional_min, uint32_t hold_min_big,
                               uint32_t* host_progress, uint32_t hold_release, uint32_t giant_step) {
     const uint32_t n_act = ld_agent(&ctrl[kCtrlNAct]);
     if (n_act == 0u) {  // (a round enqueued past the end -- or a frame without seeds: the host must not wait for more)
-        if (host_progress) {
-            __hip_atomic_store(&host_progress[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&host_progress[0], max(ld_agent(&ctrl[kCtrlRounds]), 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        if (host_progress)
+            flood_report(host_progress, max(ld_agent(&ctrl[kCtrlRounds]), 1u), 0u, false, false, ld_agent(&ctrl[kCtrlGiantDone]),
+                         ld_agent(&ctrl[kCtrlMaxFlood]) != 0u);
         return;
     }
     const uint32_t n_seeds = ld_agent(&ctrl[kCtrlNSeeds]), win_hold = ld_agent(&ctrl[kCtrlWinHold]);
@@ -2572,12 +2586,9 @@ __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift, u
     ctrl[kCtrlNMultiNext] = 0u;
     ctrl[kCtrlBigSeen] = ld_agent(&ctrl[kCtrlBigLong]) >= regional_min ? 1u : 0u;
     ctrl[kCtrlGiantStep] = (progress && want_giant) ? ld_agent(&ctrl[kCtrlLowest]) + 1u : 0u;  // (kCtrlLowest: the lowest survivor, set above)
-    if (host_progress) {  // the host enqueues the next round when it sees this one over and seeds left (flood_enqueue)
-        __hip_atomic_store(&host_progress[1], progress ? n_next : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&host_progress[2], progress ? 0u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&host_progress[3], (progress && want_giant) ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&host_progress[0], ld_agent(&ctrl[kCtrlRounds]), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (host_progress)  // the host enqueues the next round when it sees this one over and seeds left (flood_enqueue)
+        flood_report(host_progress, ld_agent(&ctrl[kCtrlRounds]), progress ? n_next : 0u, !progress, progress && want_giant,
+                     ld_agent(&ctrl[kCtrlGiantDone]), ld_agent(&ctrl[kCtrlMaxFlood]) != 0u);
 }
 
 // (Commit pass and survivors pass in ONE launch -- blocked marks in two alternating buffers, counts and flags written
@@ -2614,6 +2625,7 @@ __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, uint8
                 state[k] = 2;
                 seed_size[k] = (int32_t)A.count[k];
                 done = true;
+                if (A.count[k] > kHugeFlood) atomicMax(&A.ctrl[kCtrlMaxFlood], A.count[k]);  // (rare)
             } else if (state[k] == 0) {
                 const uint32_t own_label = A.label[A.seed_idx[k]];
                 if (own_label < kMarkBit && own_label != k) {  // its pixel now belongs to another seed's flood: skipped forever
@@ -2753,6 +2765,7 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
         ctrl[kCtrlGiantCountNext] = 0u;
         ctrl[kCtrlGiants] = 0u;
         ctrl[kCtrlGiantStep] = 0u;
+        ctrl[kCtrlMaxFlood] = 0u;
         ctrl[kCtrlGiantDone] = 0u;
         ctrl[kCtrlGiantPx] = 0u;
         ctrl[kCtrlGiantBlocks] = 0u;
@@ -3016,34 +3029,45 @@ __global__ __launch_bounds__(256) void giant_finish_kernel(FloodArgs A) {
     const uint32_t g = gs - 1u;
     const uint32_t* __restrict__ act = act_now(A);
     const uint32_t n_act = A.ctrl[kCtrlNAct];
-    const uint32_t n_pad = (n_act + 63u) & ~63u;
     const int lane = threadIdx.x & 63;
-    // the lowest seed of the list that is still alive, and the lowest marked one (what flood_advance takes from the survivors pass)
-    for (uint32_t ai = blockIdx.x * 256u + threadIdx.x; ai < n_pad; ai += gridDim.x * 256u) {
-        uint32_t kmin = 0xFFFFFFFFu, gmin = 0xFFFFFFFFu;
-        if (ai < n_act) {
-            const uint32_t k = act[ai];
-            const uint8_t t = A.tier[k];
-            if (k != g && (t & 8u) == 0u) {
-                const uint32_t own_label = A.label[A.seed_idx[k]];
-                if (own_label >= kMarkBit || own_label == k) {  // (between rounds: free, or its own ground)
-                    kmin = k;
-                    if (t & 4u) gmin = k;
+    // the lowest seed of the list that is still alive, and the lowest marked one (what flood_advance takes from the survivors
+    // pass); one set of atomics a workgroup (one a wavefront was 3 700 atomics on three addresses at 1080p: 50 us)
+    uint32_t kmin = 0xFFFFFFFFu, gmin = 0xFFFFFFFFu, nmark = 0u;
+    for (uint32_t ai = blockIdx.x * 256u + threadIdx.x; ai < n_act; ai += gridDim.x * 256u) {
+        const uint32_t k = act[ai];
+        const uint8_t t = A.tier[k];
+        if (k != g && (t & 8u) == 0u) {
+            const uint32_t own_label = A.label[A.seed_idx[k]];
+            if (own_label >= kMarkBit || own_label == k) {  // (between rounds: free, or its own ground)
+                kmin = min(kmin, k);
+                if (t & 4u) {
+                    gmin = min(gmin, k);
+                    nmark += 1u;
                 }
             }
         }
-        const uint64_t mg = __ballot(gmin != 0xFFFFFFFFu);
+    }
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off));
-            gmin = min(gmin, (uint32_t)__shfl_xor((int)gmin, off));
-        }
-        if (lane == 0) {
-            if (kmin != 0xFFFFFFFFu) atomicMin(&A.ctrl[kCtrlLowestNext], kmin);
-            if (gmin != 0xFFFFFFFFu) {
-                atomicMin(&A.ctrl[kCtrlGiantLowNext], gmin);
-                atomicAdd(&A.ctrl[kCtrlGiantCountNext], (uint32_t)__popcll(mg));
-            }
+    for (int off = 32; off >= 1; off >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off));
+        gmin = min(gmin, (uint32_t)__shfl_xor((int)gmin, off));
+        nmark += (uint32_t)__shfl_xor((int)nmark, off);
+    }
+    __shared__ uint32_t s_k[4], s_g[4], s_n[4];
+    if (lane == 0) {
+        s_k[threadIdx.x >> 6] = kmin;
+        s_g[threadIdx.x >> 6] = gmin;
+        s_n[threadIdx.x >> 6] = nmark;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        kmin = min(min(s_k[0], s_k[1]), min(s_k[2], s_k[3]));
+        gmin = min(min(s_g[0], s_g[1]), min(s_g[2], s_g[3]));
+        nmark = s_n[0] + s_n[1] + s_n[2] + s_n[3];
+        if (kmin != 0xFFFFFFFFu) atomicMin(&A.ctrl[kCtrlLowestNext], kmin);
+        if (gmin != 0xFFFFFFFFu) {
+            atomicMin(&A.ctrl[kCtrlGiantLowNext], gmin);
+            atomicAdd(&A.ctrl[kCtrlGiantCountNext], nmark);
         }
     }
     __syncthreads();
@@ -3086,13 +3110,8 @@ __global__ __launch_bounds__(256) void giant_finish_kernel(FloodArgs A) {
     ctrl[kCtrlGiantDone] = done;
     const bool again = giant != 0xFFFFFFFFu && giant == lowest;
     ctrl[kCtrlGiantStep] = again ? giant + 1u : 0u;
-    if (A.host_progress) {
-        __hip_atomic_store(&A.host_progress[0], ld_agent(&ctrl[kCtrlRounds]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&A.host_progress[1], n_act, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&A.host_progress[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&A.host_progress[3], again ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&A.host_progress[4], done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (A.host_progress)
+        flood_report(A.host_progress, ld_agent(&ctrl[kCtrlRounds]), n_act, false, again, done, ld_agent(&ctrl[kCtrlMaxFlood]) != 0u || total > kHugeFlood);
 }
 
 // Ordered tail: the reference's loop over an (ascending) list of remaining seeds, starting from
@@ -3524,6 +3543,8 @@ void enqueue_giant_step(const FloodBuffers& B, const FloodFrame& F, const FloodA
 // its own: the caller goes on enqueuing the later stages and looks at the control block when the frame is done.
 int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, uint32_t* h_ctrl, hipStream_t s) {
     P->enqueued = 0;
+    P->sizes_known = false;
+    P->max_flood = 0;
     P->use_big = B.second_tier && B.second_tier_from_start;
     if (F.seed_cap == 0) return launch_label_init(F.label, (size_t)F.w * F.h, s);
     // staged start (FloodBuffers::win_*); LIBRECTIFY_FLOOD_WINDOW="<first shift>,<growth shift>" overrides
@@ -3577,9 +3598,19 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
         // just in time (FloodBuffers::host_progress): the rounds the last frame needed less one at once, every further one when
         // the host has seen the rounds so far leave seeds.  A round that never reports (nothing should keep it) ends the
         // watch after a second: the rest goes the blind way, flood_finish picks up whatever is left.
-        volatile uint32_t* hp = B.host_progress;
-        hp[0] = hp[1] = hp[2] = hp[3] = hp[4] = 0u;
-        std::atomic_thread_fence(std::memory_order_seq_cst);
+        // (one 64-bit word, so that every look is a consistent report: flood_report)
+        unsigned long long* hp = reinterpret_cast<unsigned long long*>(B.host_progress);
+        __atomic_store_n(hp, 0ull, __ATOMIC_SEQ_CST);
+        struct Report {
+            bool any;
+            uint32_t n_left, rounds, giants;
+            bool stalled, want_giant, huge;
+        };
+        auto look = [&]() {
+            const unsigned long long w = __atomic_load_n(hp, __ATOMIC_ACQUIRE);
+            return Report{(w >> 63) != 0ull, (uint32_t)(w & 0x1FFFFFFFull), (uint32_t)((w >> 32) & 0xFFFull), (uint32_t)((w >> 44) & 0xFFFFull),
+                          ((w >> 29) & 1ull) != 0ull, ((w >> 30) & 1ull) != 0ull, ((w >> 31) & 1ull) != 0ull};
+        };
         const int first = std::min(std::max(B.jit_first, 1), 16);
         // (LIBRECTIFY_FLOOD_JIT_LEAD=1 keeps one round ahead -- the next round goes in when all but the last one enqueued are
         // over and left seeds, the host's reaction hides behind that last round, at most one round is enqueued in vain:
@@ -3591,50 +3622,49 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
         int counting = P->enqueued;
         uint32_t giants = 0;  // giant steps enqueued
         const auto t0 = std::chrono::steady_clock::now();
-        auto deadline_passed = [&](int& spins) {
+        int spins = 0;
+        auto deadline_passed = [&]() {
             if (B.jit_sleep_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(B.jit_sleep_us));
             return (++spins & (B.jit_sleep_us > 0 ? 15 : 1023)) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(1);
         };
         for (;;) {
-            uint32_t done_rounds, n_left, stalled, want_giant;
-            int spins = 0;
+            Report r{};
             bool timed_out = false;
             for (;;) {
-                done_rounds = __atomic_load_n(&B.host_progress[0], __ATOMIC_ACQUIRE);
-                n_left = __atomic_load_n(&B.host_progress[1], __ATOMIC_RELAXED);
-                stalled = __atomic_load_n(&B.host_progress[2], __ATOMIC_RELAXED);
-                want_giant = __atomic_load_n(&B.host_progress[3], __ATOMIC_RELAXED);
-                if ((int)done_rounds + lead >= counting || (done_rounds > 0u && n_left == 0u) || want_giant != 0u) break;
-                if (deadline_passed(spins)) {
+                r = look();
+                if (r.any && ((int)r.rounds + lead >= counting || r.n_left == 0u || r.want_giant)) break;
+                if (deadline_passed()) {
                     timed_out = true;
                     break;
                 }
             }
             // The lowest active seed is a marked giant: the whole device floods it (giant_*_kernel), and the next one if the
             // step's last kernel asks for it, before the next round with work goes in.
-            while (!timed_out && want_giant != 0u && n_left != 0u && stalled == 0u) {
+            while (!timed_out && r.want_giant && r.n_left != 0u && !r.stalled) {
                 enqueue_giant_step(B, F, A, s);
                 ++giants;
-                while (__atomic_load_n(&B.host_progress[4], __ATOMIC_ACQUIRE) < giants) {
-                    if (deadline_passed(spins)) {
+                for (;;) {
+                    r = look();
+                    if (r.giants >= giants) break;
+                    if (deadline_passed()) {
                         timed_out = true;
                         break;
                     }
                 }
-                if (timed_out) break;
-                done_rounds = __atomic_load_n(&B.host_progress[0], __ATOMIC_RELAXED);
-                n_left = __atomic_load_n(&B.host_progress[1], __ATOMIC_RELAXED);
-                want_giant = __atomic_load_n(&B.host_progress[3], __ATOMIC_RELAXED);
-                counting = (int)done_rounds;
+                counting = (int)r.rounds;
                 if (giants >= 4096u) break;  // (never: a step retires a seed)
             }
             if (timed_out) {
                 // (with the `rest` launch whatever the list's length: the round before them was told its successor would know)
-                for (int r = 0; r < 2; ++r, ++P->enqueued) enqueue_round(B, F, A, P->use_big, P->enqueued, s, 0xFFFFFFFEu, true);
+                for (int k = 0; k < 2; ++k, ++P->enqueued) enqueue_round(B, F, A, P->use_big, P->enqueued, s, 0xFFFFFFFEu, true);
                 break;
             }
-            if (n_left == 0u || stalled != 0u || P->enqueued >= 256) break;
-            enqueue_round(B, F, A, P->use_big, P->enqueued, s, n_left, true);
+            if (r.n_left == 0u && !r.stalled) {  // the flood is over, and the report says whether it committed a huge flood
+                P->sizes_known = true;
+                P->max_flood = r.huge ? 0xFFFFFFFFu : 0u;
+            }
+            if (r.n_left == 0u || r.stalled || P->enqueued >= 256) break;
+            enqueue_round(B, F, A, P->use_big, P->enqueued, s, r.n_left, true);
             ++P->enqueued;
             ++counting;
         }
@@ -3660,6 +3690,7 @@ int flood_finish(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, u
     A.win_shift = (uint32_t)P->win_growth;
     while (h_ctrl[kCtrlNAct] != 0u) {
         *extra = true;
+        P->sizes_known = false;
         static const bool call_debug = std::getenv("LIBRECTIFY_CALL_DEBUG") != nullptr;
         if (g_flood_debug || call_debug)
             std::fprintf(stderr, "flood after %d rounds enqueued: %u done, active %u, remain %u, stall %u\n", P->enqueued,
