@@ -180,6 +180,9 @@ struct FloodBuffers {
     // Likewise the hold-back: if the context's previous frame engaged it, this frame starts with it (a round of very
     // long walks saved); otherwise it engages after the first full round that shows such walks.
     bool hold_from_start = false;
+    // ... and the staged window of a frame of overlapping giants (kernels_flood.hip: kCtrlStaged): a frame that holds back
+    // many walks in its first round goes on with the strongest quarter of its seeds; the frame after it starts that way.
+    bool staged_from_start = false;
     int blind_rounds = 10;  // rounds flood_enqueue enqueues without looking at the control block
     // Rounds just in time (round 4; single calls): the first `jit_first` rounds are enqueued blindly, every further one only
     // when the host has SEEN, in page-locked words the last workgroup of a round writes, that the rounds so far left seeds

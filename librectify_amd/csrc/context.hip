@@ -788,6 +788,7 @@ FloodBuffers flood_buffers_for(lr_context* c) {
     if (c->flood_mode >= 2 && c->flood_mode <= 4) fbuf.second_tier = false;
     fbuf.second_tier_from_start = c->flood_big_hint;
     fbuf.hold_from_start = c->flood_hold_hint;
+    fbuf.staged_from_start = c->flood_staged_hint;
     if (c->flood_mode == 2) fbuf.n_slabs = 0;
     if (c->flood_mode == 3) fbuf.n_slabs = 2;
     if (c->flood_mode == 5) {  // second tier with room for one seed per round and no slab: the rounds stall while
@@ -930,6 +931,12 @@ int finish_flood(lr_context* c, bool* extra) {
         // frame to frame once a single frame had.
         c->flood_big_hint = true;
         c->flood_hold_hint = c->flood_tiers[3] != 0 && c->flood_tiers[8] >= 16;
+        // A frame that went on staged (many walks held back in its first round) hands that on; a frame that STARTED staged
+        // keeps handing it on while its floods still look like regions (walks in the second tier: the staged start itself
+        // keeps the giants away, so their count says nothing any more).
+        static const int staged_keep = std::getenv("LIBRECTIFY_FLOOD_STAGED_KEEP") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_STAGED_KEEP")) : 64;
+        c->flood_staged_hint = c->flood_tiers[14] != 0 && (!c->flood_staged_hint || (int)c->flood_tiers[0] >= staged_keep);
+        if (c->flood_staged_hint) c->flood_hold_hint = false;
         // (The verdict "many long walks" -- early hand-over to the second tier, flood_advance -- is NOT carried over: started
         // with it, the natural 4K frame sends 735 walks to the second tier in round one and its flood takes 1.88 ms instead
         // of 1.5, and a frame of lines that follows pays 0.7 ms for the wrong guess.)

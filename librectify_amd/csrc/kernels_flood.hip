@@ -208,6 +208,7 @@ struct FloodArgs {
     uint32_t t1_tiles;                               // first tier hands a walk to the second at this many tiles (when there is one)
     uint32_t* handover;                              // state of the walks handed to the second tier (FloodBuffers::handover)
     uint32_t team_tiles;                             // test hook: the team's table counts as full at this many tiles
+    uint32_t giant_many;                             // walks held back after which a frame counts as one of overlapping giants (see kCtrlStaged)
     uint32_t hold_min_big;                           // walks in the second tier after which the hold-back engages
     uint32_t hold_release;                           // the hold-back ends when so few seeds below the line are still active
     uint32_t t1_regional, t1_regional_min;           // ... at t1_regional tiles once the frame has had t1_regional_min walks beyond the first tier's table
@@ -303,6 +304,9 @@ enum {
     kCtrlGiantPx = 40,         // pixels of the step in progress
     kCtrlGiantBlocks = 41,     // workgroups of giant_finish_kernel that have finished
     kCtrlMaxFlood = 43,        // pixels of the largest flood committed so far, if more than kHugeFlood (the fit's launches for huge components: a bit of flood_report)
+    // A frame that holds back giant_many walks in a round with the full window goes on like a staged start (FloodBuffers::
+    // win_first_shift): the next round's window is the strongest quarter of the seeds, and it doubles from round to round.
+    kCtrlStaged = 44,
     kCtrlWindowFree = 42,      // the coming round's window before the giants' rule cut it (giant_finish_kernel applies the rule again)
     kCtrlWords = 48,
 };
@@ -325,6 +329,12 @@ __device__ __forceinline__ uint64_t m_gt_f(float a, float b) { return __builtin_
 __device__ __forceinline__ bool lane_of(uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
 __device__ __forceinline__ uint64_t uni64(uint64_t v) { return uni64((uint32_t)v, (uint32_t)(v >> 32)); }
 
+// kCtrlStaged: the frame's FIRST round is in progress with a window beyond the strongest quarter, and giant_many walks have been held back
+__device__ __forceinline__ bool giants_many(const uint32_t* ctrl, uint32_t giant_many) {
+    const uint32_t n_seeds = uni(ctrl[kCtrlNSeeds]);
+    return giant_many != 0u && uni(ctrl[kCtrlStaged]) == 0u && uni(ctrl[kCtrlRounds]) == 0u && n_seeds >= 8192u &&
+           uni(ctrl[kCtrlWindow]) > (n_seeds >> 2) && uni(ld_agent(&ctrl[kCtrlGiants])) >= giant_many;
+}
 // the active list a round with work reads, and the one it appends to (see FloodArgs::act_a)
 __device__ __forceinline__ const uint32_t* act_now(const FloodArgs& A) { return (uni(A.ctrl[kCtrlRounds]) & 1u) ? A.act_b : A.act_a; }
 __device__ __forceinline__ uint32_t* act_other(const FloodArgs& A) { return (uni(A.ctrl[kCtrlRounds]) & 1u) ? A.act_a : A.act_b; }
@@ -1014,7 +1024,9 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
     // rarely below 190 tiles from above 1500 px)
     // ... and a seed that left way-points on a long footprint in an earlier round goes straight to the second tier, whose
     // team walks it from all of them at once
-    const bool outgrown = kFirstTier && A.big_cap != 0u && (uni((uint32_t)A.tier[k]) & 1u) != 0u;
+    // (not on a frame that went on staged after its first round -- kCtrlStaged: what a weak seed reached then says little
+    // about what it reaches once the stronger seeds have committed)
+    const bool outgrown = kFirstTier && A.big_cap != 0u && (uni((uint32_t)A.tier[k]) & 1u) != 0u && uni(A.ctrl[kCtrlStaged]) == 0u;
     const bool wp_seed = kFirstTier && A.big_cap != 0u && A.wp_min_tiles != 0xFFFFFFFFu && k < A.wp_cap &&
                          uni(A.waypoints[(size_t)k * kFloodWpWords]) != 0u;
     // A seed with a log (save_log) walks a few tiles only: most footprints have shrunk to a handful of tiles by their second
@@ -1688,6 +1700,19 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
         if (!own && !(((uni((uint32_t)A.dmask[s]) >> b) & 1u) &&
                       directional(__uint_as_float(uni(__float_as_uint(A.dx[s]))), __uint_as_float(uni(__float_as_uint(A.dy[s]))), sn, cs) > thr)) {
             if (threadIdx.x == 0) A.flags[k] = kFlagSelfFail;
+            continue;
+        }
+        // A frame that has held back giant_many walks already is one of overlapping giants (a ramp under noise: thousands of
+        // weak seeds that each reach 100 000 pixels until the stronger ones have committed), and walking the table full to
+        // find the next one out is most of its first round (4K ramp: 3.2 of 4.3 ms).  From then on the walks of the weaker
+        // three quarters of the seeds are not even begun: they count as unfinished (nothing above them commits), and the end
+        // of the round closes the window in front of them -- kCtrlStaged: the strongest quarter first, twice as many a round.
+        // (only in a round whose end will close the window: flood_advance tests the same words)
+        if (A.giant_hold != 0u && k != uni(A.ctrl[kCtrlLowest]) && k >= (uni(A.ctrl[kCtrlNSeeds]) >> 2) && giants_many(A.ctrl, A.giant_many)) {
+            if (threadIdx.x == 0) {
+                A.flags[k] = kFlagIncomplete;
+                atomicMin(&A.ctrl[kCtrlBarrier], k);
+            }
             continue;
         }
         // what the first tier handed over with this entry (A.big_cap entries at most, so ai is its position in the list)
@@ -2496,7 +2521,7 @@ __device__ __forceinline__ void flood_report(uint32_t* host_progress, uint32_t r
 // End of a round (one thread: the last workgroup of the survivors pass): the next list becomes the current one.  A round without progress (possible only
 // when storage ran out on the lowest active seed) stops the rounds and leaves the rest to the ordered tail.
 __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift, uint32_t regional_min, uint32_t hold_min_big,
-                              uint32_t* host_progress, uint32_t hold_release, uint32_t giant_step) {
+                              uint32_t* host_progress, uint32_t hold_release, uint32_t giant_step, uint32_t giant_many) {
     const uint32_t n_act = ld_agent(&ctrl[kCtrlNAct]);
     if (n_act == 0u) {  // (a round enqueued past the end -- or a frame without seeds: the host must not wait for more)
         if (host_progress)
@@ -2518,10 +2543,16 @@ __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift, u
     // regions: the weakest seeds, with the lowest thresholds, own the largest footprints and stay blocked for most
     // of the rounds, re-walking them every time), the window drops to win_hold and the weakest seeds wait until every
     // seed below it is resolved; then it opens for good.  Any prefix of the seed order is a valid window.
-    unsigned long long grown = (unsigned long long)window << win_shift;
+    bool staged = ld_agent(&ctrl[kCtrlStaged]) != 0u;
+    unsigned long long grown = (unsigned long long)window << (staged ? 1u : win_shift);
     if (grown > n_seeds) grown = n_seeds;
     const uint32_t phase = ld_agent(&ctrl[kCtrlPhase]);
-    if (phase == 0u && window >= n_seeds && win_hold < n_seeds && ld_agent(&ctrl[kCtrlBigTotal]) >= hold_min_big && n_next > 0u) {
+    if (n_next > 0u && giants_many(ctrl, giant_many)) {
+        // a frame of overlapping giants (kCtrlStaged): the strongest quarter first from here on, no hold-back line besides
+        ctrl[kCtrlStaged] = 1u;
+        ctrl[kCtrlPhase] = 2u;
+        grown = n_seeds >> 2;
+    } else if (phase == 0u && window >= n_seeds && win_hold < n_seeds && ld_agent(&ctrl[kCtrlBigTotal]) >= hold_min_big && n_next > 0u) {
         grown = win_hold;
         ctrl[kCtrlPhase] = 1u;
     } else if (phase == 1u) {
@@ -2714,7 +2745,7 @@ __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, uint8
         if (atomicAdd(&A.ctrl[kCtrlDone], 1u) == gridDim.x - 1u) {
             __threadfence();
             A.ctrl[kCtrlDone] = 0u;
-            flood_advance(A.ctrl, A.win_shift, A.t1_regional_min, A.hold_min_big, A.host_progress, A.hold_release, A.giant_step);
+            flood_advance(A.ctrl, A.win_shift, A.t1_regional_min, A.hold_min_big, A.host_progress, A.hold_release, A.giant_step, A.giant_many);
         }
     }
 }
@@ -2728,7 +2759,8 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
                                                                int win_first_shift, int hold_pct, uint32_t hold_from_start,
                                                                uint32_t* __restrict__ label, size_t npix,
                                                                uint32_t* __restrict__ waypoints, uint32_t wp_cap,
-                                                               uint32_t* __restrict__ log_len, uint32_t log_seeds, uint32_t dense_div) {
+                                                               uint32_t* __restrict__ log_len, uint32_t log_seeds, uint32_t dense_div,
+                                                               uint32_t staged_from_start) {
     // (the label image is set to "free" here as well: one launch less in front of the first round)
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) label[i] = kLabelFree;
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
@@ -2765,6 +2797,7 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
         ctrl[kCtrlGiantCountNext] = 0u;
         ctrl[kCtrlGiants] = 0u;
         ctrl[kCtrlGiantStep] = 0u;
+        ctrl[kCtrlStaged] = staged_from_start;  // (the context's last frame was one of overlapping giants: FloodBuffers::staged_from_start)
         ctrl[kCtrlMaxFlood] = 0u;
         ctrl[kCtrlGiantDone] = 0u;
         ctrl[kCtrlGiantPx] = 0u;
@@ -3360,6 +3393,8 @@ FloodArgs flood_args(const FloodBuffers& B, const FloodFrame& F, bool use_big) {
     // such walks unchanged; at 640 the edge-less 4K frame pays (5.7 -> 7.0 ms).
     static const int team_tiles_env = std::getenv("LIBRECTIFY_FLOOD_TEAM_TILES") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_TEAM_TILES")) : 1024;
     A.team_tiles = B.team_tile_cap ? B.team_tile_cap : ((B.giant_hold && team_tiles_env > 0) ? (uint32_t)team_tiles_env : 0xFFFFFFFFu);
+    static const int many_env = std::getenv("LIBRECTIFY_FLOOD_GIANT_MANY") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_GIANT_MANY")) : 64;
+    A.giant_many = B.giant_hold ? (uint32_t)std::max(many_env, 0) : 0u;
     A.handover = B.handover;
     A.t1_tiles = t1_env > 8 ? (uint32_t)t1_env : 0xFFFFFFFFu;
     static const int t1r_env = std::getenv("LIBRECTIFY_FLOOD_T1_REGIONAL") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_T1_REGIONAL")) : 32;
@@ -3550,6 +3585,10 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
     // staged start (FloodBuffers::win_*); LIBRECTIFY_FLOOD_WINDOW="<first shift>,<growth shift>" overrides
     static const char* win_env = std::getenv("LIBRECTIFY_FLOOD_WINDOW");
     int win_first_shift = B.win_first_shift, win_growth = B.win_growth;
+    if (B.staged_from_start && win_first_shift <= 0) {  // the strongest quarter first, twice as many a round (kCtrlStaged)
+        win_first_shift = 2;
+        win_growth = 1;
+    }
     if (win_env) {
         win_first_shift = std::atoi(win_env);
         const char* c = std::strchr(win_env, ',');
@@ -3588,7 +3627,8 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
         hipLaunchKernelGGL(flood_init_seeds_kernel, dim3(blocks), dim3(256), 0, s, F.d_n_seeds, F.seed_cap, B.act_a, B.state,
                            B.tier, B.blocked, B.count, B.flags, F.seed_size, B.ctrl, B.dirty,
                            (uint32_t)((npix + 255) >> 8), win_first_shift, hold_pct, hold_start ? 1u : 0u, F.label, npix,
-                           B.waypoints, B.wp_cap, B.log_len, B.log_len ? B.log_seeds : 0u, dense_div);
+                           B.waypoints, B.wp_cap, B.log_len, B.log_len ? B.log_seeds : 0u, dense_div,
+                           (B.staged_from_start && !win_env && B.win_first_shift <= 0) ? 1u : 0u);
     }
     FloodArgs A = flood_args(B, F, P->use_big);
     A.win_shift = (uint32_t)win_growth;
@@ -3748,6 +3788,7 @@ int flood_finish(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, u
         tiers_out[11] = h_ctrl[kCtrlLogGiveUp];
         tiers_out[12] = h_ctrl[kCtrlGiants];
         tiers_out[13] = h_ctrl[kCtrlGiantDone];
+        tiers_out[14] = h_ctrl[kCtrlStaged];
     }
     return 0;
 }

@@ -18,9 +18,22 @@ def _stripes(W, H, period, slope):
     return (0.5 + 0.4 * np.sin((xx + slope * yy) * 2 * np.pi / period)).astype(np.float32)
 
 
+def _natural(W, H):
+    """the reference's doc image (luma) upsampled with a cubic spline: a natural image"""
+    import scipy.ndimage as ndi
+    g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "doc_image_gray.npy")).astype(np.float32) / np.float32(256.0)
+    return np.ascontiguousarray(ndi.zoom(g, (H / g.shape[0], W / g.shape[1]), order=3).astype(np.float32)[:H, :W])
+
+
 KINDS = {
     "bars1080": lambda: synth.frame(1920, 1080, 5),
     "bench4k": lambda: synth.frame(3840, 2160, 1),
+    "bench4k_2": lambda: synth.frame(3840, 2160, 2),
+    "bench4k_3": lambda: synth.frame(3840, 2160, 3),
+    "bench4k_4": lambda: synth.frame(3840, 2160, 4),
+    "natural4k": lambda: _natural(3840, 2160),
+    "natural1080": lambda: _natural(1920, 1080),
+    "doc": lambda: _natural(1000, 563),
     "regions1080": lambda: synth.region_frame(1920, 1080, 500),
     "regions4k": lambda: synth.region_frame(3840, 2160, 500),
     "edgeless4k": lambda: synth.region_frame(3840, 2160, 4),
