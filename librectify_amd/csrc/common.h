@@ -118,6 +118,7 @@ struct FloodBuffers {
     uint32_t* flags = nullptr;
     uint8_t* state = nullptr;
     uint8_t* tier = nullptr;        // per seed: 1 = its walk outgrew the first storage tier in an earlier round
+    uint32_t* blk = nullptr;        // per seed: the lower seed that blocked its last long walk (kernels_flood.hip: kCtrlDeferLow)
     uint32_t* act_a = nullptr;
     uint32_t* act_b = nullptr;
     uint32_t* ctrl = nullptr;       // kFloodCtrlWords words

@@ -6,6 +6,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <map>
 #include <mutex>
 #include <cmath>
 #include <cstdio>
@@ -159,7 +160,7 @@ static int ensure_flood_buffers(lr_context* c) {
     if (c->fb_cap_seeds >= c->cap_pix && f.slab_ring) return 0;
     LR_HIP(hipStreamSynchronize(c->stream));
     const size_t cs = c->cap_pix;
-    if (dev_alloc(f.blocked, cs) || dev_alloc(f.count, cs) || dev_alloc(f.flags, cs) || dev_alloc(f.state, cs) || dev_alloc(f.tier, cs) ||
+    if (dev_alloc(f.blocked, cs) || dev_alloc(f.count, cs) || dev_alloc(f.flags, cs) || dev_alloc(f.state, cs) || dev_alloc(f.tier, cs) || dev_alloc(f.blk, cs) ||
         dev_alloc(f.act_a, cs) || dev_alloc(f.act_b, cs) || dev_alloc(f.ctrl, kFloodCtrlWords) || dev_alloc(f.big_list, 8192) || dev_alloc(f.handover, 8192 * kFloodHandWords) ||
         dev_alloc(f.dirty, cs / 256 + 16))
         return 1;
@@ -172,7 +173,8 @@ static int ensure_flood_buffers(lr_context* c) {
     if (dev_alloc(f.waypoints, (size_t)f.wp_cap * kFloodWpWords) || dev_alloc(f.multi_list, 8192)) return 1;
     // footprint logs (FloodBuffers::rewalk_logs): per-seed words for one seed per 16 pixels, a record per 8 pixels
     f.log_seeds = f.wp_cap;
-    f.log_cap = (uint32_t)std::min<size_t>(std::max<size_t>(cs / 8, 65536), 1u << 28);
+    static const int log_div = std::getenv("LIBRECTIFY_FLOOD_LOG_CAP_DIV") ? std::max(1, std::atoi(std::getenv("LIBRECTIFY_FLOOD_LOG_CAP_DIV"))) : 8;
+    f.log_cap = (uint32_t)std::min<size_t>(std::max<size_t>(cs / (size_t)log_div, 65536), 1u << 28);
     if (dev_alloc(f.log_off, f.log_seeds) || dev_alloc(f.log_len, f.log_seeds) || dev_alloc(f.log_buf, (size_t)f.log_cap * 3)) return 1;
     if (!c->flood_aux) {
         // At a priority of its own: HIP maps streams onto a few hardware queues, and a second stream that lands on the queue
@@ -249,18 +251,15 @@ int staging_threads(int num_threads, size_t frame_bytes = 0) {
 // them; empty if unknown.  Staging helpers bind themselves there: copies by cores of the other socket reach 41 GB/s where
 // the same copies by cores of the device's own node keep the link at 54 (tools/ubench/h2d_placement.hip,
 // profiles/r04_h2d_paths.txt).  LIBRECTIFY_STAGING_BIND=0 leaves the helpers where the scheduler puts them.
-const std::vector<int>& device_node_cpus(int device) {
+// (Returned by value, copied under the lock: a reference into the cache dangled when another thread asked for a device with
+// a higher index and the outer vector grew -- the start-up pattern of the multi-device batch call.)
+std::vector<int> device_node_cpus(int device) {
     static std::mutex mu;
-    static std::vector<std::vector<int>> cache;
-    static std::vector<char> known;
+    static std::map<int, std::vector<int>> cache;
     std::lock_guard<std::mutex> lk(mu);
-    if ((int)cache.size() <= device) {
-        cache.resize((size_t)device + 1);
-        known.resize((size_t)device + 1, 0);
-    }
-    if (known[(size_t)device]) return cache[(size_t)device];
-    known[(size_t)device] = 1;
-    std::vector<int>& out = cache[(size_t)device];
+    const auto found = cache.find(device);
+    if (found != cache.end()) return found->second;
+    std::vector<int>& out = cache[device];
     static const bool off = std::getenv("LIBRECTIFY_STAGING_BIND") && std::atoi(std::getenv("LIBRECTIFY_STAGING_BIND")) == 0;
     char bus[64] = {0};
     if (off || hipDeviceGetPCIBusId(bus, (int)sizeof(bus), device) != hipSuccess) return out;
@@ -294,7 +293,7 @@ const std::vector<int>& device_node_cpus(int device) {
 }
 
 void bind_this_thread_near(int device) {
-    const std::vector<int>& cpus = device_node_cpus(device);
+    const std::vector<int> cpus = device_node_cpus(device);
     if (cpus.empty()) return;
     cpu_set_t set;
     CPU_ZERO(&set);
@@ -672,7 +671,7 @@ void ctx_destroy(lr_context* c) {
                     c->maxmag, c->keys_a, c->keys_b, c->d_counts, c->seed_idx, c->seed_bin, c->seed_thr, c->seed_size,
                     c->label, c->queue, c->comp_rank, c->comp_seed, c->comp_off, c->cursor, c->px_a, c->px_b,
                     c->scratch_w, c->d_lines, c->temp, c->d_model, c->d_best_slots,
-                    c->fb.blocked, c->fb.count, c->fb.flags, c->fb.state, c->fb.tier, c->fb.act_a, c->fb.act_b,
+                    c->fb.blocked, c->fb.count, c->fb.flags, c->fb.state, c->fb.tier, c->fb.blk, c->fb.act_a, c->fb.act_b,
                     c->fb.ctrl, c->fb.big_list, c->fb.handover, c->fb.waypoints, c->fb.multi_list, c->fb.log_off, c->fb.log_len, c->fb.log_buf, c->fb.dirty, c->fb.giant_mask, c->fb.slab_ring, c->fb.slab_hash, c->d_pairs, c->d_peak, c->d_weights,
                     c->d_samples, c->d_hcounts, c->comp_large, c->huge.tab, c->huge.jobs, c->huge.list, c->d_tables, c->d_orig, c->d_inl, c->d_flines, c->d_gctl,
                     c->d_gnorm, c->d_models, c->d_refine_table, c->d_refine_edges, c->d_cht_acc, c->d_cht_idx, c->d_cht_peak, c->d_rec, c->d_recflags};
@@ -2551,6 +2550,9 @@ int ctx_find_groups_batch_host_multi(lr_context* c, const int* devices, int n_de
         p->flood_logs = c->flood_logs;
         p->flood_log_sweep = c->flood_log_sweep;
         p->flood_giant_step = c->flood_giant_step;
+        p->flood_jit = c->flood_jit;
+        p->flood_aux_on = c->flood_aux_on;
+        p->seed_keep_ratio = c->seed_keep_ratio;
         p->estimator = c->estimator;
         p->prosac_T_N = c->prosac_T_N;
         p->cht_d = c->cht_d;

@@ -208,6 +208,8 @@ struct FloodArgs {
     uint32_t t1_tiles;                               // first tier hands a walk to the second at this many tiles (when there is one)
     uint32_t* handover;                              // state of the walks handed to the second tier (FloodBuffers::handover)
     uint32_t team_tiles;                             // test hook: the team's table counts as full at this many tiles
+    uint32_t* blk;                                   // per seed: the lower seed a long, log-less walk of it was blocked by (0xFFFFFFFF: none; see kCtrlDeferLow)
+    uint32_t defer_steps;                            // ... walks of at least this many tile steps
     uint32_t giant_many;                             // walks held back after which a frame counts as one of overlapping giants (see kCtrlStaged)
     uint32_t hold_min_big;                           // walks in the second tier after which the hold-back engages
     uint32_t hold_release;                           // the hold-back ends when so few seeds below the line are still active
@@ -307,6 +309,8 @@ enum {
     // A frame that holds back giant_many walks in a round with the full window goes on like a staged start (FloodBuffers::
     // win_first_shift): the next round's window is the strongest quarter of the seeds, and it doubles from round to round.
     kCtrlStaged = 44,
+    kCtrlDeferLow = 45,        // lowest survivor that waits for its blocker (FloodArgs::blk): the window ends in front of it
+    kCtrlDeferLowNext = 46,    // ... of the next round (survivors pass)
     kCtrlWindowFree = 42,      // the coming round's window before the giants' rule cut it (giant_finish_kernel applies the rule again)
     kCtrlWords = 48,
 };
@@ -346,6 +350,7 @@ struct WalkState {
     bool blocked;
     uint32_t steps;  // frontier records popped (diagnostics)
     uint32_t fresh;  // partial-commit walk: pixels it turned from stamps into labels
+    uint32_t blocker = 0xFFFFFFFFu;  // lowest seed whose stamp the walk's own stamps met (the second tier's walks: FloodArgs::blk)
 };
 
 // The walk works on 8x8 pixel tiles, one tile per step, one pixel per lane: the acceptance test of the
@@ -923,6 +928,7 @@ __device__ __forceinline__ void stamp_footprint(const FloodArgs& A, uint32_t k, 
     const uint32_t mine = kMarkBit | k;
     const int lr = lane >> 3, lc = lane & 7;
     bool foreign = false;
+    uint32_t fmin = 0xFFFFFFFFu;
     // (a team of wavefronts shares the tiles: each takes eight at `first`, `first + stride`, ...)
     for (uint32_t i0 = first; i0 < st.ntiles; i0 += stride) {
         uint32_t old[8];
@@ -947,10 +953,16 @@ __device__ __forceinline__ void stamp_footprint(const FloodArgs& A, uint32_t k, 
                 if (old[j] != kLabelFree) A.blocked[old[j] & ~kMarkBit] = 1u;
             } else if (old[j] < mine && old[j] >= kMarkBit) {
                 foreign = true;
+                fmin = min(fmin, old[j] & ~kMarkBit);
             }
         }
     }
-    if (__ballot(foreign)) st.blocked = true;
+    if (__ballot(foreign)) {
+        st.blocked = true;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) fmin = min(fmin, (uint32_t)__shfl_xor((int)fmin, off));
+        st.blocker = min(st.blocker, fmin);
+    }
 }
 
 // Way-points of a finished walk (see kWpK): lanes 0 .. kWpK-1 take the (lane + 1) ntiles / (kWpK + 1)-th tile in order of
@@ -1324,7 +1336,7 @@ struct TeamShared {
     uint32_t tail, end, ntiles, blocked, overflow, cnt, steps, pad;
     uint32_t adj[8];          // multi-source walk: sources whose regions share a pixel with source i (bit per source)
     uint32_t reach, ctiles;   // ... sources connected to the seed's own; tiles of the footprint kept
-    uint32_t pad2[2];
+    uint32_t blocker, pad2;   // lowest seed whose stamp this walk's stamps met (WalkState::blocker)
 };
 __device__ __forceinline__ uint32_t lds_now(const uint32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1749,6 +1761,7 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
                 sh->end = kWpK + 1u;
                 sh->ntiles = 0u;
                 sh->blocked = 0u;
+                sh->blocker = 0xFFFFFFFFu;
                 sh->overflow = 0u;
                 sh->cnt = 0u;
                 sh->steps = 0u;
@@ -1800,6 +1813,7 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
                 sh->end = first_level;
                 sh->ntiles = h_recs ? h_tiles : 0u;
                 sh->blocked = 0u;
+                sh->blocker = 0xFFFFFFFFu;
                 sh->overflow = 0u;
                 sh->cnt = 0u;
                 sh->steps = h_recs ? hb[2] : 0u;
@@ -1887,7 +1901,7 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
                         }
                     }
                 }
-                if (__ballot(foreign)) st.blocked = true;
+                if (__ballot(foreign)) st.blocked = true;  // (no blocker noted: the lowest active seed's walk, or a test hook's)
                 st.ntiles = nt;
             }
         }
@@ -1975,12 +1989,14 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
             atomicAdd(&sh->cnt, px);
             atomicAdd(&sh->steps, my_steps);
             if (st.blocked) atomicOr(&sh->blocked, 1u);
+            if (st.blocker != 0xFFFFFFFFu) atomicMin(&sh->blocker, st.blocker);
         }
         __syncthreads();
         if (wave != 0) continue;  // (the first wavefront finishes the seed; the others wait at the next seed's barrier or leave)
         st.cnt = sh->cnt;
         st.steps = sh->steps;
         st.blocked = sh->blocked != 0u;
+        st.blocker = sh->blocker;
         if (did_multi) st.ntiles = sh->ctiles;
         // a long walk that came here for the first time (handed over by the first tier) leaves its way-points now
         if (!did_multi && !in_slab && rc == 0 && wp_hdr == 0u && k < A.wp_cap && st.ntiles >= A.wp_min_tiles && st.ntiles <= kWpMaxTiles &&
@@ -1995,6 +2011,19 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
         if (rc != 0 && lane == 0) {  // no slab to go to, or the slab ran out as well: the ordered tail will finish this seed
             A.flags[k] = kFlagIncomplete;
             atomicMin(&A.ctrl[kCtrlBarrier], k);
+        }
+        // A long walk of a WEAK seed that ends blocked by lower seeds it knows, and that has no log to turn to next time, is
+        // walked again every round for as long as that seed is unresolved -- one team, tile level after tile level, while the
+        // chain of small seeds below it resolves one a round (a frame of soft blobs: thirteen rounds of 0.45 ms for seed 46 046's
+        // 2 300 steps).  It waits instead: the survivors pass closes the window in front of the lowest such seed until its
+        // blocker is resolved (kCtrlDeferLow; any prefix of the seed order is a valid window).  Only for the weaker half of
+        // the seeds: a window closed in front of a strong seed would keep the whole frame waiting.
+        if (lane == 0 && A.blk != nullptr) {
+            const bool no_log = !(k < A.log_seeds && A.log_min_tiles != 0xFFFFFFFFu && A.log_len[k] != 0u);
+            // (the LOWEST of the lower seeds it met.  Waiting for the highest -- the chain below it resolves from its lowest seed
+            // up, and the walk finds the next of them in its way every other round -- was measured and is no better: the window
+            // stays closed longer and the seeds above pay with rounds of their own, 33 instead of 22 on the frame of soft blobs)
+            A.blk[k] = (rc == 0 && st.blocked && st.blocker < k && st.steps >= A.defer_steps && k >= (A.ctrl[kCtrlNSeeds] >> 1) && no_log) ? st.blocker : 0xFFFFFFFFu;
         }
         if (lane == 0) {
             A.count[k] = st.cnt;
@@ -2577,7 +2606,7 @@ __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift, u
         // it, so that the full window can show the stall)
         const bool skip_rule = ld_agent(&ctrl[kCtrlGiantRuled]) != 0u && !moved && !want_giant;
         bool ruled = false;
-        unsigned long long grown_free = grown;
+        const unsigned long long grown_free = grown;
         if (giant != 0xFFFFFFFFu && !skip_rule) {
             // The window ends behind the lowest marked seed plus room for about kGiantProbes marked seeds more (their density
             // over the rest of the order taken as even): those walk again up to the team's table -- most fit by now, what the
@@ -2588,12 +2617,16 @@ __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift, u
             const unsigned long long line = (unsigned long long)giant + 1ull + (unsigned long long)kGiantProbes * rest / n_marked;
             (void)lowest;
             if (line < grown) {
-                grown_free = grown;
                 grown = line;
                 ruled = true;
             }
         }
-        ctrl[kCtrlWindowFree] = (uint32_t)(ruled ? grown_free : grown);
+        // ... and in front of the lowest seed that waits for its blocker (never the lowest active seed: its blocker is lower)
+        const uint32_t defer = ld_agent(&ctrl[kCtrlDeferLowNext]);
+        ctrl[kCtrlDeferLow] = defer;
+        ctrl[kCtrlDeferLowNext] = 0xFFFFFFFFu;
+        if (defer < grown && defer > lowest) grown = defer;
+        ctrl[kCtrlWindowFree] = (uint32_t)grown_free;  // (the window before the two rules cut it)
         ctrl[kCtrlGiantRuled] = ruled ? 1u : 0u;
         ctrl[kCtrlLowest] = lowest;
         ctrl[kCtrlGiantLow] = giant;
@@ -2644,7 +2677,7 @@ __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, uint8
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (uint32_t ai = blockIdx.x * 256 + threadIdx.x; ai < n_pad; ai += gridDim.x * 256) {
         bool a = false, done = false;
-        uint32_t k = 0, wpx = 0, wst = 0;
+        uint32_t k = 0, wpx = 0, wst = 0, dfr = 0xFFFFFFFFu;
         if (ai < n_act) {
             k = act[ai];
             wpx = A.count[k];        // what this round's exploration of k walked (0 if it did not walk)
@@ -2682,6 +2715,16 @@ __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, uint8
                         }
                     }
                     A.tier[k] = t;
+                    // its last long walk was blocked by a lower seed that is still unresolved (see flood_explore_team_kernel):
+                    // it waits.  (state[] of the blocker may be written in this very pass: read as unresolved, the seed waits a
+                    // round longer.)
+                    if (A.blk != nullptr) {
+                        const uint32_t bk = A.blk[k];
+                        if (bk != 0xFFFFFFFFu) {
+                            if (state[bk] != 0) A.blk[k] = 0xFFFFFFFFu;
+                            else dfr = k;
+                        }
+                    }
                 }
             }
         }
@@ -2700,6 +2743,11 @@ __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, uint8
             gmin = min(gmin, (uint32_t)__shfl_xor((int)gmin, off));
         }
         const uint64_t mg = __ballot(a && (A.tier[k] & 4u));
+        if (__ballot(dfr != 0xFFFFFFFFu) != 0ull) {  // (rare)
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) dfr = min(dfr, (uint32_t)__shfl_xor((int)dfr, off));
+            if (lane == 0) atomicMin(&A.ctrl[kCtrlDeferLowNext], dfr);
+        }
         if (lane == 0) {
             if (kmin != 0xFFFFFFFFu) atomicMin(&A.ctrl[kCtrlLowestNext], kmin);
             if (gmin != 0xFFFFFFFFu) {
@@ -2760,7 +2808,7 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
                                                                uint32_t* __restrict__ label, size_t npix,
                                                                uint32_t* __restrict__ waypoints, uint32_t wp_cap,
                                                                uint32_t* __restrict__ log_len, uint32_t log_seeds, uint32_t dense_div,
-                                                               uint32_t staged_from_start) {
+                                                               uint32_t staged_from_start, uint32_t* __restrict__ blk) {
     // (the label image is set to "free" here as well: one launch less in front of the first round)
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (size_t)gridDim.x * 256) label[i] = kLabelFree;
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
@@ -2797,6 +2845,8 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
         ctrl[kCtrlGiantCountNext] = 0u;
         ctrl[kCtrlGiants] = 0u;
         ctrl[kCtrlGiantStep] = 0u;
+        ctrl[kCtrlDeferLow] = 0xFFFFFFFFu;
+        ctrl[kCtrlDeferLowNext] = 0xFFFFFFFFu;
         ctrl[kCtrlStaged] = staged_from_start;  // (the context's last frame was one of overlapping giants: FloodBuffers::staged_from_start)
         ctrl[kCtrlMaxFlood] = 0u;
         ctrl[kCtrlGiantDone] = 0u;
@@ -2826,6 +2876,7 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
     act[k] = k;
     state[k] = 0;
     tier[k] = 0;
+    if (blk) blk[k] = 0xFFFFFFFFu;
     blocked[k] = 0u;
     count[k] = 0u;
     flags[k] = 0u;
@@ -3129,6 +3180,10 @@ __global__ __launch_bounds__(256) void giant_finish_kernel(FloodArgs A) {
             ruled = true;
         }
     }
+    {   // (and the line in front of a seed that waits for its blocker, as the last round's end drew it)
+        const uint32_t defer = ld_agent(&ctrl[kCtrlDeferLow]);
+        if (defer < grown && defer > lowest) grown = defer;
+    }
     ctrl[kCtrlWindow] = (uint32_t)grown;
     ctrl[kCtrlGiantRuled] = ruled ? 1u : 0u;
     ctrl[kCtrlLowest] = lowest;
@@ -3395,6 +3450,9 @@ FloodArgs flood_args(const FloodBuffers& B, const FloodFrame& F, bool use_big) {
     A.team_tiles = B.team_tile_cap ? B.team_tile_cap : ((B.giant_hold && team_tiles_env > 0) ? (uint32_t)team_tiles_env : 0xFFFFFFFFu);
     static const int many_env = std::getenv("LIBRECTIFY_FLOOD_GIANT_MANY") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_GIANT_MANY")) : 64;
     A.giant_many = B.giant_hold ? (uint32_t)std::max(many_env, 0) : 0u;
+    static const int defer_env = std::getenv("LIBRECTIFY_FLOOD_DEFER_STEPS") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_DEFER_STEPS")) : 512;
+    A.blk = (B.giant_hold && defer_env > 0) ? B.blk : nullptr;
+    A.defer_steps = (uint32_t)std::max(defer_env, 1);
     A.handover = B.handover;
     A.t1_tiles = t1_env > 8 ? (uint32_t)t1_env : 0xFFFFFFFFu;
     static const int t1r_env = std::getenv("LIBRECTIFY_FLOOD_T1_REGIONAL") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_T1_REGIONAL")) : 32;
@@ -3628,7 +3686,7 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
                            B.tier, B.blocked, B.count, B.flags, F.seed_size, B.ctrl, B.dirty,
                            (uint32_t)((npix + 255) >> 8), win_first_shift, hold_pct, hold_start ? 1u : 0u, F.label, npix,
                            B.waypoints, B.wp_cap, B.log_len, B.log_len ? B.log_seeds : 0u, dense_div,
-                           (B.staged_from_start && !win_env && B.win_first_shift <= 0) ? 1u : 0u);
+                           (B.staged_from_start && !win_env && B.win_first_shift <= 0) ? 1u : 0u, B.blk);
     }
     FloodArgs A = flood_args(B, F, P->use_big);
     A.win_shift = (uint32_t)win_growth;
@@ -3663,9 +3721,15 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
         uint32_t giants = 0;  // giant steps enqueued
         const auto t0 = std::chrono::steady_clock::now();
         int spins = 0;
+        // (a single call spins -- its flood is a millisecond -- but not for ever: content that takes the flood tens of
+        // milliseconds should not cost the caller a core; after two milliseconds it looks every 20 us like the lanes of a batch)
+        bool slow = false;
         auto deadline_passed = [&]() {
-            if (B.jit_sleep_us > 0) std::this_thread::sleep_for(std::chrono::microseconds(B.jit_sleep_us));
-            return (++spins & (B.jit_sleep_us > 0 ? 15 : 1023)) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(1);
+            if (B.jit_sleep_us > 0 || slow) std::this_thread::sleep_for(std::chrono::microseconds(B.jit_sleep_us > 0 ? B.jit_sleep_us : 20));
+            if ((++spins & ((B.jit_sleep_us > 0 || slow) ? 15 : 1023)) != 0) return false;
+            const auto dt = std::chrono::steady_clock::now() - t0;
+            if (dt > std::chrono::milliseconds(2)) slow = true;
+            return dt > std::chrono::seconds(1);
         };
         for (;;) {
             Report r{};

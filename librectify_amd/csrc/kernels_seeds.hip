@@ -301,7 +301,9 @@ int launch_seed_order(uint64_t* keys, uint64_t* keys_alt, const uint32_t* n_seed
     uint64_t* nxt = keys_alt;
     // (step 3 costs (keys) x (runs) x log2 L loads, a merge round (keys) x log2 L and a launch: merge while step 3 would be
     // the larger part -- an 8192 x 8192 frame with room for 490 000 seeds goes down to 8 runs in six rounds)
-    while (runs > kFinalRuns || (uint64_t)cap * runs > ((uint64_t)4 << 20)) {
+    // (never past one run: with a capacity above 4 Mi seeds -- a frame of more than 134 Mpix, a dense frame after adapt_seed_cap,
+    // lr_set_seed_capacity -- the second condition alone stayed true for ever: the host enqueued merges until L wrapped)
+    while (runs > 1u && (runs > kFinalRuns || (uint64_t)cap * runs > ((uint64_t)4 << 20))) {
         hipLaunchKernelGGL(seed_merge_kernel, dim3((cap + 255) / 256), dim3(256), 0, s, cur, nxt, L, cap, n_seeds);
         std::swap(cur, nxt);
         L *= 2u;
