@@ -371,31 +371,92 @@ def natural_frame_rates(L, ctx):
             "second_tier_walks": c["second_tier_seeds"], "walked_per_labelled": round(c.get("walked_px", 0) / max(1, c["labelled_px"]), 3)}
 
 
-def worst_case_rates(L, ctx):
+_CPU_FRAMES = r"""
+import json, os, sys, time
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import oracle_lib as O
+z = np.load(%(frames)r)
+cores = int(O.max_threads())
+counts = sorted({c for c in (8, 32, cores) if c <= cores})
+out = {}
+for name in z.files:
+    img = z[name]
+    h, w = img.shape
+    best, best_t = None, 0
+    for t in counts:
+        for rep in range(2):  # (the first call touches the oracle's work planes)
+            t0 = time.perf_counter()
+            lines, _ = O.find_line_segment_groups(img, float(max(w, h)) / 100.0, num_threads=t, seed=0)
+            O.compute_rectification_transform(lines, w, h)
+            dt = (time.perf_counter() - t0) * 1e3
+        if best is None or dt < best:
+            best, best_t = dt, t
+    out[name] = {"cpu_ms": round(best, 2), "threads": best_t}
+print(json.dumps(out))
+"""
+
+
+def cpu_frame_ms(frames):
+    """The CPU restatement (oracle/, the serial find_components of line_detector.cpp:92-122 inside it) on each of the given
+    frames, in a child process with bound OpenMP threads like cpu_baseline: best of 8 / 32 / all threads, second call."""
+    import subprocess
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "frames.npz")
+        np.savez(path, **frames)
+        code = _CPU_FRAMES % {"root": ROOT, "frames": path}
+        env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores")
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    if p.returncode != 0:
+        return {"error": p.stderr[-800:]}
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+def worst_case_rates(L, ctx, with_cpu=True):
     """Frames the ordered flood likes least, one at a time through the frame call from a pageable buffer (the latency of a
-    call depends on the content: INTEGRATION.md "Content-dependent latency"): a 4K frame WITHOUT strong edges (soft blobs
-    on a ramp: single floods of hundreds of thousands of pixels), a 4K frame of sixty bars 2000-3600 px long, and a 4K frame
-    that is nothing but a smooth ramp under blurred noise (every weak seed reaches regions of 100 000 pixels and more)."""
+    call depends on the content: INTEGRATION.md "Content-dependent latency"): 4K frames WITHOUT strong edges (soft blobs
+    on a ramp: single floods of hundreds of thousands of pixels), a 4K frame of sixty bars 2000-3600 px long, a 4K frame
+    that is nothing but a smooth ramp under blurred noise (every weak seed reaches regions of 100 000 pixels and more), and
+    the two 1080p frames the latency fuzz of round 4 found slowest: soft blobs whose strong seeds own regions beyond the
+    second storage tier, and a noiseless radial gradient (every pixel a seed of one magnitude, sixteen rings).  `cpu_ms` is
+    the CPU restatement's time for the same frame and the same two calls (cpu_frame_ms), `cpu_over_gpu` their ratio."""
     from librectify_amd import synth
 
-    w, h = W4K, H4K
+    yy, xx = np.mgrid[0:1080, 0:1920].astype(np.float64)
+    radial = (1.0 - np.hypot(xx - 960, yy - 540) / np.hypot(960, 540)).astype(np.float32)
+    frames = {"edgeless_4k": synth.region_frame(W4K, H4K, 504), "long_bars_4k": synth.long_bar_frame(W4K, H4K, 3), "ramp_4k": synth.ramp_frame(W4K, H4K),
+              "regions_4k": synth.region_frame(W4K, H4K, 500), "regions_1080": synth.region_frame(1920, 1080, 500), "radial_gradient_1080": radial}
     out = {}
     ctx.set_stage_timing(True)
-    for name, img in (("edgeless_4k", synth.region_frame(w, h, 504)), ("long_bars_4k", synth.long_bar_frame(w, h, 3)), ("ramp_4k", synth.ramp_frame(w, h))):
-        wall, flood = [], []
+    for name, img in frames.items():
+        h, w = img.shape
+        wall, flood, transform = [], [], []
         for rep in range(4):
             t0 = time.perf_counter()
             lines = ctx.find_line_segment_groups(img, float(max(w, h)) / 100.0)
+            L.compute_rectification_transform(lines, w, h)
             dt = time.perf_counter() - t0
             if rep > 0:
                 wall.append(dt)
                 flood.append(float(ctx.stage_times()[L.T_FLOOD]))
         c = ctx.stage_counters()
-        out[name] = {"wall_ms": round(float(np.mean(wall)) * 1e3, 3), "max_ms": round(float(np.max(wall)) * 1e3, 3), "flood_ms": round(float(np.mean(flood)), 3),
+        out[name] = {"frame": "%dx%d" % (w, h), "wall_ms": round(float(np.mean(wall)) * 1e3, 3), "max_ms": round(float(np.max(wall)) * 1e3, 3), "flood_ms": round(float(np.mean(flood)), 3),
                      "lines": int(len(lines)), "seeds": c["seeds"], "flood_rounds": c["flood_rounds"], "second_tier_walks": c["second_tier_seeds"],
-                     "slabs": c["slabs"], "ordered_tail_seeds": c["ordered_tail_seeds"], "giants_held": c.get("giants_held", 0)}
+                     "slabs": c["slabs"], "ordered_tail_seeds": c["ordered_tail_seeds"], "giants_held": c.get("giants_held", 0), "giant_steps": c.get("giant_steps", 0)}
     ctx.set_stage_timing(False)
-    out["note"] = "the four synthetic bench frames take `single_frame`.pageable.wall_ms; these take 1.5-4x as long on the same call"
+    if with_cpu:
+        cpu = cpu_frame_ms(frames)
+        for name in frames:
+            if name in cpu:
+                out[name]["cpu_ms"] = cpu[name]["cpu_ms"]
+                out[name]["cpu_threads"] = cpu[name]["threads"]
+                out[name]["cpu_over_gpu"] = round(cpu[name]["cpu_ms"] / out[name]["wall_ms"], 2)
+        if "error" in cpu:
+            out["cpu_error"] = cpu["error"]
+    out["note"] = ("find_line_segment_groups + compute_rectification_transform per call, mean of three calls on one context (a context hands what it "
+                   "learned about a frame's floods to the next frame: the first call of its kind is slower -- DESIGN.md section 7)")
     return out
 
 
@@ -823,7 +884,7 @@ def main(argv=None):
                 res["single_frame"] = single_frame_rates(L, ctx, wl.pageable[: min(4, wl.B)], wl.min_length)
                 res["flood"] = flood_rates(L, ctx, wl.pageable[: min(4, wl.B)])
                 res["natural_frame"] = natural_frame_rates(L, ctx)
-                res["worst_case"] = worst_case_rates(L, ctx)
+                res["worst_case"] = worst_case_rates(L, ctx, with_cpu=not args.no_cpu_baseline)
             res["roofline_8k"] = roofline_8k(L, ctx, torch, dev, wl.pageable[0] if wl.B and (wl.w, wl.h) == (W4K, H4K) else None)
         if not args.no_cpu_baseline and n_gpus == 1 and wl.B:
             res["cpu_baseline"] = cpu_baseline(wl.pageable[:2], w, h, wl.min_length)

@@ -392,6 +392,83 @@ def test_giant_walks_are_held_back_until_they_are_the_lowest(L, ctx):
     assert used[("ramp", 1)]["walked_px"] < used[("ramp", 4)]["walked_px"]
 
 
+def _radial(W, H):
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    return (1.0 - np.hypot(xx - W / 2, yy - H / 2) / np.hypot(W / 2, H / 2)).astype(np.float32)
+
+
+def test_giant_steps_label_what_the_slab_walk_and_the_oracle_label(L, ctx):
+    """Round 5: when the lowest active seed's walk outgrows the LDS tiers, its flood -- what the reference's loop does next,
+    nothing speculative (line_detector.cpp:98-119 over filter.cpp:110-153) -- is labelled by the whole device between two
+    rounds (kernels_flood.hip: kCtrlGiantStep: tile masks, union-find over the tiles' components) instead of being walked
+    through a global slab by one team.  Label image and records against the oracle with the step and without (the slab
+    walk), rounds enqueued just in time and blindly (the steps then go in from flood_finish's laps), twice each on the
+    context; on a noiseless radial gradient (sixteen rings of one magnitude: a chain of sixteen steps, and sixteen
+    components of more than 2^14 pixels for the fit's bucket sort), soft blobs, a ramp under noise and diagonal stripes.
+    The counters prove which path ran."""
+    yy, xx = np.mgrid[0:540, 0:960].astype(np.float64)
+    stripes = (0.5 + 0.4 * np.sin((xx + 0.5 * yy) * 2 * np.pi / 40)).astype(np.float32)
+    from librectify_amd import synth
+
+    frames = (("radial", _radial(1280, 720)), ("regions", synth.region_frame(1920, 1080, 500)), ("ramp", _ramp(1283, 717, 5)), ("stripes", stripes))
+    used = {}
+    try:
+        for name, img in frames:
+            ref = O.find_line_segments(img, num_threads=8)
+            for step, jit in ((True, True), (False, True), (True, False)):
+                ctx.set_flood_giant_step(step)
+                ctx.set_flood_just_in_time(jit)
+                for rep in range(2):
+                    ctx.stage_filter_host(img)
+                    ctx.stage_seeds()
+                    ctx.stage_flood()
+                    used[(name, step, jit)] = ctx.stage_counters()
+                    np.testing.assert_array_equal(ctx.download(L.BUF_LABEL), ref["label"])
+                    _assert_lines_equal(ctx.stage_fit(), ref["lines"])
+            ctx.set_flood_giant_step(True)
+            ctx.set_flood_just_in_time(True)
+            ctx.set_seed(0)
+            _assert_lines_equal(ctx.find_line_segment_groups(img, 12.8), O.find_line_segment_groups(img, 12.8, seed=0, num_threads=8)[0])
+    finally:
+        ctx.set_flood_giant_step(True)
+        ctx.set_flood_just_in_time(True)
+    for jit in (True, False):
+        assert used[("radial", True, jit)]["giant_steps"] >= 16 and used[("radial", True, jit)]["slabs"] == 0, used[("radial", True, jit)]
+        assert used[("regions", True, jit)]["giant_steps"] >= 1, used[("regions", True, jit)]
+    assert used[("radial", False, True)]["giant_steps"] == 0 and used[("radial", False, True)]["slabs"] > 0, used[("radial", False, True)]
+
+
+def test_seed_capacity_beyond_four_million_keys(L):
+    """the seed order's merge loop never ended once the capacity exceeded 2^22 keys (with one run left its
+    second condition stayed true, the host enqueued merges for ever).  Stripes of period 6 at 4K: every pixel of a flank a
+    seed of the same magnitude, 2.7 M seeds -- the first lap overflows the frame's initial capacity, the second runs with
+    5.5 M slots; then again with lr_set_seed_capacity(6 << 20) on a frame of bars.  Against the oracle."""
+    from librectify_amd import synth
+
+    yy, xx = np.mgrid[0:2160, 0:3840].astype(np.float64)
+    stripes = (0.5 + 0.4 * np.sin(xx * 2 * np.pi / 6)).astype(np.float32)
+    c2 = L.Context(0)
+    try:
+        c2.set_seed(0)
+        ref = O.find_line_segments(stripes, num_threads=8)
+        assert ref["n_seeds"] > (2 << 20), ref["n_seeds"]
+        c2.stage_filter_host(stripes)
+        assert c2.stage_seeds() == ref["n_seeds"]
+        c2.stage_flood()
+        np.testing.assert_array_equal(c2.download(L.BUF_LABEL), ref["label"])
+        _assert_lines_equal(c2.stage_fit(), ref["lines"])
+        bars = synth.frame(3840, 2160, 3)
+        refb = O.find_line_segments(bars, num_threads=8)
+        c2.set_seed_capacity(6 << 20)
+        c2.stage_filter_host(bars)
+        assert c2.stage_seeds() == refb["n_seeds"]
+        c2.stage_flood()
+        np.testing.assert_array_equal(c2.download(L.BUF_LABEL), refb["label"])
+        _assert_lines_equal(c2.stage_fit(), refb["lines"])
+    finally:
+        c2.close()
+
+
 def test_multi_source_rewalks_change_the_time_not_the_labels(L, ctx):
     """Round 4: a seed whose walk was long leaves way-points on its footprint, and its next walk starts from the seed and
     from all of them at once on a team of wavefronts, keeping what is connected to the seed (kernels_flood.hip: team_walk,
