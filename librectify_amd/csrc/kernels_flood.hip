@@ -1071,14 +1071,8 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
                 }
             }
         }
-        // (The second tier's list is full already -- eight thousand long walks in this round: a frame of overlapping giants, a
-        // noiseless gradient whose every pixel is a seed -- so a walk that outgrows this tier will be held back whatever its
-        // length, see below: it is held at kFullTiles tiles instead of walking on to the table's 190.  Radial gradient at
-        // 1080p, 78 704 seeds: first round 45 ms before.)
-        const bool tier2_full = hand_over && A.giant_hold != 0u && uni(ld_agent(&A.ctrl[kCtrlNBig])) >= A.big_cap &&
-                                k != uni(A.ctrl[kCtrlLowest]);
         if (rc != 0)  // (from the start, or from where the budgeted walk stands: the list was full)
-            rc = walk(A, k, b, thr, sn, cs, L, P, st, lane, own, nullptr, hand_over ? (tier2_full ? min(t1_tiles, kFullTiles) : t1_tiles) : 0xFFFFFFFFu,
+            rc = walk(A, k, b, thr, sn, cs, L, P, st, lane, own, nullptr, hand_over ? t1_tiles : 0xFFFFFFFFu,
                       hand_over ? A.t1_wide_tiles : 0xFFFFFFFFu, hand_over ? A.t1_wide_front : 0xFFFFFFFFu);
     }
     if (kFirstTier && rc != 0 && A.big_cap != 0u) {
@@ -1247,7 +1241,14 @@ __device__ __forceinline__ void explore_body(const FloodArgs& A, const BinTrig& 
     // bars' thousands of thin walks queued up behind each other and the same rule cost that frame 0.5 ms; with 512 it
     // gains 0.3).  The synthetic bench frames never get there (0-7 long walks), and handing THEIR walks over early costs
     // them 0.3-0.9 ms: the tiers' kernels run one after the other, and a thin walk gains nothing from a team.
-    const uint32_t t1_tiles = uni(A.ctrl[kCtrlBigSeen]) != 0u ? min(A.t1_tiles, A.t1_regional) : A.t1_tiles;
+    const uint32_t t1_usual = uni(A.ctrl[kCtrlBigSeen]) != 0u ? min(A.t1_tiles, A.t1_regional) : A.t1_tiles;
+    // The second tier's list is full already when this workgroup starts -- eight thousand long walks in this round: a frame of
+    // overlapping giants, a noiseless gradient whose every pixel is a seed -- so a walk that outgrows this tier will be held
+    // back whatever its length (explore_seed): it is held at kFullTiles tiles instead of walking on to the table's 190 (radial
+    // gradient at 1080p, 78 704 seeds: first round 45 -> 11 ms).  Read HERE, with the other words of the control block: the
+    // same read in front of every walk cost the bench frames' first round 1.1 ms (0.3 -> 1.4).
+    const bool tier2_full = A.giant_hold != 0u && A.big_cap != 0u && uni(A.ctrl[kCtrlNBig]) >= A.big_cap;
+    const uint32_t lowest = uni(A.ctrl[kCtrlLowest]);
     LdsStore L{s_ring[0], s_ring[1], s_ring[2], s_hash[0], s_hash[1], s_hash[2], s_ord};
     Pending P{s_pend[0], s_pend[1]};
     // The list is walked from its end: the first round's list is in seed order, strongest first, and the longest
@@ -1261,11 +1262,13 @@ __device__ __forceinline__ void explore_body(const FloodArgs& A, const BinTrig& 
         const bool fwd = A.no_rest != 0u && n_act > gridDim.x;
         const uint32_t k = uni(act[(A.from_end && !fwd) ? n_act - 1u - ai : ai]);
         if (k >= window) return;  // not yet in the staged window (stays active)
+        const uint32_t t1_tiles = (tier2_full && k != lowest) ? min(t1_usual, kFullTiles) : t1_usual;
         explore_seed<LdsStore, true>(A, trig, k, L, P, big_list, lane, t1_tiles);
     } else {
         for (uint32_t ai = first + uni(blockIdx.x); ai < n_act; ai += gridDim.x) {
             const uint32_t k = uni(act[A.from_end ? n_act - 1u - ai : ai]);
             if (k >= window) continue;
+            const uint32_t t1_tiles = (tier2_full && k != lowest) ? min(t1_usual, kFullTiles) : t1_usual;
             explore_seed<LdsStore, true>(A, trig, k, L, P, big_list, lane, t1_tiles);
         }
     }
