@@ -13,6 +13,11 @@
  */
 #pragma once
 
+/* (the library is built with -fvisibility=hidden: what is declared between here and the matching pop is what it exports) */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
 #ifdef __cplusplus
 namespace librectify {
 extern "C" {
@@ -111,4 +116,8 @@ void assign_to_group(const LineSegment* lines_array, int n_lines, LineSegment* n
 #ifdef __cplusplus
 } /* extern "C" */
 } /* namespace librectify */
+#endif
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
 #endif

@@ -21,6 +21,10 @@
 
 #include "librectify.h"
 
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
 #ifdef __cplusplus
 using librectify::ImageTransform;
 using librectify::LineSegment;
@@ -40,6 +44,14 @@ void lr_context_destroy(lr_context* ctx);
  * largest frame seen, 288 MB of flood overflow slabs, 32 MB of hand-over records, page-locked staging, staging threads) until the thread exits;
  * a thread that is done with the library for a while can give it back at once.  The next call makes a new one. */
 void lr_release_thread_context(void);
+/* The reference is stateless; a context is not: its device workspace is sized by the LARGEST frame it has seen (an 8192 x 8192
+ * call leaves 8.9 GB behind).  It shrinks by itself -- after eight frames in a row of at most a quarter of its capacity the
+ * workspace is given back and allocated again at the size in use -- and on request: lr_context_trim frees everything that is
+ * sized by frames (workspace, flood buffers and slabs, frame slots, page-locked staging, the batch ring; streams and events
+ * stay), the next call allocates what it needs.  lr_trim_thread_context does that for the calling thread's drop-in context
+ * and keeps the context, where lr_release_thread_context destroys it. */
+int lr_context_trim(lr_context* ctx);
+int lr_trim_thread_context(void);
 const char* lr_last_error(void);
 int lr_synchronize(lr_context* ctx);
 /* RANSAC sample stream seed (the reference seeds from std::random_device, estimator.h:35;
@@ -274,4 +286,8 @@ int lr_estimate_line_pencils_direct(lr_context* ctx, LineSegment* lines, int n, 
 
 #ifdef __cplusplus
 }
+#endif
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
 #endif

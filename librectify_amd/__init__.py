@@ -70,7 +70,7 @@ EXPORTS = [
     "lr_stage_counters", "lr_filter_kernel_ms", "lr_ransac_best", "lr_estimate_line_pencils",
     "lr_find_line_segment_groups_batch_host", "lr_find_line_segment_groups_batch_host_ptrs", "lr_host_alloc", "lr_host_free",
     "lr_set_seed_capacity", "lr_set_flood_blind_rounds", "lr_set_flood_staged", "lr_set_batch_streams", "lr_device_malloc", "lr_device_free", "lr_memcpy_h2d", "lr_cht_vanishing_point", "lr_refine_lines", "lr_set_estimator", "lr_ht_weights", "lr_prosac_solve", "lr_estimate_line_pencils_prosac", "lr_direct_solve", "lr_estimate_line_pencils_direct",
-    "lr_estimate_line_pencils_cht", "lr_set_stage_timing", "lr_release_thread_context", "lr_set_flood_partial_commits", "lr_set_flood_multi_source", "lr_set_flood_logs", "lr_set_flood_just_in_time", "lr_set_flood_giant_step",
+    "lr_estimate_line_pencils_cht", "lr_set_stage_timing", "lr_release_thread_context", "lr_set_flood_partial_commits", "lr_set_flood_multi_source", "lr_set_flood_logs", "lr_set_flood_just_in_time", "lr_set_flood_giant_step", "lr_context_trim", "lr_trim_thread_context",
     "lr_find_line_segment_groups_batch_host_multi",
 ]
 
@@ -416,6 +416,10 @@ class Context:
 
     def set_flood_just_in_time(self, on=True):
         lib().lr_set_flood_just_in_time(self._h, int(bool(on)))
+
+    def trim(self):
+        """gives the memory that is sized by the largest frame seen back to the system (the next call allocates what it needs)"""
+        _check(lib().lr_context_trim(self._h))
 
     def set_flood_giant_step(self, on=True):
         """the lowest active seed's flood by the whole device when it outgrows the LDS tiers (default); False = the slab walk"""

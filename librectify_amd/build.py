@@ -25,8 +25,10 @@ SOURCES = [
 # sqrt stay correctly rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).
 # -fno-slp-vectorize: left alone, clang packs neighbouring scalar f32 FMAs into v_pk_fma_f32, which on gfx950
 # issues slower than the two v_fma_f32 it replaces (MI355X_MICROARCH.md, "price of one filler").
+# -fvisibility=hidden: the library exports the six reference symbols and the lr_* extensions, nothing else (the headers
+# under include/ push default visibility around their declarations).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
-         "-Wno-unused-function", "-fno-slp-vectorize"] + os.environ.get("LR_EXTRA_FLAGS", "").split()
+         "-Wno-unused-function", "-fno-slp-vectorize", "-fvisibility=hidden", "-fvisibility-inlines-hidden"] + os.environ.get("LR_EXTRA_FLAGS", "").split()
 
 
 # kernels_filter.hip: inputs are finite by contract (the reference divides/compares them freely as well), so the
@@ -46,6 +48,7 @@ def needs_build():
         return True
     t = os.path.getmtime(OUT)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [
+        os.path.abspath(__file__),
         os.path.join(HERE, "..", "include", "librectify.h"),
         os.path.join(HERE, "..", "include", "librectify_amd.h"),
     ]
@@ -76,7 +79,8 @@ def build(force=False, verbose=True):
             sys.stderr.write(out.decode())
     if failed:
         raise RuntimeError("librectify_amd build failed")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"),
+                           "-o", OUT] + objs)
     return OUT
 
 

@@ -83,6 +83,7 @@ struct lr_context {
     uint32_t seed_cap_once = 0;      // test hook: capacity of the next frame's seed sort
     int frame_laps = 0;              // laps the last frame took (1; 2 if the seed sort overflowed or the flood needed more rounds)
     lramd::FloodProgress flood_prog;
+    int small_frames = 0;  // frames in a row of at most a quarter of the workspace's capacity (ctx_ensure_image_capacity gives it back after eight)
     // filter_lines + peeling on the device (kernels_groups.hip)
     size_t cap_glines = 0, cap_flines = 0;
     float* d_tables = nullptr;      // 3 pencil tables (all lines, two ping-pong round tables) x 8 arrays x cap_glines
@@ -187,6 +188,7 @@ int ctx_create(int device, lr_context** out);
 void ctx_destroy(lr_context* c);
 const std::string& get_error();
 int ctx_ensure_image_capacity(lr_context* c, int w, int h);
+int ctx_trim(lr_context* c, bool frames_too);
 int ctx_ensure_ransac_capacity(lr_context* c, size_t n_lines, size_t n_iter);
 int ctx_stage_filter(lr_context* c, const float* d_image, int w, int h, int stride);
 int ctx_stage_seeds(lr_context* c);

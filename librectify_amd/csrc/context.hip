@@ -121,10 +121,68 @@ static double now_ms() {
 void set_error(const std::string& msg) { g_error = msg; }
 const std::string& get_error() { return g_error; }
 
+// Gives the device and page-locked memory that is sized by the largest frame the context has seen back to the system: the
+// per-pixel workspace (about 130 bytes a pixel), the flood's per-seed buffers, slabs and hand-over records, the frame slots
+// and their staging buffers, the batch ring.  Streams, events and small tables stay; the next frame allocates what it needs.
+int ctx_trim(lr_context* c, bool frames_too) {
+    LR_HIP(hipSetDevice(c->device));
+    LR_HIP(hipStreamSynchronize(c->stream));
+    if (c->copy_stream) LR_HIP(hipStreamSynchronize(c->copy_stream));
+    if (c->flood_aux) LR_HIP(hipStreamSynchronize(c->flood_aux));
+    auto drop = [](auto*& p) {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+    };
+    drop(c->dx), drop(c->dy), drop(c->dmask), drop(c->cand), drop(c->cand_count), drop(c->tile_max), drop(c->tile_pass), drop(c->tile_off);
+    drop(c->keys_a), drop(c->keys_b), drop(c->seed_idx), drop(c->seed_bin), drop(c->seed_thr), drop(c->seed_size), drop(c->label), drop(c->queue);
+    drop(c->comp_rank), drop(c->comp_seed), drop(c->comp_off), drop(c->cursor), drop(c->px_a), drop(c->px_b), drop(c->scratch_w), drop(c->d_lines);
+    drop(c->comp_large), drop(c->huge.tab), drop(c->huge.jobs), drop(c->huge.list), drop(c->temp);
+    c->temp_bytes = 0;
+    c->cap_pix = 0;
+    c->cap_tiles = 0;
+    FloodBuffers& f = c->fb;
+    drop(f.blocked), drop(f.count), drop(f.flags), drop(f.state), drop(f.tier), drop(f.blk), drop(f.act_a), drop(f.act_b), drop(f.ctrl), drop(f.big_list);
+    drop(f.handover), drop(f.dirty), drop(f.giant_mask), drop(f.waypoints), drop(f.multi_list), drop(f.log_off), drop(f.log_len), drop(f.log_buf);
+    drop(f.slab_ring), drop(f.slab_hash);
+    c->fb_cap_seeds = 0;
+    // (the frame slots hold the frame that is being processed when the workspace shrinks by itself: only on request)
+    for (int s = 0; s < 2 && frames_too; ++s) {
+        drop(c->d_img_slot[s]);
+        c->cap_slot[s] = 0;
+        if (c->h_stage[s]) (void)hipHostFree(c->h_stage[s]);
+        c->h_stage[s] = nullptr;
+        c->cap_stage[s] = 0;
+    }
+    if (frames_too) {
+        for (float*& p : c->ring_img) drop(p);
+        c->ring_cap_pix = 0;
+        for (float*& p : c->ring_stage) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr;
+        }
+        c->ring_stage_cap_pix = 0;
+    }
+    c->small_frames = 0;
+    c->w = c->h = 0;
+    c->seed_cap = 0;
+    for (bool& v : c->stage_valid) v = false;
+    for (lr_context* wc : c->workers)
+        if (ctx_trim(wc, frames_too)) return 1;
+    return 0;
+}
+
 int ctx_ensure_image_capacity(lr_context* c, int w, int h) {
     const size_t npix = (size_t)w * h;
     const FilterGeom fg = filter_geometry(w, h);
     const int ntiles = fg.n_tiles;
+    // A context that has seen one large frame keeps serving small ones out of the large workspace (an 8192 x 8192 call leaves
+    // 8.9 GB behind): after eight frames in a row of at most a quarter of the capacity it is given back, and this frame
+    // allocates its own size (lr_context_trim does the same at once).
+    if (c->cap_pix != 0 && npix * 4 <= c->cap_pix) {
+        if (++c->small_frames >= 8 && ctx_trim(c, false)) return 1;
+    } else {
+        c->small_frames = 0;
+    }
     if (npix <= c->cap_pix && ntiles <= c->cap_tiles) return 0;
     LR_HIP(hipStreamSynchronize(c->stream));
     const size_t cp = std::max(npix, c->cap_pix);
@@ -155,9 +213,32 @@ int ctx_ensure_image_capacity(lr_context* c, int w, int h) {
     return 0;
 }
 
+// The overflow slabs (2.25 MB each).  With the giant step the default mode needs them for nothing but the walks of the
+// lowest active seed when the step is switched off: 16 of them (36 MB; the default pool was 128 = 288 MB).  The storage
+// test hooks (modes 2-7: no second tier, every long walk in a slab) and LIBRECTIFY_FLOOD_GIANT_STEP=0 get the full pool.
+static int ensure_flood_slabs(lr_context* c) {
+    FloodBuffers& f = c->fb;
+    static const bool giant_step_off = std::getenv("LIBRECTIFY_FLOOD_GIANT_STEP") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_GIANT_STEP")) == 0;
+    uint32_t want = (c->flood_mode == 1 && c->flood_giant_step && !giant_step_off) ? 16u : 128u;
+    if (const char* e = std::getenv("LIBRECTIFY_FLOOD_SLABS")) want = (uint32_t)std::max(1, std::atoi(e));
+    if (f.slab_ring && f.n_slabs >= want) return 0;
+    LR_HIP(hipStreamSynchronize(c->stream));
+    f.n_slabs = want;
+    f.slab_ring_cap = 1u << 14;  // (tile, entry mask) records, 16 B each
+    f.slab_hash_cap = 1u << 16;  // tile -> (walked, acceptable) records, 32 B each (48 Ki tiles = 3 M pixels)
+    uint4* r = (uint4*)f.slab_ring;
+    uint4* hsh = (uint4*)f.slab_hash;
+    if (dev_alloc(r, (size_t)f.n_slabs * f.slab_ring_cap) || dev_alloc(hsh, (size_t)f.n_slabs * f.slab_hash_cap * 2)) return 1;
+    f.slab_ring = r;
+    f.slab_hash = hsh;
+    LR_HIP(hipMemsetAsync(f.slab_hash, 0, (size_t)f.n_slabs * f.slab_hash_cap * 32, c->stream));
+    if (f.ctrl) LR_HIP(hipMemsetAsync(f.ctrl, 0, kFloodCtrlWords * sizeof(uint32_t), c->stream));  // (the generation counter starts again with the cleared tables)
+    return 0;
+}
+
 static int ensure_flood_buffers(lr_context* c) {
     FloodBuffers& f = c->fb;
-    if (c->fb_cap_seeds >= c->cap_pix && f.slab_ring) return 0;
+    if (c->fb_cap_seeds >= c->cap_pix && f.ctrl) return ensure_flood_slabs(c);
     LR_HIP(hipStreamSynchronize(c->stream));
     const size_t cs = c->cap_pix;
     if (dev_alloc(f.blocked, cs) || dev_alloc(f.count, cs) || dev_alloc(f.flags, cs) || dev_alloc(f.state, cs) || dev_alloc(f.tier, cs) || dev_alloc(f.blk, cs) ||
@@ -192,22 +273,9 @@ static int ensure_flood_buffers(lr_context* c) {
             c->flood_join.push_back(b);
         }
     }
-    f.n_slabs = 128;  // 128 x 2.25 MB = 288 MB; only walks over ~1500 tiles (both LDS tiers outgrown) get here
-    if (const char* e = std::getenv("LIBRECTIFY_FLOOD_SLABS")) f.n_slabs = (uint32_t)std::max(1, std::atoi(e));
-    f.slab_ring_cap = 1u << 14;  // (tile, entry mask) records, 16 B each
-    f.slab_hash_cap = 1u << 16;  // tile -> (walked, acceptable) records, 32 B each (48 Ki tiles = 3 M pixels)
-    {
-        uint4* r = (uint4*)f.slab_ring;
-        uint4* hsh = (uint4*)f.slab_hash;
-        if (dev_alloc(r, (size_t)f.n_slabs * f.slab_ring_cap) || dev_alloc(hsh, (size_t)f.n_slabs * f.slab_hash_cap * 2))
-            return 1;
-        f.slab_ring = r;
-        f.slab_hash = hsh;
-    }
-    LR_HIP(hipMemsetAsync(f.slab_hash, 0, (size_t)f.n_slabs * f.slab_hash_cap * 32, c->stream));
     LR_HIP(hipMemsetAsync(f.ctrl, 0, kFloodCtrlWords * sizeof(uint32_t), c->stream));
     c->fb_cap_seeds = cs;
-    return 0;
+    return ensure_flood_slabs(c);
 }
 
 int ctx_ensure_ransac_capacity(lr_context* c, size_t n_lines, size_t n_iter) {

@@ -17,7 +17,10 @@
 // CANONICAL ARITHMETIC (the GPU path mirrors it bit for bit):
 //  * fp32 wherever the reference is fp32; compiled with -ffp-contract=off, every fused
 //    multiply-add is an explicit fmaf().
-//  * 5x5 correlation: acc = fmaf(img, K, acc) in row-major tap order from acc = 0.
+//  * 5x5 derivative-of-Gaussian correlation in its SEPARABLE form (the taps of filter.cpp:65-78 are a product d(x) g(y)):
+//    a row pass and a column pass of explicit fmaf() chains, 16 operations a pixel -- conv_gradients below.  (The 25
+//    separately rounded taps in row-major order are kept as conv_gradients_25tap, for the bound tests/test_oracle_pins.py puts
+//    on the difference; the reference's own order under Eigen + -ffast-math is not defined.)
 //  * every floating-point reduction over a pixel or line set is the "wave tree" T():
 //    64 lane-strided sequential partial sums followed by an xor butterfly (32,16,..,1).
 //  * peaks are ordered by (value desc, row asc, col asc): the reference uses an unstable
