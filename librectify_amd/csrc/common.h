@@ -192,6 +192,7 @@ struct FloodBuffers {
     uint32_t* host_progress = nullptr;  // page-locked, device-visible, 8-byte aligned: one 64-bit report (kernels_flood.hip: flood_report)
     int jit_first = 0;                  // 0: off
     int jit_sleep_us = 0;               // the polling thread sleeps this long between looks (0: it spins -- single calls)
+    int jit_lead = 0;                   // rounds the host keeps enqueued ahead of the last one it has seen finished
     uint32_t big_cap_override = 0;  // test hook: seeds per round the second tier takes (0 = the default, 8192)
     uint32_t team_tile_cap = 0;     // test hook: tiles after which the second tier's team hands a walk to a slab (0 = its table)
 };

@@ -901,6 +901,15 @@ FloodBuffers flood_buffers_for(lr_context* c) {
     // enqueued just in time knows its list's length and brings the launch when it needs it.  LIBRECTIFY_FLOOD_JIT_FIRST_MAX)
     static const int jit_first_max = std::getenv("LIBRECTIFY_FLOOD_JIT_FIRST_MAX") ? std::max(1, std::atoi(std::getenv("LIBRECTIFY_FLOOD_JIT_FIRST_MAX"))) : 4;
     fbuf.jit_first = (c->flood_jit && !jit_off) ? std::min(c->flood_rounds_last > 0 ? std::max(c->flood_rounds_last - 1, 2) : 3, jit_first_max) : 0;
+    // (the lanes of a batch: LIBRECTIFY_FLOOD_JIT_FIRST_LANES / _LEAD_LANES = rounds enqueued blindly at most / rounds kept ahead)
+    static const int first_lanes = std::getenv("LIBRECTIFY_FLOOD_JIT_FIRST_LANES") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_JIT_FIRST_LANES")) : 0;
+    static const int lead_lanes = std::getenv("LIBRECTIFY_FLOOD_JIT_LEAD_LANES") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_JIT_LEAD_LANES")) : 0;
+    static const int lead_single = std::getenv("LIBRECTIFY_FLOOD_JIT_LEAD") ? std::max(0, std::atoi(std::getenv("LIBRECTIFY_FLOOD_JIT_LEAD"))) : 0;
+    fbuf.jit_lead = lead_single;
+    if (c->flood_jit_sleep_us > 0 && fbuf.jit_first > 0) {
+        if (first_lanes > 0) fbuf.jit_first = std::min(fbuf.jit_first, first_lanes);
+        fbuf.jit_lead = std::max(lead_lanes, 0);
+    }
     return fbuf;
 }
 

@@ -120,6 +120,12 @@ __device__ __forceinline__ void lane_step(Roll1& R, const int t, const float* __
     const bool ok = (yc >= 2) && (yc < h - 2) && (x >= 2) && (x < w - 2);  // conv_2d's zero border (filter.cpp:89-97)
     const float vx = ok ? ax : 0.f;
     const float vy = ok ? ay : 0.f;
+    // (Round 5, measured and not kept -- profiles/r05_filter_variants.txt: the SQUARED magnitude in the rolling rows, with a
+    // root only where a value is stored and where two squares are within a rounding interval of each other (exact: the
+    // correctly rounded root is monotone): 40.4 us against 40.6 -- the root was never on the critical path -- and 45.1 us with
+    // the tie test behind a wave-uniform branch of its own: a branch a step is worth 4-5 us of this kernel.  The arg-max
+    // below as a three-level tournament: its seven comparison masks live in SGPR pairs across 38 unrolled steps, 106
+    // scalar registers, 44 of them spilled, seven waves a SIMD instead of eight: 48 us.)
     R.mag[K] = sqrtf(vx * vx + vy * vy);
     // "first strict argmax from 0" == lowest bin attaining the maximum (all-zero responses give bin 0 both ways)
     float g[kBins];

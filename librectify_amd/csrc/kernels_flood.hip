@@ -2540,13 +2540,16 @@ __global__ __launch_bounds__(256) void flood_commit_pixels_kernel(FloodArgs A, u
 // What the device tells the host that enqueues rounds just in time (FloodBuffers::host_progress): ONE 64-bit word, so that
 // every look is a consistent report -- n_left (29 bits) | stalled << 29 | giant step asked for << 30 | a flood of more than
 // kHugeFlood pixels has been committed << 31 | rounds with work so far << 32 (12 bits) | giant steps done << 44 (16 bits) |
+// calm << 60 (every seed has walked and none outgrew the first storage tier: footprints only shrink, so none ever will --
+// the host leaves the second tier's launches out of the rounds it enqueues from then on) |
 // 1 << 63 (a report: the host zeroes the word before the frame).  (Six separate words, the count of rounds stored last,
 // let the host see "giant step asked for" beside a stale "no seeds left" and take the flood for finished.)
 __device__ __forceinline__ void flood_report(uint32_t* host_progress, uint32_t rounds, uint32_t n_left, bool stalled, bool want_giant,
-                                             uint32_t giants_done, bool huge) {
+                                             uint32_t giants_done, bool huge, bool calm = false) {
     const unsigned long long w = (unsigned long long)(n_left & 0x1FFFFFFFu) | ((unsigned long long)(stalled ? 1u : 0u) << 29) |
                                  ((unsigned long long)(want_giant ? 1u : 0u) << 30) | ((unsigned long long)(huge ? 1u : 0u) << 31) |
-                                 ((unsigned long long)min(rounds, 0xFFFu) << 32) | ((unsigned long long)min(giants_done, 0xFFFFu) << 44) | (1ull << 63);
+                                 ((unsigned long long)min(rounds, 0xFFFu) << 32) | ((unsigned long long)min(giants_done, 0xFFFFu) << 44) |
+                                 ((unsigned long long)(calm ? 1u : 0u) << 60) | (1ull << 63);
     __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_progress), w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -2655,7 +2658,8 @@ __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift, u
     ctrl[kCtrlGiantStep] = (progress && want_giant) ? ld_agent(&ctrl[kCtrlLowest]) + 1u : 0u;  // (kCtrlLowest: the lowest survivor, set above)
     if (host_progress)  // the host enqueues the next round when it sees this one over and seeds left (flood_enqueue)
         flood_report(host_progress, ld_agent(&ctrl[kCtrlRounds]), progress ? n_next : 0u, !progress, progress && want_giant,
-                     ld_agent(&ctrl[kCtrlGiantDone]), ld_agent(&ctrl[kCtrlMaxFlood]) != 0u);
+                     ld_agent(&ctrl[kCtrlGiantDone]), ld_agent(&ctrl[kCtrlMaxFlood]) != 0u,
+                     window >= n_seeds && ld_agent(&ctrl[kCtrlBigTotal]) == 0u && ld_agent(&ctrl[kCtrlSlabTotal]) == 0u);
 }
 
 // (Commit pass and survivors pass in ONE launch -- blocked marks in two alternating buffers, counts and flags written
@@ -3705,23 +3709,25 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
         struct Report {
             bool any;
             uint32_t n_left, rounds, giants;
-            bool stalled, want_giant, huge;
+            bool stalled, want_giant, huge, calm;
         };
         auto look = [&]() {
             const unsigned long long w = __atomic_load_n(hp, __ATOMIC_ACQUIRE);
             return Report{(w >> 63) != 0ull, (uint32_t)(w & 0x1FFFFFFFull), (uint32_t)((w >> 32) & 0xFFFull), (uint32_t)((w >> 44) & 0xFFFFull),
-                          ((w >> 29) & 1ull) != 0ull, ((w >> 30) & 1ull) != 0ull, ((w >> 31) & 1ull) != 0ull};
+                          ((w >> 29) & 1ull) != 0ull, ((w >> 30) & 1ull) != 0ull, ((w >> 31) & 1ull) != 0ull, ((w >> 60) & 1ull) != 0ull};
         };
         const int first = std::min(std::max(B.jit_first, 1), 16);
         // (LIBRECTIFY_FLOOD_JIT_LEAD=1 keeps one round ahead -- the next round goes in when all but the last one enqueued are
         // over and left seeds, the host's reaction hides behind that last round, at most one round is enqueued in vain:
         // measured the same as none ahead, 0.921 against 0.923 ms over eight 4K frames, blind rounds 0.937)
-        static const int lead = std::getenv("LIBRECTIFY_FLOOD_JIT_LEAD") ? std::max(0, std::atoi(std::getenv("LIBRECTIFY_FLOOD_JIT_LEAD"))) : 0;
+        const int lead = B.jit_lead;
         for (int r = 0; r < first; ++r, ++P->enqueued) enqueue_round(B, F, A, P->use_big, P->enqueued, s, 0xFFFFFFFFu, r == first - 1);
         // Rounds that count on the device (kCtrlRounds) against rounds enqueued that can still count: a round enqueued behind a
         // request for a giant step does nothing, so once a request is seen every round enqueued so far is accounted for.
         int counting = P->enqueued;
         uint32_t giants = 0;  // giant steps enqueued
+        bool calm = false;
+        FloodArgs A_calm = A;
         const auto t0 = std::chrono::steady_clock::now();
         int spins = 0;
         // (a single call spins -- its flood is a millisecond -- but not for ever: content that takes the flood tens of
@@ -3771,7 +3777,18 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
                 P->max_flood = r.huge ? 0xFFFFFFFFu : 0u;
             }
             if (r.n_left == 0u || r.stalled || P->enqueued >= 256) break;
-            enqueue_round(B, F, A, P->use_big, P->enqueued, s, r.n_left, true);
+            // A calm frame (flood_report): the rounds from here on go without the second tier's launch -- an empty launch of
+            // 512 workgroups of 512 threads and 41 KB of LDS each, which in a batch waits ~50 us for room beside the other
+            // lanes' walks.  (A walk that outgrew the first tier after all would move into a slab or count as unfinished:
+            // exact either way.)
+            static const bool calm_off = std::getenv("LIBRECTIFY_FLOOD_CALM") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_CALM")) == 0;
+            if (r.calm && !calm_off && !calm && P->use_big) {
+                calm = true;
+                A_calm = flood_args(B, F, false);
+                A_calm.win_shift = A.win_shift;
+            }
+            if (calm) enqueue_round(B, F, A_calm, false, P->enqueued, s, r.n_left, true);
+            else enqueue_round(B, F, A, P->use_big, P->enqueued, s, r.n_left, true);
             ++P->enqueued;
             ++counting;
         }
