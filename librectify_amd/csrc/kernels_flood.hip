@@ -3545,10 +3545,14 @@ void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& 
         return g;
     };
     auto has_rest = [&](int idx) { return idx < kRestRounds && grid_of(idx) < F.seed_cap; };
-    const uint32_t grid = grid_of(index);
-    const bool rest_now = has_rest(index) || (known_len != 0xFFFFFFFFu && known_len > grid);
+    // (a round enqueued with its list's length known takes a grid of exactly that many workgroups: the guess is cap / 4 in the
+    // late rounds, some 14 000 workgroups that leave at once for a list of a few hundred, and the dispatcher's time is the
+    // one thing all the frames in flight share)
+    const bool exact = known_len < 0xFFFFFFFEu && known_len <= F.seed_cap && !(test_grid > 0 && index >= kRestRounds);
+    const uint32_t grid = exact ? std::max<uint32_t>(known_len, 1u) : grid_of(index);
+    const bool rest_now = !exact && (has_rest(index) || (known_len != 0xFFFFFFFFu && known_len > grid));
     FloodArgs A = A0;
-    A.no_rest = (grid < F.seed_cap && !rest_now) ? 1u : 0u;
+    A.no_rest = (grid < F.seed_cap && !rest_now && !exact) ? 1u : 0u;
     A.next_reach = (grid_of(index + 1) < F.seed_cap && !has_rest(index + 1) && !next_known) ? grid_of(index + 1) : 0xFFFFFFFFu;
     // Way-point seeds listed by the last survivors pass are walked by teams in a launch of their own on the context's second
     // stream, BESIDE this round's exploration (one stream runs its kernels one after the other, and hipExtAnyOrderLaunch is
