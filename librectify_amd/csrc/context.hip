@@ -166,8 +166,11 @@ int ctx_trim(lr_context* c, bool frames_too) {
     c->w = c->h = 0;
     c->seed_cap = 0;
     for (bool& v : c->stage_valid) v = false;
-    for (lr_context* wc : c->workers)
-        if (ctx_trim(wc, frames_too)) return 1;
+    // (the lanes of a batch call are contexts of their own that shrink by themselves; a lane that shrinks in the middle of a
+    // call must not touch the others, which are in the middle of their frames -- only a trim on request goes through them)
+    if (frames_too)
+        for (lr_context* wc : c->workers)
+            if (ctx_trim(wc, true)) return 1;
     return 0;
 }
 

@@ -506,6 +506,18 @@ def test_workspace_shrinks_after_a_large_frame(L):
         trimmed = free_bytes()
         assert trimmed - with_big > (2 << 30), (with_small, with_big, after, trimmed)  # (what hipMemGetInfo reports lags now and then)
         _assert_lines_equal(c2.find_line_segment_groups(small, 19.2), ref)
+        # the lanes of a batch call shrink one by one, in the middle of the call, each only itself (a lane that went through
+        # the others' workspaces while they were in the middle of their frames was a GPU fault in bench.py): a batch of 4K
+        # frames, then one of sixty small frames through the same five lanes
+        c2.set_batch_streams(5)
+        big4k = np.stack([synth.frame(3840, 2160, 31 + i) for i in range(2)] * 3)
+        c2.find_line_segment_groups_batch_host(big4k, 38.4, capacity=8192, num_threads=4)
+        frames = np.stack([synth.frame(960, 540, 100 + i, bars=30) for i in range(6)] * 10)
+        out, n, _ = c2.find_line_segment_groups_batch_host(frames, 9.6, capacity=4096, num_threads=4)
+        for i in range(6):
+            want = O.find_line_segment_groups(frames[i], 9.6, seed=0)[0]
+            for j in range(i, 60, 6):
+                _assert_lines_equal(out[j, : n[j]], want)
     finally:
         c2.close()
 
