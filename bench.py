@@ -533,6 +533,8 @@ def main(argv=None):
                     help="where the timed region's frames live (the other kind and the device-resident rate are extra legs); "
                          "'device' = already in HBM: a diagnostic, NOT the metric (the line's workload says so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="with a process group: leave the gather of the results out of the steps (what a process "
+                    "group costs by being there, apart from what the gather costs)")
     ap.add_argument("--no-extra-legs", action="store_true")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the roofline leg (the filter kernel alone): the command profiled for "
@@ -609,11 +611,22 @@ def main(argv=None):
             cpus_how += " (not applied)"
     args.staging_threads = max(1, min(args.staging_threads, len(cpus) if cpus else args.staging_threads))
     ranks_seen = world
+    affinity = {"asked": len(cpus) if cpus else None, "before_first_collective": len(os.sched_getaffinity(0))}
     if pg:  # did the collective backend see every rank?
         t = torch.ones(1, dtype=torch.int32, device=cdev)
         got = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(got, t)
         ranks_seen = int(sum(int(x.item()) for x in got))
+        # RCCL builds its communicator at the first collective and sets the calling thread's affinity while it does
+        # ("Setting affinity for GPU 0 to ffffffff,..." in profiles/r04_rccl_world1.txt): the rank's own binding is applied
+        # AGAIN behind it, and the line carries the mask before, behind RCCL, and as it was left
+        affinity["after_first_collective"] = len(os.sched_getaffinity(0))
+        if cpus and cpus_how != "all":
+            try:
+                os.sched_setaffinity(0, cpus)
+            except OSError:
+                pass
+    affinity["in_timed_region"] = len(os.sched_getaffinity(0))
     gather_calls = [0]
 
     ctx = L.Context(local_rank)
@@ -680,7 +693,7 @@ def main(argv=None):
                 self.n_lines[: self.B] = n
                 for b in range(self.B):
                     self.tforms[b] = tf[b].as_array()
-            if pg:  # the path's one exchange step: gather the per-frame results over the process group (RCCL on GPUs)
+            if pg and not args.no_gather:  # the path's one exchange step: gather the per-frame results over the process group (RCCL on GPUs)
                 gather_calls[0] += 1
                 D.gather_results([self.out[b][: self.n_lines[b]] for b in range(self.B)], self.tforms[: self.B], n_total if n_total is not None else self.B * world, device=cdev)
 
@@ -805,7 +818,7 @@ def main(argv=None):
         traffic = pmc_traffic(rw, rh)
         nfr = max(1, len(filt_ms))
         res = {
-            "metric": "Mpix/s end-to-end (detect+VP) on 4K frames" if args.config == "frames4k" else "Mpix/s end-to-end (detect+VP), batch of 512 1920x1080 frames",
+            "metric": "Mpix/s end-to-end (detect+VP) on 4K frames, batch call of %d frames, %d in flight" % (args.frames, max(1, args.streams)) if args.config == "frames4k" else "Mpix/s end-to-end (detect+VP), batch of 512 1920x1080 frames",
             "value": round(value, 3) if value is not None else None,
             "unit": "Mpix/s",
             "n_gpus": n_gpus,
@@ -833,7 +846,12 @@ def main(argv=None):
                     "backend": (("nccl (RCCL)" if backend == "nccl" else backend) if pg else None),
                     "collective_tensors_on": (str(cdev) if pg else None),
                     "gather_ran": bool(pg and gather_calls[0] > 0),
-                    "gather": ("all_reduce(max count) + 2 x all_gather of the per-frame results, inside the timed region, %d calls in this run" % gather_calls[0]) if pg
+                    "host_threads_affinity_cpus": affinity,
+                    # what N ranks ask of the host's memory, the first shared resource of an 8-GPU node: a pageable frame is read
+                    # by the staging copy, written into the staging buffer and read again by the DMA engine (3 x its bytes);
+                    # a page-locked or registered frame once.  Two-socket DDR5-4800 x 24 channels is ~920 GB/s at best.
+                    "host_dram_GBps_expected": None if (kind == "device" or args.steps == 0) else round((3.0 if kind == "pageable" and not os.environ.get("LIBRECTIFY_REGISTER_FRAMES") else 1.0) * wl.B * w * h * 4.0 * args.steps / el / 1e9 * n_gpus, 1),
+                    "gather": ("2 x all_gather of the per-frame results (counts and transforms, then the segments), inside the timed region, %d calls in this run" % gather_calls[0]) if pg
                               else "none: a single rank started without a launcher has no process group and nothing to gather",
                 },
             },

@@ -2432,6 +2432,28 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
     static const bool batch_stats = std::getenv("LIBRECTIFY_BATCH_STATS") != nullptr;
     std::atomic<long long> up_wait_us{0}, lane_wait_us{0}, lead_sum_us{0};
     std::atomic<int> late_frames{0};
+    // Experiment (LIBRECTIFY_REGISTER_FRAMES=<threads>): pageable caller frames are page-locked WHERE
+    // THEY LIE (hipHostRegister) by a few helper threads running ahead of the uploader, sent by DMA from there, and released
+    // when the call is over -- no staging copy, i.e. one pass through host DRAM instead of three.  What it costs instead is
+    // the pinning itself (page-table work, ~1.3 ms a 4K frame on one thread: profiles/r05_h2d_register.txt).
+    static const int register_threads = std::getenv("LIBRECTIFY_REGISTER_FRAMES") ? std::max(0, std::atoi(std::getenv("LIBRECTIFY_REGISTER_FRAMES"))) : 0;
+    const bool reg_frames = register_threads > 0 && h_frames != nullptr && any_pageable && stride >= w;
+    std::vector<std::atomic<int>> reg_ready(reg_frames ? (size_t)batch : 0);
+    for (auto& a : reg_ready) a.store(0, std::memory_order_relaxed);
+    std::vector<std::thread> reg_pool;
+    if (reg_frames)
+        for (int t = 0; t < register_threads; ++t)
+            reg_pool.emplace_back([&, t]() {
+                (void)hipSetDevice(c->device);
+                bind_this_thread_near(c->device);
+                for (int i = t; i < batch && !abort_all.load(std::memory_order_relaxed); i += register_threads) {
+                    int ok = 2;  // 2: page-locked already (or registration refused: the staging path takes it)
+                    if (!is_page_locked(h_frames[i]))
+                        ok = hipHostRegister(const_cast<float*>(h_frames[i]), ((size_t)(h - 1) * (size_t)stride + (size_t)w) * sizeof(float), hipHostRegisterDefault) == hipSuccess ? 1 : 2;
+                    if (ok == 2) (void)hipGetLastError();
+                    reg_ready[(size_t)i].store(ok, std::memory_order_release);
+                }
+            });
     const double t_call0 = now_ms();
     auto uploader = [&]() {
         if (hipSetDevice(c->device) != hipSuccess) {
@@ -2454,6 +2476,10 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
             if (batch_stats) up_wait_us.fetch_add((long long)((now_ms() - t_w0) * 1e3));
             if (abort_all.load(std::memory_order_relaxed)) return;
             slot_busy[(size_t)slot].store(1, std::memory_order_relaxed);
+            if (reg_frames) {  // (the frame is being pinned by a helper: wait for it)
+                int sp2 = 0;
+                while (reg_ready[(size_t)i].load(std::memory_order_acquire) == 0 && !abort_all.load(std::memory_order_relaxed)) nap(sp2);
+            }
             float* stage = is_page_locked(h_frames[i]) ? nullptr : c->ring_stage[(size_t)slot];
             const double t_u0 = now_ms();
             hipEvent_t e_dbg = nullptr;
@@ -2552,6 +2578,10 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
         std::fprintf(stderr, "   a frame's transfer was finished %.3f ms (mean) before its first kernel started; %d of %d frames started within 0.05 ms of it (they waited for the link)\n",
                      lead_sum_us.load() * 1e-3 / batch, late_frames.load(), batch);
     if (h_frames) (void)hipStreamSynchronize(c->copy_stream);  // (after an error: nothing may still read the caller's frames)
+    for (auto& t : reg_pool) t.join();
+    if (reg_frames)  // the caller's frames go back to being pageable
+        for (int i = 0; i < batch; ++i)
+            if (reg_ready[(size_t)i].load(std::memory_order_acquire) == 1) (void)hipHostUnregister(const_cast<float*>(h_frames[i]));
     for (lr_context* l : lanes) l->sleep_in_wait = false;
     c->flood_multi = caller_multi;
     c->flood_logs = caller_logs;

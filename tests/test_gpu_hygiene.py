@@ -89,3 +89,31 @@ def test_staging_helpers_sleep_between_calls(L):
         assert a.tobytes() == b.tobytes() and len(a) > 0
     finally:
         c.close()
+
+
+def test_pageable_frames_page_locked_where_they_lie_give_the_same_results(L):
+    """LIBRECTIFY_REGISTER_FRAMES=<threads> (read once per process: a child): the batch call pins the caller's pageable
+    frames in place (hipHostRegister) a few frames ahead of the uploader, sends them by DMA from there -- no staging copy,
+    one pass through host DRAM instead of three -- and unpins them when the call is over.  Same records as single calls,
+    twice over the same buffers (they must have come back pageable), one of them a view with a row stride."""
+    code = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np
+import oracle_lib as O
+import librectify_amd as L
+from librectify_amd import synth
+ctx = L.Context(0); ctx.set_seed(0); ctx.set_batch_streams(4)
+wide = np.zeros((12, 540, 1000), np.float32)
+frames = wide[:, :, :960]
+for i in range(12): frames[i] = synth.frame(960, 540, 50 + i %% 4, bars=30)
+want = [O.find_line_segment_groups(np.ascontiguousarray(frames[i]), 9.6, seed=0)[0] for i in range(4)]
+for rep in range(2):
+    out, n, _ = ctx.find_line_segment_groups_batch_host(frames, 9.6, capacity=4096, num_threads=4)
+    for i in range(12):
+        assert out[i, : n[i]].tobytes() == want[i %% 4].tobytes(), ("mismatch", rep, i)
+print("ok")
+""" % (ROOT, ROOT)
+    env = dict(os.environ, LIBRECTIFY_REGISTER_FRAMES="3")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-1500:])
