@@ -536,6 +536,10 @@ def main(argv=None):
     ap.add_argument("--no-gather", action="store_true", help="with a process group: leave the gather of the results out of the steps (what a process "
                     "group costs by being there, apart from what the gather costs)")
     ap.add_argument("--no-extra-legs", action="store_true")
+    ap.add_argument("--dma-pump", default=None, metavar="DIR:MB",
+                    help="experiment (profiles/r05_dma_interference.txt): beside the timed steps a thread keeps copying 32 MB pieces "
+                         "h2d:MB = from page-locked host memory round a device region of MB megabytes, d2h:MB the other way, "
+                         "d2d:MB inside HBM; its rate goes to stderr")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the roofline leg (the filter kernel alone): the command profiled for "
                          "profiles/*_kernel_stats_roofline_leg.csv, where rocprofv3's average must agree with kernel_ms")
@@ -730,7 +734,42 @@ def main(argv=None):
     def timed_step():
         wl.step(kind, n_total)
 
+    pump = None
+    if args.dma_pump:
+        import threading
+        direction, mb = args.dma_pump.split(":")
+        piece = 32 << 20
+        n_pieces = max(1, (int(mb) << 20) // piece)
+        host_t = torch.empty(piece, dtype=torch.uint8).pin_memory()
+        dev_t = torch.empty((n_pieces, piece), dtype=torch.uint8, device=dev)
+        dev_src = torch.empty(piece, dtype=torch.uint8, device=dev)
+        pump = {"stop": False, "bytes": 0, "t": 0.0}
+
+        def pump_body():
+            st = torch.cuda.Stream(device=dev)
+            i = 0
+            t0 = time.perf_counter()
+            with torch.cuda.stream(st):
+                while not pump["stop"]:
+                    for _ in range(4):
+                        if direction == "h2d":
+                            dev_t[i % n_pieces].copy_(host_t, non_blocking=True)
+                        elif direction == "d2h":
+                            host_t.copy_(dev_t[i % n_pieces], non_blocking=True)
+                        else:
+                            dev_t[i % n_pieces].copy_(dev_src, non_blocking=True)
+                        i += 1
+                    st.synchronize()
+                    pump["bytes"] += 4 * piece
+            pump["t"] = time.perf_counter() - t0
+
+        pump["thread"] = threading.Thread(target=pump_body)
+        pump["thread"].start()
     el = timed(timed_step, args.steps)
+    if pump:
+        pump["stop"] = True
+        pump["thread"].join()
+        sys.stderr.write("dma pump %s: %.1f GB/s beside the timed steps\n" % (args.dma_pump, pump["bytes"] / pump["t"] / 1e9))
     segs = float(np.mean(wl.n_lines[: max(wl.B, 1)]))
     # stage times of frames inside the pipeline: two extra steps with the stage timers on (they cost the frame seven event
     # records, some 40 us of idle GPU: not inside the timed region)

@@ -2303,7 +2303,14 @@ static int ensure_upload_ring(lr_context* c, int R, size_t npix, bool staging) {
         c->ring_img.assign((size_t)std::max<int>(R, (int)c->ring_img.size()), nullptr);
         c->ring_cap_pix = 0;
         const size_t cap = std::max(npix, c->ring_cap_pix);
-        for (float*& p : c->ring_img) LR_HIP(hipMalloc((void**)&p, cap * sizeof(float)));
+        // (LIBRECTIFY_RING_UNCACHED=1, experiment of round 5: the frames' device buffers as uncached / fine-grained memory -- do the
+        // lanes' kernels lose less beside the transfers when the incoming frames bypass the caches?  profiles/r05_dma_interference.txt)
+        static const int ring_flags = std::getenv("LIBRECTIFY_RING_UNCACHED") ? std::atoi(std::getenv("LIBRECTIFY_RING_UNCACHED")) : 0;
+        for (float*& p : c->ring_img) {
+            if (ring_flags == 1) LR_HIP(hipExtMallocWithFlags((void**)&p, cap * sizeof(float), hipDeviceMallocUncached));
+            else if (ring_flags == 2) LR_HIP(hipExtMallocWithFlags((void**)&p, cap * sizeof(float), hipDeviceMallocFinegrained));
+            else LR_HIP(hipMalloc((void**)&p, cap * sizeof(float)));
+        }
         c->ring_cap_pix = cap;
     }
     static const bool lane_debug = std::getenv("LIBRECTIFY_LANE_DEBUG") != nullptr || std::getenv("LIBRECTIFY_BATCH_STATS") != nullptr;  // (they time the uploads)
@@ -2527,7 +2534,10 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
                 while ((slot = enq[(size_t)b].load(std::memory_order_acquire) - 1) < 0 && !abort_all.load(std::memory_order_relaxed)) nap(spins);
                 if (batch_stats) lane_wait_us.fetch_add((long long)((now_ms() - t_w0) * 1e3));
                 if (slot < 0) return;  // (whoever stopped the batch has the message)
-                if (hipStreamWaitEvent(l->stream, c->ring_ev[(size_t)slot], 0) != hipSuccess) {
+                // (experiment, profiles/r05_dma_interference.txt: =1 leaves the wait out -- the lane then works on whatever the
+                // slot holds, results are NOT the frame's -- to price the cross-stream wait apart from the transfer)
+                static const bool exp_no_wait = std::getenv("LIBRECTIFY_EXP_NO_UPLOAD_WAIT") != nullptr;
+                if (!exp_no_wait && hipStreamWaitEvent(l->stream, c->ring_ev[(size_t)slot], 0) != hipSuccess) {
                     set_error("hipStreamWaitEvent failed");
                     return fail();
                 }
@@ -2535,6 +2545,21 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
                 img_stride = w;
             } else {
                 img = d_images + (size_t)b * image_stride;
+                // (experiment, same file: resident frames, but each behind a cross-stream wait for a 4 KB transfer of its own)
+                static const bool exp_fence = std::getenv("LIBRECTIFY_EXP_RESIDENT_WAIT") != nullptr;
+                if (exp_fence) {
+                    static std::mutex mu;
+                    static void* dst = nullptr;
+                    static hipStream_t side = nullptr;
+                    static hipEvent_t evs[64] = {};
+                    std::lock_guard<std::mutex> g(mu);
+                    if (!dst) (void)hipMalloc(&dst, 4096);
+                    if (!side) (void)hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+                    if (!evs[si & 63]) (void)hipEventCreateWithFlags(&evs[si & 63], hipEventDisableTiming);
+                    (void)hipMemcpyAsync(dst, c->h_counts, 256, hipMemcpyHostToDevice, side);
+                    (void)hipEventRecord(evs[si & 63], side);
+                    (void)hipStreamWaitEvent(l->stream, evs[si & 63], 0);
+                }
             }
             std::vector<LineSegment> res;
             const double t_f0 = now_ms();
