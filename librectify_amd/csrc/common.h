@@ -190,6 +190,7 @@ struct FloodBuffers {
     // -- no launch behind the last round with work (the blind rounds of a 4K frame were 60-120 us of empty launches), at
     // the price of the host's reaction time per further round.  The calling thread polls while the flood runs.
     uint32_t* host_progress = nullptr;  // page-locked, device-visible, 8-byte aligned: one 64-bit report (kernels_flood.hip: flood_report)
+    uint32_t* host_ctrl = nullptr;      // page-locked, device-visible: the round that ends the flood leaves the control block here (no copy of it is enqueued then)
     int jit_first = 0;                  // 0: off
     int jit_sleep_us = 0;               // the polling thread sleeps this long between looks (0: it spins -- single calls)
     int jit_lead = 0;                   // rounds the host keeps enqueued ahead of the last one it has seen finished

@@ -897,6 +897,7 @@ FloodBuffers flood_buffers_for(lr_context* c) {
     // rounds just in time (FloodBuffers::host_progress): what the last frame needed less one at once (three on a new context)
     static const bool jit_off = std::getenv("LIBRECTIFY_FLOOD_JIT") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_JIT")) == 0;
     fbuf.host_progress = c->h_counts + 72;  // (the control block's copy ends at + 64)
+    fbuf.host_ctrl = c->h_counts + 16;
     fbuf.jit_sleep_us = c->flood_jit_sleep_us;
     // (at most four rounds blindly -- the rounds that always bring their `rest` launch, kernels_flood.hip kRestRounds: a later
     // blind round whose list is longer than its grid walks only a part of it, and lists stay long while a window is closed in
@@ -1035,7 +1036,6 @@ int enqueue_fit(lr_context* c) {
     // Floods of more than 2^14 pixels have launches of their own (kernels_fit.hip: huge_count_kernel, huge_sort_kernel), left
     // out when the host KNOWS that the frame has none: the flood's rounds, enqueued just in time, report their largest commit.
     const bool with_huge = !(c->flood_mode != 0 && c->flood_prog.sizes_known && c->flood_prog.max_flood <= (1u << 14));
-    LR_HIP(hipMemsetAsync(c->cursor, 0, (size_t)comp_cap * sizeof(uint32_t), c->stream));
     if (launch_component_offsets(c->seed_size, c->d_counts + kCntSeeds, c->seed_cap, kComponentMinSize, c->comp_rank,
                                  c->comp_seed, c->comp_off, c->d_counts + kCntComp, c->comp_large,
                                  (uint32_t)(c->cap_pix / 64 + 16), c->d_counts + kCntLarge, c->temp, c->temp_bytes, c->cursor,

@@ -142,13 +142,17 @@ __global__ __launch_bounds__(256) void component_offsets_kernel(const int32_t* _
                 // 1024 pixels (list filled from the front), through global memory beyond (filled from the back)
                 if (sz[j] > (int)kSortLds) large_list[large_cap - 1u - atomicAdd(n_large + 1, 1u)] = rank;
                 else if (sz[j] > 64) large_list[atomicAdd(n_large, 1u)] = rank;
+                // the scatter pass's cursor of this component: zero, or -- flagged -- its number among the huge ones (the
+                // scatter pass finds the buckets through it).  Every component's word is written here: no memset launch.
+                uint32_t cur = 0u;
                 if (sz[j] > (int)kSortLdsBig && huge_max != 0u) {  // (beyond huge_max -- never: the old way, component_sort_big_kernel<true>)
                     const uint32_t hi = atomicAdd(n_large + 2, 1u);
                     if (hi < huge_max) {
-                        cursor[rank] = hi | kHugeFlag;  // (zeroed before this launch; the scatter pass finds the buckets through it)
+                        cur = hi | kHugeFlag;
                         huge_list[hi] = rank;
                     }
                 }
+                cursor[rank] = cur;
                 rank += 1u;
                 off_px += (uint32_t)sz[j];
             }

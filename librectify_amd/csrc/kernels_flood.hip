@@ -228,6 +228,7 @@ struct FloodArgs {
     uint32_t log_max_len;                            // logs of at most this many records are written and used (what the launched kernels' tables hold)
     uint32_t log_sweep;                              // test hook: every footprint is worked out by sweeps (flood_rewalk_kernel)
     uint32_t* host_progress;                         // FloodBuffers::host_progress (nullptr: nobody is looking)
+    uint32_t* host_ctrl;                             // FloodBuffers::host_ctrl (with host_progress only)
     uint32_t giant_hold;                             // 1: only the lowest active seed walks on into a slab (see kCtrlLowest)
     uint32_t log_seeds;                              // seeds with per-seed words below (FloodBuffers::log_seeds)
     uint32_t* log_off;                               // first record of the seed's log ...
@@ -2794,15 +2795,25 @@ __global__ __launch_bounds__(256) void flood_survivors_kernel(FloodArgs A, uint8
     }
     // the workgroup that finishes last closes the round (every other one has read the control block and added its
     // counts by then)
+    __shared__ uint32_t s_closed;
     __syncthreads();
     if (threadIdx.x == 0) {
+        s_closed = 0u;
         __threadfence();
         if (atomicAdd(&A.ctrl[kCtrlDone], 1u) == gridDim.x - 1u) {
             __threadfence();
             A.ctrl[kCtrlDone] = 0u;
             flood_advance(A.ctrl, A.win_shift, A.t1_regional_min, A.hold_min_big, A.host_progress, A.hold_release, A.giant_step, A.giant_many);
+            __threadfence();
+            s_closed = 1u;
         }
     }
+    // The round that leaves no seeds (or stalls) hands the host the control block as well: the host that watched the rounds
+    // (flood_enqueue) then enqueues no copy of it -- a launch and 7 us of an idle stream between the flood and the fit.
+    if (A.host_ctrl == nullptr) return;
+    __syncthreads();
+    if (s_closed != 0u && threadIdx.x < kCtrlWords && ld_agent(&A.ctrl[kCtrlNAct]) == 0u)
+        __hip_atomic_store(&A.host_ctrl[threadIdx.x], ld_agent(&A.ctrl[threadIdx.x]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* __restrict__ n_ptr, uint32_t cap,
@@ -3490,6 +3501,8 @@ FloodArgs flood_args(const FloodBuffers& B, const FloodFrame& F, bool use_big) {
     static const bool log_sweep_env = std::getenv("LIBRECTIFY_FLOOD_LOG_SWEEP") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_LOG_SWEEP")) != 0;
     A.log_sweep = (log_sweep_env || B.log_sweep) ? 1u : 0u;
     A.host_progress = (B.jit_first > 0 && !g_flood_debug) ? B.host_progress : nullptr;
+    static const bool mirror_off = std::getenv("LIBRECTIFY_FLOOD_MIRROR") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_MIRROR")) == 0;  // (comparison)
+    A.host_ctrl = (A.host_progress && !mirror_off) ? B.host_ctrl : nullptr;
     A.giant_hold = B.giant_hold ? 1u : 0u;
     A.log_max_len = (B.rewalk_big && use_big) ? (uint32_t)kRewalkTilesBig : (uint32_t)kRewalkTiles;
     A.log_seeds = logs ? B.log_seeds : 0u;
@@ -3701,6 +3714,7 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
     }
     FloodArgs A = flood_args(B, F, P->use_big);
     A.win_shift = (uint32_t)win_growth;
+    bool ended_in_sight = false;
     // rounds enqueued blindly: two more than the context's previous frame needed (a round past the end costs five
     // empty launches, a round too few costs the frame a second lap through the fit and the grouping)
     if (A.host_progress) {
@@ -3779,6 +3793,7 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
             if (r.n_left == 0u && !r.stalled) {  // the flood is over, and the report says whether it committed a huge flood
                 P->sizes_known = true;
                 P->max_flood = r.huge ? 0xFFFFFFFFu : 0u;
+                ended_in_sight = true;
             }
             if (r.n_left == 0u || r.stalled || P->enqueued >= 256) break;
             // A calm frame (flood_report): the rounds from here on go without the second tier's launch -- an empty launch of
@@ -3786,7 +3801,9 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
             // lanes' walks.  (A walk that outgrew the first tier after all would move into a slab or count as unfinished:
             // exact either way.)
             static const bool calm_off = std::getenv("LIBRECTIFY_FLOOD_CALM") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_CALM")) == 0;
-            if (r.calm && !calm_off && !calm && P->use_big) {
+            // (not with multi-source re-walks on: their launch is the second tier's, and the round before has listed seeds for it)
+            const bool multi_on = B.aux_stream != nullptr && A.wp_min_tiles != 0xFFFFFFFFu;
+            if (r.calm && !calm_off && !calm && P->use_big && !multi_on) {
                 calm = true;
                 A_calm = flood_args(B, F, false);
                 A_calm.win_shift = A.win_shift;
@@ -3800,7 +3817,9 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
     const int batch = g_flood_debug ? 1 : std::min(std::max(B.blind_rounds, 1), 16);
     for (int r = 0; r < batch; ++r, ++P->enqueued) enqueue_round(B, F, A, P->use_big, P->enqueued, s);
     }
-    LR_HIP(hipMemcpyAsync(h_ctrl, B.ctrl, kCtrlWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    // (the host saw the flood end: the round that ended it has written the control block to B.host_ctrl itself)
+    if (!(ended_in_sight && A.host_ctrl == h_ctrl))
+        LR_HIP(hipMemcpyAsync(h_ctrl, B.ctrl, kCtrlWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     LR_HIP(hipGetLastError());
     return 0;
 }
