@@ -230,7 +230,9 @@ int lr_filter_kernel_ms(lr_context* ctx, float* ms);
  * started from several way-points at once (lr_set_flood_multi_source), [11] footprints worked out from a log instead of
  * walked (lr_set_flood_logs), [12] those of them that took the fall-back path (sweeps), [13] walks that outgrew the second
  * tier's table and were held back until their seed was the lowest active one (instead of moving into a global slab),
- * [14] giant steps: floods of the lowest active seed labelled by the whole device (lr_set_flood_giant_step). */
+ * [14] giant steps: floods of the lowest active seed labelled by the whole device (lr_set_flood_giant_step), [15] walks that
+ * outgrew the first tier in a round enqueued without the second (the context's last frame never needed it: such a walk waits
+ * a round; LIBRECTIFY_FLOOD_CALM_HINT=0 enqueues every round with the second tier). */
 int lr_stage_counters(lr_context* ctx, int64_t* out, int count);
 
 /* ---- RANSAC --------------------------------------------------------------------------- */

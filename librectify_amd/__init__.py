@@ -278,11 +278,12 @@ class Context:
         return ms.value
 
     def stage_counters(self):
-        c = np.zeros(15, np.int64)
-        _check(lib().lr_stage_counters(self._h, _ptr(c), 15))
+        c = np.zeros(16, np.int64)
+        _check(lib().lr_stage_counters(self._h, _ptr(c), 16))
         return dict(seeds=int(c[0]), components=int(c[1]), flood_rounds=int(c[2]), labelled_px=int(c[3]),
                     second_tier_seeds=int(c[4]), slabs=int(c[5]), ordered_tail_seeds=int(c[6]), frame_laps=int(c[7]),
-                    walked_px=int(c[8]), walk_steps=int(c[9]), multi_source_walks=int(c[10]), log_rewalks=int(c[11]), log_give_ups=int(c[12]), giants_held=int(c[13]), giant_steps=int(c[14]))
+                    walked_px=int(c[8]), walk_steps=int(c[9]), multi_source_walks=int(c[10]), log_rewalks=int(c[11]), log_give_ups=int(c[12]), giants_held=int(c[13]), giant_steps=int(c[14]),
+                    quiet_round_misses=int(c[15]))
 
     # ---- full path ----
     def find_line_segment_groups(self, img, min_length, refine=False, num_threads=-1, capacity=None):

@@ -447,14 +447,14 @@ int lr_stage_times(lr_context* ctx, float* ms, int count) {
 
 int lr_stage_counters(lr_context* ctx, int64_t* out, int count) {
     try {
-        const int64_t v[15] = {(int64_t)ctx->n_seeds,        (int64_t)ctx->n_comp,         (int64_t)ctx->flood_rounds,
+        const int64_t v[16] = {(int64_t)ctx->n_seeds,        (int64_t)ctx->n_comp,         (int64_t)ctx->flood_rounds,
                                (int64_t)ctx->n_px,           (int64_t)ctx->flood_tiers[0], (int64_t)ctx->flood_tiers[1],
                                (int64_t)ctx->flood_tiers[2], (int64_t)ctx->frame_laps,
                                (int64_t)(((uint64_t)ctx->flood_tiers[5] << 32) | ctx->flood_tiers[4]),
                                (int64_t)(((uint64_t)ctx->flood_tiers[7] << 32) | ctx->flood_tiers[6]),
                                (int64_t)ctx->flood_tiers[9], (int64_t)ctx->flood_tiers[10], (int64_t)ctx->flood_tiers[11], (int64_t)ctx->flood_tiers[12],
-                               (int64_t)ctx->flood_tiers[13]};
-        for (int i = 0; i < count && i < 15; ++i) out[i] = v[i];
+                               (int64_t)ctx->flood_tiers[13], (int64_t)ctx->flood_tiers[15]};
+        for (int i = 0; i < count && i < 16; ++i) out[i] = v[i];
         return 0;
     } catch (...) {
         return guard_fail("lr_stage_counters");

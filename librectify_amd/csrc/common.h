@@ -97,7 +97,7 @@ FilterGeom filter_geometry(int w, int h);
 size_t seeds_temp_bytes(int n_tiles, size_t max_seeds);
 int launch_seed_select(const uint64_t* cand, const uint32_t* cand_count, const uint32_t* tile_max, int n_tiles,
                        int cand_cap, float seed_keep_ratio, float* maxmag, uint32_t* tile_pass, uint32_t* tile_off, uint64_t* keys,
-                       uint32_t key_cap, uint32_t* n_seeds, hipStream_t s);
+                       uint32_t key_cap, uint32_t* n_seeds, uint32_t frame_tag, hipStream_t s);
 // the seed count stays on the device (*n_seeds, clamped to cap); the launches cover `cap` seeds.  keys_alt: a second buffer
 // of cap keys (the merge rounds of large frames go back and forth between the two)
 int launch_seed_order(uint64_t* keys, uint64_t* keys_alt, const uint32_t* n_seeds, uint32_t cap, const float* dx, const float* dy,
@@ -190,6 +190,7 @@ struct FloodBuffers {
     // -- no launch behind the last round with work (the blind rounds of a 4K frame were 60-120 us of empty launches), at
     // the price of the host's reaction time per further round.  The calling thread polls while the flood runs.
     uint32_t* host_progress = nullptr;  // page-locked, device-visible, 8-byte aligned: one 64-bit report (kernels_flood.hip: flood_report)
+    bool calm_hint = false;             // the context's last frame had no walk beyond the first tier: blind rounds 2.. go without the second tier's launch
     uint32_t* host_ctrl = nullptr;      // page-locked, device-visible: the round that ends the flood leaves the control block here (no copy of it is enqueued then)
     int jit_first = 0;                  // 0: off
     int jit_sleep_us = 0;               // the polling thread sleeps this long between looks (0: it spins -- single calls)
@@ -245,11 +246,13 @@ struct HugeSort {
     uint32_t* jobs = nullptr;
     uint32_t max = 0;
 };
-// n_large: seven words (kernels_fit.hip); cursor: one word per component, zeroed BEFORE launch_component_offsets
+// n_large: seven words (kernels_fit.hip), cleared by the launch; cursor: one word per component, written by it;
+// temp: fit_temp_bytes() bytes, ZERO when allocated (tagged status words); frame_tag: not 0, different from call to call
 int launch_component_offsets(const int32_t* seed_size, const uint32_t* d_n_seeds, uint32_t seed_cap, int min_size,
                              uint32_t* comp_rank, uint32_t* comp_seed, uint32_t* comp_off,
                              uint32_t* totals /*[0]=n_comp,[1]=n_px*/, uint32_t* large_list, uint32_t large_cap,
-                             uint32_t* n_large, void* temp, size_t temp_bytes, uint32_t* cursor, const HugeSort& hs, hipStream_t s);
+                             uint32_t* n_large, void* temp, size_t temp_bytes, uint32_t frame_tag, uint32_t* cursor, const HugeSort& hs,
+                             hipStream_t s);
 // with_huge = false: the caller knows that no flood of the frame has more than 2^14 pixels (the launches for those are left out)
 int launch_component_scatter(const uint32_t* label, size_t npix, const uint32_t* comp_rank, const uint32_t* comp_off,
                              uint32_t* cursor, uint32_t* px, const HugeSort& hs, uint32_t* n_large, bool with_huge, hipStream_t s);
@@ -302,16 +305,18 @@ enum {  // words of the peeling control block
     kGcBestIter0 = 4,  // [4..7]: winning iteration of each round (diagnostics)
     kGcWords = 8,
 };
+// all / round0 (both or neither): the kept segments' pencil model goes into these tables in the same launch (launch_pencil_model's work)
 int launch_filter_lines(const LineSegment* raw, const uint32_t* d_n_raw, uint32_t raw_cap, float min_length,
-                        LineSegment* out, uint32_t* gctl, float* gnorm, hipStream_t s);
+                        LineSegment* out, uint32_t* gctl, float* gnorm, const PencilTable* all, const PencilTable* round0,
+                        hipStream_t s);
 int launch_lines_bbox(LineSegment* lines, uint32_t n, uint32_t* gctl, float* gnorm, hipStream_t s);
 int launch_pencil_model(const LineSegment* lines, const uint32_t* gctl, const float* gnorm, PencilTable all,
                         PencilTable round0, uint32_t line_cap, hipStream_t s);
-int launch_result_gather(const uint32_t* counts, const uint32_t* gctl, const float* models, const LineSegment* lines,
-                         uint32_t cap_lines, void* host_block, hipStream_t s);
 int launch_peel(PencilTable cur, PencilTable nxt, PencilTable all, unsigned long long* best_slots, uint64_t seed,
                 float tol, float garbage_tol, int max_models, uint32_t* gctl, float* stage4 /* 4 floats per line */,
-                LineSegment* lines, float* models, hipStream_t s);
+                LineSegment* lines, float* models,
+                const uint32_t* counts, uint32_t cap_lines, void* gather_block /* not nullptr: the frame's result block is written at the end */,
+                hipStream_t s);
 int launch_cht_accumulate(PencilSoA m, uint32_t n, int d, unsigned long long* acc, hipStream_t s);
 int launch_cht_votes(PencilSoA m, const uint32_t* idx, uint32_t n, int d, unsigned long long* acc, bool subtract,
                      unsigned long long* n_votes, hipStream_t s);

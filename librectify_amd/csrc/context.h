@@ -49,7 +49,9 @@ struct lr_context {
     uint32_t* tile_max = nullptr;
     // stage 2
     uint32_t* tile_pass = nullptr;
-    uint32_t* tile_off = nullptr;
+    uint32_t* tile_off = nullptr;      // (the fused seed selection keeps its workgroups' status words here: zeroed when allocated)
+    uint32_t fit_tag = 0;              // ... and of the last component scan (kernels_fit.hip: component_offsets_kernel)
+    uint32_t select_tag = 0;           // tag of the last seed selection on this context (kernels_seeds.hip: seed_select_kernel)
     float* maxmag = nullptr;
     uint64_t* keys_a = nullptr;
     uint64_t* keys_b = nullptr;
@@ -163,7 +165,8 @@ struct lr_context {
     bool flood_big_hint = true;  // did the last frame's walks outgrow the first storage tier? (none yet: assume so)
     bool flood_hold_hint = false;  // did the last frame hold its weakest seeds back?
     bool flood_staged_hint = false;  // was the last frame one of overlapping giants (kernels_flood.hip: kCtrlStaged)?  Then this one starts on its strongest quarter
-    uint32_t flood_tiers[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // last flood: seeds in the second tier, slabs used, seeds of the ordered tail, hold-back, walked px (lo, hi), steps (lo, hi), walks beyond the first tier's table, multi-source re-walks, re-walks from logs, logs given up, giants held back
+    bool flood_calm_hint = false;      // the last frame's walks all stayed in the first storage tier (FloodBuffers::calm_hint)
+    uint32_t flood_tiers[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // last flood: seeds in the second tier, slabs used, seeds of the ordered tail, hold-back, walked px (lo, hi), steps (lo, hi), walks beyond the first tier's table, multi-source re-walks, re-walks from logs, logs given up, giants held back
     bool flood_partial = true;  // partial commits of blocked seeds (kernels_flood.hip); lr_set_flood_partial_commits
     int flood_log_min = 0, flood_log_walk = 0;  // thresholds of the logs (0: the defaults; the lanes of a batch call get 32 and 24)
     int flood_log_from = 1;        // first round (from 0) whose seeds turn to their logs (lanes of a batch: experiment knob LIBRECTIFY_FLOOD_LOGS_LANES_FROM)

@@ -200,6 +200,7 @@ int ctx_ensure_image_capacity(lr_context* c, int w, int h) {
         dev_alloc(c->px_b, cp) || dev_alloc(c->scratch_w, cp) || dev_alloc(c->d_lines, cp / 6 + 16) ||
         dev_alloc(c->comp_large, cp / 64 + 16))
         return 1;
+    LR_HIP(hipMemsetAsync(c->tile_off, 0, (size_t)ct * sizeof(uint32_t), c->stream));  // (seed_select_kernel's status words)
     {   // huge components: a row of buckets (2^14 pixel indices each) for up to 256 of them; the table is zero between frames
         const size_t nb = (cp + 16383) >> 14;
         c->huge.max = 256;
@@ -210,6 +211,7 @@ int ctx_ensure_image_capacity(lr_context* c, int w, int h) {
     if (c->temp) (void)hipFree(c->temp);
     c->temp = nullptr;
     LR_HIP(hipMalloc(&c->temp, tb));
+    LR_HIP(hipMemsetAsync(c->temp, 0, tb, c->stream));  // (component_offsets_kernel's status words)
     c->temp_bytes = tb;
     c->cap_pix = cp;
     c->cap_tiles = ct;
@@ -898,6 +900,9 @@ FloodBuffers flood_buffers_for(lr_context* c) {
     static const bool jit_off = std::getenv("LIBRECTIFY_FLOOD_JIT") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_JIT")) == 0;
     fbuf.host_progress = c->h_counts + 72;  // (the control block's copy ends at + 64)
     fbuf.host_ctrl = c->h_counts + 16;
+    // (LIBRECTIFY_FLOOD_CALM_HINT=0: every blind round brings the second tier's launch, as until round 5)
+    static const int calm_hint_env = std::getenv("LIBRECTIFY_FLOOD_CALM_HINT") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_CALM_HINT")) : 1;
+    fbuf.calm_hint = calm_hint_env != 0 && c->flood_calm_hint;
     fbuf.jit_sleep_us = c->flood_jit_sleep_us;
     // (at most four rounds blindly -- the rounds that always bring their `rest` launch, kernels_flood.hip kRestRounds: a later
     // blind round whose list is longer than its grid walks only a part of it, and lists stay long while a window is closed in
@@ -956,7 +961,8 @@ int enqueue_filter(lr_context* c, const float* d_image, int w, int h, int stride
 int enqueue_seeds(lr_context* c) {
     const FilterGeom fg = filter_geometry(c->w, c->h);
     if (launch_seed_select(c->cand, c->cand_count, c->tile_max, fg.n_tiles, fg.cand_cap, c->seed_keep_ratio, c->maxmag,
-                           c->tile_pass, c->tile_off, c->keys_a, c->seed_cap, c->d_counts + kCntSeeds, c->stream))
+                           c->tile_pass, c->tile_off, c->keys_a, c->seed_cap, c->d_counts + kCntSeeds, ++c->select_tag ? c->select_tag : ++c->select_tag,
+                           c->stream))
         return 1;
     if (launch_seed_order(c->keys_a, c->keys_b, c->d_counts + kCntSeeds, c->seed_cap, c->dx, c->dy, c->trig, kTraceTolerance,
                           c->seed_idx, c->seed_bin, c->seed_thr, c->stream))
@@ -998,6 +1004,7 @@ int finish_flood(lr_context* c, bool* extra) {
         std::fprintf(stderr, "flood: %d rounds, %u walks in the second tier, %u of them long, hold-back phase %u (started with it: %d)\n",
                      c->flood_rounds, c->flood_tiers[0], c->flood_tiers[8], c->flood_tiers[3], (int)c->flood_hold_hint);
     c->flood_logbig_hint = c->flood_tiers[0] > 0;
+    c->flood_calm_hint = c->flood_tiers[0] == 0 && c->flood_tiers[1] == 0 && c->flood_tiers[15] == 0;
     static const int hints_env = std::getenv("LIBRECTIFY_FLOOD_HINTS") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_HINTS")) : 1;  // (experiment knob)
     if (hints_env == 0) {  // as in round 2
         c->flood_big_hint = c->flood_tiers[0] > 0 || c->flood_tiers[1] > 0;
@@ -1038,7 +1045,7 @@ int enqueue_fit(lr_context* c) {
     const bool with_huge = !(c->flood_mode != 0 && c->flood_prog.sizes_known && c->flood_prog.max_flood <= (1u << 14));
     if (launch_component_offsets(c->seed_size, c->d_counts + kCntSeeds, c->seed_cap, kComponentMinSize, c->comp_rank,
                                  c->comp_seed, c->comp_off, c->d_counts + kCntComp, c->comp_large,
-                                 (uint32_t)(c->cap_pix / 64 + 16), c->d_counts + kCntLarge, c->temp, c->temp_bytes, c->cursor,
+                                 (uint32_t)(c->cap_pix / 64 + 16), c->d_counts + kCntLarge, c->temp, c->temp_bytes, ++c->fit_tag ? c->fit_tag : ++c->fit_tag, c->cursor,
                                  with_huge ? c->huge : HugeSort{}, c->stream))
         return 1;
     if (launch_component_scatter(c->label, npix, c->comp_rank, c->comp_off, c->cursor, c->px_a, c->huge, c->d_counts + kCntLarge, with_huge,
@@ -1071,7 +1078,7 @@ int enqueue_fit(lr_context* c) {
 // estimate_line_pencils (line_pencil.cpp:148-177) on the lines in d_flines, whose count, bounding box and control
 // words a filter_lines / lines_bbox launch has left in d_gctl / d_gnorm.
 int enqueue_groups(lr_context* c, uint32_t line_cap, int max_models, float inlier_deg, float garbage_deg, int n_iter,
-                   uint64_t seed) {
+                   uint64_t seed, bool model_done = false, bool gather = false) {
     if (max_models > kMaxPeelModels) {  // the refit models and the diagnostics slots of a frame are sized for this many
         set_error("estimate_line_pencils: max_models above " + std::to_string(kMaxPeelModels) + " (the reference uses 4, config.h:25)");
         return 1;
@@ -1079,25 +1086,22 @@ int enqueue_groups(lr_context* c, uint32_t line_cap, int max_models, float inlie
     const float tol = cos_threshold(inlier_deg), garbage_tol = cos_threshold(garbage_deg);
     const PencilTable all = table_of(c, 0);
     PencilTable tab[2] = {table_of(c, 1), table_of(c, 2)};
-    if (launch_pencil_model(c->d_flines, c->d_gctl, c->d_gnorm, all, tab[0], line_cap, c->stream)) return 1;
+    // (model_done: the launch that filtered the lines has written both tables already -- launch_filter_lines)
+    if (!model_done && launch_pencil_model(c->d_flines, c->d_gctl, c->d_gnorm, all, tab[0], line_cap, c->stream)) return 1;
     const float degeneracy_tol = 0.05f;  // line_pencil.h:25
     for (int k = 0; k < max_models; ++k) {
         if (n_iter > 0 &&
             launch_ransac_score_dev(tab[k & 1].soa(), c->d_gctl, max_models, tol, degeneracy_tol, (uint32_t)n_iter, seed,
                                     c->d_best_slots, c->stream))
             return 1;
+        // (gather: the last round's launch copies the frame's results into the page-locked block as well)
+        const bool last = gather && k == max_models - 1;
         if (launch_peel(tab[k & 1], tab[(k + 1) & 1], all, c->d_best_slots, seed, tol, garbage_tol,
-                        max_models, c->d_gctl, c->d_inl, c->d_flines, c->d_models, c->stream))
+                        max_models, c->d_gctl, c->d_inl, c->d_flines, c->d_models, c->d_counts,
+                        (uint32_t)std::min<size_t>(c->res_lines_cap, c->cap_flines), last ? c->h_res : nullptr, c->stream))
             return 1;
     }
     return 0;
-}
-
-// header (counts, peeling control block, refit models) and the first res_lines_cap grouped lines -> pinned host block
-int enqueue_result_copy(lr_context* c) {
-    static_assert(kGcWords == 8 && kResHeaderBytes == 256, "layout of the result block (result_gather_kernel)");
-    const size_t nl = std::min<size_t>(c->res_lines_cap, c->cap_flines);
-    return launch_result_gather(c->d_counts, c->d_gctl, c->d_models, c->d_flines, (uint32_t)nl, c->h_res, c->stream);
 }
 
 void record_stage_times(lr_context* c, bool with_groups) {
@@ -1998,12 +2002,14 @@ static int run_frame(lr_context* c, const float* d_image, int w, int h, int stri
         if (ensure_group_capacity(c, lc, (size_t)std::max(n_iter, 1))) return 1;
         if (ensure_result_block(c, std::max<size_t>(c->res_lines_cap, 4096))) return 1;
         if (c->timing_on) LR_HIP(hipEventRecord(c->ev[5], c->stream));
-        if (launch_filter_lines(c->d_lines, c->d_counts + kCntComp, lc, min_length, c->d_flines, c->d_gctl, c->d_gnorm,
+        const PencilTable all = table_of(c, 0), round0 = table_of(c, 1);
+        if (launch_filter_lines(c->d_lines, c->d_counts + kCntComp, lc, min_length, c->d_flines, c->d_gctl, c->d_gnorm, &all, &round0,
                                 c->stream))
             return 1;
-        if (enqueue_groups(c, lc, kMaxModels, kInlierDeg, kGarbageDeg, n_iter, c->ransac_seed)) return 1;
+        static_assert(kMaxModels >= 1 && kGcWords == 8 && kResHeaderBytes == 256, "the last peeling round carries the result block (peel_kernel)");
+        if (enqueue_groups(c, lc, kMaxModels, kInlierDeg, kGarbageDeg, n_iter, c->ransac_seed, true, true)) return 1;
         if (c->timing_on) LR_HIP(hipEventRecord(c->ev[6], c->stream));
-        return enqueue_result_copy(c);
+        return 0;
     };
     c->frame_laps = 0;
     for (int attempt = 0;; ++attempt) {

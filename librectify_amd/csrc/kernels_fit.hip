@@ -50,33 +50,16 @@ __device__ __forceinline__ void chunk_counts(const int32_t* __restrict__ seed_si
     }
 }
 
-__global__ __launch_bounds__(256) void component_sums_kernel(const int32_t* __restrict__ seed_size,
-                                                             const uint32_t* __restrict__ n_ptr, uint32_t cap,
-                                                             int min_size, uint2* __restrict__ chunk_tot,
-                                                             uint32_t* __restrict__ n_large) {
-    __shared__ uint32_t s_c[4], s_p[4];
-    const uint32_t n_seeds = min(*n_ptr, cap);
-    if (blockIdx.x == 0 && threadIdx.x == 0) n_large[0] = n_large[1] = n_large[2] = n_large[3] = 0u;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int sz[kOffPer];
-    uint32_t c, p;
-    chunk_counts(seed_size, n_seeds, min_size, blockIdx.x * kOffChunk + (uint32_t)tid * kOffPer, sz, c, p);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        c += (uint32_t)__shfl_xor((int)c, off);
-        p += (uint32_t)__shfl_xor((int)p, off);
-    }
-    if (lane == 0) {
-        s_c[wv] = c;
-        s_p[wv] = p;
-    }
-    __syncthreads();
-    if (tid == 0) chunk_tot[blockIdx.x] = make_uint2(s_c[0] + s_c[1] + s_c[2] + s_c[3], s_p[0] + s_p[1] + s_p[2] + s_p[3]);
-}
-
+// Component numbers and pixel offsets of the kept floods: an exclusive scan over the seeds in ONE launch (round 5; until then a
+// launch for the chunks' totals went first).  Every workgroup counts its chunk of 2048 seeds, PUBLISHES the two totals as
+// tagged 64-bit words (frame tag : 32 | value : 32; relaxed agent-scope stores -- the word is its own payload, no fence) and
+// adds up the words of the chunks before it, waiting for each to carry this frame's tag (workgroups are dispatched in index
+// order and none waits for a later one; the wait is bounded all the same).  Chunk 0 clears the list counters (n_large) before
+// it publishes -- with release order, the one fence of the launch -- and nobody touches them before having seen its words.
+// `status`: two words per chunk, zero when allocated; tags start at 1 and differ from frame to frame.
 __global__ __launch_bounds__(256) void component_offsets_kernel(const int32_t* __restrict__ seed_size,
                                                                 const uint32_t* __restrict__ n_ptr, uint32_t cap,
-                                                                int min_size, const uint2* __restrict__ chunk_tot,
+                                                                int min_size, unsigned long long* __restrict__ status, uint32_t tag,
                                                                 uint32_t* __restrict__ comp_rank,
                                                                 uint32_t* __restrict__ comp_seed,
                                                                 uint32_t* __restrict__ comp_off,
@@ -88,18 +71,6 @@ __global__ __launch_bounds__(256) void component_offsets_kernel(const int32_t* _
     __shared__ uint32_t s_c[4], s_p[4], s_cc[4], s_cp[4];
     const uint32_t n_seeds = min(*n_ptr, cap);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    // totals of the chunks before this one
-    uint32_t cc = 0, cp = 0;
-    for (uint32_t i = (uint32_t)tid; i < blockIdx.x; i += 256) {
-        const uint2 t = chunk_tot[i];
-        cc += t.x;
-        cp += t.y;
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        cc += (uint32_t)__shfl_xor((int)cc, off);
-        cp += (uint32_t)__shfl_xor((int)cp, off);
-    }
     const uint32_t k0 = blockIdx.x * kOffChunk + (uint32_t)tid * kOffPer;
     int sz[kOffPer];
     uint32_t c, p;
@@ -117,6 +88,41 @@ __global__ __launch_bounds__(256) void component_offsets_kernel(const int32_t* _
     if (lane == 63) {
         s_c[wv] = ic;
         s_p[wv] = ip;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long t = (unsigned long long)tag << 32;
+        const unsigned long long wc = t | (unsigned long long)(s_c[0] + s_c[1] + s_c[2] + s_c[3]);
+        const unsigned long long wp = t | (unsigned long long)(s_p[0] + s_p[1] + s_p[2] + s_p[3]);
+        if (blockIdx.x == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) __hip_atomic_store(&n_large[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&status[0], wc, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&status[1], wp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_store(&status[2u * blockIdx.x], wc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&status[2u * blockIdx.x + 1u], wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // totals of the chunks before this one
+    uint32_t cc = 0, cp = 0;
+    for (uint32_t i = (uint32_t)tid; i < blockIdx.x; i += 256) {
+        unsigned long long wc = 0ull, wp = 0ull;
+        for (uint32_t spins = 0; spins < (1u << 22); ++spins) {
+            wc = __hip_atomic_load(&status[2u * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            wp = __hip_atomic_load(&status[2u * i + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)(wc >> 32) == tag && (uint32_t)(wp >> 32) == tag) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        cc += (uint32_t)wc;
+        cp += (uint32_t)wp;
+    }
+    // (thread 0 of every later workgroup has looked at chunk 0's words: the barrier below puts the whole workgroup's atomics on
+    // n_large behind chunk 0's clearing of it)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        cc += (uint32_t)__shfl_xor((int)cc, off);
+        cp += (uint32_t)__shfl_xor((int)cp, off);
     }
     if (lane == 0) {
         s_cc[wv] = cc;
@@ -631,25 +637,22 @@ __global__ __launch_bounds__(256) void fit_kernel(const uint32_t* __restrict__ p
 
 size_t fit_temp_bytes(size_t max_pixels, uint32_t max_segments) {
     (void)max_segments;
-    // chunk totals of the component scan (8 B per 2048 seeds); seeds <= pixels
-    return (max_pixels / kOffChunk + 2) * sizeof(uint2) + 256;
+    // status words of the component scan (16 B per 2048 seeds; zero when allocated: component_offsets_kernel); seeds <= pixels
+    return (max_pixels / kOffChunk + 2) * 2 * sizeof(unsigned long long) + 256;
 }
 
 int launch_component_offsets(const int32_t* seed_size, const uint32_t* d_n_seeds, uint32_t seed_cap, int min_size,
                              uint32_t* comp_rank, uint32_t* comp_seed, uint32_t* comp_off, uint32_t* totals,
                              uint32_t* large_list, uint32_t large_cap, uint32_t* n_large, void* temp, size_t temp_bytes,
-                             uint32_t* cursor, const HugeSort& hs, hipStream_t s) {
+                             uint32_t frame_tag, uint32_t* cursor, const HugeSort& hs, hipStream_t s) {
     const uint32_t chunks = (seed_cap + kOffChunk - 1) / kOffChunk;
-    if (chunks == 0 || temp_bytes < chunks * sizeof(uint2)) {
+    if (chunks == 0 || temp_bytes < (size_t)chunks * 2 * sizeof(unsigned long long)) {
         set_error("launch_component_offsets: workspace too small");
         return 1;
     }
-    uint2* chunk_tot = static_cast<uint2*>(temp);
-    hipLaunchKernelGGL(component_sums_kernel, dim3(chunks), dim3(256), 0, s, seed_size, d_n_seeds, seed_cap, min_size,
-                       chunk_tot, n_large);
     hipLaunchKernelGGL(component_offsets_kernel, dim3(chunks), dim3(256), 0, s, seed_size, d_n_seeds, seed_cap, min_size,
-                       chunk_tot, comp_rank, comp_seed, comp_off, totals, large_list, large_cap, n_large, cursor, hs.list,
-                       hs.tab ? hs.max : 0u);
+                       static_cast<unsigned long long*>(temp), frame_tag, comp_rank, comp_seed, comp_off, totals, large_list, large_cap,
+                       n_large, cursor, hs.list, hs.tab ? hs.max : 0u);
     LR_HIP(hipGetLastError());
     return 0;
 }

@@ -229,6 +229,7 @@ struct FloodArgs {
     uint32_t log_sweep;                              // test hook: every footprint is worked out by sweeps (flood_rewalk_kernel)
     uint32_t* host_progress;                         // FloodBuffers::host_progress (nullptr: nobody is looking)
     uint32_t* host_ctrl;                             // FloodBuffers::host_ctrl (with host_progress only)
+    uint32_t quiet;                                  // this round goes without the second tier's launch on a frame that has one (flood_enqueue: calm hint)
     uint32_t giant_hold;                             // 1: only the lowest active seed walks on into a slab (see kCtrlLowest)
     uint32_t log_seeds;                              // seeds with per-seed words below (FloodBuffers::log_seeds)
     uint32_t* log_off;                               // first record of the seed's log ...
@@ -313,6 +314,7 @@ enum {
     kCtrlDeferLow = 45,        // lowest survivor that waits for its blocker (FloodArgs::blk): the window ends in front of it
     kCtrlDeferLowNext = 46,    // ... of the next round (survivors pass)
     kCtrlWindowFree = 42,      // the coming round's window before the giants' rule cut it (giant_finish_kernel applies the rule again)
+    kCtrlQuietMiss = 47,       // walks that outgrew the first tier in a round enqueued without the second (FloodArgs::quiet)
     kCtrlWords = 48,
 };
 static_assert(kCtrlWords == kFloodCtrlWords, "control block size");
@@ -1076,6 +1078,17 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
             rc = walk(A, k, b, thr, sn, cs, L, P, st, lane, own, nullptr, hand_over ? t1_tiles : 0xFFFFFFFFu,
                       hand_over ? A.t1_wide_tiles : 0xFFFFFFFFu, hand_over ? A.t1_wide_front : 0xFFFFFFFFu);
     }
+    if (kFirstTier && rc != 0 && A.big_cap == 0u && A.quiet != 0u) {
+        // outgrew the first tier in a round that was enqueued without the second (the last frame never needed it): nothing is
+        // stamped yet, the seed counts as unfinished -- nothing above it commits this round -- and the report says "not calm",
+        // so the rounds that follow bring the second tier
+        if (lane == 0) {
+            A.flags[k] = kFlagIncomplete;
+            atomicMin(&A.ctrl[kCtrlBarrier], k);
+            atomicAdd(&A.ctrl[kCtrlQuietMiss], 1u);
+        }
+        return;
+    }
     if (kFirstTier && rc != 0 && A.big_cap != 0u) {
         // outgrew the first tier: start again in the second (nothing is stamped yet, so nothing to undo)
         uint32_t pos = 0;
@@ -1188,16 +1201,17 @@ __device__ __forceinline__ void explore_seed(const FloodArgs& A, const BinTrig& 
 // One wavefront per workgroup (walks differ in length by three orders of magnitude, and a workgroup keeps its
 // LDS until its longest wave is done), one seed per wavefront.
 //
-// The host knows neither the seed count nor the length of the round's list when it enqueues the round: the grid is
-// its guess (the capacity of the seed sort, halved from round to round as the lists shrink), one entry per workgroup,
-// so that the hardware's dispatcher balances the walks.  If the list turns out longer than the guess, the entries
-// past it are taken by the `rest` launch that follows every main launch (a few workgroups striding over them; it
-// leaves at once otherwise).
+// The host knows neither the seed count nor the length of the round's list when it enqueues a round blindly: the grid is
+// its guess (the capacity of the seed sort; above kFullGridCap seeds halved from round to round as the lists shrink, with the
+// `rest` launch behind every main launch for the entries past the guess), one entry per workgroup, so that the hardware's
+// dispatcher balances the walks.  Rounds enqueued just in time know their list's length and take exactly that grid.
 // (Measured and rejected: a chip-sized grid pulling entries through one atomic counter -- 40 000 same-address atomics
 // serialise in L2, +0.4 ms per frame; one kernel whose workgroups stride over the list -- the loop around the walk
 // costs 137 spilled registers, and the slowest workgroup's eight walks in a row make the first round half again as
-// long; a grid of the full capacity in every round -- an empty workgroup costs the dispatcher 0.4 ns, 0.3 ms per frame
-// that other frames' kernels wait for; a smaller first storage tier (64-record ring, 128-tile table, 4.9 KB) for more
+// long (round 5 tried the loop again for the entries past the grid only: 96 -> 127 registers, four walks a SIMD instead of five,
+// round one 321 -> 342 us, the batch 8 % slower); a grid of the full capacity in every round WHEN EIGHT OR NINE ROUNDS WERE
+// ENQUEUED BLINDLY -- an empty workgroup costs the dispatcher 0.4 ns, 0.3 ms per frame that other frames' kernels wait for
+// (with at most four blind rounds it is the rule now: enqueue_round); a smaller first storage tier (64-record ring, 128-tile table, 4.9 KB) for more
 // walks in flight, handing longer walks to a second kernel -- the tiers' kernels run one after the other, so every
 // round lasts as long as the longest walk of EACH tier: 1.43 -> 2.0 ms per flood.)
 //
@@ -2660,7 +2674,8 @@ __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift, u
     if (host_progress)  // the host enqueues the next round when it sees this one over and seeds left (flood_enqueue)
         flood_report(host_progress, ld_agent(&ctrl[kCtrlRounds]), progress ? n_next : 0u, !progress, progress && want_giant,
                      ld_agent(&ctrl[kCtrlGiantDone]), ld_agent(&ctrl[kCtrlMaxFlood]) != 0u,
-                     window >= n_seeds && ld_agent(&ctrl[kCtrlBigTotal]) == 0u && ld_agent(&ctrl[kCtrlSlabTotal]) == 0u);
+                     window >= n_seeds && ld_agent(&ctrl[kCtrlBigTotal]) == 0u && ld_agent(&ctrl[kCtrlSlabTotal]) == 0u &&
+                         ld_agent(&ctrl[kCtrlQuietMiss]) == 0u);
 }
 
 // (Commit pass and survivors pass in ONE launch -- blocked marks in two alternating buffers, counts and flags written
@@ -2874,6 +2889,7 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
         ctrl[kCtrlLogWalks] = 0u;
         ctrl[kCtrlLogGiveUp] = 0u;
         ctrl[kCtrlSlabTotal] = 0u;
+        ctrl[kCtrlQuietMiss] = 0u;
         ctrl[kCtrlBarrier] = 0xFFFFFFFFu;
         ctrl[kCtrlBarrierNext] = 0xFFFFFFFFu;
         ctrl[kCtrlSlabs] = 0u;
@@ -3503,6 +3519,7 @@ FloodArgs flood_args(const FloodBuffers& B, const FloodFrame& F, bool use_big) {
     A.host_progress = (B.jit_first > 0 && !g_flood_debug) ? B.host_progress : nullptr;
     static const bool mirror_off = std::getenv("LIBRECTIFY_FLOOD_MIRROR") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_MIRROR")) == 0;  // (comparison)
     A.host_ctrl = (A.host_progress && !mirror_off) ? B.host_ctrl : nullptr;
+    A.quiet = 0u;
     A.giant_hold = B.giant_hold ? 1u : 0u;
     A.log_max_len = (B.rewalk_big && use_big) ? (uint32_t)kRewalkTilesBig : (uint32_t)kRewalkTiles;
     A.log_seeds = logs ? B.log_seeds : 0u;
@@ -3529,6 +3546,7 @@ FloodArgs flood_args(const FloodBuffers& B, const FloodFrame& F, bool use_big) {
 // no barrier for entries the successor "will not reach".  (Lists stay long into the late rounds when a window is closed in
 // front of waiting seeds -- the hold-back, the giants' line: a late round that walked only its first grid's worth of an
 // unordered list could leave the lowest active seed unwalked, move nothing, and send the frame to the ordered tail.)
+constexpr uint32_t kFullGridCap = 1u << 18;
 constexpr int kRestRounds = 4;  // rounds 0 .. kRestRounds - 1 always bring their `rest` launch: the rounds a frame may enqueue blindly (context.hip: jit_first_max)
 void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& A0, bool use_big, int index, hipStream_t s,
                    uint32_t known_len = 0xFFFFFFFFu, bool next_known = false) {
@@ -3554,6 +3572,10 @@ void enqueue_round(const FloodBuffers& B, const FloodFrame& F, const FloodArgs& 
     auto grid_of = [&](int idx) {
         const int shift = std::min(std::max(idx - (B.win_first_shift > 0 ? 1 : 0), 0), 2);
         uint32_t g = std::max<uint32_t>(std::min<uint32_t>(F.seed_cap, 2048u), F.seed_cap >> shift);
+        // Round 5: up to kFullGridCap seeds the guess is the whole capacity in every blind round -- 30 000 workgroups that leave
+        // at once cost round two 2.4 us, the `rest` launch they make unnecessary cost three rounds 4.7 us each (and a blind
+        // round's launch waits for room beside the other lanes' walks); the rounds enqueued just in time know their length.
+        if (F.seed_cap <= kFullGridCap) g = F.seed_cap;
         if (test_grid > 0 && idx >= kRestRounds) g = std::min<uint32_t>(g, (uint32_t)test_grid);
         return g;
     };
@@ -3739,7 +3761,22 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
         // over and left seeds, the host's reaction hides behind that last round, at most one round is enqueued in vain:
         // measured the same as none ahead, 0.921 against 0.923 ms over eight 4K frames, blind rounds 0.937)
         const int lead = B.jit_lead;
-        for (int r = 0; r < first; ++r, ++P->enqueued) enqueue_round(B, F, A, P->use_big, P->enqueued, s, 0xFFFFFFFFu, r == first - 1);
+        // The context's last frame never needed the second tier (calm_hint): the rounds enqueued blindly behind the first go
+        // without its launch -- empty on such frames, and in a batch each waits ~50 us for room beside the other lanes' walks.
+        // A walk that outgrows the first tier there counts as unfinished (explore_seed: A.quiet), the report stops saying
+        // "calm", and the rounds enqueued from then on bring the second tier.
+        const bool multi_on0 = B.aux_stream != nullptr && A.wp_min_tiles != 0xFFFFFFFFu;
+        const bool quiet = B.calm_hint && P->use_big && !multi_on0;
+        FloodArgs A_quiet = A;
+        if (quiet) {
+            A_quiet = flood_args(B, F, false);
+            A_quiet.win_shift = A.win_shift;
+            A_quiet.quiet = 1u;
+        }
+        for (int r = 0; r < first; ++r, ++P->enqueued) {
+            const bool q = quiet && r >= 1;
+            enqueue_round(B, F, q ? A_quiet : A, q ? false : P->use_big, P->enqueued, s, 0xFFFFFFFFu, r == first - 1);
+        }
         // Rounds that count on the device (kCtrlRounds) against rounds enqueued that can still count: a round enqueued behind a
         // request for a giant step does nothing, so once a request is seen every round enqueued so far is accounted for.
         int counting = P->enqueued;
@@ -3896,6 +3933,7 @@ int flood_finish(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, u
         tiers_out[12] = h_ctrl[kCtrlGiants];
         tiers_out[13] = h_ctrl[kCtrlGiantDone];
         tiers_out[14] = h_ctrl[kCtrlStaged];
+        tiers_out[15] = h_ctrl[kCtrlQuietMiss];
     }
     return 0;
 }

@@ -44,13 +44,38 @@ __device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t* s_cnt, uint3
     return before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
 
+// pencil model of one segment (line_pencil.cpp:25-32 on the normalised segments): into the table of ALL lines (kept for
+// fit_optimal's "empty set = every line" case) and the identical compacted table of round 0
+__device__ __forceinline__ void pencil_model_of(const LineSegment& l, uint32_t i, float cx, float cy, float sc, const PencilTable& all,
+                                                const PencilTable& round0) {
+    const float x1 = (l.x1 - cx) / sc, y1 = (l.y1 - cy) / sc, x2 = (l.x2 - cx) / sc, y2 = (l.y2 - cy) / sc;
+    // h = unit((x1, y1, 1) x (x2, y2, 1)) (geometry.cpp:64-69); Eigen's normalized() leaves a zero vector alone
+    float hx = y1 * 1.f - 1.f * y2, hy = 1.f * x2 - x1 * 1.f, hz = x1 * y2 - y1 * x2;
+    const float zz = (hx * hx + hy * hy) + hz * hz;
+    if (zz > 0.0f) {
+        const float nn = sqrtf(zz);
+        hx = hx / nn;
+        hy = hy / nn;
+        hz = hz / nn;
+    }
+    const float ax = (x2 + x1) / 2, ay = (y2 + y1) / 2;  // geometry.cpp:72-75
+    const float dx = x2 - x1, dy = y2 - y1;              // geometry.cpp:78-81
+    const float len = sqrtf(dx * dx + dy * dy);
+    const float ux = dx / len, uy = dy / len;
+    all.ax[i] = ax; all.ay[i] = ay; all.dx[i] = ux; all.dy[i] = uy; all.len[i] = len;
+    all.hx[i] = hx; all.hy[i] = hy; all.hz[i] = hz; all.orig[i] = i;
+    round0.ax[i] = ax; round0.ay[i] = ay; round0.dx[i] = ux; round0.dy[i] = uy; round0.len[i] = len;
+    round0.hx[i] = hx; round0.hy[i] = hy; round0.hz[i] = hz; round0.orig[i] = i;
+}
+
 // ---- filter_lines + bounding box ----------------------------------------------------------------------------
 // One workgroup: stable compaction of the fitted segments that are long and straight enough, then the bounding box of
 // what is left (min / max are exact whatever the order).  gctl: see GroupCtl in common.h.
 __global__ __launch_bounds__(kWG) void filter_lines_kernel(const LineSegment* __restrict__ raw,
                                                            const uint32_t* __restrict__ n_raw_ptr, uint32_t raw_cap,
                                                            float min_length, LineSegment* __restrict__ out,
-                                                           uint32_t* __restrict__ gctl, float* __restrict__ gnorm) {
+                                                           uint32_t* __restrict__ gctl, float* __restrict__ gnorm,
+                                                           PencilTable all, PencilTable round0, uint32_t with_model) {
     // (kFlB chunks of kWG segments at a time: their loads are in flight together and the chunks' counts are exchanged behind
     // ONE barrier -- a chunk at a time was a dependent load and two barriers per 1024 segments, 22 us for the 20 000 of a 4K
     // frame in a launch of one workgroup)
@@ -137,7 +162,16 @@ __global__ __launch_bounds__(kWG) void filter_lines_kernel(const LineSegment* __
         gctl[kGcRemaining] = n;
         gctl[kGcRound] = 0u;
         gctl[kGcActive] = n;  // lines in the compacted table of the coming round
+        s_red[0][0] = gnorm[0];
+        s_red[1][0] = gnorm[1];
+        s_red[2][0] = gnorm[2];
     }
+    // Round 5: the pencil model of the kept segments in the same launch (it was one of its own, 5 us behind this one; a frame
+    // keeps one or two thousand segments: a pass or two of the workgroup).
+    if (with_model == 0u) return;
+    __syncthreads();
+    const float cx = s_red[0][0], cy = s_red[1][0], sc = s_red[2][0];
+    for (uint32_t i = threadIdx.x; i < n; i += kWG) pencil_model_of(out[i], i, cx, cy, sc, all, round0);
 }
 
 // Same for lines that are already filtered (the refine path and lr_estimate_line_pencils upload them): bounding box
@@ -195,26 +229,7 @@ __global__ __launch_bounds__(256) void pencil_model_kernel(const LineSegment* __
                                                            PencilTable round0) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= gctl[kGcLines]) return;
-    const LineSegment l = lines[i];
-    const float cx = gnorm[0], cy = gnorm[1], sc = gnorm[2];
-    const float x1 = (l.x1 - cx) / sc, y1 = (l.y1 - cy) / sc, x2 = (l.x2 - cx) / sc, y2 = (l.y2 - cy) / sc;
-    // h = unit((x1, y1, 1) x (x2, y2, 1)) (geometry.cpp:64-69); Eigen's normalized() leaves a zero vector alone
-    float hx = y1 * 1.f - 1.f * y2, hy = 1.f * x2 - x1 * 1.f, hz = x1 * y2 - y1 * x2;
-    const float zz = (hx * hx + hy * hy) + hz * hz;
-    if (zz > 0.0f) {
-        const float nn = sqrtf(zz);
-        hx = hx / nn;
-        hy = hy / nn;
-        hz = hz / nn;
-    }
-    const float ax = (x2 + x1) / 2, ay = (y2 + y1) / 2;  // geometry.cpp:72-75
-    const float dx = x2 - x1, dy = y2 - y1;              // geometry.cpp:78-81
-    const float len = sqrtf(dx * dx + dy * dy);
-    const float ux = dx / len, uy = dy / len;
-    all.ax[i] = ax; all.ay[i] = ay; all.dx[i] = ux; all.dy[i] = uy; all.len[i] = len;
-    all.hx[i] = hx; all.hy[i] = hy; all.hz[i] = hz; all.orig[i] = i;
-    round0.ax[i] = ax; round0.ay[i] = ay; round0.dx[i] = ux; round0.dy[i] = uy; round0.len[i] = len;
-    round0.hx[i] = hx; round0.hy[i] = hy; round0.hz[i] = hz; round0.orig[i] = i;
+    pencil_model_of(lines[i], i, gnorm[0], gnorm[1], gnorm[2], all, round0);
 }
 
 // error of line (ax, ay, dx, dy) against hypothesis p (line_pencil.cpp:131-134, geometry.cpp:214-229)
@@ -287,11 +302,11 @@ __device__ void smallest_eigenvector_3x3(const float c[9], float out[3]) {
 // The kernel is a chain of short dependent phases, so what counts is the number of memory round trips: a thread keeps
 // its line of the first 1024 in registers from the start, and the inliers are staged in LDS for the refit's sums.
 constexpr uint32_t kStage = 2048;
-__global__ __launch_bounds__(kWG) void peel_kernel(PencilTable cur, PencilTable nxt, PencilTable all,
-                                                   unsigned long long* __restrict__ best_slots, uint64_t seed,
-                                                   float tol, float garbage_tol, int max_models,
-                                                   uint32_t* __restrict__ gctl, float4* __restrict__ stage_g,
-                                                   LineSegment* __restrict__ lines, float* __restrict__ models) {
+__device__ __forceinline__ void peel_body(const PencilTable& cur, const PencilTable& nxt, const PencilTable& all,
+                                          unsigned long long* __restrict__ best_slots, uint64_t seed,
+                                          float tol, float garbage_tol, int max_models,
+                                          uint32_t* __restrict__ gctl, float4* __restrict__ stage_g,
+                                          LineSegment* __restrict__ lines, float* __restrict__ models) {
     __shared__ uint32_t s_cnt[kWaves];
     __shared__ float s_bv[kWaves];
     __shared__ int s_bi[kWaves];
@@ -476,11 +491,39 @@ __global__ __launch_bounds__(kWG) void peel_kernel(PencilTable cur, PencilTable 
     }
 }
 
+// The launch: a peeling round, and -- the frame's LAST round only (gather_dst != nullptr) -- the frame's results into the
+// page-locked block the host reads after its one wait (round 5: that was a launch of its own behind the last round).  Layout
+// (context.h kResHeaderBytes = 256): words 0..7 the stage counts, words 8..15 the peeling control block, words 16..55 the
+// refit models, from byte 256 on the grouped lines (as many as there are, up to the block's capacity): only the lines that
+// exist cross the link.  The last round enqueued runs whether the peeling is over by then or not.
+__global__ __launch_bounds__(kWG) void peel_kernel(PencilTable cur, PencilTable nxt, PencilTable all,
+                                                   unsigned long long* __restrict__ best_slots, uint64_t seed,
+                                                   float tol, float garbage_tol, int max_models,
+                                                   uint32_t* __restrict__ gctl, float4* __restrict__ stage_g,
+                                                   LineSegment* __restrict__ lines, float* __restrict__ models,
+                                                   const uint32_t* __restrict__ counts, uint32_t cap_lines,
+                                                   uint32_t* __restrict__ gather_dst) {
+    peel_body(cur, nxt, all, best_slots, seed, tol, garbage_tol, max_models, gctl, stage_g, lines, models);
+    if (gather_dst == nullptr) return;
+    __syncthreads();  // (the round's own stores -- group ids, control words, the refit model -- are visible to the workgroup)
+    const uint32_t t = threadIdx.x;
+    const uint32_t* gw = gctl;
+    if (t < 8) gather_dst[t] = counts[t];
+    else if (t < 16) gather_dst[t] = gw[t - 8];
+    else if (t < 56) gather_dst[t] = reinterpret_cast<const uint32_t*>(models)[t - 16];
+    const uint32_t n = min(gw[kGcLines], cap_lines) * (uint32_t)(sizeof(LineSegment) / 4);
+    const uint32_t* lw = reinterpret_cast<const uint32_t*>(lines);
+    for (uint32_t i = t; i < n; i += kWG) gather_dst[64 + i] = lw[i];
+}
+
 }  // namespace
 
 int launch_filter_lines(const LineSegment* raw, const uint32_t* d_n_raw, uint32_t raw_cap, float min_length,
-                        LineSegment* out, uint32_t* gctl, float* gnorm, hipStream_t s) {
-    hipLaunchKernelGGL(filter_lines_kernel, dim3(1), dim3(kWG), 0, s, raw, d_n_raw, raw_cap, min_length, out, gctl, gnorm);
+                        LineSegment* out, uint32_t* gctl, float* gnorm, const PencilTable* all, const PencilTable* round0,
+                        hipStream_t s) {
+    const bool with_model = all != nullptr && round0 != nullptr;
+    hipLaunchKernelGGL(filter_lines_kernel, dim3(1), dim3(kWG), 0, s, raw, d_n_raw, raw_cap, min_length, out, gctl, gnorm,
+                       with_model ? *all : PencilTable{}, with_model ? *round0 : PencilTable{}, with_model ? 1u : 0u);
     LR_HIP(hipGetLastError());
     return 0;
 }
@@ -501,36 +544,10 @@ int launch_pencil_model(const LineSegment* lines, const uint32_t* gctl, const fl
 
 int launch_peel(PencilTable cur, PencilTable nxt, PencilTable all, unsigned long long* best_slots, uint64_t seed,
                 float tol, float garbage_tol, int max_models, uint32_t* gctl, float* stage4, LineSegment* lines,
-                float* models, hipStream_t s) {
+                float* models, const uint32_t* counts, uint32_t cap_lines, void* gather_block, hipStream_t s) {
     hipLaunchKernelGGL(peel_kernel, dim3(1), dim3(kWG), 0, s, cur, nxt, all, best_slots, seed, tol, garbage_tol,
-                       max_models, gctl, reinterpret_cast<float4*>(stage4), lines, models);
-    LR_HIP(hipGetLastError());
-    return 0;
-}
-
-// ---- a frame's results into the page-locked block the host reads after its one wait -------------------------------------
-// Layout (context.h kResHeaderBytes = 256): words 0..7 the stage counts, words 8..15 the peeling control block, words
-// 16..55 the refit models, from byte 256 on the grouped lines (as many as there are, up to the block's capacity).  One
-// launch instead of four device-to-host copies, and only the lines that exist cross the link.
-namespace {
-__global__ __launch_bounds__(256) void result_gather_kernel(const uint32_t* __restrict__ counts, const uint32_t* __restrict__ gctl,
-                                                            const uint32_t* __restrict__ models,
-                                                            const uint32_t* __restrict__ lines, uint32_t cap_lines,
-                                                            uint32_t* __restrict__ dst) {
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t < 8) dst[t] = counts[t];
-    else if (t < 16) dst[t] = gctl[t - 8];
-    else if (t < 56) dst[t] = models[t - 16];
-    const uint32_t n = min(gctl[kGcLines], cap_lines) * (uint32_t)(sizeof(LineSegment) / 4);
-    for (uint32_t i = t; i < n; i += gridDim.x * 256) dst[64 + i] = lines[i];
-}
-}  // namespace
-
-int launch_result_gather(const uint32_t* counts, const uint32_t* gctl, const float* models, const LineSegment* lines,
-                         uint32_t cap_lines, void* host_block, hipStream_t s) {
-    static_assert(sizeof(LineSegment) % 4 == 0, "LineSegment is copied word by word");
-    hipLaunchKernelGGL(result_gather_kernel, dim3(16), dim3(256), 0, s, counts, gctl, reinterpret_cast<const uint32_t*>(models),
-                       reinterpret_cast<const uint32_t*>(lines), cap_lines, static_cast<uint32_t*>(host_block));
+                       max_models, gctl, reinterpret_cast<float4*>(stage4), lines, models, counts, cap_lines,
+                       static_cast<uint32_t*>(gather_block));
     LR_HIP(hipGetLastError());
     return 0;
 }

@@ -8,6 +8,7 @@
 // which one radix sort delivers.  The candidate lists come per filter tile, so no global
 // atomic counter is touched: per-tile pass counts, one exclusive scan, one ordered write.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -139,11 +140,122 @@ __global__ __launch_bounds__(256) void seed_write_kernel(const uint64_t* __restr
     }
 }
 
+// Round 5: threshold, counts, their scan and the ordered write in ONE launch (the three launches above
+// stay for comparison: LIBRECTIFY_SEED_SELECT_FUSED=0).  At most 256 workgroups, each with a contiguous run of bands:
+//   1. every workgroup reduces all the band maxima itself (as seed_count_kernel does) -> the threshold;
+//   2. a wavefront per band counts the band's candidates above it, the counts stay in LDS; one wavefront scans them;
+//   3. the workgroup PUBLISHES its total as one 64-bit word (frame tag : 32 | total : 32) with a relaxed agent-scope store --
+//      the word is its own payload, so no fence is needed (the fence before a ticket is what made the "last workgroup does
+//      the scan" version of round 4 cost 40 us) -- and adds up the words of the workgroups before it, waiting for each to
+//      carry this frame's tag.  Workgroups are dispatched in index order and none waits for a later one: no deadlock; the
+//      wait is bounded all the same (a stuck frame returns a wrong count rather than hang the device);
+//   4. the bands' candidates above the threshold are written at (total before the workgroup) + (offset of the band).
+// `status` holds at least gridDim.x words, zero when allocated; tags start at 1 and differ from frame to frame.
+constexpr int kSelBands = 2048;  // bands per workgroup, at most (LDS)
+__global__ __launch_bounds__(256) void seed_select_kernel(const uint64_t* __restrict__ cand, const uint32_t* __restrict__ cand_count,
+                                                          const uint32_t* __restrict__ tile_max, int n_tiles, int cand_cap, int per_wg,
+                                                          float keep_ratio, float* __restrict__ maxmag,
+                                                          unsigned long long* __restrict__ status, uint32_t tag,
+                                                          uint64_t* __restrict__ keys, uint32_t cap, uint32_t* __restrict__ n_seeds) {
+    __shared__ uint32_t s_red[4], s_sum[4];
+    __shared__ uint32_t s_cnt[kSelBands];
+    __shared__ uint32_t s_total;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t m = 0;
+    for (int i0 = threadIdx.x; i0 < n_tiles; i0 += 256 * 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k * 256;
+            v[k] = i < n_tiles ? tile_max[i] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m = max(m, v[k]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+    if (lane == 0) s_red[wave] = m;
+    __syncthreads();
+    const float mx = __uint_as_float(max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3])));
+    if (blockIdx.x == 0 && threadIdx.x == 0) *maxmag = mx;
+    const float thr = mx * keep_ratio;
+    const int t0 = (int)blockIdx.x * per_wg, t1 = min(n_tiles, t0 + per_wg);
+    for (int t = t0 + wave; t < t1; t += 4) {
+        const uint32_t n = cand_count[t];
+        const uint64_t* c = cand + (size_t)t * cand_cap;
+        uint32_t cnt = 0;
+        for (uint32_t i = lane; i < n; i += 64) cnt += (__uint_as_float((uint32_t)(c[i] >> 32)) > thr) ? 1u : 0u;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, off);
+        if (lane == 0) s_cnt[t - t0] = cnt;
+    }
+    __syncthreads();
+    const int nb = max(t1 - t0, 0);
+    if (wave == 0) {  // exclusive scan of the bands' counts, 64 at a time; the workgroup's total is published at once
+        uint32_t run = 0;
+        for (int c0 = 0; c0 < nb; c0 += 64) {
+            const uint32_t v = c0 + lane < nb ? s_cnt[c0 + lane] : 0u;
+            uint32_t inc = v;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_up((int)inc, off);
+                if (lane >= off) inc += o;
+            }
+            if (c0 + lane < nb) s_cnt[c0 + lane] = run + inc - v;
+            run += (uint32_t)__shfl((int)inc, 63);
+        }
+        if (lane == 0) {
+            s_total = run;
+            __hip_atomic_store(&status[blockIdx.x], ((unsigned long long)tag << 32) | (unsigned long long)run, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // the totals of the workgroups before this one
+    uint32_t before = 0;
+    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += 256) {
+        unsigned long long w = 0ull;
+        for (uint32_t spins = 0; spins < (1u << 22); ++spins) {
+            w = __hip_atomic_load(&status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)(w >> 32) == tag) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        before += (uint32_t)w;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) before += (uint32_t)__shfl_xor((int)before, off);
+    if (lane == 0) s_sum[wave] = before;
+    __syncthreads();
+    const uint32_t base0 = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_seeds = base0 + s_total;
+    for (int t = t0 + wave; t < t1; t += 4) {
+        const uint32_t n = cand_count[t];
+        const uint64_t* c = cand + (size_t)t * cand_cap;
+        uint32_t base = base0 + s_cnt[t - t0];
+        for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            uint64_t k = 0;
+            bool pass = false;
+            if (i < n) {
+                k = c[i];
+                pass = __uint_as_float((uint32_t)(k >> 32)) > thr;
+            }
+            const uint64_t mm = __ballot(pass);
+            if (pass) {
+                const uint32_t pos = base + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
+                // beyond the sort's capacity: dropped, and the frame is repeated with a larger one (the count says so)
+                if (pos < cap) keys[pos] = ((uint64_t)(~(uint32_t)(k >> 32)) << 32) | (k & 0xFFFFFFFFull);
+            }
+            base += (uint32_t)__popcll(mm);
+        }
+    }
+}
+
 // ---- the seed order: a sort of our own for every frame size ---------------------------------------------------------------
 // The keys are unique (they end in the pixel index), so a key's place in the order is the number of smaller keys, and
 // counting needs no exchange of data between workgroups:
-//   1. every workgroup of 256 threads sorts a RUN of 1024 keys in LDS (bitonic; slots past the seed count read as the
-//      largest key) -- 40 workgroups for the 40 000 seeds of a 4K frame (round 3: ten workgroups of 4096 keys, 33 us);
+//   1. every workgroup of 512 threads sorts a RUN of 2048 keys in LDS (bitonic; slots past the seed count read as the
+//      largest key) -- 20 workgroups for the 40 000 seeds of a 4K frame (round 3: ten workgroups of 4096 keys, 33 us; round 4:
+//      runs of 1024 keys and a merge round more);
 //   2. while there are more than kFinalRuns runs: a merge round -- every key looks up its rank in the neighbouring run of
 //      its pair and writes itself at (own index + that rank) of the merged run, twice as long (keys_a <-> keys_b);
 //   3. every key counts the smaller keys of ALL other runs (branch-free lower bounds, eight runs side by side so that
@@ -153,7 +265,8 @@ __global__ __launch_bounds__(256) void seed_write_kernel(const uint64_t* __restr
 // round 3 still used above 131 072 keys (nine launches with its pad and set-up kernels), is gone from the path.
 // The host knows only the CAPACITY the frame runs with (`cap`); the seed count n stays on the device: grids cover the
 // capacity, and everything past n is skipped by count, never by a padding value in memory.
-constexpr uint32_t kRun0 = 1024;      // keys per sorted run of step 1
+constexpr uint32_t kRun0 = 2048;      // keys per sorted run of step 1 (round 5: 2048 by 512 threads -- a merge round less for a 4K frame, 19 us instead of 15 + 5 and a launch)
+constexpr uint32_t kRunThreads = kRun0 / 4;
 constexpr uint32_t kFinalRuns = 16;   // step 3 takes over when the capacity is this many runs or fewer (its cost grows with their number)
 
 __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int lane_mask) {
@@ -161,10 +274,10 @@ __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int lane_mask) {
     const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), lane_mask);
     return ((uint64_t)hi << 32) | lo;
 }
-// Bitonic sort of 1024 keys by 256 threads, four consecutive keys per thread: a compare-exchange at distance 1 or 2 is
-// inside a thread, at distance 4..128 inside a wavefront (shuffles, no barrier), and only the three steps at distance
-// >= 256 go through LDS with a barrier.
-__global__ __launch_bounds__(256) void seed_run_sort_kernel(uint64_t* __restrict__ keys, uint32_t cap,
+// Bitonic sort of kRun0 keys by kRun0 / 4 threads, four consecutive keys per thread: a compare-exchange at distance 1 or 2 is
+// inside a thread, at distance 4..128 inside a wavefront (shuffles, no barrier), and only the steps at distance
+// >= 256 (six of the 66 for 2048 keys) go through LDS with a barrier.
+__global__ __launch_bounds__(kRunThreads) void seed_run_sort_kernel(uint64_t* __restrict__ keys, uint32_t cap,
                                                             const uint32_t* __restrict__ n_ptr) {
     __shared__ uint64_t sk[kRun0];
     const uint32_t n = min(*n_ptr, cap);
@@ -295,7 +408,7 @@ int launch_seed_order(uint64_t* keys, uint64_t* keys_alt, const uint32_t* n_seed
                       BinTrig trig, float trace_tolerance, int32_t* seed_idx, int32_t* seed_bin, float* seed_thr, hipStream_t s) {
     if (cap == 0) return 0;
     const uint32_t runs0 = (cap + kRun0 - 1) / kRun0;
-    hipLaunchKernelGGL(seed_run_sort_kernel, dim3(runs0), dim3(256), 0, s, keys, cap, n_seeds);
+    hipLaunchKernelGGL(seed_run_sort_kernel, dim3(runs0), dim3(kRunThreads), 0, s, keys, cap, n_seeds);
     uint32_t L = kRun0, runs = runs0;
     uint64_t* cur = keys;
     uint64_t* nxt = keys_alt;
@@ -323,7 +436,22 @@ size_t seeds_temp_bytes(int n_tiles, size_t max_seeds) {
 
 int launch_seed_select(const uint64_t* cand, const uint32_t* cand_count, const uint32_t* tile_max, int n_tiles,
                        int cand_cap, float seed_keep_ratio, float* maxmag, uint32_t* tile_pass, uint32_t* tile_off, uint64_t* keys,
-                       uint32_t key_cap, uint32_t* n_seeds, hipStream_t s) {
+                       uint32_t key_cap, uint32_t* n_seeds, uint32_t frame_tag, hipStream_t s) {
+    static const bool fused = !(std::getenv("LIBRECTIFY_SEED_SELECT_FUSED") && std::atoi(std::getenv("LIBRECTIFY_SEED_SELECT_FUSED")) == 0);
+    // (the status words are tile_off's: n_tiles words, zero when allocated -- two words a workgroup, at most n_tiles / 4 workgroups)
+    if (fused && frame_tag != 0u && n_tiles > 0) {
+        int wgs = std::min(256, (n_tiles + 3) / 4);
+        int per_wg = (n_tiles + wgs - 1) / wgs;
+        if (per_wg > kSelBands) {
+            per_wg = kSelBands;
+            wgs = (n_tiles + per_wg - 1) / per_wg;
+        }
+        wgs = (n_tiles + per_wg - 1) / per_wg;  // (no workgroup without a band: the last one writes the count)
+        hipLaunchKernelGGL(seed_select_kernel, dim3(wgs), dim3(256), 0, s, cand, cand_count, tile_max, n_tiles, cand_cap, per_wg,
+                           seed_keep_ratio, maxmag, reinterpret_cast<unsigned long long*>(tile_off), frame_tag, keys, key_cap, n_seeds);
+        LR_HIP(hipGetLastError());
+        return 0;
+    }
     const int blocks = (n_tiles + 3) / 4;
     hipLaunchKernelGGL(seed_count_kernel, dim3(blocks), dim3(256), 0, s, cand, cand_count, tile_max, n_tiles, cand_cap,
                        seed_keep_ratio, maxmag, tile_pass);

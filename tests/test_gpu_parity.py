@@ -439,6 +439,34 @@ def test_giant_steps_label_what_the_slab_walk_and_the_oracle_label(L, ctx):
     assert used[("radial", False, True)]["giant_steps"] == 0 and used[("radial", False, True)]["slabs"] > 0, used[("radial", False, True)]
 
 
+def test_rounds_without_the_second_tier_after_a_calm_frame(L, ctx):
+    """Round 5: when the context's last frame kept every walk in the first storage tier, the rounds enqueued blindly behind
+    the first go without the second tier's launch; a walk that outgrows the first tier there counts as unfinished and the
+    rounds enqueued from then on bring the second tier.  A frame of bars (calm) followed by soft blobs, long bars and the
+    doc image on the same context: label image and records against the oracle, the counter proves the path ran."""
+    from librectify_amd import synth
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "doc_image_gray.npy")).astype(np.float32) / np.float32(256.0)
+    calm = synth.frame(960, 540, 4, bars=40)
+    others = (synth.region_frame(1280, 720, 500), synth.long_bar_frame(1280, 720, 5, K=20), np.ascontiguousarray(g))
+    ref_calm = O.find_line_segments(calm)
+    misses = 0
+    for img in others:
+        ref = O.find_line_segments(img, num_threads=8)
+        for frame, r in ((calm, ref_calm), (img, ref), (img, ref)):
+            ctx.stage_filter_host(frame)
+            ctx.stage_seeds()
+            ctx.stage_flood()
+            c = ctx.stage_counters()
+            np.testing.assert_array_equal(ctx.download(L.BUF_LABEL), r["label"])
+            _assert_lines_equal(ctx.stage_fit(), r["lines"])
+            if frame is calm:
+                assert c["second_tier_seeds"] == 0 and c["quiet_round_misses"] == 0, c
+            else:
+                misses += c["quiet_round_misses"]
+    assert misses > 0, misses
+
+
 def test_seed_capacity_beyond_four_million_keys(L):
     """the seed order's merge loop never ended once the capacity exceeded 2^22 keys (with one run left its
     second condition stayed true, the host enqueued merges for ever).  Stripes of period 6 at 4K: every pixel of a flank a
