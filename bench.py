@@ -431,8 +431,14 @@ def worst_case_rates(L, ctx, with_cpu=True):
               "regions_4k": synth.region_frame(W4K, H4K, 500), "regions_1080": synth.region_frame(1920, 1080, 500), "radial_gradient_1080": radial}
     out = {}
     ctx.set_stage_timing(True)
+    prev_shape = None
     for name, img in frames.items():
         h, w = img.shape
+        # (a context that has worked on 4K frames shrinks its workspace by itself at the eighth frame of a quarter the size --
+        # 20 ms of reallocation that would land inside one timed call of the 1080p frames: shrink explicitly where the size changes)
+        if prev_shape is not None and (h, w) != prev_shape:
+            ctx.trim()
+        prev_shape = (h, w)
         wall, flood, transform = [], [], []
         for rep in range(4):
             t0 = time.perf_counter()

@@ -164,6 +164,7 @@ struct lr_context {
     bool flood_logbig_hint = true;  // did the last frame have walks in the second tier? (their logs need a launch of their own per round: kernels_flood.hip, flood_rewalk_kernel)
     bool flood_big_hint = true;  // did the last frame's walks outgrow the first storage tier? (none yet: assume so)
     bool flood_hold_hint = false;  // did the last frame hold its weakest seeds back?
+    int flood_staged_streak = 0;     // frames in a row that started staged (every sixteenth starts without the hint)
     bool flood_staged_hint = false;  // was the last frame one of overlapping giants (kernels_flood.hip: kCtrlStaged)?  Then this one starts on its strongest quarter
     bool flood_calm_hint = false;      // the last frame's walks all stayed in the first storage tier (FloodBuffers::calm_hint)
     uint32_t flood_tiers[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // last flood: seeds in the second tier, slabs used, seeds of the ordered tail, hold-back, walked px (lo, hi), steps (lo, hi), walks beyond the first tier's table, multi-source re-walks, re-walks from logs, logs given up, giants held back

@@ -165,6 +165,8 @@ int ctx_trim(lr_context* c, bool frames_too) {
     c->small_frames = 0;
     c->w = c->h = 0;
     c->seed_cap = 0;
+    c->flood_hold_hint = c->flood_staged_hint = c->flood_calm_hint = false;  // (what the frames before taught the context goes with the workspace)
+    c->flood_staged_streak = 0;
     for (bool& v : c->stage_valid) v = false;
     // (the lanes of a batch call are contexts of their own that shrink by themselves; a lane that shrinks in the middle of a
     // call must not touch the others, which are in the middle of their frames -- only a trim on request goes through them)
@@ -176,6 +178,15 @@ int ctx_trim(lr_context* c, bool frames_too) {
 
 int ctx_ensure_image_capacity(lr_context* c, int w, int h) {
     const size_t npix = (size_t)w * h;
+    // What a context hands from frame to frame describes the previous frame of the SAME stream: a frame of another size is the
+    // start of another one (bench.py's content-latency frames: the 1080p soft blobs inherited "staged" from the 4K ones and
+    // kept it -- 17 ms a frame instead of 13.7).
+    if (c->w != 0 && (c->w != w || c->h != h)) {
+        c->flood_hold_hint = false;
+        c->flood_staged_hint = false;
+        c->flood_calm_hint = false;
+        c->flood_staged_streak = 0;
+    }
     const FilterGeom fg = filter_geometry(w, h);
     const int ntiles = fg.n_tiles;
     // A context that has seen one large frame keeps serving small ones out of the large workspace (an 8192 x 8192 call leaves
@@ -1023,6 +1034,14 @@ int finish_flood(lr_context* c, bool* extra) {
         // keeps the giants away, so their count says nothing any more).
         static const int staged_keep = std::getenv("LIBRECTIFY_FLOOD_STAGED_KEEP") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_STAGED_KEEP")) : 64;
         c->flood_staged_hint = c->flood_tiers[14] != 0 && (!c->flood_staged_hint || (int)c->flood_tiers[0] >= staged_keep);
+        // (a frame that started staged cannot tell whether it would have gone staged by itself: every sixteenth frame of such
+        // a run starts without the hint and finds out -- a ramp under noise pays 1.6 ms for that frame, soft blobs that
+        // inherited the hint from other content are rid of it)
+        c->flood_staged_streak = c->flood_staged_hint ? c->flood_staged_streak + 1 : 0;
+        if (c->flood_staged_streak >= 16) {
+            c->flood_staged_hint = false;
+            c->flood_staged_streak = 0;
+        }
         if (c->flood_staged_hint) c->flood_hold_hint = false;
         // (The verdict "many long walks" -- early hand-over to the second tier, flood_advance -- is NOT carried over: started
         // with it, the natural 4K frame sends 735 walks to the second tier in round one and its flood takes 1.88 ms instead
