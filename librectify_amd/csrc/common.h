@@ -262,7 +262,8 @@ int launch_component_sort(const uint32_t* px_in, uint32_t* px_out, const uint32_
                           uint32_t* scratch, const uint32_t* cursor, const HugeSort& hs, bool with_huge, hipStream_t s);
 int launch_fit(const uint32_t* px_sorted, const uint32_t* px_unsorted, const uint32_t* comp_off, const uint32_t* comp_seed, const uint32_t* d_n_comp,
                uint32_t comp_cap, const int32_t* seed_bin, const float* dx, const float* dy, int w, BinTrig trig,
-               float* scratch_w, LineSegment* out, hipStream_t s);
+               float* scratch_w, LineSegment* out, const uint32_t* cursor, const HugeSort& hs, const uint32_t* n_large, bool with_huge,
+               hipStream_t s);
 
 // kernels_ransac.hip
 struct PencilSoA {  // device pointers, n entries each (lines of the current round, compacted)

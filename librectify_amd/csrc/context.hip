@@ -1088,7 +1088,7 @@ int enqueue_fit(lr_context* c) {
         for (uint32_t j = 0; j < nj; ++j) std::fprintf(stderr, "   bucket job %u: start %u, %u px, table word %u\n", j, jobs[4 * j], jobs[4 * j + 1], jobs[4 * j + 2]);
     }
     if (launch_fit(c->px_b, c->px_a, c->comp_off, c->comp_seed, c->d_counts + kCntComp, comp_cap, c->seed_bin, c->dx, c->dy, c->w,
-                   c->trig, c->scratch_w, c->d_lines, c->stream))
+                   c->trig, c->scratch_w, c->d_lines, c->cursor, c->huge, c->d_counts + kCntLarge, with_huge, c->stream))
         return 1;
     if (c->timing_on) LR_HIP(hipEventRecord(c->ev[4], c->stream));
     return 0;

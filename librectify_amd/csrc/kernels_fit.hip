@@ -430,92 +430,15 @@ __global__ __launch_bounds__(1024) void huge_sort_kernel(const uint32_t* __restr
     }
 }
 
-__global__ __launch_bounds__(256) void fit_kernel(const uint32_t* __restrict__ px, const uint32_t* __restrict__ px_unsorted,
-                                                  const uint32_t* __restrict__ comp_off,
-                                                  const uint32_t* __restrict__ comp_seed, const uint32_t* __restrict__ n_comp_ptr,
-                                                  const int32_t* __restrict__ seed_bin, const float* __restrict__ dx,
-                                                  const float* __restrict__ dy, int w, BinTrig trig,
-                                                  float* __restrict__ scratch_w, LineSegment* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t comp = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (comp >= *n_comp_ptr) return;
-    const uint32_t off = comp_off[comp];
-    const uint32_t n = comp_off[comp + 1] - off;
-    const int b = seed_bin[comp_seed[comp]];
-    const float s = trig.st[b], c = trig.ct[b];
-    const uint32_t uw = (uint32_t)w;
-
-    if (n <= 64u) {
-        // A component of up to 64 pixels is one pixel per lane: everything after the first (dependent) loads stays in
-        // registers -- the general form below reads the pixel list and the weights back from memory in each of its four
-        // passes, a round trip each.  Same operations in the same order (the lane-strided sums have one term each: 0 + x),
-        // so the same bits.  Most components are this small (4K bench frame: 19 000 of 20 500; natural frame: 46 000 of 47 400).
-        const bool has = (uint32_t)lane < n;
-        // the list in ascending pixel order (the order of the reference's component lists, which the sums follow): lane
-        // `rank` gets this lane's key
-        const uint32_t key = has ? px_unsorted[off + lane] : 0xFFFFFFFFu;
-        uint32_t rank = 0;
-#pragma unroll
-        for (int j = 0; j < 64; ++j) rank += ((uint32_t)__builtin_amdgcn_readlane((int)key, j) < key) ? 1u : 0u;
-        // (the padding keys are equal and all rank n: they collide on lane n or beyond, which no sum reads)
-        const uint32_t p_sorted = (uint32_t)__builtin_amdgcn_ds_permute((int)(min(rank, 63u) << 2), (int)key);
-        const uint32_t p = has ? p_sorted : 0u;
-        float wv = 0.f;
-        if (has) wv = directional(dx[p], dy[p], s, c);
-        float acc = 0.f;
-        if (has) acc = acc + wv;
-        const float S = wave_tree(acc);
-        const float r = (float)(p / uw), cq = (float)(p % uw);
-        const float wn = wv / S;
-        float ar = 0.f, ac = 0.f;
-        if (has) {
-            ar = ar + wn * r;
-            ac = ac + wn * cq;
-        }
-        const float a_r = wave_tree(ar), a_c = wave_tree(ac);
-        const float cr = r - a_r, cc = cq - a_c;
-        float crr = 0.f, crc = 0.f, ccc = 0.f;
-        if (has) {
-            const float t = cr * wn, u = cc * wn;
-            crr = crr + t * cr;
-            crc = crc + t * cc;
-            ccc = ccc + u * cc;
-        }
-        const float cov_rr = wave_tree(crr), cov_rc = wave_tree(crc), cov_cc = wave_tree(ccc);
-        float d_r, d_c;
-        major_axis_2x2(cov_rr, cov_rc, cov_cc, d_r, d_c);
-        const float n_r = -d_c, n_c = d_r;
-        float t0 = INFINITY, t1 = -INFINITY, es = 0.f;
-        if (has) {
-            const float t = cr * d_r + cc * d_c;
-            t0 = fminf(t0, t);
-            t1 = fmaxf(t1, t);
-            es = es + fabsf(cr * n_r + cc * n_c);
-        }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            t0 = fminf(t0, __shfl_xor(t0, o));
-            t1 = fmaxf(t1, __shfl_xor(t1, o));
-        }
-        const float esum = wave_tree(es);
-        if (lane == 0) {
-            LineSegment l;
-            l.x1 = a_c + d_c * t0;
-            l.y1 = a_r + d_r * t0;
-            l.x2 = a_c + d_c * t1;
-            l.y2 = a_r + d_r * t1;
-            l.weight = S / (float)n;
-            l.err = esum / (float)n;
-            l.group_id = -1;
-            out[comp] = l;
-        }
-        return;
-    }
-
-    // Larger components: a lane takes the pixels lane, lane + 64, ... IN THAT ORDER (the canonical order of the sums), kU of them
-    // in flight at a time: the pixel list first, then the gathers it points to -- one round trip per kU pixels instead of one per
-    // pixel (the longest component of a frame is what this launch lasts: 3 700 px = 58 steps a pass on the 4K bench frame).
-    constexpr int kU = 8;
+// Components of more than 64 pixels: a lane takes the pixels lane, lane + 64, ... IN THAT ORDER (the canonical order of the
+// sums), kU of them in flight at a time: the pixel list first, then the gathers it points to -- one round trip per kU pixels
+// instead of one per pixel.  The launch lasts as long as its longest component: 3 700 px = 58 steps a pass at kU = 8 on the
+// 4K bench frame; a region of 141 000 px was 276 steps a pass, 1.25 ms of a 13 ms frame -- components beyond 2^14 pixels go
+// through fit_huge_kernel with kU = 32 (same order, same bits).
+template <int kU>
+__device__ __forceinline__ void fit_large(const uint32_t* __restrict__ px, uint32_t comp, uint32_t off, uint32_t n, float s, float c,
+                                          uint32_t uw, const float* __restrict__ dx, const float* __restrict__ dy,
+                                          float* __restrict__ scratch_w, LineSegment* __restrict__ out, int lane) {
     float acc = 0.f;
     for (uint32_t i0 = lane; i0 < n; i0 += 64u * kU) {
         uint32_t p[kU];
@@ -633,6 +556,109 @@ __global__ __launch_bounds__(256) void fit_kernel(const uint32_t* __restrict__ p
     }
 }
 
+__global__ __launch_bounds__(256) void fit_kernel(const uint32_t* __restrict__ px, const uint32_t* __restrict__ px_unsorted,
+                                                  const uint32_t* __restrict__ comp_off,
+                                                  const uint32_t* __restrict__ comp_seed, const uint32_t* __restrict__ n_comp_ptr,
+                                                  const int32_t* __restrict__ seed_bin, const float* __restrict__ dx,
+                                                  const float* __restrict__ dy, int w, BinTrig trig,
+                                                  float* __restrict__ scratch_w, LineSegment* __restrict__ out,
+                                                  const uint32_t* __restrict__ huge_cursor) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t comp = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (comp >= *n_comp_ptr) return;
+    const uint32_t off = comp_off[comp];
+    const uint32_t n = comp_off[comp + 1] - off;
+    const int b = seed_bin[comp_seed[comp]];
+    const float s = trig.st[b], c = trig.ct[b];
+    const uint32_t uw = (uint32_t)w;
+
+    if (n <= 64u) {
+        // A component of up to 64 pixels is one pixel per lane: everything after the first (dependent) loads stays in
+        // registers -- the general form below reads the pixel list and the weights back from memory in each of its four
+        // passes, a round trip each.  Same operations in the same order (the lane-strided sums have one term each: 0 + x),
+        // so the same bits.  Most components are this small (4K bench frame: 19 000 of 20 500; natural frame: 46 000 of 47 400).
+        const bool has = (uint32_t)lane < n;
+        // the list in ascending pixel order (the order of the reference's component lists, which the sums follow): lane
+        // `rank` gets this lane's key
+        const uint32_t key = has ? px_unsorted[off + lane] : 0xFFFFFFFFu;
+        uint32_t rank = 0;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) rank += ((uint32_t)__builtin_amdgcn_readlane((int)key, j) < key) ? 1u : 0u;
+        // (the padding keys are equal and all rank n: they collide on lane n or beyond, which no sum reads)
+        const uint32_t p_sorted = (uint32_t)__builtin_amdgcn_ds_permute((int)(min(rank, 63u) << 2), (int)key);
+        const uint32_t p = has ? p_sorted : 0u;
+        float wv = 0.f;
+        if (has) wv = directional(dx[p], dy[p], s, c);
+        float acc = 0.f;
+        if (has) acc = acc + wv;
+        const float S = wave_tree(acc);
+        const float r = (float)(p / uw), cq = (float)(p % uw);
+        const float wn = wv / S;
+        float ar = 0.f, ac = 0.f;
+        if (has) {
+            ar = ar + wn * r;
+            ac = ac + wn * cq;
+        }
+        const float a_r = wave_tree(ar), a_c = wave_tree(ac);
+        const float cr = r - a_r, cc = cq - a_c;
+        float crr = 0.f, crc = 0.f, ccc = 0.f;
+        if (has) {
+            const float t = cr * wn, u = cc * wn;
+            crr = crr + t * cr;
+            crc = crc + t * cc;
+            ccc = ccc + u * cc;
+        }
+        const float cov_rr = wave_tree(crr), cov_rc = wave_tree(crc), cov_cc = wave_tree(ccc);
+        float d_r, d_c;
+        major_axis_2x2(cov_rr, cov_rc, cov_cc, d_r, d_c);
+        const float n_r = -d_c, n_c = d_r;
+        float t0 = INFINITY, t1 = -INFINITY, es = 0.f;
+        if (has) {
+            const float t = cr * d_r + cc * d_c;
+            t0 = fminf(t0, t);
+            t1 = fmaxf(t1, t);
+            es = es + fabsf(cr * n_r + cc * n_c);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            t0 = fminf(t0, __shfl_xor(t0, o));
+            t1 = fmaxf(t1, __shfl_xor(t1, o));
+        }
+        const float esum = wave_tree(es);
+        if (lane == 0) {
+            LineSegment l;
+            l.x1 = a_c + d_c * t0;
+            l.y1 = a_r + d_r * t0;
+            l.x2 = a_c + d_c * t1;
+            l.y2 = a_r + d_r * t1;
+            l.weight = S / (float)n;
+            l.err = esum / (float)n;
+            l.group_id = -1;
+            out[comp] = l;
+        }
+        return;
+    }
+
+    // (a component on the list of the huge ones -- its cursor word is its flagged number there -- is fit_huge_kernel's)
+    if (huge_cursor != nullptr && n > kSortLdsBig && (huge_cursor[comp] & kHugeFlag) != 0u) return;
+    fit_large<8>(px, comp, off, n, s, c, uw, dx, dy, scratch_w, out, lane);
+}
+
+// The components of more than 2^14 pixels (the list the offsets pass made of them), a wavefront each, 32 pixels a lane in flight.
+__global__ __launch_bounds__(64) void fit_huge_kernel(const uint32_t* __restrict__ px, const uint32_t* __restrict__ comp_off,
+                                                      const uint32_t* __restrict__ comp_seed, const uint32_t* __restrict__ huge_list,
+                                                      const uint32_t* __restrict__ n_large, uint32_t huge_max,
+                                                      const int32_t* __restrict__ seed_bin, const float* __restrict__ dx,
+                                                      const float* __restrict__ dy, int w, BinTrig trig,
+                                                      float* __restrict__ scratch_w, LineSegment* __restrict__ out) {
+    if (blockIdx.x >= min(n_large[2], huge_max)) return;
+    const uint32_t comp = huge_list[blockIdx.x];
+    const uint32_t off = comp_off[comp];
+    const uint32_t n = comp_off[comp + 1] - off;
+    const int b = seed_bin[comp_seed[comp]];
+    fit_large<32>(px, comp, off, n, trig.st[b], trig.ct[b], (uint32_t)w, dx, dy, scratch_w, out, (int)threadIdx.x);
+}
+
 }  // namespace
 
 size_t fit_temp_bytes(size_t max_pixels, uint32_t max_segments) {
@@ -693,10 +719,15 @@ int launch_component_sort(const uint32_t* px_in, uint32_t* px_out, const uint32_
 
 int launch_fit(const uint32_t* px_sorted, const uint32_t* px_unsorted, const uint32_t* comp_off, const uint32_t* comp_seed, const uint32_t* d_n_comp,
                uint32_t comp_cap, const int32_t* seed_bin, const float* dx, const float* dy, int w, BinTrig trig,
-               float* scratch_w, LineSegment* out, hipStream_t s) {
+               float* scratch_w, LineSegment* out, const uint32_t* cursor, const HugeSort& hs, const uint32_t* n_large, bool with_huge,
+               hipStream_t s) {
     if (comp_cap == 0) return 0;
+    const bool huge = with_huge && hs.tab != nullptr && hs.max != 0u;
+    if (huge)  // (first: the launch lasts as long as its largest component, the small ones' launch runs behind it)
+        hipLaunchKernelGGL(fit_huge_kernel, dim3(hs.max), dim3(64), 0, s, px_sorted, comp_off, comp_seed, hs.list, n_large, hs.max, seed_bin,
+                           dx, dy, w, trig, scratch_w, out);
     hipLaunchKernelGGL(fit_kernel, dim3((comp_cap + 3) / 4), dim3(256), 0, s, px_sorted, px_unsorted, comp_off, comp_seed, d_n_comp,
-                       seed_bin, dx, dy, w, trig, scratch_w, out);
+                       seed_bin, dx, dy, w, trig, scratch_w, out, huge ? cursor : nullptr);
     LR_HIP(hipGetLastError());
     return 0;
 }

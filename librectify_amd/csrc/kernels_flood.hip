@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <sys/prctl.h>
 #include <vector>
 
 #include "common.h"
@@ -3786,13 +3787,36 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
         const auto t0 = std::chrono::steady_clock::now();
         int spins = 0;
         // (a single call spins -- its flood is a millisecond -- but not for ever: content that takes the flood tens of
-        // milliseconds should not cost the caller a core; after two milliseconds it looks every 20 us like the lanes of a batch)
-        bool slow = false;
+        // milliseconds should not cost the caller a core.  After two milliseconds it yields between looks, after twenty it
+        // sleeps 20 us between them like the lanes of a batch.  A sleep of 20 us lasts 70 with the default timer slack of
+        // 50 us -- measured as 45-77 us of idle stream between the rounds of a slow frame, eighteen times on a frame of soft
+        // blobs -- so the thread's slack is a microsecond while it watches and what it was afterwards.)
+        bool slow = false, very_slow = false;
+        const int slack_before = (B.jit_sleep_us > 0) ? prctl(PR_GET_TIMERSLACK) : -1;
+        int slack_set = -1;
+        auto short_slack = [&]() {
+            if (slack_set >= 0) return;
+            slack_set = slack_before >= 0 ? slack_before : prctl(PR_GET_TIMERSLACK);
+            if (slack_set > 1000) (void)prctl(PR_SET_TIMERSLACK, 1000UL);
+            else slack_set = -2;  // (short already, or not to be had: nothing to restore)
+        };
+        if (B.jit_sleep_us > 0) short_slack();
+        struct SlackRestore {
+            int* v;
+            ~SlackRestore() {
+                if (*v > 1000) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)*v);
+            }
+        } slack_restore{&slack_set};
         auto deadline_passed = [&]() {
-            if (B.jit_sleep_us > 0 || slow) std::this_thread::sleep_for(std::chrono::microseconds(B.jit_sleep_us > 0 ? B.jit_sleep_us : 20));
+            if (B.jit_sleep_us > 0 || very_slow) std::this_thread::sleep_for(std::chrono::microseconds(B.jit_sleep_us > 0 ? B.jit_sleep_us : 20));
+            else if (slow) std::this_thread::yield();
             if ((++spins & ((B.jit_sleep_us > 0 || slow) ? 15 : 1023)) != 0) return false;
             const auto dt = std::chrono::steady_clock::now() - t0;
             if (dt > std::chrono::milliseconds(2)) slow = true;
+            if (dt > std::chrono::milliseconds(20) && !very_slow) {
+                very_slow = true;
+                short_slack();
+            }
             return dt > std::chrono::seconds(1);
         };
         for (;;) {

@@ -447,11 +447,12 @@ def test_rounds_without_the_second_tier_after_a_calm_frame(L, ctx):
     from librectify_amd import synth
 
     g = np.load(os.path.join(ROOT, "tests", "golden", "doc_image_gray.npy")).astype(np.float32) / np.float32(256.0)
-    calm = synth.frame(960, 540, 4, bars=40)
     others = (synth.region_frame(1280, 720, 500), synth.long_bar_frame(1280, 720, 5, K=20), np.ascontiguousarray(g))
-    ref_calm = O.find_line_segments(calm)
     misses = 0
     for img in others:
+        # (a calm frame of the SAME size: what a context learned goes with the stream, and a frame of another size starts a new one)
+        calm = synth.frame(img.shape[1], img.shape[0], 4, bars=40)
+        ref_calm = O.find_line_segments(calm)
         ref = O.find_line_segments(img, num_threads=8)
         for frame, r in ((calm, ref_calm), (img, ref), (img, ref)):
             ctx.stage_filter_host(frame)
