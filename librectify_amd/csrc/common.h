@@ -224,7 +224,7 @@ struct FloodProgress {
     bool sizes_known = false;
     uint32_t max_flood = 0;
 };
-constexpr int kFloodCtrlWords = 48;
+constexpr int kFloodCtrlWords = 56;
 // Enqueues the initialisation and a first batch of rounds, then an asynchronous copy of the control block into
 // h_ctrl (kFloodCtrlWords words of pinned host memory).  Never synchronises (except in LIBRECTIFY_FLOOD_DEBUG mode).
 int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, uint32_t* h_ctrl, hipStream_t s);

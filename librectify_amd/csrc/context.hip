@@ -909,7 +909,8 @@ FloodBuffers flood_buffers_for(lr_context* c) {
     fbuf.blind_rounds = c->flood_rounds_hint;
     // rounds just in time (FloodBuffers::host_progress): what the last frame needed less one at once (three on a new context)
     static const bool jit_off = std::getenv("LIBRECTIFY_FLOOD_JIT") && std::atoi(std::getenv("LIBRECTIFY_FLOOD_JIT")) == 0;
-    fbuf.host_progress = c->h_counts + 72;  // (the control block's copy ends at + 64)
+    static_assert(16 + kFloodCtrlWords <= 72, "the control block's copy ends where the report word begins");
+    fbuf.host_progress = c->h_counts + 72;
     fbuf.host_ctrl = c->h_counts + 16;
     // (LIBRECTIFY_FLOOD_CALM_HINT=0: every blind round brings the second tier's launch, as until round 5)
     static const int calm_hint_env = std::getenv("LIBRECTIFY_FLOOD_CALM_HINT") ? std::atoi(std::getenv("LIBRECTIFY_FLOOD_CALM_HINT")) : 1;

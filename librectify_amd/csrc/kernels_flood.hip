@@ -316,7 +316,9 @@ enum {
     kCtrlDeferLowNext = 46,    // ... of the next round (survivors pass)
     kCtrlWindowFree = 42,      // the coming round's window before the giants' rule cut it (giant_finish_kernel applies the rule again)
     kCtrlQuietMiss = 47,       // walks that outgrew the first tier in a round enqueued without the second (FloodArgs::quiet)
-    kCtrlWords = 48,
+    kCtrlTeamDone = 48,        // second-tier walks of this frame's first round that are over, held ones included ...
+    kCtrlTeamGiants = 49,      // ... and how many of them were held back as giants (giants_all)
+    kCtrlWords = 56,
 };
 static_assert(kCtrlWords == kFloodCtrlWords, "control block size");
 
@@ -342,6 +344,15 @@ __device__ __forceinline__ bool giants_many(const uint32_t* ctrl, uint32_t giant
     const uint32_t n_seeds = uni(ctrl[kCtrlNSeeds]);
     return giant_many != 0u && uni(ctrl[kCtrlStaged]) == 0u && uni(ctrl[kCtrlRounds]) == 0u && n_seeds >= 8192u &&
            uni(ctrl[kCtrlWindow]) > (n_seeds >> 2) && uni(ld_agent(&ctrl[kCtrlGiants])) >= giant_many;
+}
+// The frame's first round, and nearly every second-tier walk that has ended so far ended held back (seven in eight, sixty-four at
+// least): a frame that is ALL giants -- a noiseless gradient whose every pixel is a seed of one magnitude: 8192 walks that each
+// fill the team's table before they give up, 7.9 ms of a 13 ms frame -- and the walks not yet begun are not begun
+// (flood_explore_team_kernel); the giant steps that follow label the floods whatever their seeds found out.
+__device__ __forceinline__ bool giants_all(const uint32_t* ctrl) {
+    if (uni(ctrl[kCtrlRounds]) != 0u) return false;
+    const uint32_t g = uni(ld_agent(&ctrl[kCtrlTeamGiants])), t = uni(ld_agent(&ctrl[kCtrlTeamDone]));
+    return g >= 64u && g * 8u >= t * 7u;
 }
 // the active list a round with work reads, and the one it appends to (see FloodArgs::act_a)
 __device__ __forceinline__ const uint32_t* act_now(const FloodArgs& A) { return (uni(A.ctrl[kCtrlRounds]) & 1u) ? A.act_b : A.act_a; }
@@ -1739,7 +1750,8 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
         // three quarters of the seeds are not even begun: they count as unfinished (nothing above them commits), and the end
         // of the round closes the window in front of them -- kCtrlStaged: the strongest quarter first, twice as many a round.
         // (only in a round whose end will close the window: flood_advance tests the same words)
-        if (A.giant_hold != 0u && k != uni(A.ctrl[kCtrlLowest]) && k >= (uni(A.ctrl[kCtrlNSeeds]) >> 2) && giants_many(A.ctrl, A.giant_many)) {
+        if (A.giant_hold != 0u && k != uni(A.ctrl[kCtrlLowest]) &&
+            ((k >= (uni(A.ctrl[kCtrlNSeeds]) >> 2) && giants_many(A.ctrl, A.giant_many)) || (!from_multi_list && giants_all(A.ctrl)))) {
             if (threadIdx.x == 0) {
                 A.flags[k] = kFlagIncomplete;
                 atomicMin(&A.ctrl[kCtrlBarrier], k);
@@ -1853,6 +1865,10 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
                 A.flags[k] = kFlagIncomplete;
                 atomicMin(&A.ctrl[kCtrlBarrier], k);
                 atomicAdd(&A.ctrl[kCtrlGiants], 1u);
+                if (!from_multi_list) {
+                    atomicAdd(&A.ctrl[kCtrlTeamGiants], 1u);
+                    atomicAdd(&A.ctrl[kCtrlTeamDone], 1u);
+                }
             }
             continue;
         }
@@ -2051,6 +2067,7 @@ __global__ __launch_bounds__(64 * kTeamWaves) void flood_explore_team_kernel(Flo
             // (what makes a frame "regional", explore_body: walks the first tier could not have held, however early they
             // were handed over)
             if (st.ntiles > kHandTiles) atomicAdd(&A.ctrl[kCtrlBigLong], 1u);
+            if (!from_multi_list) atomicAdd(&A.ctrl[kCtrlTeamDone], 1u);  // (giants_all)
         }
     }
 }
@@ -2891,6 +2908,8 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
         ctrl[kCtrlLogGiveUp] = 0u;
         ctrl[kCtrlSlabTotal] = 0u;
         ctrl[kCtrlQuietMiss] = 0u;
+        ctrl[kCtrlTeamDone] = 0u;
+        ctrl[kCtrlTeamGiants] = 0u;
         ctrl[kCtrlBarrier] = 0xFFFFFFFFu;
         ctrl[kCtrlBarrierNext] = 0xFFFFFFFFu;
         ctrl[kCtrlSlabs] = 0u;
