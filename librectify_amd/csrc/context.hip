@@ -2465,22 +2465,35 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
     static const bool batch_stats = std::getenv("LIBRECTIFY_BATCH_STATS") != nullptr;
     std::atomic<long long> up_wait_us{0}, lane_wait_us{0}, lead_sum_us{0};
     std::atomic<int> late_frames{0};
-    // Experiment (LIBRECTIFY_REGISTER_FRAMES=<threads>): pageable caller frames are page-locked WHERE
-    // THEY LIE (hipHostRegister) by a few helper threads running ahead of the uploader, sent by DMA from there, and released
-    // when the call is over -- no staging copy, i.e. one pass through host DRAM instead of three.  What it costs instead is
-    // the pinning itself (page-table work, ~1.3 ms a 4K frame on one thread: profiles/r05_h2d_register.txt).
-    static const int register_threads = std::getenv("LIBRECTIFY_REGISTER_FRAMES") ? std::max(0, std::atoi(std::getenv("LIBRECTIFY_REGISTER_FRAMES"))) : 0;
+    // Pageable caller frames are page-locked WHERE THEY LIE (hipHostRegister) by a few helper threads running ahead of the
+    // uploader, sent by DMA from there, and released when the call is over -- no staging copy, i.e. one pass through host DRAM
+    // instead of three.  What it costs instead is the pinning itself (page-table work, ~1.3 ms a 4K frame on one thread).
+    // Round 5: 10.93 -> 11.38 Gpix/s on the headline leg with four helpers, the 1080p batch unchanged;
+    // the default since.  A frame whose registration is refused (memory somebody else has registered, a mapping that cannot be
+    // pinned) goes through the staging copy as before; LIBRECTIFY_REGISTER_FRAMES=0 sends every frame that way,
+    // =<n> sets the helpers (profiles/r05_h2d_register.txt).
+    static const int register_threads = std::getenv("LIBRECTIFY_REGISTER_FRAMES") ? std::max(0, std::atoi(std::getenv("LIBRECTIFY_REGISTER_FRAMES"))) : 4;
     const bool reg_frames = register_threads > 0 && h_frames != nullptr && any_pageable && stride >= w;
     std::vector<std::atomic<int>> reg_ready(reg_frames ? (size_t)batch : 0);
     for (auto& a : reg_ready) a.store(0, std::memory_order_relaxed);
+    // reg_ready[i]: 0 nobody has touched the frame, 3 a helper is registering it, 1 registered, 2 the staging copy takes it
+    // (page-locked already, registration refused, or the uploader got there first).  The helpers take the frames in order; a
+    // frame the uploader reaches before any helper has is staged.  (Helpers that begin at the fourth frame, the uploader staging
+    // the call's first three rather than waiting 1.3 ms for the first registration: 11.30 against 11.41 Gpix/s -- the staging
+    // copies cost the helpers more than the wait costs the call; LIBRECTIFY_REGISTER_LEAD=<n> for the comparison.)
+    static const int reg_lead = std::getenv("LIBRECTIFY_REGISTER_LEAD") ? std::max(0, std::atoi(std::getenv("LIBRECTIFY_REGISTER_LEAD"))) : 0;
+    std::atomic<int> reg_next{std::min(batch, reg_lead)};
     std::vector<std::thread> reg_pool;
     if (reg_frames)
         for (int t = 0; t < register_threads; ++t)
-            reg_pool.emplace_back([&, t]() {
+            reg_pool.emplace_back([&]() {
                 (void)hipSetDevice(c->device);
                 bind_this_thread_near(c->device);
-                for (int i = t; i < batch && !abort_all.load(std::memory_order_relaxed); i += register_threads) {
-                    int ok = 2;  // 2: page-locked already (or registration refused: the staging path takes it)
+                for (int i = reg_next.fetch_add(1, std::memory_order_relaxed); i < batch && !abort_all.load(std::memory_order_relaxed);
+                     i = reg_next.fetch_add(1, std::memory_order_relaxed)) {
+                    int expect = 0;
+                    if (!reg_ready[(size_t)i].compare_exchange_strong(expect, 3, std::memory_order_acq_rel)) continue;  // (the uploader has it)
+                    int ok = 2;
                     if (!is_page_locked(h_frames[i]))
                         ok = hipHostRegister(const_cast<float*>(h_frames[i]), ((size_t)(h - 1) * (size_t)stride + (size_t)w) * sizeof(float), hipHostRegisterDefault) == hipSuccess ? 1 : 2;
                     if (ok == 2) (void)hipGetLastError();
@@ -2511,7 +2524,9 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
             slot_busy[(size_t)slot].store(1, std::memory_order_relaxed);
             if (reg_frames) {  // (the frame is being pinned by a helper: wait for it)
                 int sp2 = 0;
-                while (reg_ready[(size_t)i].load(std::memory_order_acquire) == 0 && !abort_all.load(std::memory_order_relaxed)) nap(sp2);
+                int expect = 0;
+                if (!reg_ready[(size_t)i].compare_exchange_strong(expect, 2, std::memory_order_acq_rel))  // (else: nobody has it -- staged)
+                    while (reg_ready[(size_t)i].load(std::memory_order_acquire) == 3 && !abort_all.load(std::memory_order_relaxed)) nap(sp2);
             }
             float* stage = is_page_locked(h_frames[i]) ? nullptr : c->ring_stage[(size_t)slot];
             const double t_u0 = now_ms();
