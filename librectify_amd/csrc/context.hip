@@ -2494,7 +2494,11 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
                     int expect = 0;
                     if (!reg_ready[(size_t)i].compare_exchange_strong(expect, 3, std::memory_order_acq_rel)) continue;  // (the uploader has it)
                     int ok = 2;
-                    if (!is_page_locked(h_frames[i]))
+                    // (a frame that is in the batch more than once is registered by its first entry only: two helpers
+                    // registering one range at the same time can both be told "done", and the second release then fails)
+                    bool first = true;
+                    for (int j = 0; j < i && first; ++j) first = h_frames[j] != h_frames[i];
+                    if (first && !is_page_locked(h_frames[i]))
                         ok = hipHostRegister(const_cast<float*>(h_frames[i]), ((size_t)(h - 1) * (size_t)stride + (size_t)w) * sizeof(float), hipHostRegisterDefault) == hipSuccess ? 1 : 2;
                     if (ok == 2) (void)hipGetLastError();
                     reg_ready[(size_t)i].store(ok, std::memory_order_release);
@@ -2647,7 +2651,8 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
     for (auto& t : reg_pool) t.join();
     if (reg_frames)  // the caller's frames go back to being pageable
         for (int i = 0; i < batch; ++i)
-            if (reg_ready[(size_t)i].load(std::memory_order_acquire) == 1) (void)hipHostUnregister(const_cast<float*>(h_frames[i]));
+            if (reg_ready[(size_t)i].load(std::memory_order_acquire) == 1 && hipHostUnregister(const_cast<float*>(h_frames[i])) != hipSuccess)
+                (void)hipGetLastError();  // (nothing to be done about it, and the caller's thread must not find it in its next call)
     for (lr_context* l : lanes) l->sleep_in_wait = false;
     c->flood_multi = caller_multi;
     c->flood_logs = caller_logs;
