@@ -2215,7 +2215,10 @@ int ctx_find_groups_host(lr_context* c, const float* buffer, int w, int h, int s
     // 3.01 ms per call with 4 MB bands, 3.49 with 1 MB, 4.07 with 512 KB (profiles/r03_single_call_sweep.txt).
     static const size_t band_bytes = std::getenv("LIBRECTIFY_UPLOAD_BAND_KB") ? (size_t)std::max(64, std::atoi(std::getenv("LIBRECTIFY_UPLOAD_BAND_KB"))) << 10 : (size_t)4 << 20;
     static const int filter_every = std::getenv("LIBRECTIFY_FILTER_EVERY") ? std::max(1, std::atoi(std::getenv("LIBRECTIFY_FILTER_EVERY"))) : 1;
-    int rpb = (int)std::max<size_t>(1, band_bytes / row_bytes);
+    // (a page-locked source goes up in ONE transfer unless the knob says otherwise: eight bands of 4 MB with an event each cost
+    // the call more than the filter gains by starting under the transfer -- 2.07 -> 1.94 ms per 4K frame, round 5)
+    static const bool band_env = std::getenv("LIBRECTIFY_UPLOAD_BAND_KB") != nullptr;
+    int rpb = (int)std::max<size_t>(1, ((stage == nullptr && !band_env) ? (size_t)h * row_bytes : band_bytes) / row_bytes);
     if ((h + rpb - 1) / rpb > StagingCrew::kMaxBands) rpb = (h + StagingCrew::kMaxBands - 1) / StagingCrew::kMaxBands;  // (as StagingCrew::begin)
     const int n_bands = (h + rpb - 1) / rpb;
     while ((int)c->band_ev.size() < n_bands) {

@@ -117,3 +117,39 @@ print("ok")
     env = dict(os.environ, LIBRECTIFY_REGISTER_FRAMES="3")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-1500:])
+
+
+def test_round5_launch_savings_and_host_path_defaults_against_their_comparison_knobs(L):
+    """Round 5's launch savings and the registration of pageable frames are defaults; each has a knob that gives the old
+    path back (read once per process: children).  With every knob at its comparison setting -- three launches for the seed
+    selection, a copy of the flood's control block, every blind round with the second tier, the staging copy for every
+    frame, bands of 1 MB for a page-locked single frame -- and with none set: the same records as the oracle's, from single
+    calls out of pageable and page-locked buffers and from a batch that holds one frame twice."""
+    code = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np
+import oracle_lib as O
+import librectify_amd as L
+from librectify_amd import synth
+ctx = L.Context(0); ctx.set_seed(0); ctx.set_batch_streams(3)
+kinds = [synth.frame(960, 540, 60, bars=30), synth.region_frame(960, 540, 500), synth.frame(960, 540, 61, bars=45)]
+want = [O.find_line_segment_groups(f, 9.6, seed=0)[0] for f in kinds]
+pinned = ctx.host_alloc((3, 540, 960))
+for i in range(3): pinned[i] = kinds[i]
+for rep in range(2):
+    for i in (0, 1, 2, 0):
+        assert ctx.find_line_segment_groups(kinds[i], 9.6).tobytes() == want[i].tobytes(), ("pageable", rep, i)
+        assert ctx.find_line_segment_groups(pinned[i], 9.6).tobytes() == want[i].tobytes(), ("page-locked", rep, i)
+    order = [0, 1, 2, 1, 0, 2, 2, 1]
+    out, n, _ = ctx.find_line_segment_groups_batch_host([kinds[i] for i in order], 9.6, capacity=4096, num_threads=4)
+    for j, i in enumerate(order):
+        assert out[j, : n[j]].tobytes() == want[i].tobytes(), ("batch", rep, j)
+print("ok")
+""" % (ROOT, ROOT)
+    knobs = dict(LIBRECTIFY_SEED_SELECT_FUSED="0", LIBRECTIFY_FLOOD_MIRROR="0", LIBRECTIFY_FLOOD_CALM_HINT="0",
+                 LIBRECTIFY_REGISTER_FRAMES="0", LIBRECTIFY_UPLOAD_BAND_KB="1024")
+    for extra in ({}, knobs):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (extra, r.stdout[-500:], r.stderr[-1500:])
