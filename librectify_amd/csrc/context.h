@@ -51,6 +51,7 @@ struct lr_context {
     uint32_t* tile_pass = nullptr;
     uint32_t* tile_off = nullptr;      // (the fused seed selection keeps its workgroups' status words here: zeroed when allocated)
     uint32_t fit_tag = 0;              // ... and of the last component scan (kernels_fit.hip: component_offsets_kernel)
+    int register_slow_calls = 0;       // batch calls still to go with the staging copy after pinning frames in place turned out slow (context.hip: find_groups_batch)
     uint32_t select_tag = 0;           // tag of the last seed selection on this context (kernels_seeds.hip: seed_select_kernel)
     float* maxmag = nullptr;
     uint64_t* keys_a = nullptr;

@@ -2476,7 +2476,11 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
     // pinned) goes through the staging copy as before; LIBRECTIFY_REGISTER_FRAMES=0 sends every frame that way,
     // =<n> sets the helpers (profiles/r05_h2d_register.txt).
     static const int register_threads = std::getenv("LIBRECTIFY_REGISTER_FRAMES") ? std::max(0, std::atoi(std::getenv("LIBRECTIFY_REGISTER_FRAMES"))) : 4;
-    const bool reg_frames = register_threads > 0 && h_frames != nullptr && any_pageable && stride >= w;
+    // (a host on which pinning is slow -- measured on this box: 1.3 ms a 4K frame on one thread, 25 GB/s; the guard trips below
+    // 6 GB/s -- gets the staging copy back: for the rest of the call, and for the context's next 32 batch calls before it tries again)
+    if (c->register_slow_calls > 0) --c->register_slow_calls;
+    const bool reg_frames = register_threads > 0 && h_frames != nullptr && any_pageable && stride >= w && c->register_slow_calls == 0;
+    std::atomic<int> reg_slow{0};
     std::vector<std::atomic<int>> reg_ready(reg_frames ? (size_t)batch : 0);
     for (auto& a : reg_ready) a.store(0, std::memory_order_relaxed);
     // reg_ready[i]: 0 nobody has touched the frame, 3 a helper is registering it, 1 registered, 2 the staging copy takes it
@@ -2494,9 +2498,11 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
                 bind_this_thread_near(c->device);
                 for (int i = reg_next.fetch_add(1, std::memory_order_relaxed); i < batch && !abort_all.load(std::memory_order_relaxed);
                      i = reg_next.fetch_add(1, std::memory_order_relaxed)) {
+                    if (reg_slow.load(std::memory_order_relaxed) >= 2) break;  // (pinning is slow here: the uploader stages the rest)
                     int expect = 0;
                     if (!reg_ready[(size_t)i].compare_exchange_strong(expect, 3, std::memory_order_acq_rel)) continue;  // (the uploader has it)
                     int ok = 2;
+                    const double t_r0 = now_ms();
                     // (a frame that is in the batch more than once is registered by its first entry only: two helpers
                     // registering one range at the same time can both be told "done", and the second release then fails)
                     bool first = true;
@@ -2504,6 +2510,7 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
                     if (first && !is_page_locked(h_frames[i]))
                         ok = hipHostRegister(const_cast<float*>(h_frames[i]), ((size_t)(h - 1) * (size_t)stride + (size_t)w) * sizeof(float), hipHostRegisterDefault) == hipSuccess ? 1 : 2;
                     if (ok == 2) (void)hipGetLastError();
+                    if (ok == 1 && (now_ms() - t_r0) * 6.0e6 > (double)((size_t)h * (size_t)stride * sizeof(float))) reg_slow.fetch_add(1, std::memory_order_relaxed);
                     reg_ready[(size_t)i].store(ok, std::memory_order_release);
                 }
             });
@@ -2652,6 +2659,7 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
                      lead_sum_us.load() * 1e-3 / batch, late_frames.load(), batch);
     if (h_frames) (void)hipStreamSynchronize(c->copy_stream);  // (after an error: nothing may still read the caller's frames)
     for (auto& t : reg_pool) t.join();
+    if (reg_slow.load() >= 2) c->register_slow_calls = 32;
     if (reg_frames)  // the caller's frames go back to being pageable
         for (int i = 0; i < batch; ++i)
             if (reg_ready[(size_t)i].load(std::memory_order_acquire) == 1 && hipHostUnregister(const_cast<float*>(h_frames[i])) != hipSuccess)
