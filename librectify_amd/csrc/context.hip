@@ -2589,10 +2589,7 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
                 while ((slot = enq[(size_t)b].load(std::memory_order_acquire) - 1) < 0 && !abort_all.load(std::memory_order_relaxed)) nap(spins);
                 if (batch_stats) lane_wait_us.fetch_add((long long)((now_ms() - t_w0) * 1e3));
                 if (slot < 0) return;  // (whoever stopped the batch has the message)
-                // (experiment, profiles/r05_dma_interference.txt: =1 leaves the wait out -- the lane then works on whatever the
-                // slot holds, results are NOT the frame's -- to price the cross-stream wait apart from the transfer)
-                static const bool exp_no_wait = std::getenv("LIBRECTIFY_EXP_NO_UPLOAD_WAIT") != nullptr;
-                if (!exp_no_wait && hipStreamWaitEvent(l->stream, c->ring_ev[(size_t)slot], 0) != hipSuccess) {
+                if (hipStreamWaitEvent(l->stream, c->ring_ev[(size_t)slot], 0) != hipSuccess) {
                     set_error("hipStreamWaitEvent failed");
                     return fail();
                 }
@@ -2600,21 +2597,6 @@ static int find_groups_batch(lr_context* c, const float* d_images, size_t image_
                 img_stride = w;
             } else {
                 img = d_images + (size_t)b * image_stride;
-                // (experiment, same file: resident frames, but each behind a cross-stream wait for a 4 KB transfer of its own)
-                static const bool exp_fence = std::getenv("LIBRECTIFY_EXP_RESIDENT_WAIT") != nullptr;
-                if (exp_fence) {
-                    static std::mutex mu;
-                    static void* dst = nullptr;
-                    static hipStream_t side = nullptr;
-                    static hipEvent_t evs[64] = {};
-                    std::lock_guard<std::mutex> g(mu);
-                    if (!dst) (void)hipMalloc(&dst, 4096);
-                    if (!side) (void)hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
-                    if (!evs[si & 63]) (void)hipEventCreateWithFlags(&evs[si & 63], hipEventDisableTiming);
-                    (void)hipMemcpyAsync(dst, c->h_counts, 256, hipMemcpyHostToDevice, side);
-                    (void)hipEventRecord(evs[si & 63], side);
-                    (void)hipStreamWaitEvent(l->stream, evs[si & 63], 0);
-                }
             }
             std::vector<LineSegment> res;
             const double t_f0 = now_ms();
