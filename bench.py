@@ -894,8 +894,9 @@ def main(argv=None):
                     "host_threads_affinity_cpus": affinity,
                     # what N ranks ask of the host's memory, the first shared resource of an 8-GPU node: a pageable frame is read
                     # by the staging copy, written into the staging buffer and read again by the DMA engine (3 x its bytes);
-                    # a page-locked or registered frame once.  Two-socket DDR5-4800 x 24 channels is ~920 GB/s at best.
-                    "host_dram_GBps_expected": None if (kind == "device" or args.steps == 0) else round((3.0 if kind == "pageable" and not os.environ.get("LIBRECTIFY_REGISTER_FRAMES") else 1.0) * wl.B * w * h * 4.0 * args.steps / el / 1e9 * n_gpus, 1),
+                    # a page-locked frame, or a pageable one that the batch call page-locks where it lies (the default since round 5;
+                    # LIBRECTIFY_REGISTER_FRAMES=0 for the staging copy), once.  Two-socket DDR5-4800 x 24 channels is ~920 GB/s at best.
+                    "host_dram_GBps_expected": None if (kind == "device" or args.steps == 0) else round((3.0 if kind == "pageable" and os.environ.get("LIBRECTIFY_REGISTER_FRAMES") == "0" else 1.0) * wl.B * w * h * 4.0 * args.steps / el / 1e9 * n_gpus, 1),
                     "gather": ("2 x all_gather of the per-frame results (counts and transforms, then the segments), inside the timed region, %d calls in this run" % gather_calls[0]) if pg
                               else "none: a single rank started without a launcher has no process group and nothing to gather",
                 },
