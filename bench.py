@@ -542,6 +542,8 @@ def main(argv=None):
     ap.add_argument("--no-gather", action="store_true", help="with a process group: leave the gather of the results out of the steps (what a process "
                     "group costs by being there, apart from what the gather costs)")
     ap.add_argument("--no-extra-legs", action="store_true")
+    ap.add_argument("--sync-gather", action="store_true", help="with a process group: gather each step's results before the next step's call "
+                    "(until round 5; default now: a worker thread gathers them while the next call runs, fence() waits for the last)")
     ap.add_argument("--dma-pump", default=None, metavar="DIR:MB",
                     help="experiment (profiles/r05_dma_interference.txt): beside the timed steps a thread keeps copying 32 MB pieces "
                          "h2d:MB = from page-locked host memory round a device region of MB megabytes, d2h:MB the other way, "
@@ -647,7 +649,48 @@ def main(argv=None):
         ctx.set_flood_mode(args.flood_mode)
     cfg = L.RectificationConfig()
 
+    class GatherWorker:
+        """The path's one exchange step, off the critical path: a thread of its own takes the steps' results in order and gathers
+        them over the process group while the rank's next batch call is running (a rank issues its collectives from this one
+        thread, in step order -- the same order on every rank).  fence() drains it: the timed region ends after the last gather."""
+
+        def __init__(self):
+            import queue
+            import threading
+
+            self.q = queue.Queue()
+            self.err = None
+            self.t = threading.Thread(target=self.run, daemon=True)
+            self.t.start()
+
+        def run(self):
+            if cdev.type == "cuda":
+                torch.cuda.set_device(cdev)
+            while True:
+                job = self.q.get()
+                try:
+                    if job is None:
+                        return
+                    if self.err is None:
+                        D.gather_results(job[0], job[1], job[2], device=cdev)
+                except Exception as e:  # (reported by drain() on the rank's main thread)
+                    self.err = e
+                finally:
+                    self.q.task_done()
+
+        def submit(self, lines, tforms, n_total):
+            self.q.put((lines, tforms, n_total))
+
+        def drain(self):
+            self.q.join()
+            if self.err is not None:
+                raise self.err
+
+    gather_worker = GatherWorker() if (pg and not args.no_gather and not args.sync_gather) else None
+
     def fence():
+        if gather_worker:
+            gather_worker.drain()
         if pg:
             dist.barrier()
         ctx.synchronize()
@@ -705,7 +748,11 @@ def main(argv=None):
                     self.tforms[b] = tf[b].as_array()
             if pg and not args.no_gather:  # the path's one exchange step: gather the per-frame results over the process group (RCCL on GPUs)
                 gather_calls[0] += 1
-                D.gather_results([self.out[b][: self.n_lines[b]] for b in range(self.B)], self.tforms[: self.B], n_total if n_total is not None else self.B * world, device=cdev)
+                nt = n_total if n_total is not None else self.B * world
+                if gather_worker:  # (the next step's call writes into self.out: the worker gets copies)
+                    gather_worker.submit([self.out[b][: self.n_lines[b]].copy() for b in range(self.B)], self.tforms[: self.B].copy(), nt)
+                else:
+                    D.gather_results([self.out[b][: self.n_lines[b]] for b in range(self.B)], self.tforms[: self.B], nt, device=cdev)
 
     def make_batch1080():
         b, e = D.shard_range(512, rank, world)
@@ -897,7 +944,7 @@ def main(argv=None):
                     # a page-locked frame, or a pageable one that the batch call page-locks where it lies (the default since round 5;
                     # LIBRECTIFY_REGISTER_FRAMES=0 for the staging copy), once.  Two-socket DDR5-4800 x 24 channels is ~920 GB/s at best.
                     "host_dram_GBps_expected": None if (kind == "device" or args.steps == 0) else round((3.0 if kind == "pageable" and os.environ.get("LIBRECTIFY_REGISTER_FRAMES") == "0" else 1.0) * wl.B * w * h * 4.0 * args.steps / el / 1e9 * n_gpus, 1),
-                    "gather": ("2 x all_gather of the per-frame results (counts and transforms, then the segments), inside the timed region, %d calls in this run" % gather_calls[0]) if pg
+                    "gather": ("2 x all_gather of the per-frame results (counts and transforms, then the segments), inside the timed region, %d calls in this run%s" % (gather_calls[0], ", by a worker thread beside the next step's batch call (the timed region ends after the last gather)" if gather_worker else "")) if pg
                               else "none: a single rank started without a launcher has no process group and nothing to gather",
                 },
             },
@@ -966,6 +1013,9 @@ def main(argv=None):
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))
+    if gather_worker:
+        gather_worker.drain()
+        gather_worker.q.put(None)
     if pg:
         dist.barrier()
         dist.destroy_process_group()
