@@ -649,44 +649,8 @@ def main(argv=None):
         ctx.set_flood_mode(args.flood_mode)
     cfg = L.RectificationConfig()
 
-    class GatherWorker:
-        """The path's one exchange step, off the critical path: a thread of its own takes the steps' results in order and gathers
-        them over the process group while the rank's next batch call is running (a rank issues its collectives from this one
-        thread, in step order -- the same order on every rank).  fence() drains it: the timed region ends after the last gather."""
-
-        def __init__(self):
-            import queue
-            import threading
-
-            self.q = queue.Queue()
-            self.err = None
-            self.t = threading.Thread(target=self.run, daemon=True)
-            self.t.start()
-
-        def run(self):
-            if cdev.type == "cuda":
-                torch.cuda.set_device(cdev)
-            while True:
-                job = self.q.get()
-                try:
-                    if job is None:
-                        return
-                    if self.err is None:
-                        D.gather_results(job[0], job[1], job[2], device=cdev)
-                except Exception as e:  # (reported by drain() on the rank's main thread)
-                    self.err = e
-                finally:
-                    self.q.task_done()
-
-        def submit(self, lines, tforms, n_total):
-            self.q.put((lines, tforms, n_total))
-
-        def drain(self):
-            self.q.join()
-            if self.err is not None:
-                raise self.err
-
-    gather_worker = GatherWorker() if (pg and not args.no_gather and not args.sync_gather) else None
+    # (the path's one exchange step runs off the critical path: librectify_amd/distributed.py GatherWorker)
+    gather_worker = D.GatherWorker(device=cdev) if (pg and not args.no_gather and not args.sync_gather) else None
 
     def fence():
         if gather_worker:
@@ -1014,8 +978,7 @@ def main(argv=None):
             res["cpu_baseline"] = None
         print(json.dumps(res))
     if gather_worker:
-        gather_worker.drain()
-        gather_worker.q.put(None)
+        gather_worker.close()
     if pg:
         dist.barrier()
         dist.destroy_process_group()

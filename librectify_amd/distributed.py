@@ -55,3 +55,56 @@ def gather_results(lines_per_frame, transforms, n_total, device=None):
             out_lines.append(p_all[r, i].view(LINE_DTYPE)[:n].copy())
             out_tf[b + i] = m_all[r, i, 1:].reshape(6, 3)
     return out_lines, out_tf
+
+
+class GatherWorker:
+    """The path's one exchange step off the critical path: a thread of its own takes the steps' results in order and gathers
+    them over the process group (gather_results) while the rank goes on with its next batch of frames.  A rank issues its
+    collectives from this one thread, in step order -- the same order on every rank; `drain()` waits for everything submitted
+    (call it on every rank before any collective of the main thread, e.g. a barrier) and re-raises what a gather raised;
+    `results` keeps the last gather's return value when `keep` is set."""
+
+    def __init__(self, device=None, keep=False):
+        import queue
+        import threading
+
+        self.device = device
+        self.keep = keep
+        self.results = None
+        self.err = None
+        self.q = queue.Queue()
+        self.t = threading.Thread(target=self._run, daemon=True)
+        self.t.start()
+
+    def _run(self):
+        import torch
+
+        if self.device is not None and torch.device(self.device).type == "cuda":
+            torch.cuda.set_device(self.device)
+        while True:
+            job = self.q.get()
+            try:
+                if job is None:
+                    return
+                if self.err is None:
+                    r = gather_results(job[0], job[1], job[2], device=self.device)
+                    if self.keep:
+                        self.results = r
+            except Exception as e:  # (reported by drain() on the rank's main thread)
+                self.err = e
+            finally:
+                self.q.task_done()
+
+    def submit(self, lines_per_frame, transforms, n_total):
+        """the arrays must stay untouched until the gather has run: hand over copies of buffers that are reused"""
+        self.q.put((lines_per_frame, transforms, n_total))
+
+    def drain(self):
+        self.q.join()
+        if self.err is not None:
+            raise self.err
+
+    def close(self):
+        self.drain()
+        self.q.put(None)
+        self.t.join()

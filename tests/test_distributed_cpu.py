@@ -76,3 +76,69 @@ def test_shard_range_covers_everything():
                 b, e = D.shard_range(n, r, world)
                 got += list(range(b, e))
             assert got == list(range(n))
+
+
+def _worker_async(rank, world, port, n_steps, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from librectify_amd import LINE_DTYPE
+    from librectify_amd import distributed as D
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gw = D.GatherWorker(keep=True)
+    n_total = 5
+    b, e = D.shard_range(n_total, rank, world)
+    buf = np.zeros((e - b, 7), LINE_DTYPE)  # (a buffer the "next step" overwrites: the worker gets copies)
+    for step in range(n_steps):
+        lines = []
+        for i in range(b, e):
+            n = (i + step) % 7
+            buf[i - b, :n]["x1"] = np.arange(n, dtype=np.float32) + 100 * i + step
+            buf[i - b, :n]["group_id"] = i
+            lines.append(buf[i - b, :n].copy())
+        tf = np.full((e - b, 6, 3), float(step), np.float32)
+        gw.submit(lines, tf, n_total)
+        buf[:] = 0  # the rank goes on while the gather runs
+    gw.drain()
+    all_lines, all_tf = gw.results
+    dist.barrier()  # (a collective of the main thread: only after the drain)
+    q.put((rank, [x.tobytes() for x in all_lines], all_tf.tobytes()))
+    gw.close()
+    dist.destroy_process_group()
+
+
+def test_gather_worker_gathers_in_step_order_beside_the_ranks_work():
+    """bench.py with a process group hands each step's results to librectify_amd.distributed.GatherWorker: a thread per rank that
+    issues the rank's collectives in step order while the rank's next batch call runs.  Two gloo ranks, six steps with lists
+    of different lengths, the rank's buffer overwritten right after each submit: both ranks end with the LAST step's results
+    of all frames, in global order."""
+    import torch.multiprocessing as mp
+
+    sys.path.insert(0, ROOT)
+    from librectify_amd import LINE_DTYPE
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 17
+    n_steps = 6
+    procs = [ctx.Process(target=_worker_async, args=(r, 2, port, n_steps, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    step = n_steps - 1
+    exp = []
+    for i in range(5):
+        n = (i + step) % 7
+        a = np.zeros(n, LINE_DTYPE)
+        a["x1"] = np.arange(n, dtype=np.float32) + 100 * i + step
+        a["group_id"] = i
+        exp.append(a.tobytes())
+    for rank, lines, tf in res:
+        assert lines == exp, rank
+        assert tf == np.full((5, 6, 3), float(step), np.float32).tobytes()
