@@ -13,6 +13,8 @@
 #include <algorithm>
 #include <cstring>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace lramd {
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(1024) void huge_sort_kernel(const uint32_t* __restr
 // sums), kU of them in flight at a time: the pixel list first, then the gathers it points to -- one round trip per kU pixels
 // instead of one per pixel.  The launch lasts as long as its longest component: 3 700 px = 58 steps a pass at kU = 8 on the
 // 4K bench frame; a region of 141 000 px was 276 steps a pass, 1.25 ms of a 13 ms frame -- components beyond 2^14 pixels go
-// through fit_huge_kernel with kU = 32 (same order, same bits).
+// through fit_huge_kernel (same order of the additions, same bits).
 template <int kU>
 __device__ __forceinline__ void fit_large(const uint32_t* __restrict__ px, uint32_t comp, uint32_t off, uint32_t n, float s, float c,
                                           uint32_t uw, const float* __restrict__ dx, const float* __restrict__ dy,
@@ -644,19 +646,233 @@ __global__ __launch_bounds__(256) void fit_kernel(const uint32_t* __restrict__ p
     fit_large<8>(px, comp, off, n, s, c, uw, dx, dy, scratch_w, out, lane);
 }
 
-// The components of more than 2^14 pixels (the list the offsets pass made of them), a wavefront each, 32 pixels a lane in flight.
-__global__ __launch_bounds__(64) void fit_huge_kernel(const uint32_t* __restrict__ px, const uint32_t* __restrict__ comp_off,
-                                                      const uint32_t* __restrict__ comp_seed, const uint32_t* __restrict__ huge_list,
-                                                      const uint32_t* __restrict__ n_large, uint32_t huge_max,
-                                                      const int32_t* __restrict__ seed_bin, const float* __restrict__ dx,
-                                                      const float* __restrict__ dy, int w, BinTrig trig,
-                                                      float* __restrict__ scratch_w, LineSegment* __restrict__ out) {
+// The components of more than 2^14 pixels (the list the offsets pass made of them), a workgroup of 1024 threads each.  The sums'
+// canonical order is a single wavefront's -- lane L adds the elements L, L + 64, ... in that order, then the tree -- and one
+// wavefront alone issues an instruction every four cycles: a region of 141 000 pixels was 0.93 ms of divisions, products and
+// gathers for ONE wavefront (1.25 ms with eight pixels a lane in flight; thirty-two or sixty-four: no difference, it is issue,
+// not latency).  So the work is split the other way: for a chunk of 4096 elements ALL sixteen wavefronts compute the elements'
+// terms (the same expressions, so the same bits) into LDS, then wavefront w adds the chunk's terms of sum w in the canonical
+// order -- lane L takes L, L + 64, ... of the chunk, chunks in ascending order: the same sequence of additions.
+// lane L of a wavefront adds the chunk's terms L, L + 64, ... to its sum IN THAT ORDER; sixteen LDS reads are in flight at a time
+// (one read and one dependent add a turn was 110 cycles a term: 2.9 of the 3.7 us a chunk took)
+__device__ __forceinline__ float huge_chunk_sum(float acc, const float* __restrict__ v, uint32_t cn, int lane) {
+    for (uint32_t j0 = (uint32_t)lane; j0 < cn; j0 += 64u * 16u) {
+        float t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const uint32_t j = j0 + 64u * (uint32_t)u;
+            t[u] = j < cn ? v[j] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (j0 + 64u * (uint32_t)u < cn) acc = acc + t[u];
+    }
+    return acc;
+}
+// LDS of the launch: 96 KB of terms (dynamic), cut into as many arrays as the pass has sums -- chunks of 24 576 elements for
+// the passes with one sum, 12 288 for the centroid's two, 8 192 for the covariance's three: a chunk costs two barriers and a
+// round trip to memory whatever its size (chunks of 4 096 for every pass: 3.7 us each, 140 of them for 141 000 pixels).
+constexpr int kHugeTerms = 24576;
+constexpr size_t kHugeLdsBytes = (size_t)kHugeTerms * sizeof(float);
+__global__ __launch_bounds__(1024) void fit_huge_kernel(const uint32_t* __restrict__ px, const uint32_t* __restrict__ comp_off,
+                                                        const uint32_t* __restrict__ comp_seed, const uint32_t* __restrict__ huge_list,
+                                                        const uint32_t* __restrict__ n_large, uint32_t huge_max,
+                                                        const int32_t* __restrict__ seed_bin, const float* __restrict__ dx,
+                                                        const float* __restrict__ dy, int w, BinTrig trig,
+                                                        float* __restrict__ scratch_w, LineSegment* __restrict__ out) {
+    extern __shared__ float s_terms[];
+    __shared__ float s_res[3];
+    __shared__ float s_mm[2][16];
     if (blockIdx.x >= min(n_large[2], huge_max)) return;
     const uint32_t comp = huge_list[blockIdx.x];
     const uint32_t off = comp_off[comp];
     const uint32_t n = comp_off[comp + 1] - off;
     const int b = seed_bin[comp_seed[comp]];
-    fit_large<32>(px, comp, off, n, trig.st[b], trig.ct[b], (uint32_t)w, dx, dy, scratch_w, out, (int)threadIdx.x);
+    const float s = trig.st[b], c = trig.ct[b];
+    const uint32_t uw = (uint32_t)w;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // pass 1: weights (kept in scratch_w for the passes below) and their sum
+    float acc = 0.f;
+    {
+        constexpr uint32_t kC = kHugeTerms;
+        constexpr int kE = (int)(kC / 1024u);
+        for (uint32_t c0 = 0; c0 < n; c0 += kC) {
+            const uint32_t cn = min(kC, n - c0);
+            uint32_t p[kE];
+            float gx[kE], gy[kE];
+#pragma unroll
+            for (int e = 0; e < kE; ++e) {
+                const uint32_t j = (uint32_t)tid + 1024u * (uint32_t)e;
+                p[e] = j < cn ? px[off + c0 + j] : 0u;
+            }
+#pragma unroll
+            for (int e = 0; e < kE; ++e) {
+                gx[e] = dx[p[e]];
+                gy[e] = dy[p[e]];
+            }
+#pragma unroll
+            for (int e = 0; e < kE; ++e) {
+                const uint32_t j = (uint32_t)tid + 1024u * (uint32_t)e;
+                if (j < cn) {
+                    const float wv = directional(gx[e], gy[e], s, c);
+                    scratch_w[off + c0 + j] = wv;
+                    s_terms[j] = wv;
+                }
+            }
+            __syncthreads();
+            if (wave == 0) acc = huge_chunk_sum(acc, s_terms, cn, lane);
+            __syncthreads();
+        }
+    }
+    if (wave == 0) {
+        const float t = wave_tree(acc);
+        if (lane == 0) s_res[0] = t;
+    }
+    __syncthreads();
+    const float S = s_res[0];
+    __syncthreads();
+
+    // pass 2: the weighted centroid (two sums: wavefronts 0 and 1)
+    acc = 0.f;
+    {
+        constexpr uint32_t kC = kHugeTerms / 2;
+        constexpr int kE = (int)(kC / 1024u);
+        for (uint32_t c0 = 0; c0 < n; c0 += kC) {
+            const uint32_t cn = min(kC, n - c0);
+            uint32_t q[kE];
+            float wq[kE];
+#pragma unroll
+            for (int e = 0; e < kE; ++e) {
+                const uint32_t j = (uint32_t)tid + 1024u * (uint32_t)e;
+                q[e] = j < cn ? px[off + c0 + j] : 0u;
+                wq[e] = j < cn ? scratch_w[off + c0 + j] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < kE; ++e) {
+                const uint32_t j = (uint32_t)tid + 1024u * (uint32_t)e;
+                if (j < cn) {
+                    const float r = (float)(q[e] / uw), cc = (float)(q[e] % uw);
+                    const float wn = wq[e] / S;
+                    s_terms[j] = wn * r;
+                    s_terms[kC + j] = wn * cc;
+                }
+            }
+            __syncthreads();
+            if (wave < 2) acc = huge_chunk_sum(acc, s_terms + (size_t)wave * kC, cn, lane);
+            __syncthreads();
+        }
+    }
+    if (wave < 2) {
+        const float t = wave_tree(acc);
+        if (lane == 0) s_res[wave] = t;
+    }
+    __syncthreads();
+    const float a_r = s_res[0], a_c = s_res[1];
+    __syncthreads();
+
+    // pass 3: the covariance (three sums: wavefronts 0, 1, 2)
+    acc = 0.f;
+    {
+        constexpr uint32_t kC = kHugeTerms / 3;
+        constexpr int kE = (int)(kC / 1024u);
+        static_assert(kC % 1024u == 0u, "a chunk is a whole number of elements per thread");
+        for (uint32_t c0 = 0; c0 < n; c0 += kC) {
+            const uint32_t cn = min(kC, n - c0);
+            uint32_t q[kE];
+            float wq[kE];
+#pragma unroll
+            for (int e = 0; e < kE; ++e) {
+                const uint32_t j = (uint32_t)tid + 1024u * (uint32_t)e;
+                q[e] = j < cn ? px[off + c0 + j] : 0u;
+                wq[e] = j < cn ? scratch_w[off + c0 + j] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < kE; ++e) {
+                const uint32_t j = (uint32_t)tid + 1024u * (uint32_t)e;
+                if (j < cn) {
+                    const float cr = (float)(q[e] / uw) - a_r, cc = (float)(q[e] % uw) - a_c;
+                    const float wn = wq[e] / S;
+                    const float t = cr * wn, u2 = cc * wn;
+                    s_terms[j] = t * cr;
+                    s_terms[kC + j] = t * cc;
+                    s_terms[2u * kC + j] = u2 * cc;
+                }
+            }
+            __syncthreads();
+            if (wave < 3) acc = huge_chunk_sum(acc, s_terms + (size_t)wave * kC, cn, lane);
+            __syncthreads();
+        }
+    }
+    if (wave < 3) {
+        const float t = wave_tree(acc);
+        if (lane == 0) s_res[wave] = t;
+    }
+    __syncthreads();
+    const float cov_rr = s_res[0], cov_rc = s_res[1], cov_cc = s_res[2];
+    __syncthreads();
+
+    float d_r, d_c;
+    major_axis_2x2(cov_rr, cov_rc, cov_cc, d_r, d_c);
+    const float n_r = -d_c, n_c = d_r;
+
+    // pass 4: the extent along the axis (minimum and maximum: any order) and the summed distance from it (wavefront 0)
+    float t0 = INFINITY, t1 = -INFINITY;
+    acc = 0.f;
+    {
+        constexpr uint32_t kC = kHugeTerms;
+        constexpr int kE = (int)(kC / 1024u);
+        for (uint32_t c0 = 0; c0 < n; c0 += kC) {
+            const uint32_t cn = min(kC, n - c0);
+            uint32_t q[kE];
+#pragma unroll
+            for (int e = 0; e < kE; ++e) {
+                const uint32_t j = (uint32_t)tid + 1024u * (uint32_t)e;
+                q[e] = j < cn ? px[off + c0 + j] : 0u;
+            }
+#pragma unroll
+            for (int e = 0; e < kE; ++e) {
+                const uint32_t j = (uint32_t)tid + 1024u * (uint32_t)e;
+                if (j < cn) {
+                    const float cr = (float)(q[e] / uw) - a_r, cc = (float)(q[e] % uw) - a_c;
+                    const float t = cr * d_r + cc * d_c;
+                    t0 = fminf(t0, t);
+                    t1 = fmaxf(t1, t);
+                    s_terms[j] = fabsf(cr * n_r + cc * n_c);
+                }
+            }
+            __syncthreads();
+            if (wave == 0) acc = huge_chunk_sum(acc, s_terms, cn, lane);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        t0 = fminf(t0, __shfl_xor(t0, o));
+        t1 = fmaxf(t1, __shfl_xor(t1, o));
+    }
+    if (lane == 0) {
+        s_mm[0][wave] = t0;
+        s_mm[1][wave] = t1;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const float esum = wave_tree(acc);
+    if (lane == 0) {
+        for (int i = 1; i < 16; ++i) {
+            t0 = fminf(t0, s_mm[0][i]);
+            t1 = fmaxf(t1, s_mm[1][i]);
+        }
+        LineSegment l;
+        l.x1 = a_c + d_c * t0;
+        l.y1 = a_r + d_r * t0;
+        l.x2 = a_c + d_c * t1;
+        l.y2 = a_r + d_r * t1;
+        l.weight = S / (float)n;
+        l.err = esum / (float)n;
+        l.group_id = -1;
+        out[comp] = l;
+    }
 }
 
 }  // namespace
@@ -723,9 +939,19 @@ int launch_fit(const uint32_t* px_sorted, const uint32_t* px_unsorted, const uin
                hipStream_t s) {
     if (comp_cap == 0) return 0;
     const bool huge = with_huge && hs.tab != nullptr && hs.max != 0u;
-    if (huge)  // (first: the launch lasts as long as its largest component, the small ones' launch runs behind it)
-        hipLaunchKernelGGL(fit_huge_kernel, dim3(hs.max), dim3(64), 0, s, px_sorted, comp_off, comp_seed, hs.list, n_large, hs.max, seed_bin,
+    if (huge) {  // (first: the launch lasts as long as its largest component, the small ones' launch runs behind it)
+        // the opt-in for more than 64 KB of dynamic LDS is a per-device attribute of the kernel: once per device of this process
+        static std::atomic<uint64_t> done_mask{0};
+        int dev = 0;
+        LR_HIP(hipGetDevice(&dev));
+        const uint64_t bit = 1ull << (dev & 63);
+        if (!(done_mask.load(std::memory_order_acquire) & bit)) {
+            LR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fit_huge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kHugeLdsBytes));
+            done_mask.fetch_or(bit, std::memory_order_release);
+        }
+        hipLaunchKernelGGL(fit_huge_kernel, dim3(hs.max), dim3(1024), kHugeLdsBytes, s, px_sorted, comp_off, comp_seed, hs.list, n_large, hs.max, seed_bin,
                            dx, dy, w, trig, scratch_w, out);
+    }
     hipLaunchKernelGGL(fit_kernel, dim3((comp_cap + 3) / 4), dim3(256), 0, s, px_sorted, px_unsorted, comp_off, comp_seed, d_n_comp,
                        seed_bin, dx, dy, w, trig, scratch_w, out, huge ? cursor : nullptr);
     LR_HIP(hipGetLastError());
