@@ -695,7 +695,7 @@ __global__ __launch_bounds__(1024) void fit_huge_kernel(const uint32_t* __restri
     // pass 1: weights (kept in scratch_w for the passes below) and their sum
     float acc = 0.f;
     {
-        constexpr uint32_t kC = kHugeTerms;
+        constexpr uint32_t kC = 16384u;  // (24 576 here: three arrays of 24 registers, 40 bytes a lane spilled)
         constexpr int kE = (int)(kC / 1024u);
         for (uint32_t c0 = 0; c0 < n; c0 += kC) {
             const uint32_t cn = min(kC, n - c0);
