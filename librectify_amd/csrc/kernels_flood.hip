@@ -318,6 +318,7 @@ enum {
     kCtrlQuietMiss = 47,       // walks that outgrew the first tier in a round enqueued without the second (FloodArgs::quiet)
     kCtrlTeamDone = 48,        // second-tier walks of this frame's first round that are over, held ones included ...
     kCtrlTeamGiants = 49,      // ... and how many of them were held back as giants (giants_all)
+    kCtrlGiantReuse = 52,      // the giant step asked for can use the tile masks and the union-find of the step before it (same test, nothing changed but that step's commit)
     kCtrlWords = 56,
 };
 static_assert(kCtrlWords == kFloodCtrlWords, "control block size");
@@ -2689,6 +2690,7 @@ __device__ void flood_advance(uint32_t* __restrict__ ctrl, uint32_t win_shift, u
     ctrl[kCtrlNMultiNext] = 0u;
     ctrl[kCtrlBigSeen] = ld_agent(&ctrl[kCtrlBigLong]) >= regional_min ? 1u : 0u;
     ctrl[kCtrlGiantStep] = (progress && want_giant) ? ld_agent(&ctrl[kCtrlLowest]) + 1u : 0u;  // (kCtrlLowest: the lowest survivor, set above)
+    ctrl[kCtrlGiantReuse] = 0u;  // (a round has run: the masks of the last step are history)
     if (host_progress)  // the host enqueues the next round when it sees this one over and seeds left (flood_enqueue)
         flood_report(host_progress, ld_agent(&ctrl[kCtrlRounds]), progress ? n_next : 0u, !progress, progress && want_giant,
                      ld_agent(&ctrl[kCtrlGiantDone]), ld_agent(&ctrl[kCtrlMaxFlood]) != 0u,
@@ -2896,6 +2898,7 @@ __global__ __launch_bounds__(256) void flood_init_seeds_kernel(const uint32_t* _
         ctrl[kCtrlGiantCountNext] = 0u;
         ctrl[kCtrlGiants] = 0u;
         ctrl[kCtrlGiantStep] = 0u;
+        ctrl[kCtrlGiantReuse] = 0u;
         ctrl[kCtrlDeferLow] = 0xFFFFFFFFu;
         ctrl[kCtrlDeferLowNext] = 0xFFFFFFFFu;
         ctrl[kCtrlStaged] = staged_from_start;  // (the context's last frame was one of overlapping giants: FloodBuffers::staged_from_start)
@@ -2993,7 +2996,7 @@ __device__ __forceinline__ uint32_t giant_pixel(uint32_t tx, uint32_t ty, uint32
 
 __global__ __launch_bounds__(256) void giant_mask_kernel(FloodArgs A, BinTrig trig) {
     const uint32_t gs = uni(A.ctrl[kCtrlGiantStep]);
-    if (gs == 0u) return;
+    if (gs == 0u || uni(A.ctrl[kCtrlGiantReuse]) != 0u) return;  // (reuse: see giant_finish_kernel)
     const uint32_t g = gs - 1u;
     const int lane = threadIdx.x & 63;
     const int s = (int)uni((uint32_t)A.seed_idx[g]);
@@ -3049,7 +3052,7 @@ __global__ __launch_bounds__(256) void giant_mask_kernel(FloodArgs A, BinTrig tr
 }
 
 __global__ __launch_bounds__(256) void giant_merge_kernel(FloodArgs A) {
-    if (A.ctrl[kCtrlGiantStep] == 0u) return;
+    if (A.ctrl[kCtrlGiantStep] == 0u || A.ctrl[kCtrlGiantReuse] != 0u) return;
     const uint32_t tiles_x = (uint32_t)A.tiles_x, tiles_y = (uint32_t)(A.h + 7) >> 3, n_tiles = tiles_x * tiles_y;
     const uint32_t uw = (uint32_t)A.w;
     uint32_t* par = A.giant_parent;
@@ -3252,6 +3255,14 @@ __global__ __launch_bounds__(256) void giant_finish_kernel(FloodArgs A) {
     ctrl[kCtrlGiantDone] = done;
     const bool again = giant != 0xFFFFFFFFu && giant == lowest;
     ctrl[kCtrlGiantStep] = again ? giant + 1u : 0u;
+    // The next step's seed passes the very same test as this one's (same bin, same threshold to the bit) and has committed
+    // nothing of its own yet: its flood is a component of the SAME mask -- this step's commit has only taken one component
+    // away -- so the step that follows leaves its mask and union-find launches at once and goes straight to the commit
+    // (noiseless stripes: a hundred steps of 110 us of union-find over all the stripes, for one stripe each).
+    ctrl[kCtrlGiantReuse] = (again && A.seed_bin[giant] == A.seed_bin[g] && __float_as_uint(A.seed_thr[giant]) == __float_as_uint(A.seed_thr[g]) &&
+                             A.label[A.seed_idx[giant]] != giant && total != 0u)
+                                ? 1u
+                                : 0u;
     if (A.host_progress)
         flood_report(A.host_progress, ld_agent(&ctrl[kCtrlRounds]), n_act, false, again, done, ld_agent(&ctrl[kCtrlMaxFlood]) != 0u || total > kHugeFlood);
 }
@@ -3851,12 +3862,18 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
             }
             // The lowest active seed is a marked giant: the whole device floods it (giant_*_kernel), and the next one if the
             // step's last kernel asks for it, before the next round with work goes in.
+            // (A step's last kernel asks for the next one when the next lowest seed is a marked giant too -- a ring after another,
+            // a stripe after another.  In such a chain the steps go in two, four, eight at a time: a step of a chain that reuses
+            // the union-find is 24 us of kernels, and the hand-over to the host and back was 21 us between every two of them.
+            // Steps enqueued behind the chain's end leave at once.)
+            uint32_t burst = 1u;
             while (!timed_out && r.want_giant && r.n_left != 0u && !r.stalled) {
-                enqueue_giant_step(B, F, A, s);
-                ++giants;
+                const uint32_t base = r.giants;
+                for (uint32_t b2 = 0; b2 < burst; ++b2) enqueue_giant_step(B, F, A, s);
+                giants += burst;
                 for (;;) {
                     r = look();
-                    if (r.giants >= giants) break;
+                    if (r.giants >= base + burst || (r.giants > base && !r.want_giant)) break;
                     if (deadline_passed()) {
                         timed_out = true;
                         break;
@@ -3864,6 +3881,7 @@ int flood_enqueue(const FloodBuffers& B, const FloodFrame& F, FloodProgress* P, 
                 }
                 counting = (int)r.rounds;
                 if (giants >= 4096u) break;  // (never: a step retires a seed)
+                burst = std::min<uint32_t>(burst * 2u, 8u);
             }
             if (timed_out) {
                 // (with the `rest` launch whatever the list's length: the round before them was told its successor would know)
